@@ -1,0 +1,148 @@
+/*
+ * rtrace_hip.h -- C ABI of the MI355X (gfx950) backend for rust-tracer's per-tile hot path.
+ *
+ * Drop-in seam (there is no FFI in the reference today; this is the natural one):
+ * the body of the closure the bucket scheduler hands to its thread pool,
+ *
+ *     /root/reference/src/rust/render.rs:283-294
+ *         let mut b = RGBABuffer::new(&ImageRegion{l: x, r: x + 64, b: y, t: y + 64});
+ *         Renderer::render_region(&opts, tscene.deref(), &mut b);          // render.rs:218-255
+ *         tx.send(b)
+ *
+ * i.e. `pub fn render_region(o: &RenderOptions, scene: &Scene, buf: &mut RGBABuffer)` and everything it
+ * calls (Renderer::raytrace render.rs:171-215, TypedGroup::intersect group.rs:72-83,
+ * Sphere::intersect / distance_from_ray primitive.rs:55-84, RGBABuffer::set_pixel_from_vector render.rs:92-109).
+ * A Rust maintainer binds these symbols from an `extern "C"` block (INTEGRATION.md shows the block);
+ * plain pointers and sizes only, no C++ or torch types, never unwinds, returns integer status codes
+ * where the reference panics.
+ *
+ * Results: the RGBA bytes are bit-identical to the reference CPU path for the same Scene / RenderOptions /
+ * ImageRegion (f32; every + - * / sqrt individually rounded, no FMA contraction, reference operation order).
+ *
+ * Threading: every entry point may be called concurrently from several host threads on one rt_scene*
+ * (the reference calls render_region from up to RTRACEMAXPROCS pool threads, render.rs:283); each call
+ * works on its own HIP stream and workspace.
+ */
+#ifndef RTRACE_HIP_H
+#define RTRACE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTRACE_HIP_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = 1,  /* NULL pointer, n == 0, spp == 0, non-finite / non-positive-radius sphere ...  */
+    RT_ERR_INVALID_REGION = 2,    /* region outside the image or t <= b / r <= l  (reference: assert!/index panic)  */
+    RT_ERR_NO_DEVICE = 3,         /* no gfx950 device visible, or device index out of range                        */
+    RT_ERR_HIP = 4,               /* a HIP runtime call or kernel launch failed; rt_last_error_message() has detail */
+    RT_ERR_OUT_OF_MEMORY = 5,
+    RT_ERR_UNSUPPORTED = 6        /* e.g. RT_TRAVERSAL_SKIP on a scene created without subtree bounds              */
+} rt_status;
+
+/* `pub type RFloat = f32` (vec.rs:6).  RT_F64 is the type-alias swap of BASELINE config 3 (every hard-coded
+ * f32 constant promoted); the reference pins nothing for it. */
+typedef enum rt_precision { RT_F32 = 0, RT_F64 = 1 } rt_precision;
+
+/* How a ray visits the items.  Both give the reference's pixels on scenes whose bounds enclose their
+ * subtrees and whose eye lies outside every bound (the default scene).
+ *   FLAT : every item in DFS order, strict `<` nearest for primary rays, any-hit for shadow rays.
+ *   SKIP : the same DFS array plus the reference's own group bounds as skip ranges, culled per ray with the
+ *          reference's rule `bound.distance_from_ray(ray) >= hit.distance` (group.rs:73) -- reproduces the
+ *          hierarchy exactly, including its inside-the-bound behaviour. */
+typedef enum rt_traversal { RT_TRAVERSAL_FLAT = 0, RT_TRAVERSAL_SKIP = 1 } rt_traversal;
+
+/* RenderOptions, render.rs:33-38 (u16 fields there too).  samples_per_pixel = k means k*k samples. */
+typedef struct rt_options {
+    uint16_t width, height, samples_per_pixel;
+} rt_options;
+
+/* ImageRegion, render.rs:42-48: pixels x in [l, r), y in [b, t); y = 0 is the TOP image row and row 0 of
+ * the tile buffer is y == b (buffer_offset render.rs:69-71). */
+typedef struct rt_region {
+    uint16_t l, t, r, b;
+} rt_region;
+
+/* A group's bound and the contiguous range of DFS item indices of its subtree (for RT_TRAVERSAL_SKIP). */
+typedef struct rt_range {
+    int32_t first, count;
+} rt_range;
+
+/* Ray counters with the reference's meaning (they must equal the CPU path's exactly) + device time. */
+typedef struct rt_stats {
+    uint64_t primary;       /* primary samples traced = sum(area) * spp^2                    */
+    uint64_t hits;          /* primary rays that hit an item                                 */
+    uint64_t shadow;        /* shadow rays cast (hit and n.light < 0), render.rs:199-207      */
+    uint64_t occluded;      /* shadow rays that hit something                                */
+    uint64_t sphere_tests;  /* ray x item tests executed by the kernels (FLAT: rays * n)     */
+    double device_ms;       /* hipEvent time of all kernels of this call on its stream       */
+} rt_stats;
+
+typedef struct rt_scene rt_scene;   /* opaque: device copies of a Scene (render.rs:138-142) */
+
+/* Number of usable devices (RT_ERR_NO_DEVICE and *n = 0 when there is none). */
+rt_status rt_device_count(int *n);
+
+/* Uploads a Scene.  Replaces Arc<Scene> construction for the device side (render.rs:144-166, main.rs:23).
+ *   dfs_items   REAL[4*n_items] = {cx,cy,cz,radius} in traversal (DFS, insertion) order -- the order
+ *               TypedGroup::intersect visits Pair::Item children (group.rs:77-82); ties between items at
+ *               exactly equal distance go to the first in this order (primitive.rs:79).
+ *   light_unit  REAL[3] Scene::directional_light, already normalised by the host in REAL (render.rs:154-159).
+ *   eye         REAL[3] Scene::eye.
+ *   bounds/ranges/n_bounds  optional (NULL/NULL/0): group bounds REAL[4*n_bounds] with their item ranges in DFS
+ *               pre-order (outer group before the groups nested in it); required for RT_TRAVERSAL_SKIP.
+ * REAL is float for RT_F32 and double for RT_F64.  All values must be finite, |coordinate| <= 1e15, radius > 0.
+ * The caller keeps ownership of every host buffer; nothing is retained but the returned handle. */
+rt_status rt_scene_create(int device, rt_precision precision,
+                          const void *dfs_items, uint32_t n_items,
+                          const void *light_unit, const void *eye,
+                          const void *bounds, const rt_range *ranges, uint32_t n_bounds,
+                          rt_scene **out);
+
+rt_status rt_scene_destroy(rt_scene *scene);
+
+/* Renderer::render_region for a batch of regions in ONE device pass (a literal launch per 64x64 bucket would
+ * starve 256 CUs).  rgba_out (HOST memory) receives the tiles back to back ("tile-major"):
+ * tile i starts at 4 * sum_{j<i} area(j) and is its own row-major RGBABuffer (render.rs:74-109).
+ * A single region {0, height, width, 0} therefore yields the row-major frame.  stats may be NULL. */
+rt_status rt_render_tiles(rt_scene *scene, const rt_options *options, rt_traversal traversal,
+                          const rt_region *tiles, uint32_t n_tiles,
+                          uint8_t *rgba_out, rt_stats *stats);
+
+/* Same, but rgba_out is DEVICE memory on the scene's device and the work is enqueued on `hip_stream`
+ * (a hipStream_t passed as void*; NULL = the null stream) without waiting for it: the caller synchronises
+ * (and may hand the buffer straight to an RCCL gather).  stats (may be NULL) receives counters
+ * only when the call can read them back, i.e. it is filled after an internal stream sync if non-NULL. */
+rt_status rt_render_tiles_device(rt_scene *scene, const rt_options *options, rt_traversal traversal,
+                                 const rt_region *tiles, uint32_t n_tiles,
+                                 void *rgba_out_device, void *hip_stream, rt_stats *stats);
+
+/* Single-bucket convenience == rt_render_tiles(..., region, 1, ...): the exact shape of the reference call. */
+rt_status rt_render_region(rt_scene *scene, const rt_options *options, rt_traversal traversal,
+                           const rt_region *region, uint8_t *rgba_out, rt_stats *stats);
+
+/* RGBABuffer::set_pixels_from_buffer (render.rs:112-126) on the device: row-wise blit of tile-major tiles (the
+ * layout rt_render_tiles_device writes, or several such shards after an RCCL gather) into a row-major RGBA frame
+ * of options->width x options->height, i.e. what PPMStdoutRGBABufferWriter::write_rgba_buffer does per bucket
+ * (render.rs:422-424).  src_px_offset[i] is tile i's first pixel in src (in pixels, 4 B each); NULL means the
+ * tiles lie back to back in list order.  Enqueued on hip_stream without waiting. */
+rt_status rt_blit_tiles_device(rt_scene *scene, const rt_options *options, const rt_region *tiles, uint32_t n_tiles,
+                               const uint32_t *src_px_offset, const void *src_tile_major_device,
+                               void *frame_rgba_device, void *hip_stream);
+
+/* Bytes rt_render_tiles writes for this tile list (4 * total area), or 0 on an invalid list. */
+uint64_t rt_tiles_rgba_bytes(const rt_region *tiles, uint32_t n_tiles);
+
+const char *rt_strerror(rt_status status);
+/* Detail of the last RT_ERR_HIP on the calling thread (static thread-local storage; never NULL). */
+const char *rt_last_error_message(void);
+int rt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTRACE_HIP_H */

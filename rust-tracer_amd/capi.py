@@ -1,0 +1,85 @@
+"""ctypes binding of include/rtrace_hip.h -- the same symbols a Rust `extern "C"` block would bind.
+
+There is no CPU fallback here: if librtrace_hip.so is missing the import of this module raises, and if no
+gfx950 device is visible every render call raises RtError(RT_ERR_NO_DEVICE)."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librtrace_hip.so")
+
+RT_OK, RT_ERR_INVALID_ARGUMENT, RT_ERR_INVALID_REGION, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_OUT_OF_MEMORY, RT_ERR_UNSUPPORTED = range(7)
+RT_F32, RT_F64 = 0, 1
+RT_TRAVERSAL_FLAT, RT_TRAVERSAL_SKIP = 0, 1
+ABI_VERSION = 1
+
+# every symbol include/rtrace_hip.h declares
+SYMBOLS = ("rt_abi_version", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render_tiles",
+           "rt_render_tiles_device", "rt_render_region", "rt_blit_tiles_device", "rt_tiles_rgba_bytes", "rt_strerror", "rt_last_error_message")
+
+
+class Options(C.Structure):      # rt_options / RenderOptions render.rs:33-38
+    _fields_ = [("width", C.c_uint16), ("height", C.c_uint16), ("samples_per_pixel", C.c_uint16)]
+
+
+class Region(C.Structure):       # rt_region / ImageRegion render.rs:42-48
+    _fields_ = [("l", C.c_uint16), ("t", C.c_uint16), ("r", C.c_uint16), ("b", C.c_uint16)]
+
+
+class Range(C.Structure):
+    _fields_ = [("first", C.c_int32), ("count", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("primary", C.c_uint64), ("hits", C.c_uint64), ("shadow", C.c_uint64), ("occluded", C.c_uint64),
+                ("sphere_tests", C.c_uint64), ("device_ms", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class RtError(RuntimeError):
+    def __init__(self, status, what, detail):
+        self.status = status
+        super().__init__("%s: %s (status %d)%s" % (what, _strerror(status), status, (" -- " + detail) if detail else ""))
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                      "There is no CPU fallback." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+lib.rt_abi_version.restype = C.c_int
+lib.rt_device_count.argtypes = [C.POINTER(C.c_int)]
+lib.rt_scene_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+lib.rt_scene_destroy.argtypes = [C.c_void_p]
+lib.rt_render_tiles.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
+lib.rt_render_tiles_device.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_void_p, C.c_uint32, C.c_void_p,
+                                       C.c_void_p, C.POINTER(Stats)]
+lib.rt_render_region.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.POINTER(Region), C.c_void_p, C.POINTER(Stats)]
+lib.rt_blit_tiles_device.argtypes = [C.c_void_p, C.POINTER(Options), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
+lib.rt_tiles_rgba_bytes.restype = C.c_uint64
+lib.rt_tiles_rgba_bytes.argtypes = [C.c_void_p, C.c_uint32]
+lib.rt_strerror.restype = C.c_char_p
+lib.rt_strerror.argtypes = [C.c_int]
+lib.rt_last_error_message.restype = C.c_char_p
+
+if lib.rt_abi_version() != ABI_VERSION:
+    raise ImportError("librtrace_hip.so ABI %d != binding ABI %d: rebuild" % (lib.rt_abi_version(), ABI_VERSION))
+
+
+def _strerror(status):
+    return lib.rt_strerror(status).decode()
+
+
+def check(status, what):
+    if status != RT_OK:
+        raise RtError(status, what, lib.rt_last_error_message().decode())
+
+
+def device_count():
+    n = C.c_int(0)
+    st = lib.rt_device_count(C.byref(n))
+    return n.value if st == RT_OK else 0

@@ -1,0 +1,440 @@
+// rt_capi.hip -- C ABI (include/rtrace_hip.h) over the gfx950 kernels.  Host side only orchestrates:
+// validation, device copies of the Scene, tile tables, streams, launches, read-back.  No pixel arithmetic
+// happens on the host and there is NO CPU fallback: without a device every render entry point fails.
+#include "../../include/rtrace_hip.h"
+#include "rt_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+rt_status hip_fail(hipError_t e, const char *what, int line)
+{
+    snprintf(g_err, sizeof g_err, "%s failed at rt_capi.hip:%d: %s", what, line, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                                                       \
+    do {                                                                    \
+        hipError_t e__ = (expr);                                            \
+        if (e__ != hipSuccess) return hip_fail(e__, #expr, __LINE__);       \
+    } while (0)
+
+// Per-call working set: own stream, tile table, counters, staging output.  A scene keeps a pool of these so
+// concurrent callers (the reference's pool threads, render.rs:283) never share one.
+struct Context {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    rt::TileDev *d_tiles = nullptr;
+    rt::TileDev *h_tiles = nullptr;   // pinned: the H2D copy of the table is truly asynchronous
+    size_t tiles_cap = 0;
+    rt::Counters *d_counters = nullptr;
+    uint8_t *d_out = nullptr;
+    size_t out_cap = 0;
+    bool busy = false;       // leased to a caller right now
+    bool inflight = false;   // released by an asynchronous caller; reusable once ev1 has completed
+
+    ~Context()
+    {
+        if (d_tiles) (void)hipFree(d_tiles);
+        if (h_tiles) (void)hipHostFree(h_tiles);
+        if (d_counters) (void)hipFree(d_counters);
+        if (d_out) (void)hipFree(d_out);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+}  // namespace
+
+struct rt_scene {
+    int device = 0;
+    rt_precision precision = RT_F32;
+    uint32_t n_items = 0, n_bounds = 0;
+    void *d_items = nullptr;       // Item<REAL>[n_items], DFS order
+    void *d_bounds = nullptr;      // Item<REAL>[n_bounds]
+    rt_range *d_ranges = nullptr;
+    double light[3] = { 0, 0, 0 }, eye[3] = { 0, 0, 0 };   // exact copies of the REAL values
+    std::mutex mu;
+    std::vector<std::unique_ptr<Context>> pool;
+};
+
+namespace {
+
+rt_status acquire(rt_scene *s, Context **out)
+{
+    std::lock_guard<std::mutex> lk(s->mu);
+    for (auto &c : s->pool) {
+        if (c->busy) continue;
+        if (c->inflight) {
+            if (hipEventQuery(c->ev1) != hipSuccess) { (void)hipGetLastError(); continue; }
+            c->inflight = false;
+        }
+        c->busy = true; *out = c.get(); return RT_OK;
+    }
+    std::unique_ptr<Context> c(new (std::nothrow) Context());
+    if (!c) return RT_ERR_OUT_OF_MEMORY;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipMalloc(&c->d_counters, sizeof(rt::Counters)));
+    c->busy = true;
+    *out = c.get();
+    s->pool.push_back(std::move(c));
+    return RT_OK;
+}
+
+void release(rt_scene *s, Context *c, bool inflight)
+{
+    std::lock_guard<std::mutex> lk(s->mu);
+    c->busy = false;
+    c->inflight = inflight;
+}
+
+struct Lease {
+    rt_scene *s; Context *c; bool inflight = false;
+    ~Lease() { if (c) release(s, c, inflight); }
+};
+
+// Validates the regions (ImageRegion invariants, inside the image) and lays out blocks + output offsets.
+rt_status build_tile_table(const rt_options *o, const rt_region *tiles, uint32_t n, std::vector<rt::TileDev> &tab,
+                           uint64_t *total_px, uint32_t *total_blocks)
+{
+    uint64_t px = 0, blocks = 0;
+    tab.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const rt_region &t = tiles[i];
+        if (!(t.l < t.r && t.b < t.t && t.r <= o->width && t.t <= o->height)) {
+            snprintf(g_err, sizeof g_err, "tile %u {l=%u,t=%u,r=%u,b=%u} is empty or outside %ux%u", i, t.l, t.t,
+                     t.r, t.b, o->width, o->height);
+            return RT_ERR_INVALID_REGION;
+        }
+        const uint32_t w = t.r - t.l, h = t.t - t.b;
+        const uint32_t bxs = (w + rt::kBlockW - 1) / rt::kBlockW, bys = (h + rt::kBlockH - 1) / rt::kBlockH;
+        if (px + (uint64_t)w * h > 0xFFFFFFFFull || blocks + (uint64_t)bxs * bys > 0x7FFFFFFFull) {
+            snprintf(g_err, sizeof g_err, "tile list too large for one pass");
+            return RT_ERR_INVALID_ARGUMENT;
+        }
+        tab[i] = rt::TileDev{ t.l, t.t, t.r, t.b, (uint32_t)px, (uint32_t)blocks, bxs };
+        px += (uint64_t)w * h;
+        blocks += (uint64_t)bxs * bys;
+    }
+    *total_px = px;
+    *total_blocks = (uint32_t)blocks;
+    return RT_OK;
+}
+
+template <typename T>
+rt::SceneView<T> view_of(const rt_scene *s)
+{
+    rt::SceneView<T> v;
+    v.items = static_cast<const rt::Item<T> *>(s->d_items);
+    v.n_items = s->n_items;
+    v.light = { (T)s->light[0], (T)s->light[1], (T)s->light[2] };
+    v.eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
+    return v;
+}
+
+// Copies the tile table through the context's pinned buffer; truly asynchronous on `stream`.
+rt_status upload_tiles(Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream)
+{
+    const size_t tab_bytes = tab.size() * sizeof(rt::TileDev);
+    if (c->tiles_cap < tab.size()) {
+        if (c->d_tiles) HIP_TRY(hipFree(c->d_tiles));
+        if (c->h_tiles) HIP_TRY(hipHostFree(c->h_tiles));
+        c->d_tiles = nullptr; c->h_tiles = nullptr; c->tiles_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_tiles, tab_bytes));
+        HIP_TRY(hipHostMalloc(&c->h_tiles, tab_bytes, hipHostMallocDefault));
+        c->tiles_cap = tab.size();
+    }
+    memcpy(c->h_tiles, tab.data(), tab_bytes);
+    HIP_TRY(hipMemcpyAsync(c->d_tiles, c->h_tiles, tab_bytes, hipMemcpyHostToDevice, stream));
+    return RT_OK;
+}
+
+// Enqueues every kernel of one pass on `stream`.  d_out must hold 4 * total_px bytes.
+rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversal trav, const std::vector<rt::TileDev> &tab,
+                       uint32_t total_blocks, uint8_t *d_out, hipStream_t stream, bool want_counters)
+{
+    if (trav != RT_TRAVERSAL_FLAT) {
+        snprintf(g_err, sizeof g_err, "RT_TRAVERSAL_SKIP is not implemented in this build");
+        return RT_ERR_UNSUPPORTED;
+    }
+    {
+        rt_status ust = upload_tiles(c, tab, stream);
+        if (ust != RT_OK) return ust;
+    }
+    if (want_counters) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(rt::Counters), stream));
+    rt::Counters *cnt = want_counters ? c->d_counters : nullptr;
+
+    HIP_TRY(hipEventRecord(c->ev0, stream));
+    const dim3 grid(total_blocks), block(rt::kBlockThreads);
+    if (s->precision == RT_F32) {
+        hipLaunchKernelGGL((rt::k_render_fused<float, 1024>), grid, block, 0, stream, view_of<float>(s), (unsigned)o->width,
+                           (unsigned)o->height, (unsigned)o->samples_per_pixel, c->d_tiles, (unsigned)tab.size(), d_out, cnt);
+    } else {
+        hipLaunchKernelGGL((rt::k_render_fused<double, 512>), grid, block, 0, stream, view_of<double>(s), (unsigned)o->width,
+                           (unsigned)o->height, (unsigned)o->samples_per_pixel, c->d_tiles, (unsigned)tab.size(), d_out, cnt);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, stream));
+    return RT_OK;
+}
+
+rt_status read_stats(rt_scene *s, Context *c, hipStream_t stream, rt_stats *st)
+{
+    rt::Counters h;
+    HIP_TRY(hipMemcpyAsync(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    st->primary = h.primary; st->hits = h.hits; st->shadow = h.shadow; st->occluded = h.occluded;
+    st->sphere_tests = (h.primary + h.shadow) * (uint64_t)s->n_items;
+    st->device_ms = ms;
+    return RT_OK;
+}
+
+bool check_common(rt_scene *s, const rt_options *o, const rt_region *tiles, uint32_t n, const void *out)
+{
+    if (!s || !o || !tiles || !out || n == 0) { snprintf(g_err, sizeof g_err, "NULL argument or n_tiles == 0"); return false; }
+    if (o->width == 0 || o->height == 0 || o->samples_per_pixel == 0) {
+        snprintf(g_err, sizeof g_err, "width, height and samples_per_pixel must be >= 1");
+        return false;
+    }
+    return true;
+}
+
+template <typename T>
+bool items_valid(const void *p, uint32_t n, bool need_positive_radius)
+{
+    const T *v = static_cast<const T *>(p);
+    for (uint64_t i = 0; i < (uint64_t)n * 4; ++i) {
+        if (!std::isfinite(v[i]) || std::fabs((double)v[i]) > 1e15) return false;
+        if (need_positive_radius && (i & 3) == 3 && !(v[i] > T(0))) return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RTRACE_HIP_ABI_VERSION; }
+
+const char *rt_last_error_message(void) { return g_err; }
+
+const char *rt_strerror(rt_status st)
+{
+    switch (st) {
+    case RT_OK: return "ok";
+    case RT_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case RT_ERR_INVALID_REGION: return "image region empty or outside the image";
+    case RT_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case RT_ERR_HIP: return "HIP runtime or kernel failure";
+    case RT_ERR_OUT_OF_MEMORY: return "out of memory";
+    case RT_ERR_UNSUPPORTED: return "unsupported request";
+    }
+    return "unknown status";
+}
+
+rt_status rt_device_count(int *n)
+{
+    if (!n) return RT_ERR_INVALID_ARGUMENT;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess || c <= 0) {
+        *n = 0;
+        snprintf(g_err, sizeof g_err, "hipGetDeviceCount: %s", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        (void)hipGetLastError();
+        return RT_ERR_NO_DEVICE;
+    }
+    *n = c;
+    return RT_OK;
+}
+
+uint64_t rt_tiles_rgba_bytes(const rt_region *tiles, uint32_t n_tiles)
+{
+    if (!tiles) return 0;
+    uint64_t px = 0;
+    for (uint32_t i = 0; i < n_tiles; ++i) {
+        if (!(tiles[i].l < tiles[i].r && tiles[i].b < tiles[i].t)) return 0;
+        px += (uint64_t)(tiles[i].r - tiles[i].l) * (tiles[i].t - tiles[i].b);
+    }
+    return px * 4;
+}
+
+rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_items, uint32_t n_items,
+                          const void *light_unit, const void *eye, const void *bounds, const rt_range *ranges,
+                          uint32_t n_bounds, rt_scene **out)
+{
+    if (out) *out = nullptr;
+    if (!out || !dfs_items || !light_unit || !eye || n_items == 0 || (precision != RT_F32 && precision != RT_F64)) {
+        snprintf(g_err, sizeof g_err, "rt_scene_create: NULL argument, n_items == 0 or bad precision");
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    if ((n_bounds != 0) != (bounds != nullptr && ranges != nullptr)) {
+        snprintf(g_err, sizeof g_err, "rt_scene_create: bounds, ranges and n_bounds must be given together");
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    const bool f32 = precision == RT_F32;
+    const bool ok = f32 ? (items_valid<float>(dfs_items, n_items, true) && (!n_bounds || items_valid<float>(bounds, n_bounds, false)))
+                        : (items_valid<double>(dfs_items, n_items, true) && (!n_bounds || items_valid<double>(bounds, n_bounds, false)));
+    if (!ok) {
+        snprintf(g_err, sizeof g_err, "rt_scene_create: items must be finite, |v| <= 1e15, radius > 0");
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    for (uint32_t i = 0; i < n_bounds; ++i) {
+        if (ranges[i].first < 0 || ranges[i].count < 0 || (uint64_t)ranges[i].first + (uint64_t)ranges[i].count > n_items) {
+            snprintf(g_err, sizeof g_err, "rt_scene_create: range %u outside the item array", i);
+            return RT_ERR_INVALID_ARGUMENT;
+        }
+    }
+    int ndev = 0;
+    rt_status st = rt_device_count(&ndev);
+    if (st != RT_OK) return st;
+    if (device < 0 || device >= ndev) {
+        snprintf(g_err, sizeof g_err, "device %d out of range (%d visible)", device, ndev);
+        return RT_ERR_NO_DEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+
+    std::unique_ptr<rt_scene> s(new (std::nothrow) rt_scene());
+    if (!s) return RT_ERR_OUT_OF_MEMORY;
+    s->device = device; s->precision = precision; s->n_items = n_items; s->n_bounds = n_bounds;
+    const size_t esz = f32 ? sizeof(float) : sizeof(double);
+    for (int k = 0; k < 3; ++k) {
+        s->light[k] = f32 ? (double)static_cast<const float *>(light_unit)[k] : static_cast<const double *>(light_unit)[k];
+        s->eye[k] = f32 ? (double)static_cast<const float *>(eye)[k] : static_cast<const double *>(eye)[k];
+        if (!std::isfinite(s->light[k]) || !std::isfinite(s->eye[k])) {
+            snprintf(g_err, sizeof g_err, "rt_scene_create: light / eye must be finite");
+            return RT_ERR_INVALID_ARGUMENT;
+        }
+    }
+    auto fail = [&](rt_status code) { rt_scene_destroy(s.release()); return code; };
+    hipError_t e;
+    if ((e = hipMalloc(&s->d_items, esz * 4 * n_items)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(items)", __LINE__));
+    if ((e = hipMemcpy(s->d_items, dfs_items, esz * 4 * n_items, hipMemcpyHostToDevice)) != hipSuccess)
+        return fail(hip_fail(e, "hipMemcpy(items)", __LINE__));
+    if (n_bounds) {
+        if ((e = hipMalloc(&s->d_bounds, esz * 4 * n_bounds)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(bounds)", __LINE__));
+        if ((e = hipMemcpy(s->d_bounds, bounds, esz * 4 * n_bounds, hipMemcpyHostToDevice)) != hipSuccess)
+            return fail(hip_fail(e, "hipMemcpy(bounds)", __LINE__));
+        if ((e = hipMalloc(&s->d_ranges, sizeof(rt_range) * n_bounds)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(ranges)", __LINE__));
+        if ((e = hipMemcpy(s->d_ranges, ranges, sizeof(rt_range) * n_bounds, hipMemcpyHostToDevice)) != hipSuccess)
+            return fail(hip_fail(e, "hipMemcpy(ranges)", __LINE__));
+    }
+    *out = s.release();
+    return RT_OK;
+}
+
+rt_status rt_scene_destroy(rt_scene *s)
+{
+    if (!s) return RT_OK;
+    (void)hipSetDevice(s->device);
+    s->pool.clear();
+    if (s->d_items) (void)hipFree(s->d_items);
+    if (s->d_bounds) (void)hipFree(s->d_bounds);
+    if (s->d_ranges) (void)hipFree(s->d_ranges);
+    delete s;
+    return RT_OK;
+}
+
+rt_status rt_render_tiles_device(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n,
+                                 void *rgba_out_device, void *hip_stream, rt_stats *stats)
+{
+    if (!check_common(s, o, tiles, n, rgba_out_device)) return RT_ERR_INVALID_ARGUMENT;
+    if ((reinterpret_cast<uintptr_t>(rgba_out_device) & 3u) != 0) {
+        snprintf(g_err, sizeof g_err, "rgba_out_device must be 4-byte aligned");
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    std::vector<rt::TileDev> tab;
+    uint64_t total_px = 0; uint32_t total_blocks = 0;
+    rt_status st = build_tile_table(o, tiles, n, tab, &total_px, &total_blocks);
+    if (st != RT_OK) return st;
+    HIP_TRY(hipSetDevice(s->device));
+    Context *c = nullptr;
+    if ((st = acquire(s, &c)) != RT_OK) return st;
+    Lease lease{ s, c };
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    st = enqueue_pass(s, c, o, trav, tab, total_blocks, static_cast<uint8_t *>(rgba_out_device), stream, stats != nullptr);
+    if (st != RT_OK) return st;
+    if (stats) return read_stats(s, c, stream, stats);
+    // Asynchronous return: the context's tile table is still in use by the enqueued work, so it goes back to
+    // the pool marked in-flight and is only reused once its end event has completed.
+    lease.inflight = true;
+    return RT_OK;
+}
+
+rt_status rt_render_tiles(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n,
+                          uint8_t *rgba_out, rt_stats *stats)
+{
+    if (!check_common(s, o, tiles, n, rgba_out)) return RT_ERR_INVALID_ARGUMENT;
+    std::vector<rt::TileDev> tab;
+    uint64_t total_px = 0; uint32_t total_blocks = 0;
+    rt_status st = build_tile_table(o, tiles, n, tab, &total_px, &total_blocks);
+    if (st != RT_OK) return st;
+    HIP_TRY(hipSetDevice(s->device));
+    Context *c = nullptr;
+    if ((st = acquire(s, &c)) != RT_OK) return st;
+    Lease lease{ s, c };
+    const size_t bytes = (size_t)total_px * 4;
+    if (c->out_cap < bytes) {
+        if (c->d_out) HIP_TRY(hipFree(c->d_out));
+        c->d_out = nullptr; c->out_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_out, bytes));
+        c->out_cap = bytes;
+    }
+    st = enqueue_pass(s, c, o, trav, tab, total_blocks, c->d_out, c->stream, stats != nullptr);
+    if (st != RT_OK) return st;
+    HIP_TRY(hipMemcpyAsync(rgba_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (stats) return read_stats(s, c, c->stream, stats);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+rt_status rt_blit_tiles_device(rt_scene *s, const rt_options *o, const rt_region *tiles, uint32_t n, const uint32_t *src_px_offset,
+                               const void *src, void *frame, void *hip_stream)
+{
+    if (!check_common(s, o, tiles, n, frame) || !src) { snprintf(g_err, sizeof g_err, "rt_blit_tiles_device: NULL argument"); return RT_ERR_INVALID_ARGUMENT; }
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(frame)) & 3u) != 0) {
+        snprintf(g_err, sizeof g_err, "rt_blit_tiles_device: buffers must be 4-byte aligned");
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    std::vector<rt::TileDev> tab;
+    uint64_t total_px = 0; uint32_t total_blocks = 0;
+    rt_status st = build_tile_table(o, tiles, n, tab, &total_px, &total_blocks);
+    if (st != RT_OK) return st;
+    if (src_px_offset)
+        for (uint32_t i = 0; i < n; ++i) tab[i].out_px = src_px_offset[i];
+    HIP_TRY(hipSetDevice(s->device));
+    Context *c = nullptr;
+    if ((st = acquire(s, &c)) != RT_OK) return st;
+    Lease lease{ s, c };
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if ((st = upload_tiles(c, tab, stream)) != RT_OK) return st;
+    hipLaunchKernelGGL(rt::k_blit_tiles, dim3(total_blocks), dim3(rt::kBlockThreads), 0, stream, (unsigned)o->width, c->d_tiles,
+                       (unsigned)n, static_cast<const unsigned *>(src), static_cast<unsigned *>(frame));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, stream));
+    lease.inflight = true;
+    return RT_OK;
+}
+
+rt_status rt_render_region(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *region, uint8_t *rgba_out,
+                           rt_stats *stats)
+{
+    return rt_render_tiles(s, o, trav, region, 1, rgba_out, stats);
+}
+
+}  // extern "C"

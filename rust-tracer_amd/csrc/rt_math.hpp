@@ -1,0 +1,59 @@
+// rt_math.hpp -- the reference's Vector / Ray / Sphere arithmetic, restated for gfx950 device code.
+//
+// Every function keeps the reference's operation ORDER and is compiled with -ffp-contract=off, so each
+// + - * / sqrt rounds once, exactly like the Rust CPU path (an FMA changes 0.24 % of the pixels).
+// T is float (RFloat = f32, vec.rs:6) or double (the type-alias swap).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits>
+
+namespace rt {
+
+template <typename T> struct V3 { T x, y, z; };
+template <typename T> struct alignas(sizeof(T) * 4) Item { T cx, cy, cz, r; };   // Sphere{center, radius} primitive.rs:38-42
+
+template <typename T> __host__ __device__ __forceinline__ constexpr T inf() { return std::numeric_limits<T>::infinity(); }
+template <typename T> __host__ __device__ __forceinline__ constexpr T eps() { return std::numeric_limits<T>::epsilon(); }
+
+__device__ __forceinline__ float rsqrt_exact(float x) { return __builtin_sqrtf(x); }    // IEEE correctly rounded
+__device__ __forceinline__ double rsqrt_exact(double x) { return __builtin_sqrt(x); }
+
+// vec.rs:15-72
+template <typename T> __device__ __forceinline__ V3<T> add(V3<T> a, V3<T> b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+template <typename T> __device__ __forceinline__ V3<T> sub(V3<T> a, V3<T> b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+template <typename T> __device__ __forceinline__ V3<T> mulf(V3<T> a, T m) { return { a.x * m, a.y * m, a.z * m }; }
+// vec.rs:77-79: x*x' + y*y' + z*z' evaluated left to right
+template <typename T> __device__ __forceinline__ T dot(V3<T> a, V3<T> b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// vec.rs:87-95: multiply by len.recip(), a true division
+template <typename T> __device__ __forceinline__ V3<T> normalized(V3<T> a)
+{
+    T len = rsqrt_exact(dot(a, a));
+    return mulf(a, T(1.0) / len);
+}
+
+// primitive.rs:55-72 Sphere::distance_from_ray, comparisons kept in the reference's sense (NaN falls through
+// exactly as `if disc < 0.0 { return INF }` lets it).
+template <typename T>
+__device__ __forceinline__ T distance_from_ray(T cx, T cy, T cz, T radius, V3<T> o, V3<T> d)
+{
+    V3<T> v = { cx - o.x, cy - o.y, cz - o.z };
+    T b = dot(v, d);
+    T disc = (b * b - dot(v, v)) + radius * radius;
+    if (disc < T(0.0)) return inf<T>();
+    T s = rsqrt_exact(disc);
+    T t2 = b + s;
+    if (t2 < T(0.0)) return inf<T>();
+    T t1 = b - s;
+    return t1 > T(0.0) ? t1 : t2;
+}
+
+// render.rs:96-103, the `scale` closure of set_pixel_from_vector: 0.5 + 255 v, clamp above, truncate.
+template <typename T> __device__ __forceinline__ unsigned scale_u8(T v)
+{
+    T r = T(0.5) + T(255.0) * v;
+    if (r > T(255.0)) return 255u;
+    if (!(r > T(0.0))) return 0u;          // Rust `as u8` saturates, NaN -> 0
+    return (unsigned)r;                    // toward zero
+}
+
+}  // namespace rt

@@ -1,0 +1,107 @@
+"""Tile sharding across the GPUs of one node and frame assembly.
+
+The reference's only parallelism is "independent 64x64 buckets on a thread pool" joined by a bounded channel
+(render.rs:264-307).  Here the same buckets are dealt round-robin over one process per GPU; each rank renders
+its shard tile-major into device memory and a single RCCL gather of the u8 shards over xGMI brings them to
+rank 0, which blits them into the row-major frame on the device.  No other collective touches the data path.
+
+The sharding arithmetic is plain Python (testable on CPU with gloo); only `FrameSharder.step` touches the GPU."""
+import numpy as np
+
+from . import capi
+from .render import buckets, RenderOptions
+
+
+def shard_indices(n_tiles, rank, world):
+    """Round-robin `tile_id % world == rank` in the scheduler's row-major bucket order (render.rs:273-298)."""
+    return list(range(rank, n_tiles, world))
+
+
+def shard_layout(options, world):
+    """For every rank: (tile indices, px offset of each tile inside the rank's shard, shard px count)."""
+    bl = buckets(options)
+    per_rank = []
+    for r in range(world):
+        idx = shard_indices(len(bl), r, world)
+        offs, px = [], 0
+        for i in idx:
+            offs.append(px)
+            px += bl[i].area()
+        per_rank.append((idx, offs, px))
+    shard_px = max(p for _, _, p in per_rank)          # shards are padded to equal length for the gather
+    return bl, per_rank, shard_px
+
+
+def gathered_tile_table(options, world):
+    """Tile list and source pixel offsets for blitting the gathered [world, shard_px] buffer into the frame."""
+    bl, per_rank, shard_px = shard_layout(options, world)
+    regions, offsets = [], []
+    for r, (idx, offs, _) in enumerate(per_rank):
+        for i, o in zip(idx, offs):
+            regions.append(tuple(bl[i]))
+            offsets.append(r * shard_px + o)
+    return regions, np.asarray(offsets, dtype=np.uint32), shard_px
+
+
+def assemble_host(options, world, gathered):
+    """CPU model of the root's blit (used by the gloo tests): gathered uint8[world, shard_px*4] -> frame[h, w, 4]."""
+    regions, offsets, shard_px = gathered_tile_table(options, world)
+    flat = np.asarray(gathered, dtype=np.uint8).reshape(-1)
+    frame = np.zeros((options.height, options.width, 4), dtype=np.uint8)
+    for (l, t, r, b), o in zip(regions, offsets):
+        n = (r - l) * (t - b) * 4
+        frame[b:t, l:r] = flat[int(o) * 4:int(o) * 4 + n].reshape(t - b, r - l, 4)
+    return frame
+
+
+class FrameSharder:
+    """One per process (= per GPU).  step() renders this rank's buckets and, for world > 1, gathers the u8
+    shards to rank 0 over RCCL and blits them into the frame there."""
+
+    def __init__(self, scene, options, rank=0, world=1, device=0, traversal=capi.RT_TRAVERSAL_FLAT):
+        import torch
+        self.torch = torch
+        self.options = RenderOptions(*options)
+        self.rank, self.world, self.device = rank, world, device
+        self.traversal = traversal
+        self.dev = scene.device(device)
+        bl, per_rank, self.shard_px = shard_layout(self.options, world)
+        self.my_regions = [tuple(bl[i]) for i in per_rank[rank][0]]
+        self.my_regions_c = self.dev._regions(self.my_regions)
+        tdev = torch.device("cuda", device)
+        self.shard = torch.zeros(self.shard_px * 4, dtype=torch.uint8, device=tdev)
+        self.frame = None
+        self.gathered = None
+        if rank == 0:
+            self.frame = torch.zeros(self.options.height * self.options.width * 4, dtype=torch.uint8, device=tdev)
+            regions, offsets, _ = gathered_tile_table(self.options, world)
+            self.all_regions_c = self.dev._regions(regions)
+            self.all_offsets = offsets
+            if world > 1:
+                # one buffer for the blit; the gather list is views of its rows
+                self.gathered_flat = torch.zeros(world * self.shard_px * 4, dtype=torch.uint8, device=tdev)
+                self.gathered = list(self.gathered_flat.view(world, self.shard_px * 4).unbind(0))
+
+    def render_shard(self, want_stats=False):
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        return self.dev.render_tiles_device(tuple(self.options), self.my_regions_c, self.shard.data_ptr(), stream,
+                                            self.traversal, want_stats)
+
+    def step(self):
+        """One frame: render shard -> (gather) -> blit on rank 0.  Everything is enqueued on torch's current stream."""
+        torch = self.torch
+        self.render_shard()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.gather(self.shard, self.gathered if self.rank == 0 else None, dst=0)
+            src = self.gathered_flat if self.rank == 0 else None
+        else:
+            src = self.shard
+        if self.rank == 0:
+            self.dev.blit_tiles_device(tuple(self.options), self.all_regions_c, src.data_ptr(), self.frame.data_ptr(),
+                                       stream, self.all_offsets)
+
+    def frame_host(self):
+        self.torch.cuda.synchronize(self.device)
+        return self.frame.cpu().numpy().reshape(self.options.height, self.options.width, 4)

@@ -1,0 +1,161 @@
+"""Host-side Scene of the drop-in: what `Scene`, `SphericalGroup::pyramid` and `Scene::default()` are in the
+reference (render.rs:138-167, group.rs:27-66), kept as the flat DFS arrays the C ABI consumes.
+
+All scene arithmetic is done in the scene's REAL type with numpy scalars (IEEE, one rounding per operation,
+reference operation order) -- centres accumulate rounding level by level, so the builder replays the
+recursion instead of using a closed form.  Rendering never happens here; see render.py / capi.py."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+def _real(precision):
+    return np.float32 if precision == capi.RT_F32 else np.float64
+
+
+def pyramid(level, origin, radius, precision=capi.RT_F32):
+    """SphericalGroup::pyramid (group.rs:58-65) -> (items REAL[n,4], bounds REAL[g,4], ranges int32[g,2]).
+
+    items are in traversal order (own sphere first, then the four sub-pyramids, dz outer / dx inner,
+    group.rs:39-53); bounds/ranges are in DFS pre-order with ranges[i] = (first item, item count) of the subtree."""
+    if level <= 1:
+        raise ValueError("Levels equal or smaller than one cause empty groups")      # group.rs:59-60
+    R = _real(precision)
+    three, half, s12 = R(3.0), R(0.5), np.sqrt(R(12.0))
+    items, bounds, ranges = [], [], []
+
+    def rec(lv, px, py, pz, r):
+        if lv == 1:
+            items.append((px, py, pz, r))
+            return
+        bi = len(bounds)
+        bounds.append((px, py, pz, three * r))          # group.rs:40-41
+        ranges.append(None)
+        first = len(items)
+        items.append((px, py, pz, r))                   # group.rs:39
+        rn = three * r / s12                            # group.rs:43
+        for dz in (-1, 1):
+            for dx in (-1, 1):
+                rec(lv - 1, px + R(dx) * rn, py + rn, pz + R(dz) * rn, r * half)
+        ranges[bi] = (first, len(items) - first)
+
+    rec(level, R(origin[0]), R(origin[1]), R(origin[2]), R(radius))
+    return (np.array(items, dtype=R).reshape(-1, 4), np.array(bounds, dtype=R).reshape(-1, 4),
+            np.array(ranges, dtype=np.int32).reshape(-1, 2))
+
+
+def normalized(v, precision=capi.RT_F32):
+    """Vector::normalized (vec.rs:92-95): v * (1/len), len = sqrt((x*x + y*y) + z*z)."""
+    R = _real(precision)
+    x, y, z = R(v[0]), R(v[1]), R(v[2])
+    ln = np.sqrt((x * x + y * y) + z * z)
+    rc = R(1.0) / ln
+    return np.array([x * rc, y * rc, z * rc], dtype=R)
+
+
+class Scene:
+    """Scene{group, directional_light, eye} (render.rs:138-142) with the group flattened to DFS arrays."""
+
+    def __init__(self, items, directional_light, eye, bounds=None, ranges=None, precision=capi.RT_F32):
+        R = _real(precision)
+        self.precision = precision
+        self.items = np.ascontiguousarray(items, dtype=R).reshape(-1, 4)
+        self.directional_light = np.ascontiguousarray(directional_light, dtype=R).reshape(3)
+        self.eye = np.ascontiguousarray(eye, dtype=R).reshape(3)
+        self.bounds = None if bounds is None else np.ascontiguousarray(bounds, dtype=R).reshape(-1, 4)
+        self.ranges = None if ranges is None else np.ascontiguousarray(ranges, dtype=np.int32).reshape(-1, 2)
+        self._device = {}
+
+    @classmethod
+    def default(cls, level=8, precision=capi.RT_F32):
+        """Scene::default() render.rs:144-166 (level 8 there)."""
+        items, bounds, ranges = pyramid(level, (0.0, -1.0, 0.0), 1.0, precision)
+        return cls(items, normalized((-1.0, -3.0, 2.0), precision), (0.0, 0.0, -4.0), bounds, ranges, precision)
+
+    @classmethod
+    def from_spheres(cls, spheres, bound, light=(-1.0, -3.0, 2.0), eye=(0.0, 0.0, -4.0), precision=capi.RT_F32):
+        """One group {bound, children = spheres as Items}; BASELINE config 1's "3 spheres, 1 light" shape."""
+        items = np.asarray(spheres, dtype=np.float64).reshape(-1, 4)
+        return cls(items, normalized(light, precision), eye, np.asarray(bound, dtype=np.float64).reshape(1, 4),
+                   np.array([[0, items.shape[0]]], dtype=np.int32), precision)
+
+    @classmethod
+    def three_spheres(cls, precision=capi.RT_F32):
+        """The build-defined config-1 scene."""
+        return cls.from_spheres([(0.0, -1.0, 0.0, 1.0), (-1.2, 0.2, 0.0, 0.5), (1.2, 0.2, 0.0, 0.5)],
+                                (0.0, -1.0, 0.0, 3.0), precision=precision)
+
+    def device(self, device=0):
+        """Uploads once per device and caches the handle (replaces Arc<Scene> sharing, render.rs:279)."""
+        if device not in self._device:
+            self._device[device] = DeviceScene(self, device)
+        return self._device[device]
+
+
+class DeviceScene:
+    """Owns an rt_scene* (device copies of a Scene)."""
+
+    def __init__(self, scene, device=0):
+        self.scene = scene
+        self.device = device
+        h = C.c_void_p()
+        nb = 0 if scene.bounds is None else scene.bounds.shape[0]
+        st = capi.lib.rt_scene_create(
+            device, scene.precision, scene.items.ctypes.data, scene.items.shape[0],
+            scene.directional_light.ctypes.data, scene.eye.ctypes.data,
+            scene.bounds.ctypes.data if nb else None, scene.ranges.ctypes.data if nb else None, nb, C.byref(h))
+        capi.check(st, "rt_scene_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            capi.lib.rt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _regions(regions):
+        arr = (capi.Region * len(regions))()
+        for i, (l, t, r, b) in enumerate(regions):
+            arr[i] = capi.Region(l, t, r, b)
+        return arr
+
+    def render_tiles(self, options, regions, traversal=capi.RT_TRAVERSAL_FLAT, want_stats=True):
+        """rt_render_tiles: regions = [(l, t, r, b), ...] -> (uint8[total_px*4] tile-major, stats dict | None)."""
+        arr = self._regions(regions)
+        nbytes = capi.lib.rt_tiles_rgba_bytes(arr, len(regions))
+        out = np.empty(max(int(nbytes), 1), dtype=np.uint8)
+        st = capi.Stats()
+        o = capi.Options(*options)
+        rc = capi.lib.rt_render_tiles(self._h, C.byref(o), traversal, arr, len(regions), out.ctypes.data,
+                                      C.byref(st) if want_stats else None)
+        capi.check(rc, "rt_render_tiles")
+        return out[:int(nbytes)], (st.as_dict() if want_stats else None)
+
+    def render_tiles_device(self, options, regions, out_ptr, stream=0, traversal=capi.RT_TRAVERSAL_FLAT, want_stats=False):
+        """rt_render_tiles_device: enqueue on `stream` (hipStream_t as int), output to device pointer `out_ptr`."""
+        arr = regions if isinstance(regions, C.Array) else self._regions(regions)
+        st = capi.Stats()
+        o = capi.Options(*options)
+        rc = capi.lib.rt_render_tiles_device(self._h, C.byref(o), traversal, arr, len(arr), C.c_void_p(out_ptr),
+                                             C.c_void_p(stream), C.byref(st) if want_stats else None)
+        capi.check(rc, "rt_render_tiles_device")
+        return st.as_dict() if want_stats else None
+
+    def blit_tiles_device(self, options, regions, src_ptr, frame_ptr, stream=0, src_px_offset=None):
+        """rt_blit_tiles_device: tile-major device tiles -> row-major device frame (set_pixels_from_buffer)."""
+        arr = regions if isinstance(regions, C.Array) else self._regions(regions)
+        offs = None
+        if src_px_offset is not None:
+            offs = np.ascontiguousarray(src_px_offset, dtype=np.uint32)
+        o = capi.Options(*options)
+        rc = capi.lib.rt_blit_tiles_device(self._h, C.byref(o), arr, len(arr), offs.ctypes.data if offs is not None else None,
+                                           C.c_void_p(src_ptr), C.c_void_p(frame_ptr), C.c_void_p(stream))
+        capi.check(rc, "rt_blit_tiles_device")

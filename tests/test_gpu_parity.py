@@ -1,0 +1,250 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle: bit-exact RGBA bytes and identical ray
+counters, on the BASELINE configs, the reference's golden image, and the domain's edge cases.  Needs an MI355X."""
+import json
+import os
+import threading
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle
+import rust_tracer_amd as rta
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+FLAT = rta.RT_TRAVERSAL_FLAT
+
+
+def full(w, h):
+    return [(0, h, w, 0)]
+
+
+def bucket_list(w, h, spp=1):
+    return [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
+
+
+def test_device_present():
+    assert rta.device_count() >= 1
+
+
+@pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64])
+def test_config1_three_spheres_single_tile(precision):
+    # BASELINE config 1: single 64x64 tile, 3 spheres, 1 light
+    s, o = util.scene_pair_spheres(util.THREE_SPHERES, util.THREE_BOUND, precision)
+    data, st = s.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)])
+    for mode in (oracle.MODE_HIERARCHY, oracle.MODE_FLAT):
+        ref, rst = o.render_region(64, 64, 1, 0, 64, 64, 0, mode)
+        np.testing.assert_array_equal(data.reshape(64, 64, 4), ref)
+        assert util.ray_stats(st) == util.ray_stats(rst)
+    assert st["sphere_tests"] == (st["primary"] + st["shadow"]) * 3
+
+
+def test_default_scene_single_tile_and_counters():
+    # SURVEY 8(d) row 1 companion: default scene 64x64 spp 1 -> 4096 / 2487 / 1923 / 909
+    s, o = util.scene_pair_default()
+    data, st = s.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)])
+    ref, rst = o.render_region(64, 64, 1, 0, 64, 64, 0)
+    np.testing.assert_array_equal(data.reshape(64, 64, 4), ref)
+    assert util.ray_stats(st) == (4096, 2487, 1923, 909) == util.ray_stats(rst)
+
+
+def test_reference_test_shape_64x128_spp2_two_buckets():
+    # render::tests::basic_rendering render.rs:466-481: 64x128, spp 2 -> exactly 2 buckets
+    s, o = util.scene_pair_default()
+    regs = bucket_list(64, 128, 2)
+    assert len(regs) == 2
+    data, st = s.device().render_tiles((64, 128, 2), regs)
+    ref, rst, n = o.render(64, 128, 2, nthreads=2)
+    assert n == 2
+    np.testing.assert_array_equal(util.stitch((64, 128), regs, data), ref)
+    assert util.ray_stats(st) == util.ray_stats(rst)
+
+
+def test_golden_make_image_1024x768_spp4(golden_dir):
+    # the reference's own output image (src/img/rtrace-output.png), RGB bit-exact; alpha against the oracle
+    ref_rgb = np.load(os.path.join(golden_dir, "make_image_1024x768_spp4_rgb.npz"))["rgb"]
+    meta = json.load(open(os.path.join(golden_dir, "make_image_1024x768_spp4_tiles.json")))
+    s, o = util.scene_pair_default()
+    regs = bucket_list(1024, 768, 4)
+    assert len(regs) == 192
+    data, st = s.device().render_tiles((1024, 768, 4), regs)
+    frame = util.stitch((1024, 768), regs, data)
+    assert int((frame[:, :, :3] != ref_rgb).any(axis=2).sum()) == 0
+    off = 0
+    for i, (l, t, r, b) in enumerate(regs):
+        tile = data[off:off + 64 * 64 * 4].reshape(64, 64, 4)
+        assert zlib.crc32(np.ascontiguousarray(tile[:, :, :3]).tobytes()) & 0xFFFFFFFF == meta["tile_crc32"][i], i
+        off += 64 * 64 * 4
+    assert util.ray_stats(st) == (12582912, 9430527, 7211901, 3586443)
+    oref, _, _ = o.render(1024, 768, 4, nthreads=os.cpu_count() or 1)
+    np.testing.assert_array_equal(frame, oref)          # includes the alpha channel
+
+
+def test_config2_800x600_clipped_edge_buckets():
+    # BASELINE config 2: 13x10 = 130 buckets, edge buckets 32 wide / 24 tall (the reference itself asserts, H5)
+    s, o = util.scene_pair_default()
+    regs = bucket_list(800, 600)
+    assert len(regs) == 130
+    data, st = s.device().render_tiles((800, 600, 1), regs)
+    ref, rst, _ = o.render(800, 600, 1, nthreads=os.cpu_count() or 1)
+    np.testing.assert_array_equal(util.stitch((800, 600), regs, data), ref)
+    assert util.ray_stats(st) == (480000, 359528, 275032, 136797) == util.ray_stats(rst)
+
+
+def test_config3_1920x1080_f32():
+    # BASELINE config 3 (f32 side) / the bench workload: 510 buckets, last row 56 px
+    s, o = util.scene_pair_default()
+    regs = bucket_list(1920, 1080)
+    assert len(regs) == 510
+    data, st = s.device().render_tiles((1920, 1080, 1), regs)
+    ref, rst, _ = o.render(1920, 1080, 1, nthreads=os.cpu_count() or 1)
+    np.testing.assert_array_equal(util.stitch((1920, 1080), regs, data), ref)
+    assert util.ray_stats(st) == (2073600, 1777280, 1337403, 730313) == util.ray_stats(rst)
+    assert st["sphere_tests"] == (2073600 + 1337403) * 21845
+
+
+def test_config3_1920x1080_f64_type_alias_swap():
+    # f64 is a separate golden (P7), pinned only by the oracle's own f64 instantiation ("parity unpinned")
+    s, o = util.scene_pair_default(rta.RT_F64)
+    regs = bucket_list(1920, 1080)
+    data, st = s.device().render_tiles((1920, 1080, 1), regs)
+    ref, rst, _ = o.render(1920, 1080, 1, nthreads=os.cpu_count() or 1)
+    np.testing.assert_array_equal(util.stitch((1920, 1080), regs, data), ref)
+    assert util.ray_stats(st) == util.ray_stats(rst)
+
+
+def test_whole_frame_as_one_region_equals_buckets():
+    # a pixel does not depend on its tile (render.rs:217): one region == 130 stitched buckets
+    s, _ = util.scene_pair_default()
+    d = s.device()
+    one, st1 = d.render_tiles((800, 600, 1), full(800, 600))
+    regs = bucket_list(800, 600)
+    many, st2 = d.render_tiles((800, 600, 1), regs)
+    np.testing.assert_array_equal(one.reshape(600, 800, 4), util.stitch((800, 600), regs, many))
+    assert util.ray_stats(st1) == util.ray_stats(st2)
+
+
+def test_tile_order_and_duplicates_are_honoured():
+    s, o = util.scene_pair_default()
+    regs = [(64, 128, 128, 64), (0, 64, 64, 0), (64, 128, 128, 64), (130, 77, 131, 76)]
+    data, st = s.device().render_tiles((256, 192, 2), regs)
+    off = 0
+    for (l, t, r, b) in regs:
+        ref, _ = o.render_region(256, 192, 2, l, t, r, b)
+        n = ref.size
+        np.testing.assert_array_equal(data[off:off + n].reshape(ref.shape), ref)
+        off += n
+    assert off == data.size
+    assert st["primary"] == (64 * 64 * 3 + 1) * 4
+
+
+@pytest.mark.parametrize("region", [(3, 19, 35, 2), (17, 18, 18, 17), (0, 5, 200, 0), (199, 150, 200, 0)])
+def test_ragged_regions(region):
+    # ImageRegion{l:2,t:18,r:34,b:2}-like odd rectangles, 1x1, single row, single column
+    s, o = util.scene_pair_default()
+    l, t, r, b = region
+    data, st = s.device().render_tiles((200, 150, 1), [region])
+    ref, rst = o.render_region(200, 150, 1, l, t, r, b)
+    np.testing.assert_array_equal(data.reshape(ref.shape), ref)
+    assert util.ray_stats(st) == util.ray_stats(rst)
+
+
+@pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64])
+def test_tie_break_first_in_dfs_order_wins(precision):
+    # primitive.rs:79 strict `>=` reject: of two items at exactly equal distance the first one keeps the hit
+    for spheres in (util.TIE_SPHERES, util.TIE_SPHERES[::-1]):
+        s, o = util.scene_pair_spheres(spheres, util.TIE_BOUND, precision)
+        data, st = s.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)])
+        ref, rst = o.render_region(64, 64, 1, 0, 64, 64, 0)
+        np.testing.assert_array_equal(data.reshape(64, 64, 4), ref)
+        assert util.ray_stats(st) == util.ray_stats(rst)
+    a, _ = util.scene_pair_spheres(util.TIE_SPHERES, util.TIE_BOUND, precision)
+    b, _ = util.scene_pair_spheres(util.TIE_SPHERES[::-1], util.TIE_BOUND, precision)
+    da, _ = a.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)])
+    db, _ = b.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)])
+    col_a, col_b = da.reshape(64, 64, 4)[:, 32], db.reshape(64, 64, 4)[:, 32]
+    assert (col_a != col_b).any(), "the tie column must depend on item order, or the scene does not exercise the rule"
+
+
+def test_pyramid_level9_87381_items_chunk_boundaries():
+    # config 5's scene size (L9 = 87,381 items = 85 LDS chunks + 341) on a small image
+    s, o = util.scene_pair_default(level=9)
+    assert s.items.shape[0] == 87381
+    regs = bucket_list(192, 128, 2)
+    data, st = s.device().render_tiles((192, 128, 2), regs)
+    ref, rst, _ = o.render(192, 128, 2, nthreads=os.cpu_count() or 1)
+    np.testing.assert_array_equal(util.stitch((192, 128), regs, data), ref)
+    assert util.ray_stats(st) == util.ray_stats(rst)
+
+
+@pytest.mark.parametrize("n_items", [1, 2, 1023, 1024, 1025])
+def test_item_counts_around_the_lds_chunk(n_items):
+    rng = np.random.default_rng(n_items)
+    sp = np.concatenate([rng.uniform(-1.5, 1.5, (n_items, 3)), rng.uniform(0.02, 0.12, (n_items, 1))], axis=1)
+    sp = sp.astype(np.float32).astype(np.float64)
+    s, o = util.scene_pair_spheres(sp, (0, 0, 0, 3.0))
+    data, st = s.device().render_tiles((96, 80, 1), [(0, 80, 96, 0)])
+    ref, rst = o.render_region(96, 80, 1, 0, 80, 96, 0, oracle.MODE_FLAT)
+    np.testing.assert_array_equal(data.reshape(ref.shape), ref)
+    assert util.ray_stats(st) == util.ray_stats(rst)
+
+
+def test_idempotent_and_stats_optional():
+    s, _ = util.scene_pair_default()
+    d = s.device()
+    a, _ = d.render_tiles((320, 200, 1), full(320, 200))
+    b, none = d.render_tiles((320, 200, 1), full(320, 200), want_stats=False)
+    assert none is None
+    np.testing.assert_array_equal(a, b)
+
+
+def test_concurrent_callers_share_one_scene():
+    # render_region is invoked concurrently from up to RTRACEMAXPROCS pool threads on the same scene (render.rs:283)
+    s, o = util.scene_pair_default()
+    d = s.device()
+    regs = bucket_list(256, 256)
+    out = [None] * len(regs)
+
+    def work(i):
+        out[i], _ = d.render_tiles((256, 256, 1), [regs[i]])
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(regs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    ref, _, _ = o.render(256, 256, 1, nthreads=4)
+    np.testing.assert_array_equal(util.stitch((256, 256), regs, np.concatenate(out)), ref)
+
+
+def test_renderer_surface_writes_reference_ppm(tmp_path):
+    # Renderer::render + PPMStdoutRGBABufferWriter: bytes of the file == oracle's PPM of the oracle frame
+    s, o = util.scene_pair_default()
+    opts = rta.RenderOptions(256, 192, 2)
+    path = str(tmp_path / "out.tga")
+    w = rta.PPMStdoutRGBABufferWriter(True, path)
+    rta.Renderer.render(opts, s, w, pool=3)
+    w.close()
+    ref, _, _ = o.render(256, 192, 2, nthreads=4)
+    oracle.write_ppm(str(tmp_path / "ref.ppm"), ref)
+    assert open(path, "rb").read() == open(str(tmp_path / "ref.ppm"), "rb").read()
+
+
+def test_error_codes_instead_of_panics():
+    s, _ = util.scene_pair_default()
+    d = s.device()
+    with pytest.raises(rta.RtError) as e:
+        d.render_tiles((64, 64, 1), [(0, 65, 64, 0)])          # outside the image
+    assert e.value.status == rta.capi.RT_ERR_INVALID_REGION
+    with pytest.raises(rta.RtError) as e:
+        d.render_tiles((64, 64, 1), [(10, 20, 10, 0)])         # empty
+    assert e.value.status == rta.capi.RT_ERR_INVALID_REGION
+    with pytest.raises(rta.RtError) as e:
+        d.render_tiles((64, 64, 0), [(0, 64, 64, 0)])          # spp == 0
+    assert e.value.status == rta.capi.RT_ERR_INVALID_ARGUMENT
+    with pytest.raises(rta.RtError) as e:
+        rta.Scene.from_spheres([(0, 0, 0, -1.0)], (0, 0, 0, 3.0)).device()
+    assert e.value.status == rta.capi.RT_ERR_INVALID_ARGUMENT
+    with pytest.raises(rta.RtError) as e:
+        rta.Scene.from_spheres([(float("nan"), 0, 0, 1.0)], (0, 0, 0, 3.0)).device()
+    assert e.value.status == rta.capi.RT_ERR_INVALID_ARGUMENT

@@ -1,0 +1,129 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/rtrace_hip.h declares (no compute
+calls without a GPU), the host-side mirror behaves like the reference's (render.rs tests), and the host scene
+builder equals the oracle's."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+import rust_tracer_amd as rta
+from rust_tracer_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rtrace_hip.h")).read()
+    declared = set(re.findall(r"\b(rt_[a-z_]+)\s*\(", hdr))
+    assert declared == set(capi.SYMBOLS)
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.rt_abi_version() == capi.ABI_VERSION
+
+
+def test_product_never_touches_the_oracle():
+    # the oracle is test infrastructure: no file of the product package may mention it
+    pkg = os.path.join(ROOT, "rust-tracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_strerror_and_sizes():
+    assert capi.lib.rt_strerror(capi.RT_OK) == b"ok"
+    assert b"region" in capi.lib.rt_strerror(capi.RT_ERR_INVALID_REGION)
+    regs = (capi.Region * 2)(capi.Region(0, 64, 64, 0), capi.Region(64, 24, 96, 0))
+    assert capi.lib.rt_tiles_rgba_bytes(regs, 2) == (64 * 64 + 32 * 24) * 4
+    bad = (capi.Region * 1)(capi.Region(5, 1, 5, 0))
+    assert capi.lib.rt_tiles_rgba_bytes(bad, 1) == 0
+
+
+@pytest.mark.skipif(rta.device_count() > 0, reason="checks the no-device behaviour")
+def test_no_device_fails_loudly_no_cpu_fallback():
+    s = rta.Scene.three_spheres()
+    with pytest.raises(rta.RtError) as e:
+        s.device()
+    assert e.value.status == capi.RT_ERR_NO_DEVICE
+
+
+def test_scene_create_rejects_bad_arguments_before_touching_a_device():
+    h = ctypes.c_void_p()
+    items = np.array([[0, 0, 0, 1]], dtype=np.float32)
+    v = np.zeros(3, dtype=np.float32)
+    rc = capi.lib.rt_scene_create(0, capi.RT_F32, None, 1, v.ctypes.data, v.ctypes.data, None, None, 0, ctypes.byref(h))
+    assert rc == capi.RT_ERR_INVALID_ARGUMENT
+    rc = capi.lib.rt_scene_create(0, capi.RT_F32, items.ctypes.data, 0, v.ctypes.data, v.ctypes.data, None, None, 0, ctypes.byref(h))
+    assert rc == capi.RT_ERR_INVALID_ARGUMENT
+    bad = np.array([[0, 0, 0, 0]], dtype=np.float32)       # radius must be > 0
+    rc = capi.lib.rt_scene_create(0, capi.RT_F32, bad.ctypes.data, 1, v.ctypes.data, v.ctypes.data, None, None, 0, ctypes.byref(h))
+    assert rc == capi.RT_ERR_INVALID_ARGUMENT
+    assert capi.lib.rt_last_error_message() != b""
+
+
+@pytest.mark.parametrize("precision,oprec", [(rta.RT_F32, oracle.F32), (rta.RT_F64, oracle.F64)])
+@pytest.mark.parametrize("level", [2, 5, 8])
+def test_host_scene_builder_equals_oracle(precision, oprec, level):
+    s = rta.Scene.default(level, precision)
+    o = oracle.Scene.default(oprec, level)
+    np.testing.assert_array_equal(s.items, o.flatten())
+    b, r = o.bounds()
+    np.testing.assert_array_equal(s.bounds, b)
+    np.testing.assert_array_equal(s.ranges, r)
+    l, e = o.light_eye()
+    np.testing.assert_array_equal(s.directional_light, l)
+    np.testing.assert_array_equal(s.eye, e)
+
+
+def test_pyramid_counts_and_level_assert():
+    # group::tests::pyramid group.rs:172-184; assert!(level > 1) group.rs:59
+    items, bounds, ranges = rta.pyramid(8, (1.0, -1.0, 0.0), 1.0)
+    assert (bounds.shape[0], items.shape[0]) == (5461, 21845)
+    with pytest.raises(ValueError):
+        rta.pyramid(1, (0, 0, 0), 1.0)
+
+
+def test_image_region():
+    # render::tests::image_region render.rs:483-499
+    r = rta.ImageRegion(l=2, t=18, r=34, b=2)
+    assert r.width() == 32 and r.height() == 16 and r.area() == 16 * 32
+    assert r.contains(r)
+    l = r._replace(l=1)
+    assert l.contains(r) and not r.contains(l)
+    assert r.buffer_offset(3, 3) == 33
+
+
+def test_bucket_list_matches_the_scheduler():
+    # render.rs:273-298 row-major, y outer; 64x128 -> 2 buckets (basic_rendering); clipped edges (H5)
+    assert [tuple(b) for b in rta.buckets(rta.RenderOptions(64, 128, 2))] == [(0, 64, 64, 0), (0, 128, 64, 64)]
+    b = rta.buckets(rta.RenderOptions(800, 600, 1))
+    assert len(b) == 130 and tuple(b[12]) == (768, 64, 800, 0) and tuple(b[-1]) == (768, 600, 800, 576)
+    assert len(rta.buckets(rta.RenderOptions(1920, 1080, 1))) == 510
+    assert sum(x.area() for x in b) == 800 * 600
+
+
+def test_ppm_writer_bytes(tmp_path):
+    # render.rs:373-401
+    w = rta.PPMStdoutRGBABufferWriter(True, str(tmp_path / "a.tga"))
+    w.begin(3, 2)
+    buf = rta.RGBABuffer(rta.ImageRegion(0, 2, 3, 0))
+    buf.buf[..., 0] = 10; buf.buf[..., 1] = 20; buf.buf[..., 2] = 33; buf.buf[..., 3] = 255
+    w.write_rgba_buffer(buf)
+    w.close()
+    assert open(str(tmp_path / "a.tga"), "rb").read() == b"P6\n3 2\n255\n" + bytes([10, 20, 33] * 6)
+    g = rta.PPMStdoutRGBABufferWriter(False, str(tmp_path / "g.tga"))
+    g.begin(3, 2)
+    g.write_rgba_buffer(buf)
+    g.close()
+    assert open(str(tmp_path / "g.tga"), "rb").read() == b"P5\n3 2\n255\n" + bytes([21] * 6)
+
+
+def test_rgba_buffer_blit_requires_containment():
+    big = rta.RGBABuffer(rta.ImageRegion(0, 64, 64, 0))
+    with pytest.raises(ValueError):
+        big.set_pixels_from_buffer(rta.RGBABuffer(rta.ImageRegion(32, 96, 96, 32)))

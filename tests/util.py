@@ -1,0 +1,41 @@
+"""Shared helpers for the parity tests: the same scene built on both sides (product host mirror / oracle)."""
+import numpy as np
+
+import oracle
+import rust_tracer_amd as rta
+
+PREC = {rta.RT_F32: oracle.F32, rta.RT_F64: oracle.F64}
+
+THREE_SPHERES = [(0.0, -1.0, 0.0, 1.0), (-1.2, 0.2, 0.0, 0.5), (1.2, 0.2, 0.0, 0.5)]
+THREE_BOUND = (0.0, -1.0, 0.0, 3.0)
+
+# two overlapping spheres mirrored in x: every ray of the pixel column x == width/2 (dir.x == 0 exactly) hits both
+# at exactly the same f32 distance, but their normals differ in x and light.x != 0 -> the colour tells who won.
+TIE_SPHERES = [(-0.3, 0.0, 0.0, 1.0), (0.3, 0.0, 0.0, 1.0)]
+TIE_BOUND = (0.0, 0.0, 0.0, 3.0)
+
+
+def scene_pair_default(precision=rta.RT_F32, level=8):
+    return rta.Scene.default(level, precision), oracle.Scene.default(PREC[precision], level)
+
+
+def scene_pair_spheres(spheres, bound, precision=rta.RT_F32, light=(-1.0, -3.0, 2.0), eye=(0.0, 0.0, -4.0)):
+    return (rta.Scene.from_spheres(spheres, bound, light, eye, precision),
+            oracle.Scene.from_spheres(spheres, bound, light, eye, PREC[precision]))
+
+
+def stitch(options, regions, data):
+    """tile-major bytes -> uint8[h, w, 4] frame (host-side set_pixels_from_buffer)."""
+    w, h = options[0], options[1]
+    frame = np.zeros((h, w, 4), dtype=np.uint8)
+    off = 0
+    for (l, t, r, b) in regions:
+        n = (r - l) * (t - b) * 4
+        frame[b:t, l:r] = data[off:off + n].reshape(t - b, r - l, 4)
+        off += n
+    assert off == data.size
+    return frame
+
+
+def ray_stats(st):
+    return tuple(int(st[k]) for k in ("primary", "hits", "shadow", "occluded"))
