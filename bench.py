@@ -101,8 +101,7 @@ def main():
         ev[i][0].record()
         fs.render_shard()
         ev[i][1].record()
-        if world > 1 or True:
-            _finish_step(fs)
+        fs.finish()
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
@@ -151,20 +150,6 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def _finish_step(fs):
-    """gather (N > 1) + blit on rank 0: the part of FrameSharder.step after the render."""
-    torch = fs.torch
-    stream = torch.cuda.current_stream(fs.device).cuda_stream
-    if fs.world > 1:
-        import torch.distributed as dist
-        dist.gather(fs.shard, fs.gathered if fs.rank == 0 else None, dst=0)
-        src = fs.gathered_flat if fs.rank == 0 else None
-    else:
-        src = fs.shard
-    if fs.rank == 0:
-        fs.dev.blit_tiles_device(tuple(fs.options), fs.all_regions_c, src.data_ptr(), fs.frame.data_ptr(), stream, fs.all_offsets)
 
 
 if __name__ == "__main__":

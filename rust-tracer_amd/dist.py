@@ -87,10 +87,9 @@ class FrameSharder:
         return self.dev.render_tiles_device(tuple(self.options), self.my_regions_c, self.shard.data_ptr(), stream,
                                             self.traversal, want_stats)
 
-    def step(self):
-        """One frame: render shard -> (gather) -> blit on rank 0.  Everything is enqueued on torch's current stream."""
+    def finish(self):
+        """The part of a frame after the render: RCCL gather of the u8 shards (world > 1) + blit on rank 0."""
         torch = self.torch
-        self.render_shard()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if self.world > 1:
             import torch.distributed as dist
@@ -101,6 +100,11 @@ class FrameSharder:
         if self.rank == 0:
             self.dev.blit_tiles_device(tuple(self.options), self.all_regions_c, src.data_ptr(), self.frame.data_ptr(),
                                        stream, self.all_offsets)
+
+    def step(self):
+        """One frame: render shard -> (gather) -> blit on rank 0.  Everything is enqueued on torch's current stream."""
+        self.render_shard()
+        self.finish()
 
     def frame_host(self):
         self.torch.cuda.synchronize(self.device)
