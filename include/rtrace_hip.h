@@ -78,7 +78,9 @@ typedef struct rt_stats {
     uint64_t hits;          /* primary rays that hit an item                                 */
     uint64_t shadow;        /* shadow rays cast (hit and n.light < 0), render.rs:199-207      */
     uint64_t occluded;      /* shadow rays that hit something                                */
-    uint64_t sphere_tests;  /* ray x item tests executed by the kernels (FLAT: rays * n)     */
+    uint64_t sphere_tests;  /* ray x item tests (FLAT: rays * n_items; SKIP: Sphere::intersect calls the
+                               reference's traversal makes, shadow rays stopping at their first hit)        */
+    uint64_t bound_tests;   /* bound.distance_from_ray calls (group.rs:73); 0 for FLAT          */
     double device_ms;       /* hipEvent time of all kernels of this call on its stream       */
 } rt_stats;
 

@@ -15,6 +15,7 @@ _LIB_PATH = os.path.join(_HERE, "librt_oracle.so")
 
 F32, F64 = 0, 1
 MODE_HIERARCHY, MODE_FLAT = 0, 1
+MODE_ANYHIT_EXIT = 2      # OR-able: shadow rays stop at the first hit (identical pixels, the GPU SKIP kernel's counters)
 
 
 class Stats(C.Structure):
@@ -49,6 +50,8 @@ def lib():
         L.orc_scene_pyramid.argtypes = [C.c_int, C.c_uint, dp, C.c_double, dp, dp]
         L.orc_scene_from_spheres.restype = C.c_void_p
         L.orc_scene_from_spheres.argtypes = [C.c_int, dp, C.c_int, dp, dp, dp]
+        L.orc_scene_from_ranges.restype = C.c_void_p
+        L.orc_scene_from_ranges.argtypes = [C.c_int, dp, C.c_int, dp, C.c_void_p, C.c_int, dp, dp]
         L.orc_scene_free.argtypes = [C.c_void_p]
         L.orc_scene_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_scene_flatten.restype = C.c_int
@@ -99,6 +102,15 @@ class Scene:
         sp, spp = _d(np.asarray(spheres4, dtype=np.float64).reshape(-1, 4))
         _, b = _d(bound4); _, l = _d(light); _, e = _d(eye)
         return cls(lib().orc_scene_from_spheres(prec, spp, sp.shape[0], b, l, e), prec)
+
+    @classmethod
+    def from_ranges(cls, items4, bounds4, ranges2, light=(-1.0, -3.0, 2.0), eye=(0.0, 0.0, -4.0), prec=F32):
+        """Arbitrary nesting from DFS items + pre-order ranges (ranges[0] = root {0, n})."""
+        it, itp = _d(np.asarray(items4, dtype=np.float64).reshape(-1, 4))
+        bd, bdp = _d(np.asarray(bounds4, dtype=np.float64).reshape(-1, 4))
+        rg = np.ascontiguousarray(ranges2, dtype=np.int32).reshape(-1, 2)
+        _, l = _d(light); _, e = _d(eye)
+        return cls(lib().orc_scene_from_ranges(prec, itp, it.shape[0], bdp, rg.ctypes.data, rg.shape[0], l, e), prec)
 
     def __del__(self):
         try:

@@ -76,6 +76,13 @@ orc_scene *orc_scene_from_spheres(int prec, const double *spheres4, int n, const
     return wrap(prec, NULL, scene_from_spheres_f64(spheres4, n, bound4, light_unnormalised, eye));
 }
 
+orc_scene *orc_scene_from_ranges(int prec, const double *items4, int n, const double *bounds4, const int32_t *ranges2, int nb,
+                                 const double light_unnormalised[3], const double eye[3])
+{
+    if (prec == ORC_F32) return wrap(prec, scene_from_ranges_f32(items4, n, bounds4, ranges2, nb, light_unnormalised, eye), NULL);
+    return wrap(prec, NULL, scene_from_ranges_f64(items4, n, bounds4, ranges2, nb, light_unnormalised, eye));
+}
+
 void orc_scene_free(orc_scene *s)
 {
     if (!s) return;
@@ -189,13 +196,13 @@ void orc_scene_intersect(const orc_scene *s, int mode, const double r6[6], doubl
     if (s->prec == ORC_F32) {
         ray_f32 r = { { (float)r6[0], (float)r6[1], (float)r6[2] }, { (float)r6[3], (float)r6[4], (float)r6[5] } };
         hit_f32 h = { (float)hit_in, { 0.f, 0.f, 0.f } };
-        scene_intersect_f32(s->s32, mode, &h, &r, &st);
+        scene_intersect_f32(s->s32, mode, 0, &h, &r, &st);
         out[0] = h.distance; out[1] = h.pos.x; out[2] = h.pos.y; out[3] = h.pos.z;
         return;
     }
     ray_f64 r = { { r6[0], r6[1], r6[2] }, { r6[3], r6[4], r6[5] } };
     hit_f64 h = { hit_in, { 0., 0., 0. } };
-    scene_intersect_f64(s->s64, mode, &h, &r, &st);
+    scene_intersect_f64(s->s64, mode, 0, &h, &r, &st);
     out[0] = h.distance; out[1] = h.pos.x; out[2] = h.pos.y; out[3] = h.pos.z;
 }
 

@@ -26,7 +26,9 @@ extern "C" {
 
 enum { ORC_F32 = 0, ORC_F64 = 1 };
 enum { ORC_MODE_HIERARCHY = 0,   /* the reference's bounding-sphere tree traversal (group.rs:72-83) */
-       ORC_MODE_FLAT = 1 };      /* every item in DFS order, no culling (the GPU flat-scan semantics) */
+       ORC_MODE_FLAT = 1,        /* every item in DFS order, no culling (the GPU flat-scan semantics) */
+       ORC_MODE_ANYHIT_EXIT = 2  /* OR-able flag: shadow rays stop at their first hit (same pixels, fewer tests) */
+     };
 
 typedef struct {
     uint64_t primary;        /* primary samples traced */
@@ -48,6 +50,10 @@ orc_scene *orc_scene_pyramid(int prec, unsigned level, const double origin[3], d
  * (group.rs:118-151) and what BASELINE config 1 ("3 spheres, 1 light") needs. */
 orc_scene *orc_scene_from_spheres(int prec, const double *spheres4, int n, const double bound4[4],
                                   const double light_unnormalised[3], const double eye[3]);
+/* Arbitrary nesting: DFS items + pre-order group ranges {first, count} (the description rt_scene_create takes);
+ * ranges[0] must be the root {0, n}. */
+orc_scene *orc_scene_from_ranges(int prec, const double *items4, int n, const double *bounds4, const int32_t *ranges2, int nb,
+                                 const double light_unnormalised[3], const double eye[3]);
 void orc_scene_free(orc_scene *s);
 
 void orc_scene_counts(const orc_scene *s, int *n_groups, int *n_items);     /* TypedGroup::count group.rs:93-109 */

@@ -131,16 +131,24 @@ static N(pair) N(pyramid_recursive)(unsigned level, N(vec) p, REAL r)
     return out;
 }
 
-/* group.rs:72-83  TypedGroup::intersect -- bound cull with `>=`, then children in insertion order */
-static void N(group_intersect)(const N(group) *g, N(hit) *h, const N(ray) *r, orc_stats *st)
+/* group.rs:72-83  TypedGroup::intersect -- bound cull with `>=`, then children in insertion order.
+ * anyhit != 0 (shadow rays only, ORC_MODE_ANYHIT_EXIT): stop at the first hit.  The reference keeps walking,
+ * but render.rs:208 only asks has_missed(), so pixels are identical; only the test counters differ -- this is
+ * the traversal the GPU SKIP kernel executes, and its counters must equal these. */
+static int N(group_intersect)(const N(group) *g, N(hit) *h, const N(ray) *r, orc_stats *st, int anyhit)
 {
     st->bound_tests++;
-    if (N(sphere_distance_from_ray)(&g->bound, r) >= h->distance) return;
+    if (N(sphere_distance_from_ray)(&g->bound, r) >= h->distance) return 0;
     for (int i = 0; i < g->n_children; ++i) {
         const N(pair) *c = &g->children[i];
-        if (c->is_group) N(group_intersect)(c->group, h, r, st);
-        else { st->sphere_tests++; N(sphere_intersect)(&c->item, h, r); }
+        if (c->is_group) { if (N(group_intersect)(c->group, h, r, st, anyhit)) return 1; }
+        else {
+            st->sphere_tests++;
+            N(sphere_intersect)(&c->item, h, r);
+            if (anyhit && !(h->distance == RINF)) return 1;
+        }
     }
+    return 0;
 }
 
 /* render.rs:138-142  Scene, plus the DFS-flattened item list the GPU boundary consumes */
@@ -198,10 +206,10 @@ static void N(flat_intersect)(const N(scene) *s, N(hit) *h, const N(ray) *r, orc
     st->sphere_tests += (uint64_t)s->n_flat;
 }
 
-static inline void N(scene_intersect)(const N(scene) *s, int mode, N(hit) *h, const N(ray) *r, orc_stats *st)
+static inline void N(scene_intersect)(const N(scene) *s, int mode, int is_shadow, N(hit) *h, const N(ray) *r, orc_stats *st)
 {
-    if (mode == ORC_MODE_FLAT) N(flat_intersect)(s, h, r, st);
-    else N(group_intersect)(s->group, h, r, st);
+    if ((mode & 1) == ORC_MODE_FLAT) N(flat_intersect)(s, h, r, st);
+    else N(group_intersect)(s->group, h, r, st, is_shadow && (mode & ORC_MODE_ANYHIT_EXIT));
 }
 
 /* render.rs:171-215  Renderer::raytrace */
@@ -213,7 +221,7 @@ static REAL N(raytrace)(const N(scene) *s, int mode, const N(ray) *r, N(vec) *c,
 
     st->primary++;
     N(hit) h; h.distance = RINF; h.pos.x = h.pos.y = h.pos.z = (REAL)0.0;    /* Hit::missed() primitive.rs:22-27 */
-    N(scene_intersect)(s, mode, &h, r, st);
+    N(scene_intersect)(s, mode, 0, &h, r, st);
     if (h.distance == RINF) {                                                  /* has_missed primitive.rs:29-31 */
         *c = N(vadd)(*c, BACKGROUND);
         return (REAL)0.0;
@@ -231,7 +239,7 @@ static REAL N(raytrace)(const N(scene) *s, int mode, const N(ray) *r, N(vec) *c,
     h.distance = RINF;                                                         /* set_missed render.rs:202 */
     N(ray) sr; sr.pos = p; sr.dir = N(vmulf)(s->directional_light, (REAL)-1.0);
     st->shadow++;
-    N(scene_intersect)(s, mode, &h, &sr, st);
+    N(scene_intersect)(s, mode, 1, &h, &sr, st);
     if (h.distance == RINF) {
         *c = N(vadd)(N(vadd)(*c, N(vmulf)(OBJECT, -g)), AMBIENT_OFFSET);       /* render.rs:209 */
         return (REAL)1.0;
@@ -313,6 +321,49 @@ static N(scene) *N(scene_from_spheres)(const double *sp4, int n, const double b4
         p.item.center.z = (REAL)sp4[4 * i + 2]; p.item.radius = (REAL)sp4[4 * i + 3];
         N(group_push)(s->group, p);
     }
+    N(vec) l = { (REAL)lu[0], (REAL)lu[1], (REAL)lu[2] };
+    s->directional_light = N(vnormalized)(l);
+    s->eye.x = (REAL)e[0]; s->eye.y = (REAL)e[1]; s->eye.z = (REAL)e[2];
+    N(scene_finish)(s);
+    return s;
+}
+
+/* General tree from DFS items + pre-order group ranges (the same description the C ABI takes): group k bounds
+ * items [first, first+count).  Returns NULL if the ranges do not nest. */
+static N(group) *N(tree_rec)(const double *it4, const double *b4, const int32_t *rg, int nb, int *bi, int *pos)
+{
+    int k = (*bi)++;
+    int first = rg[2 * k], end = first + rg[2 * k + 1];
+    if (first != *pos) return NULL;
+    N(group) *g = N(group_new)();
+    g->bound.center.x = (REAL)b4[4 * k]; g->bound.center.y = (REAL)b4[4 * k + 1];
+    g->bound.center.z = (REAL)b4[4 * k + 2]; g->bound.radius = (REAL)b4[4 * k + 3];
+    while (*pos < end) {
+        N(pair) p; memset(&p, 0, sizeof p);
+        if (*bi < nb && rg[2 * (*bi)] == *pos) {
+            if (rg[2 * (*bi)] + rg[2 * (*bi) + 1] > end) { N(group_free)(g); return NULL; }
+            p.is_group = 1;
+            p.group = N(tree_rec)(it4, b4, rg, nb, bi, pos);
+            if (!p.group) { N(group_free)(g); return NULL; }
+        } else {
+            p.item.center.x = (REAL)it4[4 * (*pos)]; p.item.center.y = (REAL)it4[4 * (*pos) + 1];
+            p.item.center.z = (REAL)it4[4 * (*pos) + 2]; p.item.radius = (REAL)it4[4 * (*pos) + 3];
+            (*pos)++;
+        }
+        N(group_push)(g, p);
+    }
+    return g;
+}
+
+static N(scene) *N(scene_from_ranges)(const double *it4, int n, const double *b4, const int32_t *rg, int nb,
+                                      const double lu[3], const double e[3])
+{
+    if (nb < 1 || rg[0] != 0 || rg[1] != n) return NULL;     /* the first range is the root group over all items */
+    int bi = 0, pos = 0;
+    N(group) *root = N(tree_rec)(it4, b4, rg, nb, &bi, &pos);
+    if (!root || bi != nb || pos != n) { N(group_free)(root); return NULL; }
+    N(scene) *s = (N(scene) *)calloc(1, sizeof(N(scene)));
+    s->group = root;
     N(vec) l = { (REAL)lu[0], (REAL)lu[1], (REAL)lu[2] };
     s->directional_light = N(vnormalized)(l);
     s->eye.x = (REAL)e[0]; s->eye.y = (REAL)e[1]; s->eye.z = (REAL)e[2];

@@ -3,6 +3,7 @@
 // happens on the host and there is NO CPU fallback: without a device every render entry point fails.
 #include "../../include/rtrace_hip.h"
 #include "rt_kernels.hpp"
+#include "rt_skip.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -65,6 +66,8 @@ struct rt_scene {
     void *d_items = nullptr;       // Item<REAL>[n_items], DFS order
     void *d_bounds = nullptr;      // Item<REAL>[n_bounds]
     rt_range *d_ranges = nullptr;
+    void *d_prim = nullptr, *d_shad = nullptr;   // Node<REAL>[n_nodes]: skip-pointer streams (RT_TRAVERSAL_SKIP)
+    uint32_t n_nodes = 0;
     double light[3] = { 0, 0, 0 }, eye[3] = { 0, 0, 0 };   // exact copies of the REAL values
     std::mutex mu;
     std::vector<std::unique_ptr<Context>> pool;
@@ -146,6 +149,87 @@ rt::SceneView<T> view_of(const rt_scene *s)
     return v;
 }
 
+template <typename T>
+rt::SkipView<T> skip_view_of(const rt_scene *s)
+{
+    rt::SkipView<T> v;
+    v.prim = static_cast<const rt::Node<T> *>(s->d_prim);
+    v.shad = static_cast<const rt::Node<T> *>(s->d_shad);
+    v.items = static_cast<const rt::Item<T> *>(s->d_items);
+    v.n_nodes = s->n_nodes;
+    v.light = { (T)s->light[0], (T)s->light[1], (T)s->light[2] };
+    v.eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
+    return v;
+}
+
+// Merges items and group bounds into the DFS pre-order node stream of rt_skip.hpp.  ranges must form a laminar
+// family given in pre-order (outer group before the groups nested in it).  Groups without items are dropped:
+// their bound test cannot change any hit.
+template <typename T>
+rt_status build_raw_stream(const T *items, uint32_t n_items, const T *bounds, const rt_range *ranges, uint32_t n_bounds,
+                           std::vector<rt::RawNode<T>> &out)
+{
+    out.clear();
+    out.reserve((size_t)n_items + n_bounds);
+    struct Open { uint32_t node; uint32_t end; };
+    std::vector<Open> stack;
+    uint32_t b = 0;
+    for (uint32_t pos = 0; pos <= n_items; ++pos) {
+        while (!stack.empty() && stack.back().end == pos) {           // subtree complete: its skip target is here
+            out[stack.back().node].skip = (uint32_t)out.size();
+            stack.pop_back();
+        }
+        if (pos == n_items) break;
+        while (b < n_bounds && (uint32_t)ranges[b].first == pos) {
+            const uint32_t end = pos + (uint32_t)ranges[b].count;
+            if (!stack.empty() && end > stack.back().end) {
+                snprintf(g_err, sizeof g_err, "rt_scene_create: range %u is not nested inside its enclosing group", b);
+                return RT_ERR_INVALID_ARGUMENT;
+            }
+            if (ranges[b].count > 0) {
+                stack.push_back({ (uint32_t)out.size(), end });
+                out.push_back({ bounds[4 * b], bounds[4 * b + 1], bounds[4 * b + 2], bounds[4 * b + 3], 0u, 0u });
+            }
+            ++b;
+        }
+        if (b < n_bounds && (uint32_t)ranges[b].first < pos) {
+            snprintf(g_err, sizeof g_err, "rt_scene_create: ranges are not in DFS pre-order at %u", b);
+            return RT_ERR_INVALID_ARGUMENT;
+        }
+        out.push_back({ items[4 * pos], items[4 * pos + 1], items[4 * pos + 2], items[4 * pos + 3], 0u, pos });
+    }
+    if (b != n_bounds || !stack.empty()) {
+        snprintf(g_err, sizeof g_err, "rt_scene_create: ranges are not a DFS pre-order nesting of the item array");
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    // a BOUND is marked by skip != 0; skip targets are > the node's own index >= 0, so they are never 0
+    return RT_OK;
+}
+
+template <typename T>
+rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, const rt_range *ranges)
+{
+    std::vector<rt::RawNode<T>> raw;
+    rt_status st = build_raw_stream<T>(static_cast<const T *>(items), s->n_items, static_cast<const T *>(bounds), ranges, s->n_bounds, raw);
+    if (st != RT_OK) return st;
+    s->n_nodes = (uint32_t)raw.size();
+    rt::RawNode<T> *d_raw = nullptr;
+    HIP_TRY(hipMalloc(&d_raw, sizeof(rt::RawNode<T>) * raw.size()));
+    hipError_t e = hipMemcpy(d_raw, raw.data(), sizeof(rt::RawNode<T>) * raw.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&s->d_prim, sizeof(rt::Node<T>) * raw.size());
+    if (e == hipSuccess) e = hipMalloc(&s->d_shad, sizeof(rt::Node<T>) * raw.size());
+    if (e == hipSuccess) {
+        const rt::V3<T> eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
+        hipLaunchKernelGGL((rt::k_build_streams<T>), dim3((s->n_nodes + 255) / 256), dim3(256), 0, nullptr, d_raw, s->n_nodes, eye,
+                           static_cast<rt::Node<T> *>(s->d_prim), static_cast<rt::Node<T> *>(s->d_shad));
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    (void)hipFree(d_raw);
+    if (e != hipSuccess) return hip_fail(e, "upload_streams", __LINE__);
+    return RT_OK;
+}
+
 // Copies the tile table through the context's pinned buffer; truly asynchronous on `stream`.
 rt_status upload_tiles(Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream)
 {
@@ -167,8 +251,12 @@ rt_status upload_tiles(Context *c, const std::vector<rt::TileDev> &tab, hipStrea
 rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversal trav, const std::vector<rt::TileDev> &tab,
                        uint32_t total_blocks, uint8_t *d_out, hipStream_t stream, bool want_counters)
 {
-    if (trav != RT_TRAVERSAL_FLAT) {
-        snprintf(g_err, sizeof g_err, "RT_TRAVERSAL_SKIP is not implemented in this build");
+    if (trav != RT_TRAVERSAL_FLAT && trav != RT_TRAVERSAL_SKIP) {
+        snprintf(g_err, sizeof g_err, "unknown traversal %d", (int)trav);
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    if (trav == RT_TRAVERSAL_SKIP && s->n_nodes == 0) {
+        snprintf(g_err, sizeof g_err, "RT_TRAVERSAL_SKIP needs a scene created with subtree bounds");
         return RT_ERR_UNSUPPORTED;
     }
     {
@@ -180,19 +268,25 @@ rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversa
 
     HIP_TRY(hipEventRecord(c->ev0, stream));
     const dim3 grid(total_blocks), block(rt::kBlockThreads);
-    if (s->precision == RT_F32) {
-        hipLaunchKernelGGL((rt::k_render_fused<float, 1024>), grid, block, 0, stream, view_of<float>(s), (unsigned)o->width,
-                           (unsigned)o->height, (unsigned)o->samples_per_pixel, c->d_tiles, (unsigned)tab.size(), d_out, cnt);
+    const unsigned w = o->width, h = o->height, spp = o->samples_per_pixel, nt = (unsigned)tab.size();
+    if (trav == RT_TRAVERSAL_FLAT) {
+        if (s->precision == RT_F32)
+            hipLaunchKernelGGL((rt::k_render_fused<float, 1024>), grid, block, 0, stream, view_of<float>(s), w, h, spp, c->d_tiles, nt, d_out, cnt);
+        else
+            hipLaunchKernelGGL((rt::k_render_fused<double, 512>), grid, block, 0, stream, view_of<double>(s), w, h, spp, c->d_tiles, nt, d_out, cnt);
+    } else if (s->precision == RT_F32) {
+        if (cnt) hipLaunchKernelGGL((rt::k_render_skip<float, true>), grid, block, 0, stream, skip_view_of<float>(s), w, h, spp, c->d_tiles, nt, d_out, cnt);
+        else hipLaunchKernelGGL((rt::k_render_skip<float, false>), grid, block, 0, stream, skip_view_of<float>(s), w, h, spp, c->d_tiles, nt, d_out, cnt);
     } else {
-        hipLaunchKernelGGL((rt::k_render_fused<double, 512>), grid, block, 0, stream, view_of<double>(s), (unsigned)o->width,
-                           (unsigned)o->height, (unsigned)o->samples_per_pixel, c->d_tiles, (unsigned)tab.size(), d_out, cnt);
+        if (cnt) hipLaunchKernelGGL((rt::k_render_skip<double, true>), grid, block, 0, stream, skip_view_of<double>(s), w, h, spp, c->d_tiles, nt, d_out, cnt);
+        else hipLaunchKernelGGL((rt::k_render_skip<double, false>), grid, block, 0, stream, skip_view_of<double>(s), w, h, spp, c->d_tiles, nt, d_out, cnt);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, stream));
     return RT_OK;
 }
 
-rt_status read_stats(rt_scene *s, Context *c, hipStream_t stream, rt_stats *st)
+rt_status read_stats(rt_scene *s, Context *c, hipStream_t stream, rt_traversal trav, rt_stats *st)
 {
     rt::Counters h;
     HIP_TRY(hipMemcpyAsync(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, stream));
@@ -200,7 +294,8 @@ rt_status read_stats(rt_scene *s, Context *c, hipStream_t stream, rt_stats *st)
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     st->primary = h.primary; st->hits = h.hits; st->shadow = h.shadow; st->occluded = h.occluded;
-    st->sphere_tests = (h.primary + h.shadow) * (uint64_t)s->n_items;
+    if (trav == RT_TRAVERSAL_FLAT) { st->sphere_tests = (h.primary + h.shadow) * (uint64_t)s->n_items; st->bound_tests = 0; }
+    else { st->sphere_tests = h.sphere_tests; st->bound_tests = h.bound_tests; }
     st->device_ms = ms;
     return RT_OK;
 }
@@ -334,6 +429,10 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
         if ((e = hipMemcpy(s->d_ranges, ranges, sizeof(rt_range) * n_bounds, hipMemcpyHostToDevice)) != hipSuccess)
             return fail(hip_fail(e, "hipMemcpy(ranges)", __LINE__));
     }
+    if (n_bounds) {
+        rt_status sst = f32 ? upload_streams<float>(s.get(), dfs_items, bounds, ranges) : upload_streams<double>(s.get(), dfs_items, bounds, ranges);
+        if (sst != RT_OK) return fail(sst);
+    }
     *out = s.release();
     return RT_OK;
 }
@@ -346,6 +445,8 @@ rt_status rt_scene_destroy(rt_scene *s)
     if (s->d_items) (void)hipFree(s->d_items);
     if (s->d_bounds) (void)hipFree(s->d_bounds);
     if (s->d_ranges) (void)hipFree(s->d_ranges);
+    if (s->d_prim) (void)hipFree(s->d_prim);
+    if (s->d_shad) (void)hipFree(s->d_shad);
     delete s;
     return RT_OK;
 }
@@ -369,7 +470,7 @@ rt_status rt_render_tiles_device(rt_scene *s, const rt_options *o, rt_traversal 
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     st = enqueue_pass(s, c, o, trav, tab, total_blocks, static_cast<uint8_t *>(rgba_out_device), stream, stats != nullptr);
     if (st != RT_OK) return st;
-    if (stats) return read_stats(s, c, stream, stats);
+    if (stats) return read_stats(s, c, stream, trav, stats);
     // Asynchronous return: the context's tile table is still in use by the enqueued work, so it goes back to
     // the pool marked in-flight and is only reused once its end event has completed.
     lease.inflight = true;
@@ -398,7 +499,7 @@ rt_status rt_render_tiles(rt_scene *s, const rt_options *o, rt_traversal trav, c
     st = enqueue_pass(s, c, o, trav, tab, total_blocks, c->d_out, c->stream, stats != nullptr);
     if (st != RT_OK) return st;
     HIP_TRY(hipMemcpyAsync(rgba_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
-    if (stats) return read_stats(s, c, c->stream, stats);
+    if (stats) return read_stats(s, c, c->stream, trav, stats);
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
 }

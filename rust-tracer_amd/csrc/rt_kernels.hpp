@@ -28,6 +28,7 @@ template <typename T> struct SceneView {
 
 struct Counters {          // same meaning as the reference-side ray statistics
     unsigned long long primary, hits, shadow, occluded;
+    unsigned long long sphere_tests, bound_tests;   // per-ray tests executed (SKIP traversal counts them exactly)
 };
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned v)

@@ -248,3 +248,116 @@ def test_error_codes_instead_of_panics():
     with pytest.raises(rta.RtError) as e:
         rta.Scene.from_spheres([(float("nan"), 0, 0, 1.0)], (0, 0, 0, 3.0)).device()
     assert e.value.status == rta.capi.RT_ERR_INVALID_ARGUMENT
+
+
+# ----------------------------------------------------------------------------------------------------------
+# RT_TRAVERSAL_SKIP: the reference's own hierarchy (group.rs:72-83) as a skip-pointer stream.  Pixels must be
+# the hierarchy's, and every lane must perform exactly the reference's tests: the item/bound test counters equal
+# the oracle's (with shadow rays stopping at their first hit, which cannot change a pixel).
+# ----------------------------------------------------------------------------------------------------------
+SKIP = rta.RT_TRAVERSAL_SKIP
+HIER_EXIT = oracle.MODE_HIERARCHY | oracle.MODE_ANYHIT_EXIT
+
+
+@pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64])
+def test_skip_config1_three_spheres(precision):
+    s, o = util.scene_pair_spheres(util.THREE_SPHERES, util.THREE_BOUND, precision)
+    data, st = s.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)], SKIP)
+    ref, rst = o.render_region(64, 64, 1, 0, 64, 64, 0, HIER_EXIT)
+    np.testing.assert_array_equal(data.reshape(64, 64, 4), ref)
+    assert util.all_stats(st) == util.all_stats(rst)
+
+
+def test_skip_golden_make_image_1024x768_spp4(golden_dir):
+    ref_rgb = np.load(os.path.join(golden_dir, "make_image_1024x768_spp4_rgb.npz"))["rgb"]
+    s, o = util.scene_pair_default()
+    regs = bucket_list(1024, 768, 4)
+    data, st = s.device().render_tiles((1024, 768, 4), regs, SKIP)
+    frame = util.stitch((1024, 768), regs, data)
+    assert int((frame[:, :, :3] != ref_rgb).any(axis=2).sum()) == 0
+    oref, rst, _ = o.render(1024, 768, 4, os.cpu_count() or 1, HIER_EXIT)
+    np.testing.assert_array_equal(frame, oref)
+    assert util.all_stats(st) == util.all_stats(rst)
+
+
+@pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64])
+def test_skip_config3_1920x1080(precision):
+    s, o = util.scene_pair_default(precision)
+    regs = bucket_list(1920, 1080)
+    data, st = s.device().render_tiles((1920, 1080, 1), regs, SKIP)
+    ref, rst, _ = o.render(1920, 1080, 1, os.cpu_count() or 1, HIER_EXIT)
+    np.testing.assert_array_equal(util.stitch((1920, 1080), regs, data), ref)
+    assert util.all_stats(st) == util.all_stats(rst)
+
+
+def test_skip_config2_800x600_and_flat_agree():
+    s, o = util.scene_pair_default()
+    regs = bucket_list(800, 600)
+    a, sa = s.device().render_tiles((800, 600, 1), regs, SKIP)
+    b, sb = s.device().render_tiles((800, 600, 1), regs, FLAT)
+    np.testing.assert_array_equal(a, b)                       # SURVEY.md P3 on the GPU
+    assert util.ray_stats(sa) == util.ray_stats(sb) == (480000, 359528, 275032, 136797)
+    _, rst, _ = o.render(800, 600, 1, os.cpu_count() or 1, HIER_EXIT)
+    assert util.all_stats(sa) == util.all_stats(rst)
+
+
+def test_skip_pyramid_level9():
+    s, o = util.scene_pair_default(level=9)
+    regs = bucket_list(320, 256, 2)
+    data, st = s.device().render_tiles((320, 256, 2), regs, SKIP)
+    ref, rst, _ = o.render(320, 256, 2, os.cpu_count() or 1, HIER_EXIT)
+    np.testing.assert_array_equal(util.stitch((320, 256), regs, data), ref)
+    assert util.all_stats(st) == util.all_stats(rst)
+
+
+@pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64])
+def test_skip_reproduces_the_inside_bound_cull_flat_does_not(precision):
+    # the reference's result is DEFINED by the hierarchy; SKIP follows it, FLAT is the flat semantics
+    s, o = util.scene_pair_ranges(util.INSIDE_ITEMS, util.INSIDE_BOUNDS, util.INSIDE_RANGES, precision)
+    hier, hst = o.render_region(64, 64, 1, 0, 64, 64, 0, HIER_EXIT)
+    flat, _ = o.render_region(64, 64, 1, 0, 64, 64, 0, oracle.MODE_FLAT)
+    assert (hier != flat).any()
+    a, sa = s.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)], SKIP)
+    b, _ = s.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)], FLAT)
+    np.testing.assert_array_equal(a.reshape(64, 64, 4), hier)
+    np.testing.assert_array_equal(b.reshape(64, 64, 4), flat)
+    assert util.all_stats(sa) == util.all_stats(hst)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_skip_random_nested_scenes_with_loose_and_tight_bounds(seed):
+    # items and sub-groups interleaved, bounds that do not enclose their subtree: culling changes pixels, so this
+    # checks the per-lane cull rule, the resume masking and the wave-level jump against the recursive oracle
+    items, bounds, ranges = util.random_nested_scene(seed)
+    s, o = util.scene_pair_ranges(items, bounds, ranges, eye=(0.1, 0.2, -4.0))
+    regs = [(0, 96, 128, 0), (5, 70, 69, 6)]
+    data, st = s.device().render_tiles((128, 96, 2), regs, SKIP)
+    off = 0
+    tot = None
+    for (l, t, r, b) in regs:
+        ref, rst = o.render_region(128, 96, 2, l, t, r, b, HIER_EXIT)
+        np.testing.assert_array_equal(data[off:off + ref.size].reshape(ref.shape), ref)
+        off += ref.size
+        tot = rst if tot is None else {k: tot[k] + rst[k] for k in tot}
+    assert util.all_stats(st) == util.all_stats(tot)
+
+
+def test_skip_tie_break_and_ragged():
+    for spheres in (util.TIE_SPHERES, util.TIE_SPHERES[::-1]):
+        s, o = util.scene_pair_spheres(spheres, util.TIE_BOUND)
+        data, st = s.device().render_tiles((64, 64, 1), [(3, 61, 64, 1)], SKIP)
+        ref, rst = o.render_region(64, 64, 1, 3, 61, 64, 1, HIER_EXIT)
+        np.testing.assert_array_equal(data.reshape(ref.shape), ref)
+        assert util.all_stats(st) == util.all_stats(rst)
+
+
+def test_skip_needs_bounds_and_rejects_bad_nesting():
+    s = rta.Scene(np.array([[0, 0, 0, 1.0]]), rta.normalized((-1, -3, 2)), (0, 0, -4))
+    with pytest.raises(rta.RtError) as e:
+        s.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)], SKIP)
+    assert e.value.status == rta.capi.RT_ERR_UNSUPPORTED
+    bad = rta.Scene(np.array([[0, 0, 0, 1.0], [1, 0, 0, 1.0], [2, 0, 0, 1.0]]), rta.normalized((-1, -3, 2)), (0, 0, -4),
+                    np.array([[0, 0, 0, 9.0], [0, 0, 0, 9.0], [0, 0, 0, 9.0]]), np.array([[0, 3], [0, 2], [1, 2]], dtype=np.int32))
+    with pytest.raises(rta.RtError) as e:
+        bad.device()
+    assert e.value.status == rta.capi.RT_ERR_INVALID_ARGUMENT

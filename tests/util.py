@@ -39,3 +39,46 @@ def stitch(options, regions, data):
 
 def ray_stats(st):
     return tuple(int(st[k]) for k in ("primary", "hits", "shadow", "occluded"))
+
+
+# the eye lies INSIDE group A's bound, so A's bound "distance" is its exit distance (primitive.rs:70-71)
+# and A is culled (group.rs:73) although it holds the nearer item Y.  hierarchy -> X, flat scan -> Y.
+INSIDE_ITEMS = [(0.0, 0.0, -4.0 + 2.3, 0.4), (0.0, 0.0, -4.0 + 2.0, 0.5)]
+INSIDE_BOUNDS = [(0.0, 0.0, -2.0, 10.0), (0.0, 0.0, -4.0 + 0.3, 2.3)]
+INSIDE_RANGES = [(0, 2), (1, 1)]
+
+
+def scene_pair_ranges(items, bounds, ranges, precision=rta.RT_F32, light=(-1.0, -3.0, 2.0), eye=(0.0, 0.0, -4.0)):
+    s = rta.Scene(np.asarray(items, dtype=np.float64), rta.normalized(light, precision), eye,
+                  np.asarray(bounds, dtype=np.float64), np.asarray(ranges, dtype=np.int32), precision)
+    return s, oracle.Scene.from_ranges(items, bounds, ranges, light, eye, PREC[precision])
+
+
+def random_nested_scene(seed, depth=3, fan=3, leaf_items=3):
+    """A random laminar tree (items and sub-groups interleaved in random order) with tight-ish random bounds:
+    some bounds do NOT enclose their subtree, so culling really changes results and order matters."""
+    rng = np.random.default_rng(seed)
+    items, bounds, ranges = [], [], []
+
+    def rec(d, centre, scale):
+        bi = len(bounds)
+        bounds.append(None); ranges.append(None)
+        first = len(items)
+        kids = ["item"] * leaf_items + (["group"] * fan if d > 0 else [])
+        rng.shuffle(kids)
+        for k in kids:
+            c = centre + rng.uniform(-scale, scale, 3)
+            if k == "item":
+                items.append((c[0], c[1], c[2], float(rng.uniform(0.08, 0.35) * scale)))
+            else:
+                rec(d - 1, c, scale * 0.55)
+        bounds[bi] = (centre[0], centre[1], centre[2], float(scale * rng.uniform(1.2, 2.6)))
+        ranges[bi] = (first, len(items) - first)
+
+    rec(depth, np.array([0.0, 0.0, 0.0]), 1.2)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    return f32(items), f32(bounds), np.asarray(ranges, dtype=np.int32)
+
+
+def all_stats(st):
+    return tuple(int(st[k]) for k in ("primary", "hits", "shadow", "occluded", "sphere_tests", "bound_tests"))
