@@ -5,7 +5,11 @@ A "step" is one frame: every 64x64 bucket of the frame through the HIP hot path 
 RCCL gather of the u8 shards to rank 0 when N > 1, and the blit into the row-major frame.  The scene is already
 resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+The headline uses the product's default traversal, RT_TRAVERSAL_SKIP (the reference's own bounding-sphere
+hierarchy walked as a skip-pointer stream, bit-identical pixels and identical per-ray test counts).  The
+north-star "linear scan" kernel (RT_TRAVERSAL_FLAT) is timed beside it in the same run and reported under "flat".
+
+    python bench.py --gpus 1 --steps 100 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 """
@@ -20,9 +24,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT, SPP, LEVEL = 1920, 1080, 1, 8
-HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_OPS = 256 * 4 * 32 * 2.4e9   # un-fused f32 lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz (FMA is forbidden by parity)
-BYTES_PER_TEST = 16              # one ray x one item = one {cx,cy,cz,r} f32 record
+N_ITEMS = 21845
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_OPS = 256 * 4 * 32 * 2.4e9     # un-fused f32 lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz (no FMA: parity)
+BYTES_PER_TEST = 16                      # one ray x one sphere = one {cx,cy,cz,r} f32 record
 
 
 def cpu_baseline(budget_s=12.0):
@@ -43,17 +48,20 @@ def cpu_baseline(budget_s=12.0):
         frames += 1
         spent += dt
     return {"value": round(rays / best / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "%d full frames of the same %dx%d spp %d L%d workload, hierarchical traversal, best frame; "
-                      "1 core: %.3f Mrays/s" % (frames, WIDTH, HEIGHT, SPP, LEVEL, rays / t_single / 1e6),
+            "sample": "%d full frames of the same %dx%d spp %d L%d workload on %d threads (64x64 buckets), reference "
+                      "hierarchical traversal, best frame; 1 thread: %.3f Mrays/s"
+                      % (frames, WIDTH, HEIGHT, SPP, LEVEL, cores, rays / t_single / 1e6),
             "ms_per_frame": round(best * 1e3, 2), "single_core_value": round(rays / t_single / 1e6, 3)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-flat", action="store_true", help="skip the secondary flat-scan measurement")
+    ap.add_argument("--traversal", choices=("skip", "flat"), default="skip", help="traversal of the headline measurement")
     args = ap.parse_args()
 
     import torch
@@ -64,7 +72,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -76,74 +85,93 @@ def main():
 
     scene = rta.Scene.default(LEVEL, rta.RT_F32)
     opts = rta.RenderOptions(WIDTH, HEIGHT, SPP)
-    fs = FrameSharder(scene, opts, rank, world, local)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ray counters of this rank's shard (must equal the oracle's; checked by tests) -> rays per frame
-    st = fs.render_shard(want_stats=True)
-    cnt = torch.tensor([st["primary"], st["shadow"], st["sphere_tests"]], dtype=torch.int64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(cnt)
-    primary, shadow, tests = (int(v) for v in cnt.tolist())
-    my_tests = st["sphere_tests"]
+    def measure(traversal, steps, warmup):
+        """-> dict with whole-job ms/step (max over ranks), this rank's kernel ms (HIP events), ray/test counters."""
+        fs = FrameSharder(scene, opts, rank, world, local, traversal)
+        st = fs.render_shard(want_stats=True)          # counters of this rank's shard (equal the oracle's; tests)
+        cnt = torch.tensor([st["primary"], st["shadow"]], dtype=torch.int64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(cnt)
+        primary, shadow = (int(v) for v in cnt.tolist())
+        for _ in range(warmup):
+            fs.step()
+        barrier()
+        # HIP events on the stream the kernel is launched on: torch's current stream is handed through the C ABI
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ev[i][0].record()
+            fs.render_shard()
+            ev[i][1].record()
+            fs.finish()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return {"elapsed": float(tt.item()), "kern_ms": kern_ms, "primary": primary, "shadow": shadow,
+                "my_tests": st["sphere_tests"] + st["bound_tests"], "my_stats": st}
 
-    for _ in range(args.warmup):
-        fs.step()
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        # HIP events on the stream the kernel is launched on (torch's current stream is passed through the C ABI)
-        ev[i][0].record()
-        fs.render_shard()
-        ev[i][1].record()
-        fs.finish()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-
-    tt = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed, kern_ms_max = (float(v) for v in tt.tolist())
-
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        rays = primary + shadow
-        value = rays / (ms_per_step * 1e-3) / 1e6
-        alg_bytes = my_tests * BYTES_PER_TEST                    # this rank's launch
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    def roofline(m, kernel, note):
+        alg = m["my_tests"] * BYTES_PER_TEST
+        ach = alg / (m["kern_ms"] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_n%d" % world)
+                traffic = json.load(open(tpath)).get("%s_n%d" % (kernel, world))
             except Exception:
                 traffic = None
+        return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
+                "kernel_ms": round(m["kern_ms"], 4), "tests_per_launch": m["my_tests"], "note": note}
+
+    head_trav = rta.RT_TRAVERSAL_SKIP if args.traversal == "skip" else rta.RT_TRAVERSAL_FLAT
+    m = measure(head_trav, args.steps, args.warmup)
+    flat = None
+    if args.traversal == "skip" and not args.no_flat:
+        flat = measure(rta.RT_TRAVERSAL_FLAT, max(2, min(5, args.steps)), 1)
+
+    if rank == 0:
+        ms_per_step = m["elapsed"] / args.steps * 1e3
+        rays = m["primary"] + m["shadow"]
+        skip_note = ("algorithmic bytes = 16 B x (item + bound tests the reference's traversal makes for rank 0's rays, "
+                     "counted by the kernel and equal to the CPU path's) / hipEvent duration of k_render_skip; records "
+                     "arrive through the scalar cache / L2 (the whole scene is < 1 MB), so this is a logical rate, not "
+                     "HBM traffic (SURVEY.md H3)")
+        flat_note = ("algorithmic bytes = 16 B x (primary + shadow rays) x 21845 items of rank 0's launch / hipEvent "
+                     "duration of k_render_fused; every record staged to LDS is re-used by all rays of a workgroup, so the "
+                     "logical rate exceeds the HBM peak; the binding limit is un-fused f32 VALU issue (see valu)")
         out = {
             "metric": "Mrays/sec + ms/frame, 1920x1080 20k-sphere scene",
-            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (the reference's deterministic default scene: pyramid level 8)",
-            "config": {"workload": "1920x1080, 21845 spheres (pyramid L8), spp 1, f32, flat DFS scan, 510 64x64 buckets "
-                                   "round-robin over %d GPU(s), RCCL gather + device blit to rank 0" % world,
-                       "width": WIDTH, "height": HEIGHT, "samples_per_pixel": SPP, "n_spheres": 21845,
-                       "primary_rays": primary, "shadow_rays": shadow, "parallelism": "tiles/%d" % world},
-            "mprimary_per_s": round(primary / (ms_per_step * 1e-3) / 1e6, 3),
-            "kernel_ms": round(kern_ms, 4),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "note": "logical scan rate: 16 B x (primary+shadow rays) x 21845 items of rank 0's launch / its "
-                                 "hipEvent duration; items are re-used from LDS/L2 so this may exceed 1 (SURVEY.md H3); "
-                                 "the binding limit is un-fused f32 VALU issue, see valu"},
-            "valu": {"ops_per_test": 17, "achieved_Tops": round(my_tests * 17 / (kern_ms * 1e-3) / 1e12, 2),
-                     "peak_Tops": round(VALU_PEAK_OPS / 1e12, 1),
-                     "frac": round(my_tests * 17 / (kern_ms * 1e-3) / VALU_PEAK_OPS, 4)},
+            "value": round(rays / (ms_per_step * 1e-3) / 1e6, 3), "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (the reference's deterministic default scene: pyramid level 8)",
+            "config": {"workload": "1920x1080, 21845 spheres (pyramid L8), spp 1, f32, %s traversal, 510 64x64 buckets "
+                                   "round-robin over %d GPU(s), RCCL gather + device blit to rank 0" % (args.traversal, world),
+                       "width": WIDTH, "height": HEIGHT, "samples_per_pixel": SPP, "n_spheres": N_ITEMS,
+                       "primary_rays": m["primary"], "shadow_rays": m["shadow"], "traversal": args.traversal,
+                       "parallelism": "tiles/%d" % world},
+            "mprimary_per_s": round(m["primary"] / (ms_per_step * 1e-3) / 1e6, 3),
+            "roofline": roofline(m, "k_render_skip" if args.traversal == "skip" else "k_render_fused",
+                                 skip_note if args.traversal == "skip" else flat_note),
         }
+        if flat is not None:
+            fms = flat["elapsed"] / max(2, min(5, args.steps)) * 1e3
+            out["flat"] = {"ms_per_step": round(fms, 4), "value": round(rays / (fms * 1e-3) / 1e6, 3), "unit": "Mrays/s",
+                           "roofline": roofline(flat, "k_render_fused", flat_note),
+                           "valu": {"ops_per_test": 17,
+                                    "achieved_Tops": round(flat["my_tests"] * 17 / (flat["kern_ms"] * 1e-3) / 1e12, 2),
+                                    "peak_Tops": round(VALU_PEAK_OPS / 1e12, 1),
+                                    "frac": round(flat["my_tests"] * 17 / (flat["kern_ms"] * 1e-3) / VALU_PEAK_OPS, 4)}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
