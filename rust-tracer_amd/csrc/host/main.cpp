@@ -1,0 +1,187 @@
+// main.cpp -- the `rtrace` binary: same flags, environment knob, defaults, quirks and exit behaviour as
+// /root/reference/src/rust/main.rs:22-90 (clap 2.19 App "rtrace" 0.2.0), with the per-tile work done by the HIP
+// backend.  Flags that do not exist in the reference (--device, --devices, --traversal, --level, --stats) only
+// add GPU selection; none of the reference's flags changes meaning.
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "render.hpp"
+
+using namespace rtrace;
+
+namespace {
+
+[[noreturn]] void panic(const std::string &msg)
+{
+    // `unwrap()` / `expect()` / `assert!` in the reference abort the process with exit status 101
+    fprintf(stderr, "thread 'main' panicked at '%s'\n", msg.c_str());
+    exit(101);
+}
+
+const char *USAGE =
+    "rtrace 0.2.0\n"
+    "Sebastian Thiel <byronimo@mail.com>\n"
+    "A toy-raytracer for rendering a scene with spheres\n\n"
+    "USAGE:\n"
+    "    rtrace [OPTIONS] <output>\n\n"
+    "OPTIONS:\n"
+    "        --width <X>                     The width of the output image [default: 1024]\n"
+    "        --height <Y>                    The height of the output image [default: 1024]\n"
+    "        --samples-per-pixel <SAMPLES>   Amount of samples per pixel. 4 means 16 over-samples [default: 1]\n"
+    "        --num-cores <numcores>          Amount of cores to do the rendering on [default: 1]\n"
+    "                                        If this is not set, you may also use the RTRACEMAXPROCS\n"
+    "                                        environment variable, e.g. RTRACEMAXPROCS=4.\n"
+    "                                        The commandline always overrides environment variables.\n"
+    "    -h, --help                          Prints help information\n"
+    "    -V, --version                       Prints version information\n\n"
+    "MI355X backend (not in the reference):\n"
+    "        --device <N>                    first GPU to render on [default: 0]\n"
+    "        --devices <N>                   number of GPUs; buckets are dealt round-robin [default: 1]\n"
+    "        --traversal <skip|flat>         hierarchy walk (default) or flat DFS scan; identical pixels\n"
+    "        --level <N>                     pyramid level of the default scene [default: 8]\n"
+    "        --stats                         print ray counters and device time on stderr\n\n"
+    "ARGS:\n"
+    "    <output>    Either a file with .tga extension, or - to write file to stdout\n";
+
+template <typename T> T parse_or_panic(const std::string &s)
+{
+    // str::parse::<uN>().unwrap(): digits only (an optional leading '+'), value must fit
+    const char *p = s.c_str();
+    if (*p == '+') ++p;
+    if (!*p) panic("called `Result::unwrap()` on an `Err` value: ParseIntError { kind: Empty }");
+    unsigned long long v = 0;
+    for (; *p; ++p) {
+        if (*p < '0' || *p > '9') panic("called `Result::unwrap()` on an `Err` value: ParseIntError { kind: InvalidDigit }");
+        v = v * 10 + (unsigned)(*p - '0');
+        if (v > (unsigned long long)std::numeric_limits<T>::max())
+            panic("called `Result::unwrap()` on an `Err` value: ParseIntError { kind: Overflow }");
+    }
+    return (T)v;
+}
+
+bool ends_with_tga_extension(const std::string &path)
+{
+    // Path::extension() == "tga": text after the last '.' of the file name, which must not start the name
+    const size_t slash = path.find_last_of('/');
+    const std::string name = slash == std::string::npos ? path : path.substr(slash + 1);
+    const size_t dot = name.find_last_of('.');
+    if (dot == std::string::npos || dot == 0) return false;
+    return name.substr(dot + 1) == "tga";
+}
+
+std::string with_tga_extension(const std::string &path)
+{
+    const size_t slash = path.find_last_of('/');
+    const size_t dot = path.find_last_of('.');
+    if (dot == std::string::npos || (slash != std::string::npos && dot < slash) || dot == (slash == std::string::npos ? 0 : slash + 1))
+        return path + ".tga";
+    return path.substr(0, dot) + ".tga";
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    // main.rs:24-29: RTRACEMAXPROCS, default 1, unparsable -> 1
+    size_t nc_from_env = 1;
+    if (const char *e = getenv("RTRACEMAXPROCS")) {
+        char *end = nullptr;
+        errno = 0;
+        unsigned long long v = strtoull(e, &end, 10);
+        if (*e && *e != '-' && end && *end == '\0' && errno == 0) nc_from_env = (size_t)v;
+    }
+
+    std::string width = "1024", height = "1024", ssp = "1", numcores = "1", output;
+    std::string device = "0", devices = "1", traversal = "skip", level = "8";
+    bool have_output = false, stats = false;
+    auto take = [&](int &i, const std::string &arg, const char *name, std::string &dst) -> bool {
+        const std::string flag = std::string("--") + name;
+        if (arg == flag) {
+            if (i + 1 >= argc) { fprintf(stderr, "error: The argument '%s <value>' requires a value but none was supplied\n", flag.c_str()); exit(1); }
+            dst = argv[++i];
+            return true;
+        }
+        if (arg.compare(0, flag.size() + 1, flag + "=") == 0) { dst = arg.substr(flag.size() + 1); return true; }
+        return false;
+    };
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "-h" || a == "--help") { fputs(USAGE, stdout); return 0; }
+        if (a == "-V" || a == "--version") { puts("rtrace 0.2.0"); return 0; }
+        if (a == "--stats") { stats = true; continue; }
+        if (take(i, a, "width", width) || take(i, a, "height", height) || take(i, a, "samples-per-pixel", ssp) ||
+            take(i, a, "num-cores", numcores) || take(i, a, "device", device) || take(i, a, "devices", devices) ||
+            take(i, a, "traversal", traversal) || take(i, a, "level", level))
+            continue;
+        if (a.size() > 1 && a[0] == '-' && a != "-") {
+            fprintf(stderr, "error: Found argument '%s' which wasn't expected, or isn't valid in this context\n\nFor more information try --help\n", a.c_str());
+            return 1;
+        }
+        if (have_output) {
+            fprintf(stderr, "error: Found argument '%s' which wasn't expected, or isn't valid in this context\n", a.c_str());
+            return 1;
+        }
+        output = a;
+        have_output = true;
+    }
+    if (!have_output || output.empty()) {                         // .required(true).empty_values(false)  main.rs:51-54
+        fprintf(stderr, "error: The following required arguments were not provided:\n    <output>\n\nUSAGE:\n    rtrace [OPTIONS] <output>\n\nFor more information try --help\n");
+        return 1;
+    }
+
+    // main.rs:56-61: the command line only wins when it asks for more than one core
+    const size_t num_cores = parse_or_panic<size_t>(numcores);
+    const size_t pool_size = num_cores > 1 ? num_cores : nc_from_env;
+    if (pool_size == 0) panic("assertion failed: num_threads >= 1");            // ThreadPool::new(0) asserts
+
+    // main.rs:63-76
+    FileOrAnyWriter sink;
+    if (output != "-") {
+        if (!ends_with_tga_extension(output)) {
+            printf("Output file '%s' must have the tga extension, e.g. %s\n", output.c_str(), with_tga_extension(output).c_str());
+            return 0;                                             // `return;` from main: status 0, as in the reference
+        }
+        sink.f = fopen(output.c_str(), "wb");
+        if (!sink.f) panic(std::string("called `Result::unwrap()` on an `Err` value: ") + strerror(errno));
+        sink.is_file = true;
+    } else {
+        sink.f = stdout;
+    }
+
+    // main.rs:78-82 (u16 fields)
+    const RenderOptions options{ parse_or_panic<uint16_t>(width), parse_or_panic<uint16_t>(height), parse_or_panic<uint16_t>(ssp) };
+
+    int status = 0;
+    try {
+        const Scene scene = Scene::with_level(parse_or_panic<uint32_t>(level));          // Arc::new(Default::default())  main.rs:23
+        Backend be;
+        if (traversal == "flat") be.traversal = RT_TRAVERSAL_FLAT;
+        else if (traversal == "skip") be.traversal = RT_TRAVERSAL_SKIP;
+        else { fprintf(stderr, "error: --traversal must be skip or flat\n"); return 1; }
+        const int dev0 = parse_or_panic<int>(device), ndev = parse_or_panic<int>(devices);
+        if (ndev < 1) { fprintf(stderr, "error: --devices must be >= 1\n"); return 1; }
+        for (int d = 0; d < ndev; ++d) be.devices.push_back(std::make_shared<DeviceScene>(scene, dev0 + d));
+
+        ThreadPool pool(pool_size);
+        RenderStats st;
+        {
+            PPMStdoutRGBABufferWriter writer(true, sink);                                // main.rs:84-87
+            st = Renderer::render(options, be, writer, pool);
+        }                                                                                // Drop writes the final image
+        if (stats)
+            fprintf(stderr, "primary %llu hits %llu shadow %llu occluded %llu item_tests %llu bound_tests %llu device_ms %.3f\n",
+                    (unsigned long long)st.primary, (unsigned long long)st.hits, (unsigned long long)st.shadow,
+                    (unsigned long long)st.occluded, (unsigned long long)st.sphere_tests, (unsigned long long)st.bound_tests, st.device_ms);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "thread 'main' panicked at '%s'\n", e.what());
+        status = 101;
+    }
+    if (sink.is_file) fclose(sink.f); else fflush(stdout);
+    return status;                                                // process::exit(0)  main.rs:89
+}

@@ -1,0 +1,139 @@
+#include "render.hpp"
+
+#include <unistd.h>
+
+#include <exception>
+
+namespace rtrace {
+
+static constexpr uint16_t CHUNK_SIZE = 64;                        // render.rs:264
+
+static void check(rt_status st, const char *what)
+{
+    if (st != RT_OK)
+        throw std::runtime_error(std::string(what) + ": " + rt_strerror(st) + " -- " + rt_last_error_message());
+}
+
+DeviceScene::DeviceScene(const Scene &scene, int device)
+{
+    const FlatScene f = scene.flatten();
+    const RFloat light[3] = { scene.directional_light.x, scene.directional_light.y, scene.directional_light.z };
+    const RFloat eye[3] = { scene.eye.x, scene.eye.y, scene.eye.z };
+    const rt_precision prec = sizeof(RFloat) == 4 ? RT_F32 : RT_F64;
+    static_assert(sizeof(rt_range) == 2 * sizeof(int32_t), "ranges are {first, count} pairs");
+    check(rt_scene_create(device, prec, f.items.data(), (uint32_t)(f.items.size() / 4), light, eye, f.bounds.data(),
+                          reinterpret_cast<const rt_range *>(f.ranges.data()), (uint32_t)(f.ranges.size() / 2), &h_),
+          "rt_scene_create");
+}
+
+void PPMStdoutRGBABufferWriter::write_buffer_with_header()
+{
+    if (!buffer_dirty_) return;
+    FILE *out = out_.f;
+    if (out_.is_file) {                                           // set_len(0) + seek(Start(0))  render.rs:366-367
+        fflush(out);
+        if (ftruncate(fileno(out), 0) != 0) throw std::runtime_error("called `Result::unwrap()` on an `Err` value: ftruncate");
+        fseek(out, 0, SEEK_SET);
+    }
+    if (!width_ || !height_) throw std::runtime_error("begin() called");
+    fprintf(out, "%s\n%u %u\n255\n", rgb_ ? "P6" : "P5", (unsigned)*width_, (unsigned)*height_);
+    const std::vector<uint8_t> &buf = image_->buffer();
+    std::vector<uint8_t> line;
+    line.reserve(buf.size() / 4 * 3);
+    for (size_t po = 0; po < buf.size(); po += RGBABuffer::components()) {
+        const uint8_t *b = &buf[po];
+        if (rgb_) { line.push_back(b[0]); line.push_back(b[1]); line.push_back(b[2]); }
+        else line.push_back((uint8_t)(((float)b[0] + (float)b[1] + (float)b[2]) / 3.0f));      // render.rs:399
+    }
+    if (fwrite(line.data(), 1, line.size(), out) != line.size()) throw std::runtime_error("called `Result::unwrap()` on an `Err` value: write");
+    fflush(out);
+    buffer_dirty_ = false;
+}
+
+std::vector<ImageRegion> Renderer::buckets(const RenderOptions &o)
+{
+    // render.rs:273-298: row-major, y outer.  The reference asserts w % 64 == 0 && h % 64 == 0 (render.rs:265-266);
+    // edge buckets are clipped here instead so that 800x600 and 1920x1080 render (a pixel does not depend on its bucket).
+    std::vector<ImageRegion> out;
+    for (uint32_t y = 0; y < o.height; y += CHUNK_SIZE)
+        for (uint32_t x = 0; x < o.width; x += CHUNK_SIZE)
+            out.push_back(ImageRegion{ (uint16_t)x, (uint16_t)std::min<uint32_t>(y + CHUNK_SIZE, o.height),
+                                       (uint16_t)std::min<uint32_t>(x + CHUNK_SIZE, o.width), (uint16_t)y });
+    return out;
+}
+
+RenderStats Renderer::render(const RenderOptions &o, const Backend &be, RGBABufferWriter &writer, ThreadPool &pool)
+{
+    if (be.devices.empty()) throw std::runtime_error("no device scene: the HIP backend has no CPU fallback");
+    writer.begin(o.width, o.height);
+
+    const std::vector<ImageRegion> all = buckets(o);
+    size_t count = all.size();
+    // Deal buckets round-robin over the devices, then cut each device's list into batches: one rt_render_tiles call
+    // per batch (a launch per 64x64 bucket would leave 255 of 256 CUs idle).
+    const size_t ndev = be.devices.size();
+    struct Batch { size_t dev; std::vector<ImageRegion> regs; };
+    std::vector<Batch> batches;
+    for (size_t d = 0; d < ndev; ++d) {
+        std::vector<ImageRegion> mine;
+        for (size_t i = d; i < all.size(); i += ndev) mine.push_back(all[i]);
+        const size_t calls = std::max<size_t>(1, (pool.size() + ndev - 1) / ndev);
+        const size_t per = be.buckets_per_call ? be.buckets_per_call : std::max<size_t>(1, (mine.size() + calls - 1) / calls);
+        for (size_t i = 0; i < mine.size(); i += per)
+            batches.push_back(Batch{ d, std::vector<ImageRegion>(mine.begin() + i, mine.begin() + std::min(mine.size(), i + per)) });
+    }
+
+    // One message per finished bucket plus one end-of-batch marker (which carries the batch's failure, if any).
+    struct Msg { std::optional<RGBABuffer> buf; bool batch_end = false; std::exception_ptr err; };
+    SyncChannel<Msg> chan(4);                                     // sync_channel::<RGBABuffer>(4)  render.rs:271
+    const rt_options opts{ o.width, o.height, o.samples_per_pixel };
+    RenderStats total;
+    std::mutex stats_mu;
+
+    for (const Batch &b : batches) {
+        pool.execute([&, b] {
+            std::exception_ptr err;
+            try {
+                static_assert(sizeof(ImageRegion) == sizeof(rt_region), "ImageRegion is layout-compatible with rt_region");
+                size_t px = 0;
+                for (const ImageRegion &r : b.regs) px += r.area();
+                std::vector<uint8_t> rgba(px * 4);
+                rt_stats st{};
+                check(rt_render_tiles(be.devices[b.dev]->handle(), &opts, be.traversal,
+                                      reinterpret_cast<const rt_region *>(b.regs.data()), (uint32_t)b.regs.size(), rgba.data(), &st),
+                      "rt_render_tiles");
+                {
+                    std::lock_guard<std::mutex> lk(stats_mu);
+                    total.primary += st.primary; total.hits += st.hits; total.shadow += st.shadow; total.occluded += st.occluded;
+                    total.sphere_tests += st.sphere_tests; total.bound_tests += st.bound_tests; total.device_ms += st.device_ms;
+                }
+                size_t off = 0;
+                for (const ImageRegion &r : b.regs) {
+                    chan.send(Msg{ RGBABuffer(r, rgba.data() + off), false, nullptr });      // tx.send(b)  render.rs:293
+                    off += r.area() * 4;
+                }
+            } catch (...) {
+                err = std::current_exception();
+            }
+            chan.send(Msg{ std::nullopt, true, err });
+        });
+    }
+
+    // Read the results and pass them to the writer  render.rs:300-307
+    std::exception_ptr first_err;
+    for (size_t open = batches.size(); open > 0;) {
+        Msg m = chan.recv();
+        if (m.batch_end) {
+            if (m.err && !first_err) first_err = m.err;
+            --open;
+        } else if (!first_err) {
+            writer.write_rgba_buffer(*m.buf);
+            count -= 1;
+        }
+    }
+    if (first_err) std::rethrow_exception(first_err);             // the reference panics here
+    if (count != 0) throw std::runtime_error("We really should have processed all chunks here");   // render.rs:308-309
+    return total;
+}
+
+}  // namespace rtrace

@@ -1,0 +1,137 @@
+// render.hpp -- host-side mirror of render.rs around the device seam.
+//
+// Everything here is what STAYS on the host when the backend is dropped in behind the crate: RenderOptions,
+// ImageRegion, RGBABuffer, the RGBABufferWriter trait, the PPM writer and the 64x64 bucket scheduler.  The one call
+// that moved is the closure body of render.rs:283-294 (RGBABuffer::new + Renderer::render_region): it is now
+// rt_render_tiles() on a batch of buckets (include/rtrace_hip.h).  No pixel arithmetic happens on the host.
+#pragma once
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/rtrace_hip.h"
+#include "scene.hpp"
+#include "threadpool.hpp"
+
+namespace rtrace {
+
+struct RenderOptions {                                            // render.rs:33-38
+    uint16_t width, height, samples_per_pixel;
+};
+
+struct ImageRegion {                                              // render.rs:42-72
+    uint16_t l, t, r, b;
+    uint16_t width() const { return r - l; }
+    uint16_t height() const { return t - b; }
+    size_t area() const { return (size_t)width() * (size_t)height(); }
+    bool contains(const ImageRegion &o) const { return o.l >= l && o.b >= b && o.t <= t && o.r <= r; }
+    size_t buffer_offset(uint16_t x, uint16_t y) const { return (size_t)(y - b) * width() + (size_t)(x - l); }
+    bool operator==(const ImageRegion &o) const { return l == o.l && t == o.t && r == o.r && b == o.b; }
+};
+
+class RGBABuffer {                                                // render.rs:74-135
+public:
+    explicit RGBABuffer(const ImageRegion &r) : buf_(r.area() * components(), 0), reg_(r) {}
+    RGBABuffer(const ImageRegion &r, const uint8_t *src) : buf_(src, src + r.area() * components()), reg_(r) {}
+    static size_t components() { return 4; }
+
+    void set_pixels_from_buffer(const RGBABuffer &b)              // render.rs:112-126
+    {
+        if (!reg_.contains(b.reg_)) throw std::runtime_error("assertion failed: self.reg.contains(&b.reg)");
+        const size_t w = (size_t)b.reg_.width() * components();
+        if (reg_ == b.reg_) { buf_ = b.buf_; return; }
+        for (uint16_t y = b.reg_.b; y < b.reg_.t; ++y) {
+            const size_t bl = reg_.buffer_offset(b.reg_.l, y) * components();
+            const size_t their = b.reg_.buffer_offset(b.reg_.l, y) * components();
+            std::copy(b.buf_.begin() + their, b.buf_.begin() + their + w, buf_.begin() + bl);
+        }
+    }
+    const std::vector<uint8_t> &buffer() const { return buf_; }
+    const ImageRegion &region() const { return reg_; }
+
+private:
+    std::vector<uint8_t> buf_;
+    ImageRegion reg_;
+};
+
+struct RGBABufferWriter {                                         // trait, render.rs:20-30
+    virtual ~RGBABufferWriter() = default;
+    virtual void begin(uint16_t x, uint16_t y) = 0;
+    virtual void write_rgba_buffer(const RGBABuffer &buffer) = 0;
+};
+
+struct FileOrAnyWriter {                                          // render.rs:313-316
+    FILE *f = nullptr;
+    bool is_file = false;
+};
+
+class PPMStdoutRGBABufferWriter : public RGBABufferWriter {       // render.rs:319-434
+public:
+    PPMStdoutRGBABufferWriter(bool write_rgb, FileOrAnyWriter &out) : out_(out), rgb_(write_rgb) {}
+    ~PPMStdoutRGBABufferWriter() override                         // Drop, render.rs:331-335
+    {
+        try { write_buffer_with_header(); } catch (...) {}
+    }
+
+    void begin(uint16_t x, uint16_t y) override                   // render.rs:411-420
+    {
+        width_ = x; height_ = y;
+        image_.emplace(ImageRegion{ 0, y, x, 0 });
+    }
+    void write_rgba_buffer(const RGBABuffer &buffer) override     // render.rs:422-433
+    {
+        image_->set_pixels_from_buffer(buffer);
+        buffer_dirty_ = true;
+        const auto now = std::chrono::steady_clock::now();
+        if (out_.is_file && (!last_written_at_ || *last_written_at_ + std::chrono::seconds(1) <= now)) {
+            last_written_at_ = now;
+            write_buffer_with_header();
+        }
+    }
+    void write_buffer_with_header();                              // render.rs:359-407
+
+private:
+    FileOrAnyWriter &out_;
+    std::optional<uint16_t> width_, height_;
+    std::optional<RGBABuffer> image_;
+    bool rgb_;
+    std::optional<std::chrono::steady_clock::time_point> last_written_at_;
+    bool buffer_dirty_ = false;
+};
+
+// Device copies of a Scene on one GPU (replaces handing Arc<Scene> to the pool threads, render.rs:279).
+class DeviceScene {
+public:
+    DeviceScene(const Scene &scene, int device);
+    ~DeviceScene() { rt_scene_destroy(h_); }
+    DeviceScene(const DeviceScene &) = delete;
+    DeviceScene &operator=(const DeviceScene &) = delete;
+    rt_scene *handle() const { return h_; }
+
+private:
+    rt_scene *h_ = nullptr;
+};
+
+struct RenderStats {
+    uint64_t primary = 0, hits = 0, shadow = 0, occluded = 0, sphere_tests = 0, bound_tests = 0;
+    double device_ms = 0;
+};
+
+struct Backend {                                                  // additions that do not exist in the reference
+    std::vector<std::shared_ptr<DeviceScene>> devices;            // buckets are dealt round-robin over these
+    rt_traversal traversal = RT_TRAVERSAL_SKIP;
+    size_t buckets_per_call = 0;                                  // 0 = split each device's buckets evenly over the pool
+};
+
+struct Renderer {
+    // render.rs:260-310.  `pool` keeps the reference's meaning (RTRACEMAXPROCS / --num-cores host scheduler threads).
+    static RenderStats render(const RenderOptions &o, const Backend &backend, RGBABufferWriter &writer, ThreadPool &pool);
+    static std::vector<ImageRegion> buckets(const RenderOptions &o);
+};
+
+}  // namespace rtrace

@@ -71,6 +71,10 @@ struct rt_scene {
     double light[3] = { 0, 0, 0 }, eye[3] = { 0, 0, 0 };   // exact copies of the REAL values
     std::mutex mu;
     std::vector<std::unique_ptr<Context>> pool;
+    // Immutable device copies of recently used tile tables (a scheduler re-submits the same bucket list every
+    // frame): a hit means a pass enqueues nothing but its kernel.
+    struct CachedTable { std::vector<rt::TileDev> host; rt::TileDev *dev = nullptr; };
+    std::vector<CachedTable> tables;
 };
 
 namespace {
@@ -230,6 +234,11 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
     return RT_OK;
 }
 
+constexpr size_t kMaxCachedTables = 32;
+
+// Device copy of `tab`: from the scene's cache when seen before (or cacheable now), else through the context.
+rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, const rt::TileDev **out);
+
 // Copies the tile table through the context's pinned buffer; truly asynchronous on `stream`.
 rt_status upload_tiles(Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream)
 {
@@ -247,6 +256,29 @@ rt_status upload_tiles(Context *c, const std::vector<rt::TileDev> &tab, hipStrea
     return RT_OK;
 }
 
+rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, const rt::TileDev **out)
+{
+    const size_t bytes = tab.size() * sizeof(rt::TileDev);
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        for (auto &t : s->tables)
+            if (t.host.size() == tab.size() && memcmp(t.host.data(), tab.data(), bytes) == 0) { *out = t.dev; return RT_OK; }
+        if (s->tables.size() < kMaxCachedTables) {
+            rt_scene::CachedTable t;
+            HIP_TRY(hipMalloc(&t.dev, bytes));
+            hipError_t e = hipMemcpy(t.dev, tab.data(), bytes, hipMemcpyHostToDevice);    // blocking, once per table
+            if (e != hipSuccess) { (void)hipFree(t.dev); return hip_fail(e, "hipMemcpy(tile table)", __LINE__); }
+            t.host = tab;
+            *out = t.dev;
+            s->tables.push_back(std::move(t));
+            return RT_OK;
+        }
+    }
+    rt_status st = upload_tiles(c, tab, stream);
+    if (st == RT_OK) *out = c->d_tiles;
+    return st;
+}
+
 // Enqueues every kernel of one pass on `stream`.  d_out must hold 4 * total_px bytes.
 rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversal trav, const std::vector<rt::TileDev> &tab,
                        uint32_t total_blocks, uint8_t *d_out, hipStream_t stream, bool want_counters)
@@ -259,8 +291,9 @@ rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversa
         snprintf(g_err, sizeof g_err, "RT_TRAVERSAL_SKIP needs a scene created with subtree bounds");
         return RT_ERR_UNSUPPORTED;
     }
+    const rt::TileDev *d_tab = nullptr;
     {
-        rt_status ust = upload_tiles(c, tab, stream);
+        rt_status ust = device_table(s, c, tab, stream, &d_tab);
         if (ust != RT_OK) return ust;
     }
     if (want_counters) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(rt::Counters), stream));
@@ -271,15 +304,15 @@ rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversa
     const unsigned w = o->width, h = o->height, spp = o->samples_per_pixel, nt = (unsigned)tab.size();
     if (trav == RT_TRAVERSAL_FLAT) {
         if (s->precision == RT_F32)
-            hipLaunchKernelGGL((rt::k_render_fused<float, 1024>), grid, block, 0, stream, view_of<float>(s), w, h, spp, c->d_tiles, nt, d_out, cnt);
+            hipLaunchKernelGGL((rt::k_render_fused<float, 1024>), grid, block, 0, stream, view_of<float>(s), w, h, spp, d_tab, nt, d_out, cnt);
         else
-            hipLaunchKernelGGL((rt::k_render_fused<double, 512>), grid, block, 0, stream, view_of<double>(s), w, h, spp, c->d_tiles, nt, d_out, cnt);
+            hipLaunchKernelGGL((rt::k_render_fused<double, 512>), grid, block, 0, stream, view_of<double>(s), w, h, spp, d_tab, nt, d_out, cnt);
     } else if (s->precision == RT_F32) {
-        if (cnt) hipLaunchKernelGGL((rt::k_render_skip<float, true>), grid, block, 0, stream, skip_view_of<float>(s), w, h, spp, c->d_tiles, nt, d_out, cnt);
-        else hipLaunchKernelGGL((rt::k_render_skip<float, false>), grid, block, 0, stream, skip_view_of<float>(s), w, h, spp, c->d_tiles, nt, d_out, cnt);
+        if (cnt) hipLaunchKernelGGL((rt::k_render_skip<float, true>), grid, block, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt, d_out, cnt);
+        else hipLaunchKernelGGL((rt::k_render_skip<float, false>), grid, block, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt, d_out, cnt);
     } else {
-        if (cnt) hipLaunchKernelGGL((rt::k_render_skip<double, true>), grid, block, 0, stream, skip_view_of<double>(s), w, h, spp, c->d_tiles, nt, d_out, cnt);
-        else hipLaunchKernelGGL((rt::k_render_skip<double, false>), grid, block, 0, stream, skip_view_of<double>(s), w, h, spp, c->d_tiles, nt, d_out, cnt);
+        if (cnt) hipLaunchKernelGGL((rt::k_render_skip<double, true>), grid, block, 0, stream, skip_view_of<double>(s), w, h, spp, d_tab, nt, d_out, cnt);
+        else hipLaunchKernelGGL((rt::k_render_skip<double, false>), grid, block, 0, stream, skip_view_of<double>(s), w, h, spp, d_tab, nt, d_out, cnt);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, stream));
@@ -442,6 +475,7 @@ rt_status rt_scene_destroy(rt_scene *s)
     if (!s) return RT_OK;
     (void)hipSetDevice(s->device);
     s->pool.clear();
+    for (auto &t : s->tables) (void)hipFree(t.dev);
     if (s->d_items) (void)hipFree(s->d_items);
     if (s->d_bounds) (void)hipFree(s->d_bounds);
     if (s->d_ranges) (void)hipFree(s->d_ranges);
@@ -523,8 +557,9 @@ rt_status rt_blit_tiles_device(rt_scene *s, const rt_options *o, const rt_region
     if ((st = acquire(s, &c)) != RT_OK) return st;
     Lease lease{ s, c };
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    if ((st = upload_tiles(c, tab, stream)) != RT_OK) return st;
-    hipLaunchKernelGGL(rt::k_blit_tiles, dim3(total_blocks), dim3(rt::kBlockThreads), 0, stream, (unsigned)o->width, c->d_tiles,
+    const rt::TileDev *d_tab = nullptr;
+    if ((st = device_table(s, c, tab, stream, &d_tab)) != RT_OK) return st;
+    hipLaunchKernelGGL(rt::k_blit_tiles, dim3(total_blocks), dim3(rt::kBlockThreads), 0, stream, (unsigned)o->width, d_tab,
                        (unsigned)n, static_cast<const unsigned *>(src), static_cast<unsigned *>(frame));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, stream));

@@ -1,0 +1,124 @@
+"""The `rtrace` binary (C++ host mirror of main.rs:22-90) -- flag / env / exit-status behaviour on CPU, bytes of the
+written PPM on the GPU."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTRACE = os.path.join(ROOT, "rust-tracer_amd", "rtrace")
+RTRACE64 = os.path.join(ROOT, "rust-tracer_amd", "rtrace64")
+HOST_TESTS = os.path.join(ROOT, "rust-tracer_amd", "host_tests")
+
+
+def run(args, env=None, exe=RTRACE, cwd=None):
+    e = dict(os.environ)
+    e.pop("RTRACEMAXPROCS", None)
+    e.update(env or {})
+    return subprocess.run([exe] + args, capture_output=True, env=e, cwd=cwd, timeout=600)
+
+
+def test_binaries_built():
+    for p in (RTRACE, RTRACE64, HOST_TESTS):
+        assert os.access(p, os.X_OK), "%s missing: run __graft_entry__.build()" % p
+
+
+def test_host_unit_tests_pass():
+    r = subprocess.run([HOST_TESTS], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"host_tests ok" in r.stdout
+
+
+def test_version_and_help():
+    assert run(["--version"]).stdout.strip() == b"rtrace 0.2.0"          # main.rs:33
+    h = run(["--help"])
+    assert h.returncode == 0
+    for flag in (b"--width", b"--height", b"--samples-per-pixel", b"--num-cores", b"RTRACEMAXPROCS", b"<output>"):
+        assert flag in h.stdout
+
+
+def test_missing_output_is_a_usage_error():
+    r = run([])
+    assert r.returncode == 1 and b"<output>" in r.stderr                  # clap: required(true), exit status 1
+
+
+def test_wrong_extension_prints_hint_and_exits_zero(tmp_path):
+    # main.rs:66-70: println! + return (status 0), nothing is written
+    r = run([str(tmp_path / "picture.png")])
+    assert r.returncode == 0
+    assert b"must have the tga extension, e.g." in r.stdout and b"picture.tga" in r.stdout
+    assert not (tmp_path / "picture.png").exists()
+
+
+@pytest.mark.parametrize("args", [["--width=abc", "o.tga"], ["--height=70000", "o.tga"], ["--samples-per-pixel=-1", "o.tga"],
+                                  ["--num-cores=x", "o.tga"]])
+def test_unparsable_numbers_panic_like_unwrap(args, tmp_path):
+    r = run(args, cwd=str(tmp_path))                                      # .parse().unwrap() -> exit status 101
+    assert r.returncode == 101 and b"panicked" in r.stderr
+
+
+def _have_gpu():
+    import rust_tracer_amd as rta
+    return rta.device_count() > 0
+
+
+@pytest.mark.skipif(_have_gpu(), reason="no-device behaviour")
+def test_without_a_gpu_it_fails_loudly(tmp_path):
+    r = run(["--width=64", "--height=64", str(tmp_path / "o.tga")])
+    assert r.returncode == 101 and b"no usable gfx950 device" in r.stderr
+
+
+def _oracle_ppm(tmp_path, w, h, spp, prec=oracle.F32, level=8):
+    o = oracle.Scene.default(prec, level)
+    img, st, _ = o.render(w, h, spp, nthreads=os.cpu_count() or 1)
+    p = str(tmp_path / "ref.ppm")
+    oracle.write_ppm(p, img)
+    return open(p, "rb").read(), st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trav", ["skip", "flat"])
+@pytest.mark.parametrize("env,extra", [({}, []), ({"RTRACEMAXPROCS": "4"}, []), ({"RTRACEMAXPROCS": "2"}, ["--num-cores=3"])])
+def test_cli_writes_the_reference_bytes(tmp_path, trav, env, extra):
+    out = str(tmp_path / "out.tga")
+    r = run(["--width=256", "--height=192", "--samples-per-pixel=2", "--traversal=" + trav, "--stats"] + extra + [out], env)
+    assert r.returncode == 0, r.stderr.decode()
+    ref, st = _oracle_ppm(tmp_path, 256, 192, 2)
+    assert open(out, "rb").read() == ref
+    assert ("primary %d hits %d shadow %d occluded %d" % (st["primary"], st["hits"], st["shadow"], st["occluded"])).encode() in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_stdout_sink_and_clipped_sizes(tmp_path):
+    r = run(["--width=200", "--height=150", "-"])                        # `-` = stdout  main.rs:64,74-75
+    assert r.returncode == 0, r.stderr.decode()
+    ref, _ = _oracle_ppm(tmp_path, 200, 150, 1)
+    assert r.stdout == ref
+
+
+@pytest.mark.gpu
+def test_cli_f64_type_alias_swap(tmp_path):
+    out = str(tmp_path / "out.tga")
+    r = run(["--width=320", "--height=256", out], exe=RTRACE64)
+    assert r.returncode == 0, r.stderr.decode()
+    ref, _ = _oracle_ppm(tmp_path, 320, 256, 1, oracle.F64)
+    assert open(out, "rb").read() == ref
+
+
+@pytest.mark.gpu
+def test_make_image_reproduces_the_reference_image(tmp_path, golden_dir):
+    # `make image` (Makefile:6-7 of the reference): --samples-per-pixel=4 --width=1024 --height=768 out.tga
+    out = str(tmp_path / "out.tga")
+    r = run(["--samples-per-pixel=4", "--width=1024", "--height=768", out])
+    assert r.returncode == 0, r.stderr.decode()
+    data = open(out, "rb").read()
+    head = b"P6\n1024 768\n255\n"
+    assert data.startswith(head)
+    rgb = np.frombuffer(data[len(head):], dtype=np.uint8).reshape(768, 1024, 3)
+    ref = np.load(os.path.join(golden_dir, "make_image_1024x768_spp4_rgb.npz"))["rgb"]
+    assert int((rgb != ref).any(axis=2).sum()) == 0
+    assert hashlib.md5(data).hexdigest() == "63e866ff6d39850bbcf0fcea87024d19"
