@@ -1,5 +1,6 @@
 # Same targets as the reference's Makefile (/root/reference/Makefile:1-7): `make image` builds the renderer and
 # renders the 1024x768, 16-samples-per-pixel image to out.tga -- here through the MI355X backend.
+SHELL := /bin/bash
 .PHONY: all rtrace image test clean
 
 all: rtrace
