@@ -139,6 +139,10 @@ rt_status rt_blit_tiles_device(rt_scene *scene, const rt_options *options, const
 /* Bytes rt_render_tiles writes for this tile list (4 * total area), or 0 on an invalid list. */
 uint64_t rt_tiles_rgba_bytes(const rt_region *tiles, uint32_t n_tiles);
 
+/* Device self-test: compares the traversal loops' lean correctly-rounded f32 sqrt with the compiler's IEEE sqrt on
+ * ALL 2^32 bit patterns; *mismatches must come back 0 (first_bad_bits = 0xFFFFFFFF).  ~10 ms on an MI355X. */
+rt_status rt_selftest_sqrt(int device, uint64_t *mismatches, uint32_t *first_bad_bits);
+
 const char *rt_strerror(rt_status status);
 /* Detail of the last RT_ERR_HIP on the calling thread (static thread-local storage; never NULL). */
 const char *rt_last_error_message(void);

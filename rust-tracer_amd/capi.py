@@ -15,7 +15,7 @@ ABI_VERSION = 1
 
 # every symbol include/rtrace_hip.h declares
 SYMBOLS = ("rt_abi_version", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render_tiles",
-           "rt_render_tiles_device", "rt_render_region", "rt_blit_tiles_device", "rt_tiles_rgba_bytes", "rt_strerror", "rt_last_error_message")
+           "rt_render_tiles_device", "rt_render_region", "rt_blit_tiles_device", "rt_selftest_sqrt", "rt_tiles_rgba_bytes", "rt_strerror", "rt_last_error_message")
 
 
 class Options(C.Structure):      # rt_options / RenderOptions render.rs:33-38
@@ -60,6 +60,7 @@ lib.rt_render_tiles_device.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, 
 lib.rt_render_region.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.POINTER(Region), C.c_void_p, C.POINTER(Stats)]
 lib.rt_blit_tiles_device.argtypes = [C.c_void_p, C.POINTER(Options), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]
+lib.rt_selftest_sqrt.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
 lib.rt_tiles_rgba_bytes.restype = C.c_uint64
 lib.rt_tiles_rgba_bytes.argtypes = [C.c_void_p, C.c_uint32]
 lib.rt_strerror.restype = C.c_char_p
@@ -83,3 +84,10 @@ def device_count():
     n = C.c_int(0)
     st = lib.rt_device_count(C.byref(n))
     return n.value if st == RT_OK else 0
+
+
+def selftest_sqrt(device=0):
+    """rt_selftest_sqrt -> (mismatches, first_bad_bits) over all 2^32 f32 bit patterns."""
+    bad, first = C.c_uint64(0), C.c_uint32(0)
+    check(lib.rt_selftest_sqrt(device, C.byref(bad), C.byref(first)), "rt_selftest_sqrt")
+    return bad.value, first.value

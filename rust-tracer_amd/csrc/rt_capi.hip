@@ -7,8 +7,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -42,6 +44,9 @@ struct Context {
     rt::Counters *d_counters = nullptr;
     uint8_t *d_out = nullptr;
     size_t out_cap = 0;
+    void *d_sample_gdot = nullptr;    // SPLIT path: per-sample n.light [spp*spp][n_px] (REAL)
+    uint8_t *d_sample_state = nullptr;
+    size_t sample_cap = 0;            // bytes of d_sample_gdot
     bool busy = false;       // leased to a caller right now
     bool inflight = false;   // released by an asynchronous caller; reusable once ev1 has completed
 
@@ -51,6 +56,8 @@ struct Context {
         if (h_tiles) (void)hipHostFree(h_tiles);
         if (d_counters) (void)hipFree(d_counters);
         if (d_out) (void)hipFree(d_out);
+        if (d_sample_gdot) (void)hipFree(d_sample_gdot);
+        if (d_sample_state) (void)hipFree(d_sample_state);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -95,7 +102,7 @@ rt_status acquire(rt_scene *s, Context **out)
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
-    HIP_TRY(hipMalloc(&c->d_counters, sizeof(rt::Counters)));
+    HIP_TRY(hipMalloc(&c->d_counters, sizeof(rt::Counters) * rt::kCounterStripes));
     c->busy = true;
     *out = c.get();
     s->pool.push_back(std::move(c));
@@ -220,8 +227,11 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
     rt::RawNode<T> *d_raw = nullptr;
     HIP_TRY(hipMalloc(&d_raw, sizeof(rt::RawNode<T>) * raw.size()));
     hipError_t e = hipMemcpy(d_raw, raw.data(), sizeof(rt::RawNode<T>) * raw.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&s->d_prim, sizeof(rt::Node<T>) * raw.size());
-    if (e == hipSuccess) e = hipMalloc(&s->d_shad, sizeof(rt::Node<T>) * raw.size());
+    // one zeroed pad node at [n]: the traversal prefetches nodes[i + 1] without a bounds check
+    if (e == hipSuccess) e = hipMalloc(&s->d_prim, sizeof(rt::Node<T>) * (raw.size() + 1));
+    if (e == hipSuccess) e = hipMalloc(&s->d_shad, sizeof(rt::Node<T>) * (raw.size() + 1));
+    if (e == hipSuccess) e = hipMemset(s->d_prim, 0, sizeof(rt::Node<T>) * (raw.size() + 1));
+    if (e == hipSuccess) e = hipMemset(s->d_shad, 0, sizeof(rt::Node<T>) * (raw.size() + 1));
     if (e == hipSuccess) {
         const rt::V3<T> eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
         hipLaunchKernelGGL((rt::k_build_streams<T>), dim3((s->n_nodes + 255) / 256), dim3(256), 0, nullptr, d_raw, s->n_nodes, eye,
@@ -279,9 +289,72 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
     return st;
 }
 
+// Tuning variant of k_render_skip (rt_skip.hpp VAR bits); RT_SKIP_VARIANT overrides the default for A/B runs.
+constexpr int kSkipVariantDefault = 0;
+
+int skip_variant()
+{
+    // read per call so one process can interleave variants (A/B timing in tools/ab_skip.py)
+    const char *e = getenv("RT_SKIP_VARIANT");
+    return e ? atoi(e) & 3 : kSkipVariantDefault;
+}
+
+// spp > 1 runs sample-parallel (one thread per sample + a resolve pass) unless spp*spp exceeds grid.y's limit.
+bool use_split(unsigned spp) { return spp > 1 && (unsigned long long)spp * spp <= 65535ull; }
+
+template <typename T, bool COUNT, int VAR>
+rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t stream, unsigned w, unsigned h, unsigned spp,
+                          const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt)
+{
+    const dim3 b(rt::kBlockThreads);
+    rt::SampleBuf<T> sb{ nullptr, nullptr, (unsigned)total_px };
+    if (!use_split(spp)) {
+        hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, false>), grid, b, 0, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb);
+        return RT_OK;
+    }
+    const size_t ns = (size_t)spp * spp, need = ns * total_px * sizeof(T);
+    if (c->sample_cap < need) {
+        if (c->d_sample_gdot) HIP_TRY(hipFree(c->d_sample_gdot));
+        if (c->d_sample_state) HIP_TRY(hipFree(c->d_sample_state));
+        c->d_sample_gdot = nullptr; c->d_sample_state = nullptr; c->sample_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_sample_gdot, need));
+        HIP_TRY(hipMalloc(&c->d_sample_state, ns * total_px));
+        c->sample_cap = need;
+    }
+    sb.gdot = static_cast<T *>(c->d_sample_gdot);
+    sb.state = c->d_sample_state;
+    hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, true>), dim3(grid.x, (unsigned)ns), b, 0, stream, skip_view_of<T>(s), w, h, spp, d_tab,
+                       nt, d_out, cnt, sb);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL((rt::k_resolve_samples<T>), dim3((unsigned)((total_px + 255) / 256)), dim3(256), 0, stream, sb, spp, d_out);
+    return RT_OK;
+}
+
+template <typename T, bool COUNT>
+rt_status launch_skip_var(const rt_scene *s, Context *c, dim3 grid, hipStream_t stream, unsigned w, unsigned h, unsigned spp,
+                          const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt)
+{
+    switch (skip_variant()) {
+    case 1: return launch_skip_one<T, COUNT, 1>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt);
+    case 2: return launch_skip_one<T, COUNT, 2>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt);
+    case 3: return launch_skip_one<T, COUNT, 3>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt);
+    default: return launch_skip_one<T, COUNT, 0>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt);
+    }
+}
+
+rt_status launch_skip(const rt_scene *s, Context *c, dim3 grid, hipStream_t stream, unsigned w, unsigned h, unsigned spp,
+                      const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt)
+{
+    if (s->precision == RT_F32)
+        return cnt ? launch_skip_var<float, true>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt)
+                   : launch_skip_var<float, false>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt);
+    return cnt ? launch_skip_var<double, true>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt)
+               : launch_skip_var<double, false>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt);
+}
+
 // Enqueues every kernel of one pass on `stream`.  d_out must hold 4 * total_px bytes.
 rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversal trav, const std::vector<rt::TileDev> &tab,
-                       uint32_t total_blocks, uint8_t *d_out, hipStream_t stream, bool want_counters)
+                       uint32_t total_blocks, uint64_t total_px, uint8_t *d_out, hipStream_t stream, bool want_counters)
 {
     if (trav != RT_TRAVERSAL_FLAT && trav != RT_TRAVERSAL_SKIP) {
         snprintf(g_err, sizeof g_err, "unknown traversal %d", (int)trav);
@@ -296,7 +369,7 @@ rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversa
         rt_status ust = device_table(s, c, tab, stream, &d_tab);
         if (ust != RT_OK) return ust;
     }
-    if (want_counters) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(rt::Counters), stream));
+    if (want_counters) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(rt::Counters) * rt::kCounterStripes, stream));
     rt::Counters *cnt = want_counters ? c->d_counters : nullptr;
 
     HIP_TRY(hipEventRecord(c->ev0, stream));
@@ -307,12 +380,9 @@ rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversa
             hipLaunchKernelGGL((rt::k_render_fused<float, 1024>), grid, block, 0, stream, view_of<float>(s), w, h, spp, d_tab, nt, d_out, cnt);
         else
             hipLaunchKernelGGL((rt::k_render_fused<double, 512>), grid, block, 0, stream, view_of<double>(s), w, h, spp, d_tab, nt, d_out, cnt);
-    } else if (s->precision == RT_F32) {
-        if (cnt) hipLaunchKernelGGL((rt::k_render_skip<float, true>), grid, block, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt, d_out, cnt);
-        else hipLaunchKernelGGL((rt::k_render_skip<float, false>), grid, block, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt, d_out, cnt);
     } else {
-        if (cnt) hipLaunchKernelGGL((rt::k_render_skip<double, true>), grid, block, 0, stream, skip_view_of<double>(s), w, h, spp, d_tab, nt, d_out, cnt);
-        else hipLaunchKernelGGL((rt::k_render_skip<double, false>), grid, block, 0, stream, skip_view_of<double>(s), w, h, spp, d_tab, nt, d_out, cnt);
+        rt_status lst = launch_skip(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt);
+        if (lst != RT_OK) return lst;
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, stream));
@@ -321,14 +391,26 @@ rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversa
 
 rt_status read_stats(rt_scene *s, Context *c, hipStream_t stream, rt_traversal trav, rt_stats *st)
 {
-    rt::Counters h;
-    HIP_TRY(hipMemcpyAsync(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, stream));
+    std::vector<rt::Counters> stripes(rt::kCounterStripes);
+    HIP_TRY(hipMemcpyAsync(stripes.data(), c->d_counters, sizeof(rt::Counters) * rt::kCounterStripes, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    rt::Counters h{};
+    for (const rt::Counters &k : stripes) {
+        h.primary += k.primary; h.hits += k.hits; h.shadow += k.shadow; h.occluded += k.occluded;
+        h.sphere_tests += k.sphere_tests; h.bound_tests += k.bound_tests; h.wave_steps += k.wave_steps;
+        h.max_wave_steps = std::max(h.max_wave_steps, k.max_wave_steps);
+        h.max_wave_cycles = std::max(h.max_wave_cycles, k.max_wave_cycles);
+        h.max_wave_ref100mhz = std::max(h.max_wave_ref100mhz, k.max_wave_ref100mhz);
+    }
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     st->primary = h.primary; st->hits = h.hits; st->shadow = h.shadow; st->occluded = h.occluded;
     if (trav == RT_TRAVERSAL_FLAT) { st->sphere_tests = (h.primary + h.shadow) * (uint64_t)s->n_items; st->bound_tests = 0; }
     else { st->sphere_tests = h.sphere_tests; st->bound_tests = h.bound_tests; }
+    if (getenv("RT_DEBUG_STEPS"))
+        fprintf(stderr, "[rtrace_hip] wave_steps %llu max_wave_steps %llu longest wave: %llu cycles, %.2f us, %.0f MHz\n", h.wave_steps,
+                h.max_wave_steps, h.max_wave_cycles, h.max_wave_ref100mhz / 100.0,
+                h.max_wave_ref100mhz ? 100.0 * h.max_wave_cycles / h.max_wave_ref100mhz : 0.0);
     st->device_ms = ms;
     return RT_OK;
 }
@@ -502,7 +584,7 @@ rt_status rt_render_tiles_device(rt_scene *s, const rt_options *o, rt_traversal 
     if ((st = acquire(s, &c)) != RT_OK) return st;
     Lease lease{ s, c };
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    st = enqueue_pass(s, c, o, trav, tab, total_blocks, static_cast<uint8_t *>(rgba_out_device), stream, stats != nullptr);
+    st = enqueue_pass(s, c, o, trav, tab, total_blocks, total_px, static_cast<uint8_t *>(rgba_out_device), stream, stats != nullptr);
     if (st != RT_OK) return st;
     if (stats) return read_stats(s, c, stream, trav, stats);
     // Asynchronous return: the context's tile table is still in use by the enqueued work, so it goes back to
@@ -530,7 +612,7 @@ rt_status rt_render_tiles(rt_scene *s, const rt_options *o, rt_traversal trav, c
         HIP_TRY(hipMalloc(&c->d_out, bytes));
         c->out_cap = bytes;
     }
-    st = enqueue_pass(s, c, o, trav, tab, total_blocks, c->d_out, c->stream, stats != nullptr);
+    st = enqueue_pass(s, c, o, trav, tab, total_blocks, total_px, c->d_out, c->stream, stats != nullptr);
     if (st != RT_OK) return st;
     HIP_TRY(hipMemcpyAsync(rgba_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
     if (stats) return read_stats(s, c, c->stream, trav, stats);
@@ -564,6 +646,33 @@ rt_status rt_blit_tiles_device(rt_scene *s, const rt_options *o, const rt_region
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, stream));
     lease.inflight = true;
+    return RT_OK;
+}
+
+rt_status rt_selftest_sqrt(int device, uint64_t *mismatches, uint32_t *first_bad_bits)
+{
+    if (!mismatches || !first_bad_bits) return RT_ERR_INVALID_ARGUMENT;
+    int ndev = 0;
+    rt_status st = rt_device_count(&ndev);
+    if (st != RT_OK) return st;
+    if (device < 0 || device >= ndev) return RT_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long *d_bad = nullptr;
+    unsigned *d_first = nullptr;
+    HIP_TRY(hipMalloc(&d_bad, sizeof *d_bad));
+    HIP_TRY(hipMalloc(&d_first, sizeof *d_first));
+    HIP_TRY(hipMemset(d_bad, 0, sizeof *d_bad));
+    HIP_TRY(hipMemset(d_first, 0xFF, sizeof *d_first));
+    // all 2^32 bit patterns: non-negative values, negatives, infinities and NaNs
+    hipLaunchKernelGGL(rt::k_selftest_sqrt, dim3(256 * 32), dim3(256), 0, nullptr, 0u, 1ull << 32, d_bad, d_first);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    unsigned long long bad = 0; unsigned first = 0;
+    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&first, d_first, sizeof first, hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad); (void)hipFree(d_first);
+    if (e != hipSuccess) return hip_fail(e, "rt_selftest_sqrt", __LINE__);
+    *mismatches = bad; *first_bad_bits = first;
     return RT_OK;
 }
 

@@ -26,9 +26,15 @@ template <typename T> struct SceneView {
     V3<T> light, eye;      // Scene::directional_light (unit), Scene::eye  render.rs:138-142
 };
 
+// Counter slots are striped (kCounterStripes copies, picked by block index, summed on the host): tens of thousands of
+// waves adding to ONE address serialise at ~88 atomics/us, which made a stats pass 15x slower than the render itself.
+constexpr unsigned kCounterStripes = 256;
+
 struct Counters {          // same meaning as the reference-side ray statistics
     unsigned long long primary, hits, shadow, occluded;
     unsigned long long sphere_tests, bound_tests;   // per-ray tests executed (SKIP traversal counts them exactly)
+    unsigned long long wave_steps, max_wave_steps;  // SKIP: node visits summed over waves / of the busiest wave (diagnostic)
+    unsigned long long max_wave_cycles, max_wave_ref100mhz;   // diagnostic: s_memtime / s_memrealtime span of the longest wave
 };
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned v)
@@ -167,6 +173,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_fused(SceneView<T> sc,
     }
 
     if (counters) {
+        counters += blockIdx.x % kCounterStripes;
         const unsigned long long prim = wave_sum(inside ? spp * spp : 0u);
         const unsigned long long hits = wave_sum(c_hits), sh = wave_sum(c_shadow), oc = wave_sum(c_occ);
         if (lane == 0) {
@@ -176,6 +183,21 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_fused(SceneView<T> sc,
             atomicAdd(&counters->occluded, oc);
         }
     }
+}
+
+// Exhaustive self-test of sqrt_rn_lean against the compiler's IEEE sqrt: every f32 bit pattern in [first, first+count).
+__global__ void k_selftest_sqrt(unsigned first, unsigned long long count, unsigned long long *mismatches, unsigned *first_bad)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
+        const unsigned bits = first + (unsigned)k;
+        const float x = __uint_as_float(bits);
+        const float a = sqrt_rn_lean(x), b = rsqrt_exact(x);
+        const bool same = __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
+        if (!same) { ++bad; atomicMin(first_bad, bits); }
+    }
+    if (bad) atomicAdd(mismatches, bad);
 }
 
 // RGBABuffer::set_pixels_from_buffer (render.rs:112-126): tile-major tiles -> row-major frame, 4 B per lane.

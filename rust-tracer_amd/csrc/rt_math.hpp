@@ -18,6 +18,26 @@ template <typename T> __host__ __device__ __forceinline__ constexpr T eps() { re
 __device__ __forceinline__ float rsqrt_exact(float x) { return __builtin_sqrtf(x); }    // IEEE correctly rounded
 __device__ __forceinline__ double rsqrt_exact(double x) { return __builtin_sqrt(x); }
 
+// Correctly rounded f32 sqrt for the traversal loops, x >= 0 (or NaN, or negative -> NaN).  Same result as
+// rsqrt_exact() for every input (checked exhaustively on the device by rt_selftest_sqrt), ~half the instructions
+// of the compiler's expansion in the common case: v_sqrt_f32 is within 1 ulp, so the correctly rounded root is
+// s-1ulp, s or s+1ulp, decided by the sign of the exactly computed residuals fma(-s', s, x).  Inputs below 2^-96
+// (denormal residuals would lose bits) take the general path; that branch is almost never taken.
+__device__ __forceinline__ float sqrt_rn_lean(float x)
+{
+    // |x| < 2^-96 (zeros, denormals, tiny values of either sign): general path.  +inf needs none: its residuals are NaN.
+    if (__builtin_expect(__builtin_fabsf(x) < 0x1p-96f, 0)) return __builtin_sqrtf(x);
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u);
+    const float su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = __builtin_fmaf(-sd, s, x);
+    const float ru = __builtin_fmaf(-su, s, x);
+    s = (rd <= 0.0f) ? sd : s;
+    s = (ru > 0.0f) ? su : s;
+    return s;
+}
+__device__ __forceinline__ double sqrt_rn_lean(double x) { return __builtin_sqrt(x); }
+
 // vec.rs:15-72
 template <typename T> __device__ __forceinline__ V3<T> add(V3<T> a, V3<T> b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
 template <typename T> __device__ __forceinline__ V3<T> sub(V3<T> a, V3<T> b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }

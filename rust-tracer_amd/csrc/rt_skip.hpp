@@ -67,24 +67,67 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 
 constexpr unsigned kNever = 0xFFFFFFFFu;
 
-template <typename T, bool COUNT>
+// Hand-placed scalar loads (hipcc sinks an ordinary speculative load below the work it should overlap).  hipcc does
+// not count an asm load: the value may only be used after sload_wait() on it (cdna guide 5.7 item 1).
+typedef int __attribute__((ext_vector_type(8))) i32x8;
+__device__ __forceinline__ i32x8 sload8(const void *base, unsigned byte_off)
+{
+    i32x8 r;
+    asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(r) : "s"(base), "s"(byte_off) : "memory");
+    return r;
+}
+__device__ __forceinline__ void sload_wait(i32x8 &a, i32x8 &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b) : : "memory"); }
+
+template <typename T> __device__ __forceinline__ Node<T> as_node(const i32x8 &r);
+template <> __device__ __forceinline__ Node<float> as_node<float>(const i32x8 &r)
+{
+    Node<float> n;
+    n.a0 = __int_as_float(r[0]); n.a1 = __int_as_float(r[1]); n.a2 = __int_as_float(r[2]); n.a3 = __int_as_float(r[3]);
+    n.a4 = __int_as_float(r[4]); n.skip = (unsigned)r[5]; n.item = (unsigned)r[6];
+    return n;
+}
+
+// VAR bits (tuning variants, all bit-identical in output and counters):
+//   1 = sqrt_rn_lean (same value as the IEEE sqrt for every input, about half the instructions)
+//   2 = the records of both possible successors (i+1 and skip) are fetched with hand-placed scalar loads while node i
+//       is processed, so the dependent scalar-load latency leaves the wave's critical path
+//
+// SPLIT = false: one thread renders its pixel completely (all spp*spp samples in the reference's order) -- used for
+//   spp == 1, where it is a single pass.
+// SPLIT = true : one thread traces ONE sample (blockIdx.y = ssx * spp + ssy) and stores the sample's outcome
+//   {state, n.light}; k_resolve_samples then accumulates each pixel's samples in the reference's order.  A frame's
+//   run time is bounded by its slowest wave, and a wave that walks 16 samples one after the other is 16x slower.
+enum SampleState : uint8_t { kMiss = 0, kAmbient = 1, kLit = 2, kShadowed = 3 };     // the four exits of render.rs:190-213
+
+template <typename T> struct SampleBuf {
+    T *gdot;             // [spp*spp][n_px]  n.light of the sample (meaningful for kLit / kShadowed)
+    uint8_t *state;      // [spp*spp][n_px]
+    unsigned n_px;
+};
+
+template <typename T, bool COUNT, int VAR, bool SPLIT>
 __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, unsigned width, unsigned height, unsigned spp,
                                                               const TileDev *__restrict__ tiles, unsigned n_tiles,
-                                                              uint8_t *__restrict__ out, Counters *__restrict__ counters)
+                                                              uint8_t *__restrict__ out, Counters *__restrict__ counters,
+                                                              SampleBuf<T> sb)
 {
+    const unsigned gblock = blockIdx.x;                                      // 16x16 pixel block index
     unsigned lo = 0, hi = n_tiles - 1;
     while (lo < hi) {
         unsigned mid = (lo + hi + 1) >> 1;
-        if (tiles[mid].blk_first <= blockIdx.x) lo = mid; else hi = mid - 1;
+        if (tiles[mid].blk_first <= gblock) lo = mid; else hi = mid - 1;
     }
     const TileDev tile = tiles[lo];
-    const unsigned lb = blockIdx.x - tile.blk_first;
+    const unsigned lb = gblock - tile.blk_first;
     const unsigned bx = lb % tile.blks_x, by = lb / tile.blks_x;
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned x = tile.l + bx * kBlockW + (wave & 1) * 8 + (lane & 7);
     const unsigned y = tile.b + by * kBlockH + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = x < tile.r && y < tile.t;
     if (__ballot(inside) == 0) return;          // waves are independent here: no LDS, no barrier
+
+    unsigned long long t_start = 0, r_start = 0;
+    if (COUNT) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
 
     const T ssf = T(spp);
     const T total_recip = T(1.0) / (ssf * ssf);
@@ -100,10 +143,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
 
     V3<T> g = { T(0.0), T(0.0), T(0.0) };
     T alpha = T(0.0);
-    unsigned c_hits = 0, c_shadow = 0, c_occ = 0, c_items = 0, c_bounds = 0;
+    unsigned c_hits = 0, c_shadow = 0, c_occ = 0, c_items = 0, c_bounds = 0, c_steps = 0;
 
-    for (unsigned ssx = 0; ssx < spp; ++ssx) {
-        for (unsigned ssy = 0; ssy < spp; ++ssy) {
+    const unsigned ss_first = SPLIT ? blockIdx.y / spp : 0u, ss_last = SPLIT ? ss_first + 1 : spp;
+    for (unsigned ssx = ss_first; ssx < ss_last; ++ssx) {
+        for (unsigned ssy = SPLIT ? blockIdx.y % spp : 0u; ssy < (SPLIT ? blockIdx.y % spp + 1 : spp); ++ssy) {
             const T xres = T(x) + T(ssx) / ssf;
             const T yres = T(y) + T(ssy) / ssf;
             V3<T> dir = { xres - half_w, (fh - yres) - half_h, fw };
@@ -114,40 +158,59 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             unsigned best_item = 0;
             unsigned resume = inside ? 0u : kNever;
             unsigned i = 0;
-            while (i < n) {
-                const Node<T> nd = sc.prim[i];                          // wave-uniform record -> SGPRs
+            Node<T> nd = sc.prim[0];                                    // wave-uniform record -> SGPRs
+            for (;;) {
+                i32x8 pf_next, pf_skip;
+                if constexpr ((VAR & 2) && sizeof(T) == 4) {            // both successors; the array has a pad node at [n]
+                    pf_next = sload8(sc.prim, (i + 1) * 32u);
+                    pf_skip = sload8(sc.prim, nd.skip * 32u);
+                }
                 const bool active = i >= resume;
                 // Sphere::distance_from_ray with the ray-independent parts pre-formed (primitive.rs:55-72)
                 const T b = (nd.a0 * dir.x + nd.a1 * dir.y) + nd.a2 * dir.z;
                 const T disc = (b * b - nd.a3) + nd.a4;
+                const bool pos = !(disc < T(0.0));
+                const bool is_bound = nd.skip != 0u;
                 T d = inf<T>();
-                if (!(disc < T(0.0))) {
-                    const T s = rsqrt_exact(disc);
+                if (pos) {
+                    const T s = (VAR & 1) ? sqrt_rn_lean(disc) : rsqrt_exact(disc);
                     const T t2 = b + s;
                     if (!(t2 < T(0.0))) {
                         const T t1 = b - s;
                         d = t1 > T(0.0) ? t1 : t2;
                     }
                 }
-                if (nd.skip != 0u) {                                    // BOUND  group.rs:73
+                unsigned ni;
+                if (is_bound) {                                         // BOUND  group.rs:73
                     const bool cull = active && (d >= best);
                     if (cull) resume = nd.skip;
                     if (COUNT) c_bounds += active ? 1u : 0u;
-                    i = (__ballot(active && !cull) == 0) ? nd.skip : i + 1;
+                    ni = (__ballot(active && !cull) == 0) ? nd.skip : i + 1;
                 } else {                                                // ITEM   primitive.rs:78-83
                     if (active && !(d >= best)) { best = d; best_item = nd.item; }
                     if (COUNT) c_items += active ? 1u : 0u;
-                    i = i + 1;
+                    ni = i + 1;
                 }
+                if (COUNT) ++c_steps;
+                // the asm loads must have landed before their registers can be reused, also on the way out
+                if constexpr ((VAR & 2) && sizeof(T) == 4) sload_wait(pf_next, pf_skip);
+                if (ni >= n) break;
+                if constexpr ((VAR & 2) && sizeof(T) == 4) {
+                    nd = as_node<T>(ni == i + 1 ? pf_next : pf_skip);   // ni is i+1 or nd.skip, nothing else
+                } else {
+                    nd = sc.prim[ni];
+                }
+                i = ni;
             }
 
             // ---------------- shade  render.rs:190-199 ----------------
             bool need_shadow = false;
             T gdot = T(0.0);
             V3<T> sp = { T(0.0), T(0.0), T(0.0) };
+            uint8_t state = kMiss;
             if (inside) {
                 if (best == inf<T>()) {
-                    g = add(g, BACKGROUND);
+                    if (!SPLIT) g = add(g, BACKGROUND);
                 } else {
                     ++c_hits;
                     const Item<T> it = sc.items[best_item];
@@ -155,7 +218,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                     const V3<T> nrm = normalized(add(eye, sub(mulf(dir, best), c)));       // primitive.rs:83
                     gdot = dot(nrm, light);
                     if (gdot >= T(0.0)) {
-                        g = add(g, AMBIENT);
+                        state = kAmbient;
+                        if (!SPLIT) g = add(g, AMBIENT);
                     } else {
                         need_shadow = true;
                         ++c_shadow;
@@ -172,52 +236,74 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             resume = need_shadow ? 0u : kNever;
             i = 0;
             if (__ballot(need_shadow) != 0) {
-                while (i < n) {
-                    const Node<T> nd = sc.shad[i];
+                Node<T> nd = sc.shad[0];
+                for (;;) {
+                    i32x8 pf_next, pf_skip;
+                    if constexpr ((VAR & 2) && sizeof(T) == 4) {
+                        pf_next = sload8(sc.shad, (i + 1) * 32u);
+                        pf_skip = sload8(sc.shad, nd.skip * 32u);
+                    }
                     const bool active = i >= resume;
                     const V3<T> v = { nd.a0 - sp.x, nd.a1 - sp.y, nd.a2 - sp.z };
                     const T b = dot(v, sdir);
                     const T disc = (b * b - dot(v, v)) + nd.a3;
+                    const bool pos = !(disc < T(0.0));
                     bool hit = false;
-                    if (!(disc < T(0.0))) {
-                        const T t2 = b + rsqrt_exact(disc);
-                        hit = !(t2 < T(0.0));
-                    }
+                    if (pos) hit = !((b + ((VAR & 1) ? sqrt_rn_lean(disc) : rsqrt_exact(disc))) < T(0.0));
+                    unsigned ni;
                     if (nd.skip != 0u) {
                         const bool cull = active && !hit;
                         if (cull) resume = nd.skip;
                         if (COUNT) c_bounds += active ? 1u : 0u;
-                        i = (__ballot(active && hit) == 0) ? nd.skip : i + 1;
+                        ni = (__ballot(active && hit) == 0) ? nd.skip : i + 1;
                     } else {
                         const bool fin = active && hit;
                         if (COUNT) c_items += active ? 1u : 0u;
                         if (fin) { occluded = true; resume = kNever; }
                         if (__ballot(fin) != 0) {
                             // some lane retired: go straight to the next node any lane still wants
-                            const unsigned nxt = (unsigned)__builtin_amdgcn_readfirstlane(
+                            ni = (unsigned)__builtin_amdgcn_readfirstlane(
                                 (int)wave_min_u32(resume == kNever ? kNever : (resume > i ? resume : i + 1)));
-                            if (nxt == kNever) break;
-                            i = nxt;
                         } else {
-                            i = i + 1;
+                            ni = i + 1;
                         }
                     }
+                    if (COUNT) ++c_steps;
+                    if constexpr ((VAR & 2) && sizeof(T) == 4) sload_wait(pf_next, pf_skip);
+                    if (ni >= n) break;                                 // also ni == kNever: every lane retired
+                    if constexpr ((VAR & 2) && sizeof(T) == 4) {
+                        if (ni == i + 1) nd = as_node<T>(pf_next);
+                        else if (ni == nd.skip) nd = as_node<T>(pf_skip);
+                        else nd = sc.shad[ni];                          // wave_min jump after a lane retired
+                    } else {
+                        nd = sc.shad[ni];
+                    }
+                    i = ni;
                 }
             }
 
             if (need_shadow) {
                 if (!occluded) {
-                    g = add(add(g, mulf(OBJECT, -gdot)), AMBIENT);          // render.rs:209
-                    alpha += T(1.0);
+                    state = kLit;
+                    if (!SPLIT) {
+                        g = add(add(g, mulf(OBJECT, -gdot)), AMBIENT);      // render.rs:209
+                        alpha += T(1.0);
+                    }
                 } else {
                     ++c_occ;
-                    g = add(add(g, BACKGROUND), mulf(AMBIENT, -gdot));      // render.rs:212
+                    state = kShadowed;
+                    if (!SPLIT) g = add(add(g, BACKGROUND), mulf(AMBIENT, -gdot));      // render.rs:212
                 }
+            }
+            if (SPLIT && inside) {
+                const size_t p = (size_t)blockIdx.y * sb.n_px + (size_t)tile.out_px + (size_t)(y - tile.b) * (tile.r - tile.l) + (x - tile.l);
+                sb.gdot[p] = gdot;
+                sb.state[p] = state;
             }
         }
     }
 
-    if (inside) {
+    if (!SPLIT && inside) {
         g = mulf(g, total_recip);
         alpha *= total_recip;
         const unsigned tw = tile.r - tile.l;
@@ -227,7 +313,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     }
 
     if (COUNT) {
-        const unsigned long long prim = wave_sum(inside ? spp * spp : 0u);
+        counters += (blockIdx.x + blockIdx.y) % kCounterStripes;
+        const unsigned long long prim = wave_sum(inside ? (SPLIT ? 1u : spp * spp) : 0u);
         const unsigned long long hits = wave_sum(c_hits), sh = wave_sum(c_shadow), oc = wave_sum(c_occ);
         const unsigned long long its = wave_sum(c_items), bds = wave_sum(c_bounds);
         if (lane == 0) {
@@ -237,8 +324,41 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             atomicAdd(&counters->occluded, oc);
             atomicAdd(&counters->sphere_tests, its);
             atomicAdd(&counters->bound_tests, bds);
+            atomicAdd(&counters->wave_steps, (unsigned long long)c_steps);
+            atomicMax(&counters->max_wave_steps, (unsigned long long)c_steps);
+            atomicMax(&counters->max_wave_cycles, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start));
+            atomicMax(&counters->max_wave_ref100mhz, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r_start));
         }
     }
+}
+
+// Second pass of the SPLIT path: render.rs:233-252 for one pixel -- its samples' contributions accumulated strictly
+// in the reference's order (ssx outer, ssy inner; each term added on its own, never pre-summed), then quantised.
+template <typename T>
+__global__ __launch_bounds__(kBlockThreads) void k_resolve_samples(SampleBuf<T> sb, unsigned spp, uint8_t *__restrict__ out)
+{
+    const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= sb.n_px) return;
+    const V3<T> OBJECT = { T(0xae) / T(255.0), T(0x31) / T(255.0), T(0x31) / T(255.0) };
+    const V3<T> BACKGROUND = { T(0x22) / T(255.0), T(0x0a) / T(255.0), T(0x0a) / T(255.0) };
+    const V3<T> AMBIENT = { BACKGROUND.x * T(0.8), BACKGROUND.y * T(0.8), BACKGROUND.z * T(0.8) };
+    const T ssf = T(spp);
+    const T total_recip = T(1.0) / (ssf * ssf);
+    V3<T> g = { T(0.0), T(0.0), T(0.0) };
+    T alpha = T(0.0);
+    const unsigned ns = spp * spp;
+    for (unsigned k = 0; k < ns; ++k) {
+        const size_t q = (size_t)k * sb.n_px + p;
+        const uint8_t st = sb.state[q];
+        const T gdot = sb.gdot[q];
+        if (st == kMiss) g = add(g, BACKGROUND);                                        // render.rs:191
+        else if (st == kAmbient) g = add(g, AMBIENT);                                   // render.rs:196
+        else if (st == kLit) { g = add(add(g, mulf(OBJECT, -gdot)), AMBIENT); alpha += T(1.0); }      // render.rs:209-210
+        else g = add(add(g, BACKGROUND), mulf(AMBIENT, -gdot));                         // render.rs:212
+    }
+    g = mulf(g, total_recip);
+    alpha *= total_recip;
+    reinterpret_cast<unsigned *>(out)[p] = scale_u8(g.x) | (scale_u8(g.y) << 8) | (scale_u8(g.z) << 16) | (scale_u8(alpha) << 24);
 }
 
 }  // namespace rt

@@ -361,3 +361,9 @@ def test_skip_needs_bounds_and_rejects_bad_nesting():
     with pytest.raises(rta.RtError) as e:
         bad.device()
     assert e.value.status == rta.capi.RT_ERR_INVALID_ARGUMENT
+
+
+def test_lean_sqrt_is_correctly_rounded_for_every_f32():
+    # the traversal loops use a lean correctly-rounded sqrt; it must equal the IEEE sqrt bit for bit on all 2^32 inputs
+    bad, first = rta.capi.selftest_sqrt(0)
+    assert bad == 0, "first differing input bits: 0x%08x" % first

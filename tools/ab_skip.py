@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""A/B timing of k_render_skip tuning variants, interleaved in ONE process (cdna guide rule 24).
+Checks every variant's frame and counters against variant 0 first.  usage: ab_skip.py [rounds] [w h spp level]"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import rust_tracer_amd as rta
+
+libc = ctypes.CDLL(None)
+
+
+def setvar(v):
+    os.environ["RT_SKIP_VARIANT"] = str(v)
+    libc.setenv(b"RT_SKIP_VARIANT", str(v).encode(), 1)      # getenv() in the library reads the C environment
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    w, h, spp, level = (int(a) for a in sys.argv[2:6]) if len(sys.argv) > 5 else (1920, 1080, 1, 8)
+    variants = [int(v) for v in os.environ.get("AB_VARIANTS", "0,1,2,3").split(",")]
+    scene = rta.Scene.default(level)
+    dev = scene.device(0)
+    opts = (w, h, spp)
+    regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(*opts))]
+    regs_c = dev._regions(regs)
+    out = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    ref = None
+    for v in variants:
+        setvar(v)
+        st = dev.render_tiles_device(opts, regs_c, out.data_ptr(), stream, rta.RT_TRAVERSAL_SKIP, want_stats=True)
+        torch.cuda.synchronize()
+        frame = out.cpu().numpy().copy()
+        key = (st["primary"], st["hits"], st["shadow"], st["occluded"], st["sphere_tests"], st["bound_tests"])
+        if ref is None:
+            ref = (frame, key)
+        else:
+            assert np.array_equal(frame, ref[0]), "variant %d changes pixels" % v
+            assert key == ref[1], "variant %d changes counters %r vs %r" % (v, key, ref[1])
+    times = {v: [] for v in variants}
+    for r in range(rounds + 2):
+        for v in variants:
+            setvar(v)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dev.render_tiles_device(opts, regs_c, out.data_ptr(), stream, rta.RT_TRAVERSAL_SKIP)
+            e1.record()
+            torch.cuda.synchronize()
+            if r >= 2:
+                times[v].append(e0.elapsed_time(e1) / 5 * 1e3)
+    print("%dx%d spp %d L%d, %d rounds x 5 launches, us per launch" % (w, h, spp, level, rounds))
+    for v in variants:
+        t = np.array(times[v])
+        print("variant %d: median %.1f  min %.1f  max %.1f" % (v, np.median(t), t.min(), t.max()))
+
+
+if __name__ == "__main__":
+    main()
