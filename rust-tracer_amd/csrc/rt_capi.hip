@@ -290,7 +290,7 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
 }
 
 // Tuning variant of k_render_skip (rt_skip.hpp VAR bits); RT_SKIP_VARIANT overrides the default for A/B runs.
-constexpr int kSkipVariantDefault = 0;
+constexpr int kSkipVariantDefault = 1;   // lean sqrt; the prefetch (2) only pays for a lone wave, it costs throughput under load
 
 int skip_variant()
 {
