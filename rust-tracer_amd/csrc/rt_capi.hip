@@ -4,6 +4,7 @@
 #include "../../include/rtrace_hip.h"
 #include "rt_kernels.hpp"
 #include "rt_skip.hpp"
+#include "rt_flat.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -75,6 +76,8 @@ struct rt_scene {
     rt_range *d_ranges = nullptr;
     void *d_prim = nullptr, *d_shad = nullptr;   // Node<REAL>[n_nodes]: skip-pointer streams (RT_TRAVERSAL_SKIP)
     uint32_t n_nodes = 0;
+    void *d_fprim = nullptr, *d_fprim_rr = nullptr, *d_fshad = nullptr;   // pre-formed per-item terms (RT_TRAVERSAL_FLAT)
+    uint32_t n_padded = 0;
     double light[3] = { 0, 0, 0 }, eye[3] = { 0, 0, 0 };   // exact copies of the REAL values
     std::mutex mu;
     std::vector<std::unique_ptr<Context>> pool;
@@ -123,7 +126,7 @@ struct Lease {
 
 // Validates the regions (ImageRegion invariants, inside the image) and lays out blocks + output offsets.
 rt_status build_tile_table(const rt_options *o, const rt_region *tiles, uint32_t n, std::vector<rt::TileDev> &tab,
-                           uint64_t *total_px, uint32_t *total_blocks)
+                           uint64_t *total_px, uint32_t *total_blocks, uint32_t block_w = rt::kBlockW, uint32_t block_h = rt::kBlockH)
 {
     uint64_t px = 0, blocks = 0;
     tab.resize(n);
@@ -135,7 +138,7 @@ rt_status build_tile_table(const rt_options *o, const rt_region *tiles, uint32_t
             return RT_ERR_INVALID_REGION;
         }
         const uint32_t w = t.r - t.l, h = t.t - t.b;
-        const uint32_t bxs = (w + rt::kBlockW - 1) / rt::kBlockW, bys = (h + rt::kBlockH - 1) / rt::kBlockH;
+        const uint32_t bxs = (w + block_w - 1) / block_w, bys = (h + block_h - 1) / block_h;
         if (px + (uint64_t)w * h > 0xFFFFFFFFull || blocks + (uint64_t)bxs * bys > 0x7FFFFFFFull) {
             snprintf(g_err, sizeof g_err, "tile list too large for one pass");
             return RT_ERR_INVALID_ARGUMENT;
@@ -158,6 +161,37 @@ rt::SceneView<T> view_of(const rt_scene *s)
     v.light = { (T)s->light[0], (T)s->light[1], (T)s->light[2] };
     v.eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
     return v;
+}
+
+template <typename T>
+rt::FlatView<T> flat_view_of(const rt_scene *s)
+{
+    rt::FlatView<T> v;
+    v.prim = static_cast<const rt::Quad<T> *>(s->d_fprim);
+    v.prim_rr = static_cast<const T *>(s->d_fprim_rr);
+    v.shad = static_cast<const rt::Quad<T> *>(s->d_fshad);
+    v.items = static_cast<const rt::Item<T> *>(s->d_items);
+    v.n_items = s->n_items;
+    v.n_padded = s->n_padded;
+    v.light = { (T)s->light[0], (T)s->light[1], (T)s->light[2] };
+    v.eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
+    return v;
+}
+
+template <typename T>
+rt_status upload_flat(rt_scene *s)
+{
+    s->n_padded = (s->n_items + 3u) & ~3u;
+    HIP_TRY(hipMalloc(&s->d_fprim, sizeof(rt::Quad<T>) * s->n_padded));
+    HIP_TRY(hipMalloc(&s->d_fprim_rr, sizeof(T) * s->n_padded));
+    HIP_TRY(hipMalloc(&s->d_fshad, sizeof(rt::Quad<T>) * s->n_padded));
+    const rt::V3<T> eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
+    hipLaunchKernelGGL((rt::k_build_flat<T>), dim3((s->n_padded + 255) / 256), dim3(256), 0, nullptr,
+                       static_cast<const rt::Item<T> *>(s->d_items), s->n_items, s->n_padded, eye, static_cast<rt::Quad<T> *>(s->d_fprim),
+                       static_cast<T *>(s->d_fprim_rr), static_cast<rt::Quad<T> *>(s->d_fshad));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return RT_OK;
 }
 
 template <typename T>
@@ -299,6 +333,13 @@ int skip_variant()
     return e ? atoi(e) & 3 : kSkipVariantDefault;
 }
 
+// RT_FLAT_VARIANT=1 selects the first-generation flat kernel (k_render_fused, 16x16 blocks) for A/B runs.
+int flat_variant()
+{
+    const char *e = getenv("RT_FLAT_VARIANT");
+    return e ? atoi(e) : 2;
+}
+
 // spp > 1 runs sample-parallel (one thread per sample + a resolve pass) unless spp*spp exceeds grid.y's limit.
 bool use_split(unsigned spp) { return spp > 1 && (unsigned long long)spp * spp <= 65535ull; }
 
@@ -375,11 +416,16 @@ rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversa
     HIP_TRY(hipEventRecord(c->ev0, stream));
     const dim3 grid(total_blocks), block(rt::kBlockThreads);
     const unsigned w = o->width, h = o->height, spp = o->samples_per_pixel, nt = (unsigned)tab.size();
-    if (trav == RT_TRAVERSAL_FLAT) {
+    if (trav == RT_TRAVERSAL_FLAT && flat_variant() == 1) {           // first-generation kernel, kept for A/B runs
         if (s->precision == RT_F32)
             hipLaunchKernelGGL((rt::k_render_fused<float, 1024>), grid, block, 0, stream, view_of<float>(s), w, h, spp, d_tab, nt, d_out, cnt);
         else
             hipLaunchKernelGGL((rt::k_render_fused<double, 512>), grid, block, 0, stream, view_of<double>(s), w, h, spp, d_tab, nt, d_out, cnt);
+    } else if (trav == RT_TRAVERSAL_FLAT) {
+        if (s->precision == RT_F32)
+            hipLaunchKernelGGL((rt::k_render_flat2<float, 1024>), grid, block, 0, stream, flat_view_of<float>(s), w, h, spp, d_tab, nt, d_out, cnt);
+        else
+            hipLaunchKernelGGL((rt::k_render_flat2<double, 512>), grid, block, 0, stream, flat_view_of<double>(s), w, h, spp, d_tab, nt, d_out, cnt);
     } else {
         rt_status lst = launch_skip(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt);
         if (lst != RT_OK) return lst;
@@ -544,6 +590,10 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
         if ((e = hipMemcpy(s->d_ranges, ranges, sizeof(rt_range) * n_bounds, hipMemcpyHostToDevice)) != hipSuccess)
             return fail(hip_fail(e, "hipMemcpy(ranges)", __LINE__));
     }
+    {
+        rt_status fst = f32 ? upload_flat<float>(s.get()) : upload_flat<double>(s.get());
+        if (fst != RT_OK) return fail(fst);
+    }
     if (n_bounds) {
         rt_status sst = f32 ? upload_streams<float>(s.get(), dfs_items, bounds, ranges) : upload_streams<double>(s.get(), dfs_items, bounds, ranges);
         if (sst != RT_OK) return fail(sst);
@@ -563,6 +613,9 @@ rt_status rt_scene_destroy(rt_scene *s)
     if (s->d_ranges) (void)hipFree(s->d_ranges);
     if (s->d_prim) (void)hipFree(s->d_prim);
     if (s->d_shad) (void)hipFree(s->d_shad);
+    if (s->d_fprim) (void)hipFree(s->d_fprim);
+    if (s->d_fprim_rr) (void)hipFree(s->d_fprim_rr);
+    if (s->d_fshad) (void)hipFree(s->d_fshad);
     delete s;
     return RT_OK;
 }
@@ -577,7 +630,9 @@ rt_status rt_render_tiles_device(rt_scene *s, const rt_options *o, rt_traversal 
     }
     std::vector<rt::TileDev> tab;
     uint64_t total_px = 0; uint32_t total_blocks = 0;
-    rt_status st = build_tile_table(o, tiles, n, tab, &total_px, &total_blocks);
+    const bool flat2 = trav == RT_TRAVERSAL_FLAT && flat_variant() != 1;
+    rt_status st = build_tile_table(o, tiles, n, tab, &total_px, &total_blocks, flat2 ? rt::kFlatBlockW : rt::kBlockW,
+                                    flat2 ? rt::kFlatBlockH : rt::kBlockH);
     if (st != RT_OK) return st;
     HIP_TRY(hipSetDevice(s->device));
     Context *c = nullptr;
@@ -599,7 +654,9 @@ rt_status rt_render_tiles(rt_scene *s, const rt_options *o, rt_traversal trav, c
     if (!check_common(s, o, tiles, n, rgba_out)) return RT_ERR_INVALID_ARGUMENT;
     std::vector<rt::TileDev> tab;
     uint64_t total_px = 0; uint32_t total_blocks = 0;
-    rt_status st = build_tile_table(o, tiles, n, tab, &total_px, &total_blocks);
+    const bool flat2 = trav == RT_TRAVERSAL_FLAT && flat_variant() != 1;
+    rt_status st = build_tile_table(o, tiles, n, tab, &total_px, &total_blocks, flat2 ? rt::kFlatBlockW : rt::kBlockW,
+                                    flat2 ? rt::kFlatBlockH : rt::kBlockH);
     if (st != RT_OK) return st;
     HIP_TRY(hipSetDevice(s->device));
     Context *c = nullptr;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A/B timing of k_render_skip tuning variants, interleaved in ONE process (cdna guide rule 24).
-Checks every variant's frame and counters against variant 0 first.  usage: ab_skip.py [rounds] [w h spp level]"""
+"""A/B timing of kernel tuning variants, interleaved in ONE process (cdna guide rule 24).  Checks every variant's frame
+and counters against the first variant.  usage: ab.py [rounds] [w h spp level]
+env: AB_TRAVERSAL=skip|flat  AB_ENV=RT_SKIP_VARIANT|RT_FLAT_VARIANT  AB_VARIANTS=0,1,...  AB_LAUNCHES=5"""
 import ctypes
 import os
 import sys
@@ -14,9 +15,14 @@ import rust_tracer_amd as rta
 libc = ctypes.CDLL(None)
 
 
+TRAV = rta.RT_TRAVERSAL_FLAT if os.environ.get("AB_TRAVERSAL", "skip") == "flat" else TRAV
+ENV = os.environ.get("AB_ENV", "RT_SKIP_VARIANT")
+LAUNCHES = int(os.environ.get("AB_LAUNCHES", "5"))
+
+
 def setvar(v):
-    os.environ["RT_SKIP_VARIANT"] = str(v)
-    libc.setenv(b"RT_SKIP_VARIANT", str(v).encode(), 1)      # getenv() in the library reads the C environment
+    os.environ[ENV] = str(v)
+    libc.setenv(ENV.encode(), str(v).encode(), 1)      # getenv() in the library reads the C environment
 
 
 def main():
@@ -33,7 +39,7 @@ def main():
     ref = None
     for v in variants:
         setvar(v)
-        st = dev.render_tiles_device(opts, regs_c, out.data_ptr(), stream, rta.RT_TRAVERSAL_SKIP, want_stats=True)
+        st = dev.render_tiles_device(opts, regs_c, out.data_ptr(), stream, TRAV, want_stats=True)
         torch.cuda.synchronize()
         frame = out.cpu().numpy().copy()
         key = (st["primary"], st["hits"], st["shadow"], st["occluded"], st["sphere_tests"], st["bound_tests"])
@@ -48,13 +54,13 @@ def main():
             setvar(v)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(5):
-                dev.render_tiles_device(opts, regs_c, out.data_ptr(), stream, rta.RT_TRAVERSAL_SKIP)
+            for _ in range(LAUNCHES):
+                dev.render_tiles_device(opts, regs_c, out.data_ptr(), stream, TRAV)
             e1.record()
             torch.cuda.synchronize()
             if r >= 2:
-                times[v].append(e0.elapsed_time(e1) / 5 * 1e3)
-    print("%dx%d spp %d L%d, %d rounds x 5 launches, us per launch" % (w, h, spp, level, rounds))
+                times[v].append(e0.elapsed_time(e1) / LAUNCHES * 1e3)
+    print("%dx%d spp %d L%d, %d rounds x %d launches, us per launch" % (w, h, spp, level, rounds, LAUNCHES))
     for v in variants:
         t = np.array(times[v])
         print("variant %d: median %.1f  min %.1f  max %.1f" % (v, np.median(t), t.min(), t.max()))
