@@ -26,7 +26,8 @@ if ROOT not in sys.path:
 WIDTH, HEIGHT, SPP, LEVEL = 1920, 1080, 1, 8
 N_ITEMS = 21845
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_OPS = 256 * 4 * 32 * 2.4e9     # un-fused f32 lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz (no FMA: parity)
+VALU_PEAK_OPS = 256 * 4 * 16 * 2 * 2.4e9  # un-fused f32 lane-ops/s with packed v_pk_mul/add: 256 CU x 4 SIMD x 16 lanes x 2 x
+                                          # 2.4 GHz = 78.6 T (the 157 TF headline needs FMA, which parity forbids)
 BYTES_PER_TEST = 16                      # one ray x one sphere = one {cx,cy,cz,r} f32 record
 
 
@@ -52,6 +53,17 @@ def cpu_baseline(budget_s=12.0):
                       "hierarchical traversal, best frame; 1 thread: %.3f Mrays/s"
                       % (frames, WIDTH, HEIGHT, SPP, LEVEL, cores, rays / t_single / 1e6),
             "ms_per_frame": round(best * 1e3, 2), "single_core_value": round(rays / t_single / 1e6, 3)}
+
+
+def flat_valu(m):
+    """Useful un-fused f32 ops of the flat scan (8 per primary test with the pre-formed terms, 16 per shadow test,
+    primitive.rs:56-58) over the kernel time, against the packed un-fused VALU peak."""
+    st = m["my_stats"]
+    ops = (st["primary"] * 8 + st["shadow"] * 16) * N_ITEMS
+    t = m["kern_ms"] * 1e-3
+    return {"ops_per_test": "8 primary / 16 shadow", "achieved_Tops": round(ops / t / 1e12, 2),
+            "peak_Tops": round(VALU_PEAK_OPS / 1e12, 1), "frac": round(ops / t / VALU_PEAK_OPS, 4),
+            "note": "shadow rays count all 21845 items although the any-hit scan stops early, so this is an upper bound"}
 
 
 def main():
@@ -102,17 +114,21 @@ def main():
         for _ in range(warmup):
             fs.step()
         barrier()
-        # HIP events on the stream the kernel is launched on: torch's current stream is handed through the C ABI
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         t0 = time.perf_counter()
         for i in range(steps):
-            ev[i][0].record()
             fs.render_shard()
-            ev[i][1].record()
             fs.finish()
         barrier()
         elapsed = time.perf_counter() - t0
-        kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        # per-launch duration of the render kernel alone: `steps` launches back to back between two HIP events on the
+        # launch stream (nothing else enqueued in between; agrees with rocprofv3 --kernel-trace --stats)
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record()
+        for _ in range(steps):
+            fs.render_shard()
+        k1.record()
+        torch.cuda.synchronize()
+        kern_ms = k0.elapsed_time(k1) / steps
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         if dist is not None:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -147,7 +163,7 @@ def main():
                      "arrive through the scalar cache / L2 (the whole scene is < 1 MB), so this is a logical rate, not "
                      "HBM traffic (SURVEY.md H3)")
         flat_note = ("algorithmic bytes = 16 B x (primary + shadow rays) x 21845 items of rank 0's launch / hipEvent "
-                     "duration of k_render_fused; every record staged to LDS is re-used by all rays of a workgroup, so the "
+                     "duration of k_render_flat2; every record staged to LDS is re-used by all rays of a workgroup, so the "
                      "logical rate exceeds the HBM peak; the binding limit is un-fused f32 VALU issue (see valu)")
         out = {
             "metric": "Mrays/sec + ms/frame, 1920x1080 20k-sphere scene",
@@ -161,17 +177,14 @@ def main():
                        "primary_rays": m["primary"], "shadow_rays": m["shadow"], "traversal": args.traversal,
                        "parallelism": "tiles/%d" % world},
             "mprimary_per_s": round(m["primary"] / (ms_per_step * 1e-3) / 1e6, 3),
-            "roofline": roofline(m, "k_render_skip" if args.traversal == "skip" else "k_render_fused",
+            "roofline": roofline(m, "k_render_skip" if args.traversal == "skip" else "k_render_flat2",
                                  skip_note if args.traversal == "skip" else flat_note),
         }
         if flat is not None:
             fms = flat["elapsed"] / max(2, min(5, args.steps)) * 1e3
             out["flat"] = {"ms_per_step": round(fms, 4), "value": round(rays / (fms * 1e-3) / 1e6, 3), "unit": "Mrays/s",
-                           "roofline": roofline(flat, "k_render_fused", flat_note),
-                           "valu": {"ops_per_test": 17,
-                                    "achieved_Tops": round(flat["my_tests"] * 17 / (flat["kern_ms"] * 1e-3) / 1e12, 2),
-                                    "peak_Tops": round(VALU_PEAK_OPS / 1e12, 1),
-                                    "frac": round(flat["my_tests"] * 17 / (flat["kern_ms"] * 1e-3) / VALU_PEAK_OPS, 4)}}
+                           "roofline": roofline(flat, "k_render_flat2", flat_note),
+                           "valu": flat_valu(flat)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

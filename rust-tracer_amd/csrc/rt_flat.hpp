@@ -8,6 +8,11 @@
 //  * items are consumed four at a time: the 4 x R discriminants are reduced with v_max3 and ONE branch rejects the
 //    whole group (a ray's line meets only a handful of the 21,845 spheres); the exact sqrt path runs per item only
 //    inside that rarely-taken branch, in item order, so strict-`<` / first-in-DFS-order tie-breaking is unchanged;
+//  * the arithmetic is written on 2-vectors over ITEM PAIRS (v_pk_mul_f32 / v_pk_add_f32): each half is rounded on
+//    its own, so results are bit-identical to scalar code, at half the VALU issue slots (a plain f32 VALU op costs
+//    4 cycles per wave64 on CDNA4 -- measured: instruction count x 4 / 1024 SIMDs was exactly the kernel's duration --
+//    and the 157 TF vector peak is only reachable with packed ops).  Items are therefore stored pair-interleaved:
+//    quad 2p = {x0,x1,y0,y1}, quad 2p+1 = {z0,z1,w0,w1} for items 2p, 2p+1;
 //  * every lane carries R = 2 pixels (rows y and y + 16 of a 16x32 block): each ds_read_b128 broadcast feeds two
 //    rays, which keeps the LDS pipe (4 cycles per wave-read) below the VALU time of the group.
 #pragma once
@@ -20,10 +25,37 @@ constexpr int kFlatR = 2;
 
 template <typename T> struct alignas(sizeof(T) * 4) Quad { T x, y, z, w; };
 
+// Two values processed by one instruction where the hardware can (f32: v_pk_*; f64 has no packed form).
+template <typename T> struct P2;
+template <> struct P2<float> {
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    v2 v;
+    __device__ __forceinline__ P2() {}
+    __device__ __forceinline__ P2(float lo, float hi) { v.x = lo; v.y = hi; }
+    __device__ __forceinline__ explicit P2(float both) { v.x = both; v.y = both; }
+    __device__ __forceinline__ explicit P2(v2 a) : v(a) {}
+    __device__ __forceinline__ P2 operator+(P2 o) const { return P2(v + o.v); }
+    __device__ __forceinline__ P2 operator-(P2 o) const { return P2(v - o.v); }
+    __device__ __forceinline__ P2 operator*(P2 o) const { return P2(v * o.v); }
+    __device__ __forceinline__ float lo() const { return v.x; }
+    __device__ __forceinline__ float hi() const { return v.y; }
+};
+template <> struct P2<double> {
+    double a, b;
+    __device__ __forceinline__ P2() {}
+    __device__ __forceinline__ P2(double lo, double hi) : a(lo), b(hi) {}
+    __device__ __forceinline__ explicit P2(double both) : a(both), b(both) {}
+    __device__ __forceinline__ P2 operator+(P2 o) const { return P2(a + o.a, b + o.b); }
+    __device__ __forceinline__ P2 operator-(P2 o) const { return P2(a - o.a, b - o.b); }
+    __device__ __forceinline__ P2 operator*(P2 o) const { return P2(a * o.a, b * o.b); }
+    __device__ __forceinline__ double lo() const { return a; }
+    __device__ __forceinline__ double hi() const { return b; }
+};
+
 template <typename T> struct FlatView {
-    const Quad<T> *prim;    // {vx, vy, vz, vv} per item, DFS order, padded to a multiple of 4 items
+    const Quad<T> *prim;    // pair-interleaved {vx0,vx1,vy0,vy1},{vz0,vz1,vv0,vv1}; DFS order, padded to a multiple of 4 items
     const T *prim_rr;       // rr per item, padded (pad items have vv = +big, rr = 0: disc < 0, never a hit)
-    const Quad<T> *shad;    // {cx, cy, cz, rr}, padded (pad items carry rr = -1e30: disc < 0 for every ray)
+    const Quad<T> *shad;    // pair-interleaved {cx0,cx1,cy0,cy1},{cz0,cz1,rr0,rr1} (pad items carry rr = -1e30: disc < 0)
     const Item<T> *items;   // centres for the normal of the winning item
     uint32_t n_items, n_padded;
     V3<T> light, eye;
@@ -36,20 +68,26 @@ __global__ void k_build_flat(const Item<T> *__restrict__ items, unsigned n, unsi
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_padded) return;
+    T vx, vy, vz, vv, rr, cx, cy, cz, srr;
     if (i < n) {
         const Item<T> it = items[i];
         const V3<T> v = { it.cx - eye.x, it.cy - eye.y, it.cz - eye.z };
-        const T rr = it.r * it.r;
-        prim[i] = { v.x, v.y, v.z, dot(v, v) };
-        prim_rr[i] = rr;
-        shad[i] = { it.cx, it.cy, it.cz, rr };
+        vx = v.x; vy = v.y; vz = v.z; vv = dot(v, v);
+        rr = it.r * it.r;
+        cx = it.cx; cy = it.cy; cz = it.cz; srr = rr;
     } else {
-        // padding: b = 0, disc = (0 - 1) + 0 < 0 for every ray -> can never hit, never NaN
-        prim[i] = { T(0), T(0), T(0), T(1) };
-        prim_rr[i] = T(0);
+        // primary pad: b = 0, disc = (0 - 1) + 0 < 0 for every ray -> can never hit, never NaN
+        vx = T(0); vy = T(0); vz = T(0); vv = T(1); rr = T(0);
         // shadow pad: rr = -1e30.  |b*b - vv| is a rounding residue of vv <= 3e30 (validated scene), so disc < 0 always
-        shad[i] = { T(0), T(0), T(0), T(-1e30) };
+        cx = T(0); cy = T(0); cz = T(0); srr = T(-1e30);
     }
+    // scalar view of the pair-interleaved quads: item i is half (i & 1) of quads 2*(i/2) and 2*(i/2)+1
+    T *pq = reinterpret_cast<T *>(prim + 2 * (i >> 1));
+    T *sq = reinterpret_cast<T *>(shad + 2 * (i >> 1));
+    const unsigned h = i & 1u;
+    pq[0 + h] = vx; pq[2 + h] = vy; pq[4 + h] = vz; pq[6 + h] = vv;
+    sq[0 + h] = cx; sq[2 + h] = cy; sq[4 + h] = cz; sq[6 + h] = srr;
+    prim_rr[i] = rr;
 }
 
 template <typename T> __device__ __forceinline__ T max3(T a, T b, T c) { return fmax(fmax(a, b), c); }
@@ -125,19 +163,21 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_flat2(FlatView<T> sc, 
                 for (unsigned j = threadIdx.x; j < cnt; j += kBlockThreads) s_rr[j] = sc.prim_rr[base + j];
                 __syncthreads();
                 for (unsigned j = 0; j < cnt; j += 4) {
-                    const Quad<T> a0 = s_q[j], a1 = s_q[j + 1], a2 = s_q[j + 2], a3 = s_q[j + 3];
+                    // items j, j+1 in quads qa/qb; items j+2, j+3 in qc/qd; rr of all four in one quad
+                    const Quad<T> qa = s_q[j], qb = s_q[j + 1], qc = s_q[j + 2], qd = s_q[j + 3];
                     const Quad<T> rr = *reinterpret_cast<const Quad<T> *>(&s_rr[j]);
+                    const P2<T> x01(qa.x, qa.y), y01(qa.z, qa.w), z01(qb.x, qb.y), w01(qb.z, qb.w), r01(rr.x, rr.y);
+                    const P2<T> x23(qc.x, qc.y), y23(qc.z, qc.w), z23(qd.x, qd.y), w23(qd.z, qd.w), r23(rr.z, rr.w);
                     T b[kFlatR][4], disc[kFlatR][4];
 #pragma unroll
                     for (int r = 0; r < kFlatR; ++r) {
-                        b[r][0] = (a0.x * dir[r].x + a0.y * dir[r].y) + a0.z * dir[r].z;
-                        b[r][1] = (a1.x * dir[r].x + a1.y * dir[r].y) + a1.z * dir[r].z;
-                        b[r][2] = (a2.x * dir[r].x + a2.y * dir[r].y) + a2.z * dir[r].z;
-                        b[r][3] = (a3.x * dir[r].x + a3.y * dir[r].y) + a3.z * dir[r].z;
-                        disc[r][0] = (b[r][0] * b[r][0] - a0.w) + rr.x;
-                        disc[r][1] = (b[r][1] * b[r][1] - a1.w) + rr.y;
-                        disc[r][2] = (b[r][2] * b[r][2] - a2.w) + rr.z;
-                        disc[r][3] = (b[r][3] * b[r][3] - a3.w) + rr.w;
+                        const P2<T> dx(dir[r].x), dy(dir[r].y), dz(dir[r].z);
+                        const P2<T> b01 = (x01 * dx + y01 * dy) + z01 * dz;          // primitive.rs:57, two items at once
+                        const P2<T> b23 = (x23 * dx + y23 * dy) + z23 * dz;
+                        const P2<T> d01 = (b01 * b01 - w01) + r01;                   // primitive.rs:58
+                        const P2<T> d23 = (b23 * b23 - w23) + r23;
+                        b[r][0] = b01.lo(); b[r][1] = b01.hi(); b[r][2] = b23.lo(); b[r][3] = b23.hi();
+                        disc[r][0] = d01.lo(); disc[r][1] = d01.hi(); disc[r][2] = d23.lo(); disc[r][3] = d23.hi();
                     }
                     T m = max3(disc[0][0], disc[0][1], disc[0][2]);
                     m = max3(m, disc[0][3], disc[1][0]);
@@ -202,18 +242,24 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_flat2(FlatView<T> sc, 
                 __syncthreads();
                 if (pending[0] || pending[1]) {
                     for (unsigned j = 0; j < cnt; j += 4) {
-                        const Quad<T> a0 = s_q[j], a1 = s_q[j + 1], a2 = s_q[j + 2], a3 = s_q[j + 3];
+                        const Quad<T> qa = s_q[j], qb = s_q[j + 1], qc = s_q[j + 2], qd = s_q[j + 3];
+                        const P2<T> x01(qa.x, qa.y), y01(qa.z, qa.w), z01(qb.x, qb.y), r01(qb.z, qb.w);
+                        const P2<T> x23(qc.x, qc.y), y23(qc.z, qc.w), z23(qd.x, qd.y), r23(qd.z, qd.w);
+                        const P2<T> lx(sdir.x), ly(sdir.y), lz(sdir.z);
                         T b[kFlatR][4], disc[kFlatR][4];
 #pragma unroll
                         for (int r = 0; r < kFlatR; ++r) {
-                            const V3<T> v0 = { a0.x - sp[r].x, a0.y - sp[r].y, a0.z - sp[r].z };
-                            const V3<T> v1 = { a1.x - sp[r].x, a1.y - sp[r].y, a1.z - sp[r].z };
-                            const V3<T> v2 = { a2.x - sp[r].x, a2.y - sp[r].y, a2.z - sp[r].z };
-                            const V3<T> v3 = { a3.x - sp[r].x, a3.y - sp[r].y, a3.z - sp[r].z };
-                            b[r][0] = dot(v0, sdir); disc[r][0] = (b[r][0] * b[r][0] - dot(v0, v0)) + a0.w;
-                            b[r][1] = dot(v1, sdir); disc[r][1] = (b[r][1] * b[r][1] - dot(v1, v1)) + a1.w;
-                            b[r][2] = dot(v2, sdir); disc[r][2] = (b[r][2] * b[r][2] - dot(v2, v2)) + a2.w;
-                            b[r][3] = dot(v3, sdir); disc[r][3] = (b[r][3] * b[r][3] - dot(v3, v3)) + a3.w;
+                            const P2<T> ox(sp[r].x), oy(sp[r].y), oz(sp[r].z);
+                            const P2<T> vx01 = x01 - ox, vy01 = y01 - oy, vz01 = z01 - oz;           // primitive.rs:56
+                            const P2<T> vx23 = x23 - ox, vy23 = y23 - oy, vz23 = z23 - oz;
+                            const P2<T> b01 = (vx01 * lx + vy01 * ly) + vz01 * lz;
+                            const P2<T> b23 = (vx23 * lx + vy23 * ly) + vz23 * lz;
+                            const P2<T> vv01 = (vx01 * vx01 + vy01 * vy01) + vz01 * vz01;
+                            const P2<T> vv23 = (vx23 * vx23 + vy23 * vy23) + vz23 * vz23;
+                            const P2<T> d01 = (b01 * b01 - vv01) + r01;
+                            const P2<T> d23 = (b23 * b23 - vv23) + r23;
+                            b[r][0] = b01.lo(); b[r][1] = b01.hi(); b[r][2] = b23.lo(); b[r][3] = b23.hi();
+                            disc[r][0] = d01.lo(); disc[r][1] = d01.hi(); disc[r][2] = d23.lo(); disc[r][3] = d23.hi();
                         }
                         // a finished (or absent) ray must not keep re-entering the slow path
                         const T m0 = pending[0] ? fmax(max3(disc[0][0], disc[0][1], disc[0][2]), disc[0][3]) : T(-1.0);
