@@ -153,17 +153,6 @@ rt_status build_tile_table(const rt_options *o, const rt_region *tiles, uint32_t
 }
 
 template <typename T>
-rt::SceneView<T> view_of(const rt_scene *s)
-{
-    rt::SceneView<T> v;
-    v.items = static_cast<const rt::Item<T> *>(s->d_items);
-    v.n_items = s->n_items;
-    v.light = { (T)s->light[0], (T)s->light[1], (T)s->light[2] };
-    v.eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
-    return v;
-}
-
-template <typename T>
 rt::FlatView<T> flat_view_of(const rt_scene *s)
 {
     rt::FlatView<T> v;
@@ -333,13 +322,6 @@ int skip_variant()
     return e ? atoi(e) & 3 : kSkipVariantDefault;
 }
 
-// RT_FLAT_VARIANT=1 selects the first-generation flat kernel (k_render_fused, 16x16 blocks) for A/B runs.
-int flat_variant()
-{
-    const char *e = getenv("RT_FLAT_VARIANT");
-    return e ? atoi(e) : 2;
-}
-
 // spp > 1 runs sample-parallel (one thread per sample + a resolve pass) unless spp*spp exceeds grid.y's limit.
 bool use_split(unsigned spp) { return spp > 1 && (unsigned long long)spp * spp <= 65535ull; }
 
@@ -416,12 +398,7 @@ rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversa
     HIP_TRY(hipEventRecord(c->ev0, stream));
     const dim3 grid(total_blocks), block(rt::kBlockThreads);
     const unsigned w = o->width, h = o->height, spp = o->samples_per_pixel, nt = (unsigned)tab.size();
-    if (trav == RT_TRAVERSAL_FLAT && flat_variant() == 1) {           // first-generation kernel, kept for A/B runs
-        if (s->precision == RT_F32)
-            hipLaunchKernelGGL((rt::k_render_fused<float, 1024>), grid, block, 0, stream, view_of<float>(s), w, h, spp, d_tab, nt, d_out, cnt);
-        else
-            hipLaunchKernelGGL((rt::k_render_fused<double, 512>), grid, block, 0, stream, view_of<double>(s), w, h, spp, d_tab, nt, d_out, cnt);
-    } else if (trav == RT_TRAVERSAL_FLAT) {
+    if (trav == RT_TRAVERSAL_FLAT) {
         if (s->precision == RT_F32)
             hipLaunchKernelGGL((rt::k_render_flat2<float, 1024>), grid, block, 0, stream, flat_view_of<float>(s), w, h, spp, d_tab, nt, d_out, cnt);
         else
@@ -630,7 +607,7 @@ rt_status rt_render_tiles_device(rt_scene *s, const rt_options *o, rt_traversal 
     }
     std::vector<rt::TileDev> tab;
     uint64_t total_px = 0; uint32_t total_blocks = 0;
-    const bool flat2 = trav == RT_TRAVERSAL_FLAT && flat_variant() != 1;
+    const bool flat2 = trav == RT_TRAVERSAL_FLAT;
     rt_status st = build_tile_table(o, tiles, n, tab, &total_px, &total_blocks, flat2 ? rt::kFlatBlockW : rt::kBlockW,
                                     flat2 ? rt::kFlatBlockH : rt::kBlockH);
     if (st != RT_OK) return st;
@@ -654,7 +631,7 @@ rt_status rt_render_tiles(rt_scene *s, const rt_options *o, rt_traversal trav, c
     if (!check_common(s, o, tiles, n, rgba_out)) return RT_ERR_INVALID_ARGUMENT;
     std::vector<rt::TileDev> tab;
     uint64_t total_px = 0; uint32_t total_blocks = 0;
-    const bool flat2 = trav == RT_TRAVERSAL_FLAT && flat_variant() != 1;
+    const bool flat2 = trav == RT_TRAVERSAL_FLAT;
     rt_status st = build_tile_table(o, tiles, n, tab, &total_px, &total_blocks, flat2 ? rt::kFlatBlockW : rt::kBlockW,
                                     flat2 ? rt::kFlatBlockH : rt::kBlockH);
     if (st != RT_OK) return st;

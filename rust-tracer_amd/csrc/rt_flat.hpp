@@ -2,7 +2,11 @@
 // the un-fused f32 VALU roofline (FMA is forbidden by parity, so a test costs 8 ops for a primary ray, 16 for a
 // shadow ray -- nothing else should issue).
 //
-// What changed against k_render_fused (rt_kernels.hpp), which spent 19 VALU + 9 SALU instructions per test:
+// One thread per pixel pair does everything Renderer::render_region does for its pixels (render.rs:218-255):
+// supersample loop (ssx outer, ssy inner), primary-ray generation, nearest-hit scan over the item array staged
+// through LDS in chunks, shade, shadow any-hit scan with a workgroup-level early-out, sequential f32 accumulation,
+// f32 -> u8 quantisation.  What it does to stay off everything but the VALU (a first version that tested one item at a
+// time with the full 17-op expression spent 19 VALU + 9 SALU instructions per test and ran 2.1x slower):
 //  * primary rays share Scene::eye, so the ray-independent terms of primitive.rs:56-58 are pre-formed per item
 //    (v = c - eye, vv = dot(v, v), rr = r*r; same individually rounded ops): 8 VALU per test instead of 17;
 //  * items are consumed four at a time: the 4 x R discriminants are reduced with v_max3 and ONE branch rejects the

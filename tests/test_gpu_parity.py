@@ -367,3 +367,48 @@ def test_lean_sqrt_is_correctly_rounded_for_every_f32():
     # the traversal loops use a lean correctly-rounded sqrt; it must equal the IEEE sqrt bit for bit on all 2^32 inputs
     bad, first = rta.capi.selftest_sqrt(0)
     assert bad == 0, "first differing input bits: 0x%08x" % first
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Committed vectors (tests/golden/oracle_vectors.json): the expected bytes are data in the repository, so these
+# checks do not depend on running the oracle at test time.
+# ----------------------------------------------------------------------------------------------------------
+def _vector_cases():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vectors.json")
+    return json.load(open(path))["cases"]
+
+
+def _scene_for(case):
+    prec = rta.RT_F64 if case["precision"] == "f64" else rta.RT_F32
+    if case["scene"] == "default8":
+        return rta.Scene.default(8, prec)
+    if case["scene"] == "default9":
+        return rta.Scene.default(9, prec)
+    if case["scene"] == "three_spheres":
+        return rta.Scene.three_spheres(prec)
+    if case["scene"] == "tie":
+        return rta.Scene.from_spheres(util.TIE_SPHERES, util.TIE_BOUND, precision=prec)
+    if case["scene"] == "inside":
+        return util.scene_pair_ranges(util.INSIDE_ITEMS, util.INSIDE_BOUNDS, util.INSIDE_RANGES, prec)[0]
+    raise KeyError(case["scene"])
+
+
+@pytest.mark.parametrize("case", _vector_cases(), ids=lambda c: c["name"])
+@pytest.mark.parametrize("trav", [SKIP, FLAT], ids=["skip", "flat"])
+def test_committed_vectors(case, trav):
+    if case["scene"] == "inside" and (trav == FLAT) != bool(case.get("flat")):
+        pytest.skip("the inside-bound scene has one golden per traversal semantics")
+    s = _scene_for(case)
+    w, h, spp = case["width"], case["height"], case["spp"]
+    regs = bucket_list(w, h, spp)
+    assert len(regs) == case["buckets"]
+    data, st = s.device().render_tiles((w, h, spp), regs, trav)
+    off = 0
+    for i, (l, t, r, b) in enumerate(regs):
+        n = (r - l) * (t - b) * 4
+        assert zlib.crc32(data[off:off + n].tobytes()) & 0xFFFFFFFF == case["tile_crc32"][i], (case["name"], i)
+        off += n
+    for k in ("primary", "hits", "shadow", "occluded"):
+        assert st[k] == case["stats"][k], k
+    if trav == SKIP:
+        assert (st["sphere_tests"], st["bound_tests"]) == (case["stats"]["sphere_tests"], case["stats"]["bound_tests"])
