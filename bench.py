@@ -2,7 +2,8 @@
 """Headline benchmark: Mrays/s + ms/frame on the 1920x1080, 21,845-sphere default scene (BASELINE.json).
 
 A "step" is one frame: every 64x64 bucket of the frame through the HIP hot path (primary + shadow rays), the
-RCCL gather of the u8 shards to rank 0 when N > 1, and the blit into the row-major frame.  The scene is already
+RCCL gather of the u8 shards to rank 0 and the blit into the row-major frame when N > 1 (at N = 1 the buckets are
+rendered straight into the frame: render and blit are one kernel).  The scene is already
 resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 
 The headline uses the product's default traversal, RT_TRAVERSAL_SKIP (the reference's own bounding-sphere
@@ -116,8 +117,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for i in range(steps):
-            fs.render_shard()
-            fs.finish()
+            fs.step()
         barrier()
         elapsed = time.perf_counter() - t0
         # per-launch duration of the render kernel alone: `steps` launches back to back between two HIP events on the
@@ -125,7 +125,7 @@ def main():
         k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         k0.record()
         for _ in range(steps):
-            fs.render_shard()
+            fs.render_frame() if world == 1 else fs.render_shard()
         k1.record()
         torch.cuda.synchronize()
         kern_ms = k0.elapsed_time(k1) / steps
@@ -172,7 +172,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (the reference's deterministic default scene: pyramid level 8)",
             "config": {"workload": "1920x1080, 21845 spheres (pyramid L8), spp 1, f32, %s traversal, 510 64x64 buckets "
-                                   "round-robin over %d GPU(s), RCCL gather + device blit to rank 0" % (args.traversal, world),
+                                   "round-robin over %d GPU(s)%s" % (args.traversal, world, ", RCCL gather + device blit to rank 0" if world > 1 else
+                                                                  ", rendered straight into the row-major frame"),
                        "width": WIDTH, "height": HEIGHT, "samples_per_pixel": SPP, "n_spheres": N_ITEMS,
                        "primary_rays": m["primary"], "shadow_rays": m["shadow"], "traversal": args.traversal,
                        "parallelism": "tiles/%d" % world},

@@ -123,6 +123,13 @@ rt_status rt_render_tiles_device(rt_scene *scene, const rt_options *options, rt_
                                  const rt_region *tiles, uint32_t n_tiles,
                                  void *rgba_out_device, void *hip_stream, rt_stats *stats);
 
+/* rt_render_tiles_device + rt_blit_tiles_device in one pass: every listed bucket is rendered straight into its place
+ * in a row-major RGBA frame of options->width x options->height in device memory -- what the writer's image holds
+ * after write_rgba_buffer() for each bucket (render.rs:422-424).  Pixels outside the listed buckets are left alone. */
+rt_status rt_render_frame_device(rt_scene *scene, const rt_options *options, rt_traversal traversal,
+                                 const rt_region *tiles, uint32_t n_tiles,
+                                 void *frame_rgba_device, void *hip_stream, rt_stats *stats);
+
 /* Single-bucket convenience == rt_render_tiles(..., region, 1, ...): the exact shape of the reference call. */
 rt_status rt_render_region(rt_scene *scene, const rt_options *options, rt_traversal traversal,
                            const rt_region *region, uint8_t *rgba_out, rt_stats *stats);

@@ -15,7 +15,7 @@ ABI_VERSION = 1
 
 # every symbol include/rtrace_hip.h declares
 SYMBOLS = ("rt_abi_version", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render_tiles",
-           "rt_render_tiles_device", "rt_render_region", "rt_blit_tiles_device", "rt_selftest_sqrt", "rt_tiles_rgba_bytes", "rt_strerror", "rt_last_error_message")
+           "rt_render_tiles_device", "rt_render_frame_device", "rt_render_region", "rt_blit_tiles_device", "rt_selftest_sqrt", "rt_tiles_rgba_bytes", "rt_strerror", "rt_last_error_message")
 
 
 class Options(C.Structure):      # rt_options / RenderOptions render.rs:33-38
@@ -57,6 +57,7 @@ lib.rt_scene_destroy.argtypes = [C.c_void_p]
 lib.rt_render_tiles.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
 lib.rt_render_tiles_device.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_void_p, C.c_uint32, C.c_void_p,
                                        C.c_void_p, C.POINTER(Stats)]
+lib.rt_render_frame_device.argtypes = lib.rt_render_tiles_device.argtypes
 lib.rt_render_region.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.POINTER(Region), C.c_void_p, C.POINTER(Stats)]
 lib.rt_blit_tiles_device.argtypes = [C.c_void_p, C.POINTER(Options), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]

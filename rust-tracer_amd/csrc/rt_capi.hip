@@ -307,6 +307,7 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
             return RT_OK;
         }
     }
+    if (!c) { *out = nullptr; return RT_OK; }                       // cache full and no context to upload through
     rt_status st = upload_tiles(c, tab, stream);
     if (st == RT_OK) *out = c->d_tiles;
     return st;
@@ -327,12 +328,12 @@ bool use_split(unsigned spp) { return spp > 1 && (unsigned long long)spp * spp <
 
 template <typename T, bool COUNT, int VAR>
 rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t stream, unsigned w, unsigned h, unsigned spp,
-                          const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt)
+                          const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt, unsigned frame_w)
 {
     const dim3 b(rt::kBlockThreads);
     rt::SampleBuf<T> sb{ nullptr, nullptr, (unsigned)total_px };
     if (!use_split(spp)) {
-        hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, false>), grid, b, 0, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb);
+        hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, false>), grid, b, 0, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb, frame_w);
         return RT_OK;
     }
     const size_t ns = (size_t)spp * spp, need = ns * total_px * sizeof(T);
@@ -347,37 +348,35 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     sb.gdot = static_cast<T *>(c->d_sample_gdot);
     sb.state = c->d_sample_state;
     hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, true>), dim3(grid.x, (unsigned)ns), b, 0, stream, skip_view_of<T>(s), w, h, spp, d_tab,
-                       nt, d_out, cnt, sb);
+                       nt, d_out, cnt, sb, frame_w);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL((rt::k_resolve_samples<T>), dim3((unsigned)((total_px + 255) / 256)), dim3(256), 0, stream, sb, spp, d_out);
+    hipLaunchKernelGGL((rt::k_resolve_samples<T>), grid, b, 0, stream, sb, spp, d_tab, nt, d_out, frame_w);
     return RT_OK;
 }
 
 template <typename T, bool COUNT>
 rt_status launch_skip_var(const rt_scene *s, Context *c, dim3 grid, hipStream_t stream, unsigned w, unsigned h, unsigned spp,
-                          const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt)
+                          const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt, unsigned frame_w)
 {
     switch (skip_variant()) {
-    case 1: return launch_skip_one<T, COUNT, 1>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt);
-    case 2: return launch_skip_one<T, COUNT, 2>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt);
-    case 3: return launch_skip_one<T, COUNT, 3>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt);
-    default: return launch_skip_one<T, COUNT, 0>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt);
+    case 1: return launch_skip_one<T, COUNT, 1>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
+    case 2: return launch_skip_one<T, COUNT, 2>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
+    case 3: return launch_skip_one<T, COUNT, 3>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
+    default: return launch_skip_one<T, COUNT, 0>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
     }
 }
 
 rt_status launch_skip(const rt_scene *s, Context *c, dim3 grid, hipStream_t stream, unsigned w, unsigned h, unsigned spp,
-                      const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt)
+                      const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt, unsigned frame_w)
 {
     if (s->precision == RT_F32)
-        return cnt ? launch_skip_var<float, true>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt)
-                   : launch_skip_var<float, false>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt);
-    return cnt ? launch_skip_var<double, true>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt)
-               : launch_skip_var<double, false>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt);
+        return cnt ? launch_skip_var<float, true>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w)
+                   : launch_skip_var<float, false>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
+    return cnt ? launch_skip_var<double, true>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w)
+               : launch_skip_var<double, false>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
 }
 
-// Enqueues every kernel of one pass on `stream`.  d_out must hold 4 * total_px bytes.
-rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversal trav, const std::vector<rt::TileDev> &tab,
-                       uint32_t total_blocks, uint64_t total_px, uint8_t *d_out, hipStream_t stream, bool want_counters)
+rt_status check_traversal(const rt_scene *s, rt_traversal trav)
 {
     if (trav != RT_TRAVERSAL_FLAT && trav != RT_TRAVERSAL_SKIP) {
         snprintf(g_err, sizeof g_err, "unknown traversal %d", (int)trav);
@@ -387,27 +386,46 @@ rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversa
         snprintf(g_err, sizeof g_err, "RT_TRAVERSAL_SKIP needs a scene created with subtree bounds");
         return RT_ERR_UNSUPPORTED;
     }
+    return RT_OK;
+}
+
+// The render kernels of one pass.  c may be NULL when the pass needs no per-call device state (no counters, no
+// sample buffers): then nothing but the kernel itself is enqueued.
+rt_status launch_render(rt_scene *s, Context *c, const rt_options *o, rt_traversal trav, const rt::TileDev *d_tab, unsigned nt,
+                        uint32_t total_blocks, uint64_t total_px, uint8_t *d_out, unsigned frame_w, hipStream_t stream, rt::Counters *cnt)
+{
+    const dim3 grid(total_blocks), block(rt::kBlockThreads);
+    const unsigned w = o->width, h = o->height, spp = o->samples_per_pixel;
+    if (trav == RT_TRAVERSAL_FLAT) {
+        if (s->precision == RT_F32)
+            hipLaunchKernelGGL((rt::k_render_flat2<float, 1024>), grid, block, 0, stream, flat_view_of<float>(s), w, h, spp, d_tab, nt, d_out, cnt, frame_w);
+        else
+            hipLaunchKernelGGL((rt::k_render_flat2<double, 512>), grid, block, 0, stream, flat_view_of<double>(s), w, h, spp, d_tab, nt, d_out, cnt, frame_w);
+    } else {
+        rt_status lst = launch_skip(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
+        if (lst != RT_OK) return lst;
+    }
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// Enqueues every kernel of one pass on `stream` through a leased context.  d_out must hold 4 * total_px bytes
+// (tile-major) or the whole frame (frame_w != 0).
+rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversal trav, const std::vector<rt::TileDev> &tab,
+                       uint32_t total_blocks, uint64_t total_px, uint8_t *d_out, unsigned frame_w, hipStream_t stream, bool want_counters)
+{
     const rt::TileDev *d_tab = nullptr;
     {
         rt_status ust = device_table(s, c, tab, stream, &d_tab);
         if (ust != RT_OK) return ust;
     }
-    if (want_counters) HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(rt::Counters) * rt::kCounterStripes, stream));
-    rt::Counters *cnt = want_counters ? c->d_counters : nullptr;
-
-    HIP_TRY(hipEventRecord(c->ev0, stream));
-    const dim3 grid(total_blocks), block(rt::kBlockThreads);
-    const unsigned w = o->width, h = o->height, spp = o->samples_per_pixel, nt = (unsigned)tab.size();
-    if (trav == RT_TRAVERSAL_FLAT) {
-        if (s->precision == RT_F32)
-            hipLaunchKernelGGL((rt::k_render_flat2<float, 1024>), grid, block, 0, stream, flat_view_of<float>(s), w, h, spp, d_tab, nt, d_out, cnt);
-        else
-            hipLaunchKernelGGL((rt::k_render_flat2<double, 512>), grid, block, 0, stream, flat_view_of<double>(s), w, h, spp, d_tab, nt, d_out, cnt);
-    } else {
-        rt_status lst = launch_skip(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt);
-        if (lst != RT_OK) return lst;
+    if (want_counters) {
+        HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(rt::Counters) * rt::kCounterStripes, stream));
+        HIP_TRY(hipEventRecord(c->ev0, stream));
     }
-    HIP_TRY(hipGetLastError());
+    rt_status st = launch_render(s, c, o, trav, d_tab, (unsigned)tab.size(), total_blocks, total_px, d_out, frame_w, stream,
+                                 want_counters ? c->d_counters : nullptr);
+    if (st != RT_OK) return st;
     HIP_TRY(hipEventRecord(c->ev1, stream));
     return RT_OK;
 }
@@ -597,42 +615,66 @@ rt_status rt_scene_destroy(rt_scene *s)
     return RT_OK;
 }
 
-rt_status rt_render_tiles_device(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n,
-                                 void *rgba_out_device, void *hip_stream, rt_stats *stats)
+// Shared body of rt_render_tiles_device (frame_w == 0, tile-major output) and rt_render_frame_device (row-major frame).
+static rt_status render_device(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n, void *out_device,
+                               unsigned frame_w, void *hip_stream, rt_stats *stats)
 {
-    if (!check_common(s, o, tiles, n, rgba_out_device)) return RT_ERR_INVALID_ARGUMENT;
-    if ((reinterpret_cast<uintptr_t>(rgba_out_device) & 3u) != 0) {
-        snprintf(g_err, sizeof g_err, "rgba_out_device must be 4-byte aligned");
+    if (!check_common(s, o, tiles, n, out_device)) return RT_ERR_INVALID_ARGUMENT;
+    if ((reinterpret_cast<uintptr_t>(out_device) & 3u) != 0) {
+        snprintf(g_err, sizeof g_err, "the device output buffer must be 4-byte aligned");
         return RT_ERR_INVALID_ARGUMENT;
     }
+    rt_status st = check_traversal(s, trav);
+    if (st != RT_OK) return st;
     std::vector<rt::TileDev> tab;
     uint64_t total_px = 0; uint32_t total_blocks = 0;
     const bool flat2 = trav == RT_TRAVERSAL_FLAT;
-    rt_status st = build_tile_table(o, tiles, n, tab, &total_px, &total_blocks, flat2 ? rt::kFlatBlockW : rt::kBlockW,
-                                    flat2 ? rt::kFlatBlockH : rt::kBlockH);
+    st = build_tile_table(o, tiles, n, tab, &total_px, &total_blocks, flat2 ? rt::kFlatBlockW : rt::kBlockW, flat2 ? rt::kFlatBlockH : rt::kBlockH);
     if (st != RT_OK) return st;
     HIP_TRY(hipSetDevice(s->device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    uint8_t *out = static_cast<uint8_t *>(out_device);
+    const bool split = trav == RT_TRAVERSAL_SKIP && use_split(o->samples_per_pixel);
+    if (!stats && !split) {
+        // Fast path: a cached tile table and no per-call device state -> the call enqueues exactly one kernel.
+        const rt::TileDev *d_tab = nullptr;
+        if ((st = device_table(s, nullptr, tab, stream, &d_tab)) != RT_OK) return st;
+        if (d_tab) return launch_render(s, nullptr, o, trav, d_tab, (unsigned)tab.size(), total_blocks, total_px, out, frame_w, stream, nullptr);
+    }
     Context *c = nullptr;
     if ((st = acquire(s, &c)) != RT_OK) return st;
     Lease lease{ s, c };
-    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    st = enqueue_pass(s, c, o, trav, tab, total_blocks, total_px, static_cast<uint8_t *>(rgba_out_device), stream, stats != nullptr);
+    st = enqueue_pass(s, c, o, trav, tab, total_blocks, total_px, out, frame_w, stream, stats != nullptr);
     if (st != RT_OK) return st;
     if (stats) return read_stats(s, c, stream, trav, stats);
-    // Asynchronous return: the context's tile table is still in use by the enqueued work, so it goes back to
-    // the pool marked in-flight and is only reused once its end event has completed.
+    // Asynchronous return: the context's buffers are still in use by the enqueued work, so it goes back to the pool
+    // marked in-flight and is only reused once its end event has completed.
     lease.inflight = true;
     return RT_OK;
+}
+
+rt_status rt_render_tiles_device(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n,
+                                 void *rgba_out_device, void *hip_stream, rt_stats *stats)
+{
+    return render_device(s, o, trav, tiles, n, rgba_out_device, 0u, hip_stream, stats);
+}
+
+rt_status rt_render_frame_device(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n,
+                                 void *frame_rgba_device, void *hip_stream, rt_stats *stats)
+{
+    return render_device(s, o, trav, tiles, n, frame_rgba_device, o ? (unsigned)o->width : 0u, hip_stream, stats);
 }
 
 rt_status rt_render_tiles(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n,
                           uint8_t *rgba_out, rt_stats *stats)
 {
     if (!check_common(s, o, tiles, n, rgba_out)) return RT_ERR_INVALID_ARGUMENT;
+    rt_status st = check_traversal(s, trav);
+    if (st != RT_OK) return st;
     std::vector<rt::TileDev> tab;
     uint64_t total_px = 0; uint32_t total_blocks = 0;
     const bool flat2 = trav == RT_TRAVERSAL_FLAT;
-    rt_status st = build_tile_table(o, tiles, n, tab, &total_px, &total_blocks, flat2 ? rt::kFlatBlockW : rt::kBlockW,
+    st = build_tile_table(o, tiles, n, tab, &total_px, &total_blocks, flat2 ? rt::kFlatBlockW : rt::kBlockW,
                                     flat2 ? rt::kFlatBlockH : rt::kBlockH);
     if (st != RT_OK) return st;
     HIP_TRY(hipSetDevice(s->device));
@@ -646,7 +688,7 @@ rt_status rt_render_tiles(rt_scene *s, const rt_options *o, rt_traversal trav, c
         HIP_TRY(hipMalloc(&c->d_out, bytes));
         c->out_cap = bytes;
     }
-    st = enqueue_pass(s, c, o, trav, tab, total_blocks, total_px, c->d_out, c->stream, stats != nullptr);
+    st = enqueue_pass(s, c, o, trav, tab, total_blocks, total_px, c->d_out, 0u, c->stream, stats != nullptr);
     if (st != RT_OK) return st;
     HIP_TRY(hipMemcpyAsync(rgba_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
     if (stats) return read_stats(s, c, c->stream, trav, stats);
@@ -669,11 +711,18 @@ rt_status rt_blit_tiles_device(rt_scene *s, const rt_options *o, const rt_region
     if (src_px_offset)
         for (uint32_t i = 0; i < n; ++i) tab[i].out_px = src_px_offset[i];
     HIP_TRY(hipSetDevice(s->device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const rt::TileDev *d_tab = nullptr;
+    if ((st = device_table(s, nullptr, tab, stream, &d_tab)) != RT_OK) return st;
+    if (d_tab) {                                                    // cached table: one kernel, nothing else
+        hipLaunchKernelGGL(rt::k_blit_tiles, dim3(total_blocks), dim3(rt::kBlockThreads), 0, stream, (unsigned)o->width, d_tab, (unsigned)n,
+                           static_cast<const unsigned *>(src), static_cast<unsigned *>(frame));
+        HIP_TRY(hipGetLastError());
+        return RT_OK;
+    }
     Context *c = nullptr;
     if ((st = acquire(s, &c)) != RT_OK) return st;
     Lease lease{ s, c };
-    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    const rt::TileDev *d_tab = nullptr;
     if ((st = device_table(s, c, tab, stream, &d_tab)) != RT_OK) return st;
     hipLaunchKernelGGL(rt::k_blit_tiles, dim3(total_blocks), dim3(rt::kBlockThreads), 0, stream, (unsigned)o->width, d_tab,
                        (unsigned)n, static_cast<const unsigned *>(src), static_cast<unsigned *>(frame));

@@ -100,7 +100,8 @@ template <> __device__ __forceinline__ float max3<float>(float a, float b, float
 template <typename T, int CHUNK>
 __global__ __launch_bounds__(kBlockThreads) void k_render_flat2(FlatView<T> sc, unsigned width, unsigned height, unsigned spp,
                                                                const TileDev *__restrict__ tiles, unsigned n_tiles,
-                                                               uint8_t *__restrict__ out, Counters *__restrict__ counters)
+                                                               uint8_t *__restrict__ out, Counters *__restrict__ counters,
+                                                               unsigned frame_w)
 {
     // one LDS array (16-B aligned): [0, CHUNK) quads, then CHUNK scalars of rr (primary pass only)
     __shared__ Quad<T> s_q[CHUNK + CHUNK / 4];
@@ -305,8 +306,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_flat2(FlatView<T> sc, 
         if (inside[r]) {
             const V3<T> c = mulf(g[r], total_recip);
             const T a = alpha[r] * total_recip;
-            const unsigned tw = tile.r - tile.l;
-            const size_t px = (size_t)tile.out_px + (size_t)(ys[r] - tile.b) * tw + (x - tile.l);
+            const size_t px = out_index(tile, x, ys[r], frame_w);
             reinterpret_cast<unsigned *>(out)[px] = scale_u8(c.x) | (scale_u8(c.y) << 8) | (scale_u8(c.z) << 16) | (scale_u8(a) << 24);
         }
     }

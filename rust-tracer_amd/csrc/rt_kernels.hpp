@@ -22,6 +22,13 @@ struct TileDev {
 // waves adding to ONE address serialise at ~88 atomics/us, which made a stats pass 15x slower than the render itself.
 constexpr unsigned kCounterStripes = 256;
 
+// Where pixel (x, y) of `tile` goes: tile-major (each bucket its own row-major RGBABuffer, render.rs:69-71) when
+// frame_w == 0, or straight into a row-major frame of that width (the result of set_pixels_from_buffer, render.rs:112-126).
+__device__ __forceinline__ size_t out_index(const TileDev &tile, unsigned x, unsigned y, unsigned frame_w)
+{
+    return frame_w ? (size_t)y * frame_w + x : (size_t)tile.out_px + (size_t)(y - tile.b) * (tile.r - tile.l) + (x - tile.l);
+}
+
 struct Counters {          // same meaning as the reference-side ray statistics
     unsigned long long primary, hits, shadow, occluded;
     unsigned long long sphere_tests, bound_tests;   // per-ray tests executed (SKIP traversal counts them exactly)

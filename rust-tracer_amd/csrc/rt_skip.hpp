@@ -109,7 +109,7 @@ template <typename T, bool COUNT, int VAR, bool SPLIT>
 __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, unsigned width, unsigned height, unsigned spp,
                                                               const TileDev *__restrict__ tiles, unsigned n_tiles,
                                                               uint8_t *__restrict__ out, Counters *__restrict__ counters,
-                                                              SampleBuf<T> sb)
+                                                              SampleBuf<T> sb, unsigned frame_w)
 {
     const unsigned gblock = blockIdx.x;                                      // 16x16 pixel block index
     unsigned lo = 0, hi = n_tiles - 1;
@@ -169,27 +169,29 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                 // Sphere::distance_from_ray with the ray-independent parts pre-formed (primitive.rs:55-72)
                 const T b = (nd.a0 * dir.x + nd.a1 * dir.y) + nd.a2 * dir.z;
                 const T disc = (b * b - nd.a3) + nd.a4;
-                const bool pos = !(disc < T(0.0));
                 const bool is_bound = nd.skip != 0u;
-                T d = inf<T>();
-                if (pos) {
-                    const T s = (VAR & 1) ? sqrt_rn_lean(disc) : rsqrt_exact(disc);
-                    const T t2 = b + s;
-                    if (!(t2 < T(0.0))) {
-                        const T t1 = b - s;
-                        d = t1 > T(0.0) ? t1 : t2;
-                    }
-                }
                 unsigned ni;
-                if (is_bound) {                                         // BOUND  group.rs:73
-                    const bool cull = active && (d >= best);
-                    if (cull) resume = nd.skip;
-                    if (COUNT) c_bounds += active ? 1u : 0u;
-                    ni = (__ballot(active && !cull) == 0) ? nd.skip : i + 1;
-                } else {                                                // ITEM   primitive.rs:78-83
-                    if (active && !(d >= best)) { best = d; best_item = nd.item; }
-                    if (COUNT) c_items += active ? 1u : 0u;
-                    ni = i + 1;
+                {
+                    const bool pos = !(disc < T(0.0));
+                    T d = inf<T>();
+                    if (pos) {
+                        const T s = (VAR & 1) ? sqrt_rn_lean(disc) : rsqrt_exact(disc);
+                        const T t2 = b + s;
+                        if (!(t2 < T(0.0))) {
+                            const T t1 = b - s;
+                            d = t1 > T(0.0) ? t1 : t2;
+                        }
+                    }
+                    if (is_bound) {                                     // BOUND  group.rs:73
+                        const bool cull = active && (d >= best);
+                        if (cull) resume = nd.skip;
+                        if (COUNT) c_bounds += active ? 1u : 0u;
+                        ni = (__ballot(active && !cull) == 0) ? nd.skip : i + 1;
+                    } else {                                            // ITEM   primitive.rs:78-83
+                        if (active && !(d >= best)) { best = d; best_item = nd.item; }
+                        if (COUNT) c_items += active ? 1u : 0u;
+                        ni = i + 1;
+                    }
                 }
                 if (COUNT) ++c_steps;
                 // the asm loads must have landed before their registers can be reused, also on the way out
@@ -247,9 +249,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                     const V3<T> v = { nd.a0 - sp.x, nd.a1 - sp.y, nd.a2 - sp.z };
                     const T b = dot(v, sdir);
                     const T disc = (b * b - dot(v, v)) + nd.a3;
-                    const bool pos = !(disc < T(0.0));
                     bool hit = false;
-                    if (pos) hit = !((b + ((VAR & 1) ? sqrt_rn_lean(disc) : rsqrt_exact(disc))) < T(0.0));
+                    {
+                        const bool pos = !(disc < T(0.0));
+                        if (pos) hit = !((b + ((VAR & 1) ? sqrt_rn_lean(disc) : rsqrt_exact(disc))) < T(0.0));
+                    }
                     unsigned ni;
                     if (nd.skip != 0u) {
                         const bool cull = active && !hit;
@@ -306,8 +310,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     if (!SPLIT && inside) {
         g = mulf(g, total_recip);
         alpha *= total_recip;
-        const unsigned tw = tile.r - tile.l;
-        const size_t px = (size_t)tile.out_px + (size_t)(y - tile.b) * tw + (x - tile.l);
+        const size_t px = out_index(tile, x, y, frame_w);
         const unsigned rgba = scale_u8(g.x) | (scale_u8(g.y) << 8) | (scale_u8(g.z) << 16) | (scale_u8(alpha) << 24);
         reinterpret_cast<unsigned *>(out)[px] = rgba;
     }
@@ -335,10 +338,20 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
 // Second pass of the SPLIT path: render.rs:233-252 for one pixel -- its samples' contributions accumulated strictly
 // in the reference's order (ssx outer, ssy inner; each term added on its own, never pre-summed), then quantised.
 template <typename T>
-__global__ __launch_bounds__(kBlockThreads) void k_resolve_samples(SampleBuf<T> sb, unsigned spp, uint8_t *__restrict__ out)
+__global__ __launch_bounds__(kBlockThreads) void k_resolve_samples(SampleBuf<T> sb, unsigned spp, const TileDev *__restrict__ tiles,
+                                                                  unsigned n_tiles, uint8_t *__restrict__ out, unsigned frame_w)
 {
-    const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= sb.n_px) return;
+    unsigned lo = 0, hi = n_tiles - 1;
+    while (lo < hi) {
+        unsigned mid = (lo + hi + 1) >> 1;
+        if (tiles[mid].blk_first <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const TileDev tile = tiles[lo];
+    const unsigned lb = blockIdx.x - tile.blk_first;
+    const unsigned x = tile.l + (lb % tile.blks_x) * kBlockW + (threadIdx.x & 15);
+    const unsigned y = tile.b + (lb / tile.blks_x) * kBlockH + (threadIdx.x >> 4);
+    if (!(x < tile.r && y < tile.t)) return;
+    const size_t p = out_index(tile, x, y, 0);                   // the samples are always stored tile-major
     const V3<T> OBJECT = { T(0xae) / T(255.0), T(0x31) / T(255.0), T(0x31) / T(255.0) };
     const V3<T> BACKGROUND = { T(0x22) / T(255.0), T(0x0a) / T(255.0), T(0x0a) / T(255.0) };
     const V3<T> AMBIENT = { BACKGROUND.x * T(0.8), BACKGROUND.y * T(0.8), BACKGROUND.z * T(0.8) };
@@ -358,7 +371,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_resolve_samples(SampleBuf<T> 
     }
     g = mulf(g, total_recip);
     alpha *= total_recip;
-    reinterpret_cast<unsigned *>(out)[p] = scale_u8(g.x) | (scale_u8(g.y) << 8) | (scale_u8(g.z) << 16) | (scale_u8(alpha) << 24);
+    reinterpret_cast<unsigned *>(out)[out_index(tile, x, y, frame_w)] =
+        scale_u8(g.x) | (scale_u8(g.y) << 8) | (scale_u8(g.z) << 16) | (scale_u8(alpha) << 24);
 }
 
 }  // namespace rt

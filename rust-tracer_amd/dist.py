@@ -102,9 +102,19 @@ class FrameSharder:
                                        stream, self.all_offsets)
 
     def step(self):
-        """One frame: render shard -> (gather) -> blit on rank 0.  Everything is enqueued on torch's current stream."""
-        self.render_shard()
-        self.finish()
+        """One frame.  world > 1: render shard -> RCCL gather -> blit on rank 0.  world == 1: the buckets are rendered
+        straight into the row-major frame (rt_render_frame_device = render + blit in one kernel).  Everything is enqueued
+        on torch's current stream."""
+        if self.world == 1:
+            self.render_frame()
+        else:
+            self.render_shard()
+            self.finish()
+
+    def render_frame(self, want_stats=False):
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        return self.dev.render_frame_device(tuple(self.options), self.my_regions_c, self.frame.data_ptr(), stream,
+                                            self.traversal, want_stats)
 
     def frame_host(self):
         self.torch.cuda.synchronize(self.device)

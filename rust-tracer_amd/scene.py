@@ -149,6 +149,16 @@ class DeviceScene:
         capi.check(rc, "rt_render_tiles_device")
         return st.as_dict() if want_stats else None
 
+    def render_frame_device(self, options, regions, frame_ptr, stream=0, traversal=capi.RT_TRAVERSAL_SKIP, want_stats=False):
+        """rt_render_frame_device: the buckets rendered straight into a row-major device frame (render + blit fused)."""
+        arr = regions if isinstance(regions, C.Array) else self._regions(regions)
+        st = capi.Stats()
+        o = capi.Options(*options)
+        rc = capi.lib.rt_render_frame_device(self._h, C.byref(o), traversal, arr, len(arr), C.c_void_p(frame_ptr),
+                                             C.c_void_p(stream), C.byref(st) if want_stats else None)
+        capi.check(rc, "rt_render_frame_device")
+        return st.as_dict() if want_stats else None
+
     def blit_tiles_device(self, options, regions, src_ptr, frame_ptr, stream=0, src_px_offset=None):
         """rt_blit_tiles_device: tile-major device tiles -> row-major device frame (set_pixels_from_buffer)."""
         arr = regions if isinstance(regions, C.Array) else self._regions(regions)

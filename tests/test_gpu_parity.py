@@ -412,3 +412,64 @@ def test_committed_vectors(case, trav):
         assert st[k] == case["stats"][k], k
     if trav == SKIP:
         assert (st["sphere_tests"], st["bound_tests"]) == (case["stats"]["sphere_tests"], case["stats"]["bound_tests"])
+
+
+@pytest.mark.parametrize("trav", [SKIP, FLAT], ids=["skip", "flat"])
+@pytest.mark.parametrize("size", [(800, 600, 1), (320, 200, 2)])
+def test_render_frame_device_equals_tiles_plus_blit(trav, size):
+    # rt_render_frame_device == rt_render_tiles_device + rt_blit_tiles_device == host stitch of rt_render_tiles
+    import torch
+    w, h, spp = size
+    s, _ = util.scene_pair_default()
+    d = s.device()
+    regs = bucket_list(w, h, spp)
+    host, _ = d.render_tiles((w, h, spp), regs, trav)
+    expect = util.stitch((w, h), regs, host)
+    stream = torch.cuda.current_stream().cuda_stream
+    frame = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    st = d.render_frame_device((w, h, spp), regs, frame.data_ptr(), stream, trav, want_stats=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(frame.cpu().numpy().reshape(h, w, 4), expect)
+    assert st["primary"] == w * h * spp * spp
+    shard = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    frame2 = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    d.render_tiles_device((w, h, spp), regs, shard.data_ptr(), stream, trav)
+    d.blit_tiles_device((w, h, spp), regs, shard.data_ptr(), frame2.data_ptr(), stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(frame2.cpu().numpy().reshape(h, w, 4), expect)
+
+
+def test_frame_mode_leaves_unlisted_buckets_alone():
+    import torch
+    s, _ = util.scene_pair_default()
+    d = s.device()
+    regs = bucket_list(256, 192)
+    frame = torch.full((256 * 192 * 4,), 7, dtype=torch.uint8, device="cuda")
+    d.render_frame_device((256, 192, 1), regs[::2], frame.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = frame.cpu().numpy().reshape(192, 256, 4)
+    host, _ = d.render_tiles((256, 192, 1), regs)
+    full = util.stitch((256, 192), regs, host)
+    for i, (l, t, r, b) in enumerate(regs):
+        if i % 2 == 0:
+            np.testing.assert_array_equal(got[b:t, l:r], full[b:t, l:r])
+        else:
+            assert (got[b:t, l:r] == 7).all()
+
+
+def test_many_async_calls_in_flight_reuse_nothing_they_should_not():
+    # back-to-back asynchronous passes with different tile lists on one stream: results must not interfere
+    import torch
+    s, o = util.scene_pair_default()
+    d = s.device()
+    stream = torch.cuda.current_stream().cuda_stream
+    jobs = []
+    for k in range(12):
+        regs = bucket_list(128 + 64 * (k % 3), 128)
+        buf = torch.zeros(sum((r - l) * (t - b) for l, t, r, b in regs) * 4, dtype=torch.uint8, device="cuda")
+        d.render_tiles_device((128 + 64 * (k % 3), 128, 1 + (k % 2)), regs, buf.data_ptr(), stream, SKIP)
+        jobs.append((128 + 64 * (k % 3), 1 + (k % 2), regs, buf))
+    torch.cuda.synchronize()
+    for w, spp, regs, buf in jobs:
+        ref, _, _ = o.render(w, 128, spp, nthreads=4)
+        np.testing.assert_array_equal(util.stitch((w, 128), regs, buf.cpu().numpy()), ref)

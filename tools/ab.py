@@ -15,7 +15,7 @@ import rust_tracer_amd as rta
 libc = ctypes.CDLL(None)
 
 
-TRAV = rta.RT_TRAVERSAL_FLAT if os.environ.get("AB_TRAVERSAL", "skip") == "flat" else TRAV
+TRAV = rta.RT_TRAVERSAL_FLAT if os.environ.get("AB_TRAVERSAL", "skip") == "flat" else rta.RT_TRAVERSAL_SKIP
 ENV = os.environ.get("AB_ENV", "RT_SKIP_VARIANT")
 LAUNCHES = int(os.environ.get("AB_LAUNCHES", "5"))
 
