@@ -5,7 +5,10 @@ The reference's only parallelism is "independent 64x64 buckets on a thread pool"
 its shard tile-major into device memory and a single RCCL gather of the u8 shards over xGMI brings them to
 rank 0, which blits them into the row-major frame on the device.  No other collective touches the data path.
 
-The sharding arithmetic is plain Python (testable on CPU with gloo); only `FrameSharder.step` touches the GPU."""
+The sharding arithmetic is plain Python (testable on CPU with gloo); only `FrameSharder.step` touches the GPU.
+
+Load order: PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as the system one librtrace_hip.so links),
+so a process that uses both must `import torch` BEFORE `import rust_tracer_amd` (bench.py and tests/conftest.py do)."""
 import numpy as np
 
 from . import capi
