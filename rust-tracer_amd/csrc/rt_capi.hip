@@ -314,13 +314,14 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
 }
 
 // Tuning variant of k_render_skip (rt_skip.hpp VAR bits); RT_SKIP_VARIANT overrides the default for A/B runs.
-constexpr int kSkipVariantDefault = 1;   // lean sqrt; the prefetch (2) only pays for a lone wave, it costs throughput under load
+constexpr int kSkipVariantDefault = 5;   // hand-written f32 traversal loops (4) + lean sqrt in the C++ loops (1); the prefetch (2)
+                                         // only pays for a lone wave and costs throughput under load
 
 int skip_variant()
 {
     // read per call so one process can interleave variants (A/B timing in tools/ab_skip.py)
     const char *e = getenv("RT_SKIP_VARIANT");
-    return e ? atoi(e) & 3 : kSkipVariantDefault;
+    return e ? atoi(e) & 7 : kSkipVariantDefault;
 }
 
 // spp > 1 runs sample-parallel (one thread per sample + a resolve pass) unless spp*spp exceeds grid.y's limit.
@@ -362,6 +363,7 @@ rt_status launch_skip_var(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     case 1: return launch_skip_one<T, COUNT, 1>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
     case 2: return launch_skip_one<T, COUNT, 2>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
     case 3: return launch_skip_one<T, COUNT, 3>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
+    case 5: return launch_skip_one<T, COUNT, 5>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
     default: return launch_skip_one<T, COUNT, 0>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
     }
 }

@@ -14,6 +14,7 @@
 // reference performs for its ray -- including the reference's behaviour when a ray starts inside a bound.
 #pragma once
 #include "rt_kernels.hpp"
+#include "rt_skip_asm.hpp"
 
 namespace rt {
 
@@ -89,6 +90,7 @@ template <> __device__ __forceinline__ Node<float> as_node<float>(const i32x8 &r
 
 // VAR bits (tuning variants, all bit-identical in output and counters):
 //   1 = sqrt_rn_lean (same value as the IEEE sqrt for every input, about half the instructions)
+//   4 = (f32, launches that do not count tests) the primary traversal loop hand-written in assembly, rt_skip_asm.hpp
 //   2 = the records of both possible successors (i+1 and skip) are fetched with hand-placed scalar loads while node i
 //       is processed, so the dependent scalar-load latency leaves the wave's critical path
 //
@@ -158,6 +160,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             unsigned best_item = 0;
             unsigned resume = inside ? 0u : kNever;
             unsigned i = 0;
+            if constexpr ((VAR & 4) && !COUNT && sizeof(T) == 4) {
+                skip_primary_asm(sc.prim, n, dir.x, dir.y, dir.z, resume, best, best_item);
+            } else {
             Node<T> nd = sc.prim[0];                                    // wave-uniform record -> SGPRs
             for (;;) {
                 i32x8 pf_next, pf_skip;
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                 }
                 i = ni;
             }
+            }
 
             // ---------------- shade  render.rs:190-199 ----------------
             bool need_shadow = false;
@@ -237,7 +243,19 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             bool occluded = false;
             resume = need_shadow ? 0u : kNever;
             i = 0;
-            if (__ballot(need_shadow) != 0) {
+            if constexpr ((VAR & 4) && !COUNT && sizeof(T) == 4) {
+                if (__ballot(need_shadow) != 0) {
+                    while (i < n) {
+                        unsigned fin;
+                        i = skip_shadow_asm(sc.shad, n, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
+                        if (i >= n) break;
+                        if (fin) { occluded = true; resume = kNever; }
+                        // some lane retired at item i: go straight to the next node any lane still wants
+                        i = (unsigned)__builtin_amdgcn_readfirstlane(
+                            (int)wave_min_u32(resume == kNever ? kNever : (resume > i ? resume : i + 1)));
+                    }
+                }
+            } else if (__ballot(need_shadow) != 0) {
                 Node<T> nd = sc.shad[0];
                 for (;;) {
                     i32x8 pf_next, pf_skip;

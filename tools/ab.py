@@ -42,6 +42,10 @@ def main():
         st = dev.render_tiles_device(opts, regs_c, out.data_ptr(), stream, TRAV, want_stats=True)
         torch.cuda.synchronize()
         frame = out.cpu().numpy().copy()
+        out.zero_()
+        dev.render_tiles_device(opts, regs_c, out.data_ptr(), stream, TRAV)          # the launch the timing uses (no counters)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), frame), "variant %d: the launch without counters renders different pixels" % v
         key = (st["primary"], st["hits"], st["shadow"], st["occluded"], st["sphere_tests"], st["bound_tests"])
         if ref is None:
             ref = (frame, key)
