@@ -317,11 +317,17 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
 constexpr int kSkipVariantDefault = 5;   // hand-written f32 traversal loops (4) + lean sqrt in the C++ loops (1); the prefetch (2)
                                          // only pays for a lone wave and costs throughput under load
 
-int skip_variant()
+// A pass of at most this many waves leaves the 8,192 wave slots of the chip under-filled for most of its duration: its
+// time is its longest wave's chain, and the prefetching loop flavour (VAR 2) shortens exactly that (measured: 1080p
+// 125 -> 118 us, 960x540 132 -> 115 us; but 3840x2160 260 -> 304 us, so larger passes keep the plain flavour).
+constexpr uint64_t kLatencyRegimeWaves = 6 * 8192;
+
+int skip_variant(uint64_t waves)
 {
-    // read per call so one process can interleave variants (A/B timing in tools/ab_skip.py)
+    // read per call so one process can interleave variants (A/B timing in tools/ab.py)
     const char *e = getenv("RT_SKIP_VARIANT");
-    return e ? atoi(e) & 7 : kSkipVariantDefault;
+    if (e) return atoi(e) & 7;
+    return kSkipVariantDefault | (waves <= kLatencyRegimeWaves ? 2 : 0);
 }
 
 // spp > 1 runs sample-parallel (one thread per sample + a resolve pass) unless spp*spp exceeds grid.y's limit.
@@ -359,11 +365,12 @@ template <typename T, bool COUNT>
 rt_status launch_skip_var(const rt_scene *s, Context *c, dim3 grid, hipStream_t stream, unsigned w, unsigned h, unsigned spp,
                           const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt, unsigned frame_w)
 {
-    switch (skip_variant()) {
+    switch (skip_variant((uint64_t)grid.x * 4 * (use_split(spp) ? (uint64_t)spp * spp : 1))) {
     case 1: return launch_skip_one<T, COUNT, 1>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
     case 2: return launch_skip_one<T, COUNT, 2>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
     case 3: return launch_skip_one<T, COUNT, 3>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
     case 5: return launch_skip_one<T, COUNT, 5>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
+    case 7: return launch_skip_one<T, COUNT, 7>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
     default: return launch_skip_one<T, COUNT, 0>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
     }
 }

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             unsigned resume = inside ? 0u : kNever;
             unsigned i = 0;
             if constexpr ((VAR & 4) && !COUNT && sizeof(T) == 4) {
-                skip_primary_asm(sc.prim, n, dir.x, dir.y, dir.z, resume, best, best_item);
+                skip_primary_asm<(VAR & 2) != 0>(sc.prim, n, dir.x, dir.y, dir.z, resume, best, best_item);
             } else {
             Node<T> nd = sc.prim[0];                                    // wave-uniform record -> SGPRs
             for (;;) {
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                 if (__ballot(need_shadow) != 0) {
                     while (i < n) {
                         unsigned fin;
-                        i = skip_shadow_asm(sc.shad, n, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
+                        i = skip_shadow_asm<(VAR & 2) != 0>(sc.shad, n, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
                         if (i >= n) break;
                         if (fin) { occluded = true; resume = kNever; }
                         // some lane retired at item i: go straight to the next node any lane still wants
