@@ -112,12 +112,10 @@ def main():
         if dist is not None:
             dist.all_reduce(cnt)
         primary, shadow = (int(v) for v in cnt.tolist())
-        for _ in range(warmup):
-            fs.step()
+        fs.run(warmup)
         barrier()
         t0 = time.perf_counter()
-        for i in range(steps):
-            fs.step()
+        fs.run(steps)                                  # N > 1: gather(k) on RCCL's stream overlaps render(k+1)
         barrier()
         elapsed = time.perf_counter() - t0
         # per-launch duration of the render kernel alone: `steps` launches back to back between two HIP events on the

@@ -58,12 +58,17 @@ def assemble_host(options, world, gathered):
 
 
 class FrameSharder:
-    """One per process (= per GPU).  step() renders this rank's buckets and, for world > 1, gathers the u8
-    shards to rank 0 over RCCL and blits them into the frame there."""
+    """One per process (= per GPU).  world == 1: a step renders the buckets straight into the row-major frame.
+    world > 1: a step renders this rank's buckets tile-major, one RCCL gather brings the u8 shards to rank 0, and rank 0
+    blits them into the frame.  run() pipelines consecutive frames: the gather of frame k (RCCL's own stream) overlaps
+    the render of frame k+1, so a sequence of frames costs max(render, gather + blit) per frame instead of their sum."""
 
-    def __init__(self, scene, options, rank=0, world=1, device=0, traversal=capi.RT_TRAVERSAL_FLAT):
+    def __init__(self, scene, options, rank=0, world=1, device=0, traversal=capi.RT_TRAVERSAL_SKIP, force_collective=False):
         import torch
         self.torch = torch
+        # force_collective: take the shard -> gather -> blit path even for world == 1 (a one-rank RCCL gather); lets a
+        # single-GPU test drive exactly the code the 8-GPU run executes
+        self.collective = world > 1 or force_collective
         self.options = RenderOptions(*options)
         self.rank, self.world, self.device = rank, world, device
         self.traversal = traversal
@@ -72,52 +77,78 @@ class FrameSharder:
         self.my_regions = [tuple(bl[i]) for i in per_rank[rank][0]]
         self.my_regions_c = self.dev._regions(self.my_regions)
         tdev = torch.device("cuda", device)
-        self.shard = torch.zeros(self.shard_px * 4, dtype=torch.uint8, device=tdev)
+        # two shard buffers: frame k+1 is rendered while frame k's shard is still being gathered
+        self.shards = [torch.zeros(self.shard_px * 4, dtype=torch.uint8, device=tdev) for _ in range(2)]
+        self.shard = self.shards[0]
         self.frame = None
-        self.gathered = None
         if rank == 0:
             self.frame = torch.zeros(self.options.height * self.options.width * 4, dtype=torch.uint8, device=tdev)
             regions, offsets, _ = gathered_tile_table(self.options, world)
             self.all_regions_c = self.dev._regions(regions)
             self.all_offsets = offsets
-            if world > 1:
-                # one buffer for the blit; the gather list is views of its rows
-                self.gathered_flat = torch.zeros(world * self.shard_px * 4, dtype=torch.uint8, device=tdev)
-                self.gathered = list(self.gathered_flat.view(world, self.shard_px * 4).unbind(0))
+            if self.collective:
+                # one buffer per in-flight frame for the blit; the gather lists are views of its rows
+                self.gathered_flat = [torch.zeros(world * self.shard_px * 4, dtype=torch.uint8, device=tdev) for _ in range(2)]
+                self.gathered = [list(g.view(world, self.shard_px * 4).unbind(0)) for g in self.gathered_flat]
 
-    def render_shard(self, want_stats=False):
-        stream = self.torch.cuda.current_stream(self.device).cuda_stream
-        return self.dev.render_tiles_device(tuple(self.options), self.my_regions_c, self.shard.data_ptr(), stream,
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def render_shard(self, want_stats=False, slot=0):
+        """This rank's buckets, tile-major, into shard buffer `slot` (enqueued on torch's current stream)."""
+        return self.dev.render_tiles_device(tuple(self.options), self.my_regions_c, self.shards[slot].data_ptr(), self._stream(),
                                             self.traversal, want_stats)
-
-    def finish(self):
-        """The part of a frame after the render: RCCL gather of the u8 shards (world > 1) + blit on rank 0."""
-        torch = self.torch
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.gather(self.shard, self.gathered if self.rank == 0 else None, dst=0)
-            src = self.gathered_flat if self.rank == 0 else None
-        else:
-            src = self.shard
-        if self.rank == 0:
-            self.dev.blit_tiles_device(tuple(self.options), self.all_regions_c, src.data_ptr(), self.frame.data_ptr(),
-                                       stream, self.all_offsets)
-
-    def step(self):
-        """One frame.  world > 1: render shard -> RCCL gather -> blit on rank 0.  world == 1: the buckets are rendered
-        straight into the row-major frame (rt_render_frame_device = render + blit in one kernel).  Everything is enqueued
-        on torch's current stream."""
-        if self.world == 1:
-            self.render_frame()
-        else:
-            self.render_shard()
-            self.finish()
 
     def render_frame(self, want_stats=False):
-        stream = self.torch.cuda.current_stream(self.device).cuda_stream
-        return self.dev.render_frame_device(tuple(self.options), self.my_regions_c, self.frame.data_ptr(), stream,
+        """world == 1: the buckets straight into the row-major frame (rt_render_frame_device = render + blit fused)."""
+        return self.dev.render_frame_device(tuple(self.options), self.my_regions_c, self.frame.data_ptr(), self._stream(),
                                             self.traversal, want_stats)
+
+    def gather(self, slot=0, async_op=False):
+        """The one collective on the data path: equal-length u8 shards to rank 0 over RCCL."""
+        import torch.distributed as dist
+        return dist.gather(self.shards[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, async_op=async_op)
+
+    def blit(self, slot=0):
+        """Rank 0: gathered shards -> row-major frame (set_pixels_from_buffer on the device)."""
+        if self.rank == 0:
+            src = self.gathered_flat[slot] if self.collective else self.shards[slot]
+            self.dev.blit_tiles_device(tuple(self.options), self.all_regions_c, src.data_ptr(), self.frame.data_ptr(),
+                                       self._stream(), self.all_offsets)
+
+    def step(self):
+        """One complete frame, nothing left in flight."""
+        if not self.collective:
+            self.render_frame()
+        else:
+            self.render_shard(slot=0)
+            self.gather(slot=0)
+            self.blit(slot=0)
+
+    def run(self, steps):
+        """`steps` complete frames.  world > 1: software-pipelined, gather(k) overlaps render(k+1); every frame has been
+        blitted on rank 0 when this returns (the caller still synchronises the device)."""
+        if not self.collective:
+            for _ in range(steps):
+                self.render_frame()
+            return
+        works = [None, None]
+        for k in range(steps):
+            slot = k & 1
+            if works[slot] is not None:          # frame k-2 used this shard buffer: its gather must have finished
+                works[slot].wait()
+                works[slot] = None
+            self.render_shard(slot=slot)
+            works[slot] = self.gather(slot=slot, async_op=True)
+            prev = slot ^ 1
+            if k > 0 and works[prev] is not None:
+                works[prev].wait()               # frame k-1 has arrived (this only orders the stream, the host runs on)
+                works[prev] = None
+                self.blit(slot=prev)
+        last = (steps - 1) & 1
+        if steps > 0 and works[last] is not None:
+            works[last].wait()
+            self.blit(slot=last)
 
     def frame_host(self):
         self.torch.cuda.synchronize(self.device)

@@ -1,0 +1,57 @@
+"""The multi-GPU code path on ONE GPU: a one-rank RCCL process group drives exactly what `bench.py --gpus N` runs
+(double-buffered shards, asynchronous gather overlapped with the next render, device blit on rank 0)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import rust_tracer_amd as rta
+from rust_tracer_amd.dist import FrameSharder
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def one_rank_rccl():
+    import torch
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("size", [(1920, 1080, 1), (800, 600, 2)])
+def test_pipelined_gather_path_produces_the_oracle_frame(one_rank_rccl, size):
+    import torch
+    w, h, spp = size
+    s, o = util.scene_pair_default()
+    ref, _, _ = o.render(w, h, spp, nthreads=os.cpu_count() or 1)
+    fs = FrameSharder(s, (w, h, spp), 0, 1, 0, rta.RT_TRAVERSAL_SKIP, force_collective=True)
+    for sh in fs.shards:
+        sh.fill_(0xAB)                      # poison: every byte the blit reads must have been rendered + gathered
+    for g in fs.gathered_flat:
+        g.fill_(0xCD)
+    fs.step()
+    np.testing.assert_array_equal(fs.frame_host(), ref)
+    for steps in (1, 2, 5):
+        fs.frame.zero_()
+        torch.cuda.synchronize()
+        fs.run(steps)
+        np.testing.assert_array_equal(fs.frame_host(), ref)
+
+
+def test_fused_single_gpu_path_equals_collective_path(one_rank_rccl):
+    s, _ = util.scene_pair_default()
+    a = FrameSharder(s, (1024, 768, 1), 0, 1, 0, rta.RT_TRAVERSAL_SKIP)
+    b = FrameSharder(s, (1024, 768, 1), 0, 1, 0, rta.RT_TRAVERSAL_SKIP, force_collective=True)
+    a.run(3)
+    b.run(3)
+    np.testing.assert_array_equal(a.frame_host(), b.frame_host())
