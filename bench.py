@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flat", action="store_true", help="skip the secondary flat-scan measurement")
     ap.add_argument("--traversal", choices=("skip", "flat"), default="skip", help="traversal of the headline measurement")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="diagnostic: take the shard -> RCCL gather -> blit path even at N = 1 (needs torch.distributed.run)")
     args = ap.parse_args()
 
     import torch
@@ -91,9 +93,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     scene = rta.Scene.default(LEVEL, rta.RT_F32)
@@ -106,7 +109,7 @@ def main():
 
     def measure(traversal, steps, warmup):
         """-> dict with whole-job ms/step (max over ranks), this rank's kernel ms (HIP events), ray/test counters."""
-        fs = FrameSharder(scene, opts, rank, world, local, traversal)
+        fs = FrameSharder(scene, opts, rank, world, local, traversal, force_collective=args.force_collective)
         st = fs.render_shard(want_stats=True)          # counters of this rank's shard (equal the oracle's; tests)
         cnt = torch.tensor([st["primary"], st["shadow"]], dtype=torch.int64, device="cuda")
         if dist is not None:
@@ -123,7 +126,7 @@ def main():
         k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         k0.record()
         for _ in range(steps):
-            fs.render_frame() if world == 1 else fs.render_shard()
+            fs.render_shard() if fs.collective else fs.render_frame()
         k1.record()
         torch.cuda.synchronize()
         kern_ms = k0.elapsed_time(k1) / steps
