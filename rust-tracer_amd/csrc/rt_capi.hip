@@ -72,8 +72,6 @@ struct rt_scene {
     rt_precision precision = RT_F32;
     uint32_t n_items = 0, n_bounds = 0;
     void *d_items = nullptr;       // Item<REAL>[n_items], DFS order
-    void *d_bounds = nullptr;      // Item<REAL>[n_bounds]
-    rt_range *d_ranges = nullptr;
     void *d_prim = nullptr, *d_shad = nullptr;   // Node<REAL>[n_nodes]: skip-pointer streams (RT_TRAVERSAL_SKIP)
     uint32_t n_nodes = 0;
     void *d_fprim = nullptr, *d_fprim_rr = nullptr, *d_fshad = nullptr;   // pre-formed per-item terms (RT_TRAVERSAL_FLAT)
@@ -89,6 +87,8 @@ struct rt_scene {
 
 namespace {
 
+constexpr size_t kMaxContexts = 8;
+
 rt_status acquire(rt_scene *s, Context **out)
 {
     std::lock_guard<std::mutex> lk(s->mu);
@@ -99,6 +99,16 @@ rt_status acquire(rt_scene *s, Context **out)
             c->inflight = false;
         }
         c->busy = true; *out = c.get(); return RT_OK;
+    }
+    // A caller that keeps enqueuing asynchronous passes without ever synchronising must not grow the pool (and its
+    // per-sample buffers) without bound: past kMaxContexts, wait for the oldest pass still in flight and reuse its context.
+    if (s->pool.size() >= kMaxContexts) {
+        for (auto &c : s->pool) {
+            if (c->busy || !c->inflight) continue;
+            HIP_TRY(hipEventSynchronize(c->ev1));
+            c->inflight = false;
+            c->busy = true; *out = c.get(); return RT_OK;
+        }
     }
     std::unique_ptr<Context> c(new (std::nothrow) Context());
     if (!c) return RT_ERR_OUT_OF_MEMORY;
@@ -586,14 +596,6 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
     if ((e = hipMalloc(&s->d_items, esz * 4 * n_items)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(items)", __LINE__));
     if ((e = hipMemcpy(s->d_items, dfs_items, esz * 4 * n_items, hipMemcpyHostToDevice)) != hipSuccess)
         return fail(hip_fail(e, "hipMemcpy(items)", __LINE__));
-    if (n_bounds) {
-        if ((e = hipMalloc(&s->d_bounds, esz * 4 * n_bounds)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(bounds)", __LINE__));
-        if ((e = hipMemcpy(s->d_bounds, bounds, esz * 4 * n_bounds, hipMemcpyHostToDevice)) != hipSuccess)
-            return fail(hip_fail(e, "hipMemcpy(bounds)", __LINE__));
-        if ((e = hipMalloc(&s->d_ranges, sizeof(rt_range) * n_bounds)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(ranges)", __LINE__));
-        if ((e = hipMemcpy(s->d_ranges, ranges, sizeof(rt_range) * n_bounds, hipMemcpyHostToDevice)) != hipSuccess)
-            return fail(hip_fail(e, "hipMemcpy(ranges)", __LINE__));
-    }
     {
         rt_status fst = f32 ? upload_flat<float>(s.get()) : upload_flat<double>(s.get());
         if (fst != RT_OK) return fail(fst);
@@ -613,8 +615,6 @@ rt_status rt_scene_destroy(rt_scene *s)
     s->pool.clear();
     for (auto &t : s->tables) (void)hipFree(t.dev);
     if (s->d_items) (void)hipFree(s->d_items);
-    if (s->d_bounds) (void)hipFree(s->d_bounds);
-    if (s->d_ranges) (void)hipFree(s->d_ranges);
     if (s->d_prim) (void)hipFree(s->d_prim);
     if (s->d_shad) (void)hipFree(s->d_shad);
     if (s->d_fprim) (void)hipFree(s->d_fprim);

@@ -514,3 +514,21 @@ def test_config5_4096x4096_level9_spp4_selected_buckets():
     big = [(x, y + 1024, x + 1024, y) for y in range(0, 4096, 1024) for x in range(0, 4096, 1024)]
     data2, _ = s.device().render_tiles(opts, big, SKIP, want_stats=False)
     np.testing.assert_array_equal(util.stitch((4096, 4096), regs, data), util.stitch((4096, 4096), big, data2))
+
+
+@pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64])
+@pytest.mark.parametrize("trav", [SKIP, FLAT], ids=["skip", "flat"])
+def test_tangent_ray_zero_discriminant(precision, trav):
+    # pixel (32, 32) of a 64x64 image looks exactly along +z; for a sphere at (0.5, 0, -2) r 0.5 and the eye at (0, 0, -4)
+    # the discriminant is EXACTLY 0 (4 - 4.25 + 0.25): the tangent hit goes through the small-input branch of the exact
+    # square root (the scaled path of the hand-written loops)
+    spheres = [(0.5, 0.0, -2.0, 0.5), (-3.0, 2.0, 1.0, 0.75)]
+    s, o = util.scene_pair_spheres(spheres, (0.0, 0.0, 0.0, 6.0), precision)
+    d, pos = o.intersect((0, 0, -4, 0, 0, 1))
+    assert d == 2.0                                         # the oracle agrees this ray grazes the first sphere at t = 2
+    data, st = s.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)], trav)
+    ref, rst = o.render_region(64, 64, 1, 0, 64, 64, 0, HIER_EXIT if trav == SKIP else oracle.MODE_FLAT)
+    np.testing.assert_array_equal(data.reshape(64, 64, 4), ref)
+    assert util.ray_stats(st) == util.ray_stats(rst)
+    assert data.reshape(64, 64, 4)[32, 32, 3] in (0, 255)   # the pixel is a hit (lit or shadowed), not background
+    assert tuple(data.reshape(64, 64, 4)[32, 32, :3]) != (34, 10, 10)
