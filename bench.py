@@ -24,7 +24,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-WIDTH, HEIGHT, SPP, LEVEL = 1920, 1080, 1, 8
+# name -> (width, height, samples_per_pixel, pyramid level).  The default is the configuration BASELINE.json's metric is
+# quoted on; the others are BASELINE's neighbouring configs, for scaling / sizing experiments (never the headline).
+WORKLOADS = {"1080p": (1920, 1080, 1, 8), "config2": (800, 600, 1, 8), "make_image": (1024, 768, 4, 8),
+             "config5": (4096, 4096, 4, 9)}
+WIDTH, HEIGHT, SPP, LEVEL = WORKLOADS["1080p"]
 N_ITEMS = 21845
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_OPS = 256 * 4 * 16 * 2 * 2.4e9  # un-fused f32 lane-ops/s with packed v_pk_mul/add: 256 CU x 4 SIMD x 16 lanes x 2 x
@@ -77,7 +81,12 @@ def main():
     ap.add_argument("--traversal", choices=("skip", "flat"), default="skip", help="traversal of the headline measurement")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: take the shard -> RCCL gather -> blit path even at N = 1 (needs torch.distributed.run)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1080p",
+                    help="1080p = the headline workload; the others are BASELINE's neighbouring configs")
     args = ap.parse_args()
+    global WIDTH, HEIGHT, SPP, LEVEL, N_ITEMS
+    WIDTH, HEIGHT, SPP, LEVEL = WORKLOADS[args.workload]
+    N_ITEMS = (4 ** LEVEL - 1) // 3
 
     import torch
     import rust_tracer_amd as rta
@@ -163,17 +172,19 @@ def main():
                      "counted by the kernel and equal to the CPU path's) / hipEvent duration of k_render_skip; records "
                      "arrive through the scalar cache / L2 (the whole scene is < 1 MB), so this is a logical rate, not "
                      "HBM traffic (SURVEY.md H3)")
-        flat_note = ("algorithmic bytes = 16 B x (primary + shadow rays) x 21845 items of rank 0's launch / hipEvent "
+        flat_note = ("algorithmic bytes = 16 B x (primary + shadow rays) x n_spheres items of rank 0's launch / hipEvent "
                      "duration of k_render_flat2; every record staged to LDS is re-used by all rays of a workgroup, so the "
                      "logical rate exceeds the HBM peak; the binding limit is un-fused f32 VALU issue (see valu)")
         out = {
-            "metric": "Mrays/sec + ms/frame, 1920x1080 20k-sphere scene",
+            "metric": "Mrays/sec + ms/frame, 1920x1080 20k-sphere scene" if args.workload == "1080p" else
+                      "Mrays/sec + ms/frame, %dx%d spp %d L%d (non-headline workload %s)" % (WIDTH, HEIGHT, SPP, LEVEL, args.workload),
             "value": round(rays / (ms_per_step * 1e-3) / 1e6, 3), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (the reference's deterministic default scene: pyramid level 8)",
-            "config": {"workload": "1920x1080, 21845 spheres (pyramid L8), spp 1, f32, %s traversal, 510 64x64 buckets "
-                                   "round-robin over %d GPU(s)%s" % (args.traversal, world, ", RCCL gather + device blit to rank 0" if world > 1 else
+            "config": {"workload": "%dx%d, %d spheres (pyramid L%d), spp %d, f32, %s traversal, %d 64x64 buckets "
+                                   "round-robin over %d GPU(s)%s" % (WIDTH, HEIGHT, N_ITEMS, LEVEL, SPP, args.traversal,
+                                                                      -(-WIDTH // 64) * -(-HEIGHT // 64), world, ", RCCL gather + device blit to rank 0" if world > 1 else
                                                                   ", rendered straight into the row-major frame"),
                        "width": WIDTH, "height": HEIGHT, "samples_per_pixel": SPP, "n_spheres": N_ITEMS,
                        "primary_rays": m["primary"], "shadow_rays": m["shadow"], "traversal": args.traversal,
