@@ -42,7 +42,8 @@ def cpu_baseline(budget_s=12.0):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     o = oracle.Scene.default(oracle.F32, LEVEL)
     t0 = time.perf_counter()
-    _, st, _ = o.render(WIDTH, HEIGHT, SPP, nthreads=1)
+    # one single-threaded frame (the reference's default RTRACEMAXPROCS=1), unless the workload is far too big for that
+    _, st, _ = o.render(WIDTH, HEIGHT, SPP, nthreads=1 if WIDTH * HEIGHT * SPP * SPP <= 2.5e7 else cores)
     t_single = time.perf_counter() - t0
     rays = st["primary"] + st["shadow"]
     best, frames, spent = None, 0, 0.0
@@ -181,7 +182,7 @@ def main():
             "value": round(rays / (ms_per_step * 1e-3) / 1e6, 3), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (the reference's deterministic default scene: pyramid level 8)",
+            "data": "synthetic (the reference's deterministic default scene: pyramid level %d)" % LEVEL,
             "config": {"workload": "%dx%d, %d spheres (pyramid L%d), spp %d, f32, %s traversal, %d 64x64 buckets "
                                    "round-robin over %d GPU(s)%s" % (WIDTH, HEIGHT, N_ITEMS, LEVEL, SPP, args.traversal,
                                                                       -(-WIDTH // 64) * -(-HEIGHT // 64), world, ", RCCL gather + device blit to rank 0" if world > 1 else

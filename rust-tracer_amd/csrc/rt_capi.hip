@@ -87,7 +87,7 @@ struct rt_scene {
 
 namespace {
 
-constexpr size_t kMaxContexts = 8;
+constexpr size_t kMaxContexts = 3;   // enough to keep the device fed; each may hold per-sample buffers (GBs at 4096^2 x 16)
 
 rt_status acquire(rt_scene *s, Context **out)
 {
