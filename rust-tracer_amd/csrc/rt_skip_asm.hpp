@@ -74,18 +74,17 @@ namespace rt {
         "s_and_b64 vcc, vcc, s[52:53]\n\t"  /* lanes that need the exact distance */ \
         "s_cbranch_vccz 4f\n\t"  /* no active lane can hit this node: go (= vcc) is already empty */ \
   /* ---- correctly rounded root ---- */ \
+        "v_sqrt_f32_e32 %[root], %[disc]\n\t" \
         "v_cmp_lt_f32_e64 s[60:61], |%[disc]|, %[tiny]\n\t" \
         "s_and_b64 s[56:57], s[60:61], vcc\n\t" \
         "s_cbranch_scc1 9f\n\t"  /* some needed lane below 2^-96: scaled path */ \
-        "v_sqrt_f32_e32 %[root], %[disc]\n\t" \
-        "s_nop 0\n\t" \
         "v_add_u32_e32 %[t0], -1, %[root]\n\t" \
         "v_add_u32_e32 %[t1], 1, %[root]\n\t" \
         "v_fma_f32 %[t3], -%[t0], %[root], %[disc]\n\t" \
         "v_fma_f32 %[t4], -%[t1], %[root], %[disc]\n\t" \
         "v_cmp_ge_f32_e64 s[56:57], 0, %[t3]\n\t" \
         "v_cmp_lt_f32_e64 s[58:59], 0, %[t4]\n\t" \
-        "s_nop 1\n\t" \
+        "s_nop 0\n\t" \
         "v_cndmask_b32_e64 %[root], %[root], %[t0], s[56:57]\n\t" \
         "v_cndmask_b32_e64 %[root], %[root], %[t1], s[58:59]\n" \
         "8:\n\t" \
@@ -95,7 +94,6 @@ namespace rt {
         "v_cmp_lt_f32_e64 s[56:57], 0, %[t4]\n\t"  /* t1 > 0 */ \
         "v_cmp_le_f32_e64 s[58:59], 0, %[t3]\n\t"  /* t2 >= 0 */ \
         "s_and_b64 vcc, vcc, s[58:59]\n\t" \
-        "s_nop 0\n\t" \
         "v_cndmask_b32_e64 %[t4], %[t3], %[t4], s[56:57]\n\t"  /* d = t1 > 0 ? t1 : t2 */ \
         "v_cmp_lt_f32_e64 s[56:57], %[t4], %[best]\n\t"  /* d < hit.distance */ \
         "s_and_b64 vcc, vcc, s[56:57]\n"  /* go */ \
@@ -113,7 +111,6 @@ namespace rt {
         "5:\n\t" \
   /* ---- ITEM (primitive.rs:78-83) ---- */ \
         "v_mov_b32_e32 %[t5], s46\n\t" \
-        "s_nop 0\n\t" \
         "v_cndmask_b32_e32 %[best], %[best], %[t4], vcc\n\t" \
         "v_cndmask_b32_e32 %[bitem], %[bitem], %[t5], vcc\n" \
         "6:\n\t" \
@@ -193,18 +190,17 @@ __device__ __forceinline__ void skip_primary_asm(const void *nodes, unsigned n, 
         "v_cmp_gt_f32_e64 s[54:55], 0, %[b]\n\t"  /* b < 0: t2 may still be negative */ \
         "s_and_b64 s[54:55], s[54:55], vcc\n\t" \
         "s_cbranch_scc0 4f\n\t"  /* nobody needs the root: hit = candidates */ \
+        "v_sqrt_f32_e32 %[root], %[disc]\n\t" \
         "v_cmp_lt_f32_e64 s[60:61], |%[disc]|, %[tiny]\n\t" \
         "s_and_b64 s[56:57], s[60:61], s[54:55]\n\t" \
         "s_cbranch_scc1 9f\n\t" \
-        "v_sqrt_f32_e32 %[root], %[disc]\n\t" \
-        "s_nop 0\n\t" \
         "v_add_u32_e32 %[t0], -1, %[root]\n\t" \
         "v_add_u32_e32 %[t1], 1, %[root]\n\t" \
         "v_fma_f32 %[t3], -%[t0], %[root], %[disc]\n\t" \
         "v_fma_f32 %[t4], -%[t1], %[root], %[disc]\n\t" \
         "v_cmp_ge_f32_e64 s[56:57], 0, %[t3]\n\t" \
         "v_cmp_lt_f32_e64 s[58:59], 0, %[t4]\n\t" \
-        "s_nop 1\n\t" \
+        "s_nop 0\n\t" \
         "v_cndmask_b32_e64 %[root], %[root], %[t0], s[56:57]\n\t" \
         "v_cndmask_b32_e64 %[root], %[root], %[t1], s[58:59]\n" \
         "8:\n\t" \
