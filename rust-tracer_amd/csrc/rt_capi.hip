@@ -178,15 +178,24 @@ rt::FlatView<T> flat_view_of(const rt_scene *s)
 }
 
 template <typename T>
-rt_status upload_flat(rt_scene *s)
+rt_status upload_flat(rt_scene *s, const void *host_items)
 {
     s->n_padded = (s->n_items + 3u) & ~3u;
+    // any-hit scan order of the shadow pass: radius descending (stable), see k_build_flat
+    std::vector<unsigned> order(s->n_items);
+    for (unsigned i = 0; i < s->n_items; ++i) order[i] = i;
+    const T *it = static_cast<const T *>(host_items);
+    std::stable_sort(order.begin(), order.end(), [it](unsigned a, unsigned b) { return it[4 * a + 3] > it[4 * b + 3]; });
+    unsigned *d_order = nullptr;
+    HIP_TRY(hipMalloc(&d_order, sizeof(unsigned) * s->n_items));
+    struct Free { unsigned *p; ~Free() { (void)hipFree(p); } } free_order{ d_order };
+    HIP_TRY(hipMemcpy(d_order, order.data(), sizeof(unsigned) * s->n_items, hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&s->d_fprim, sizeof(rt::Quad<T>) * s->n_padded));
     HIP_TRY(hipMalloc(&s->d_fprim_rr, sizeof(T) * s->n_padded));
     HIP_TRY(hipMalloc(&s->d_fshad, sizeof(rt::Quad<T>) * s->n_padded));
     const rt::V3<T> eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
     hipLaunchKernelGGL((rt::k_build_flat<T>), dim3((s->n_padded + 255) / 256), dim3(256), 0, nullptr,
-                       static_cast<const rt::Item<T> *>(s->d_items), s->n_items, s->n_padded, eye, static_cast<rt::Quad<T> *>(s->d_fprim),
+                       static_cast<const rt::Item<T> *>(s->d_items), d_order, s->n_items, s->n_padded, eye, static_cast<rt::Quad<T> *>(s->d_fprim),
                        static_cast<T *>(s->d_fprim_rr), static_cast<rt::Quad<T> *>(s->d_fshad));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
@@ -597,7 +606,7 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
     if ((e = hipMemcpy(s->d_items, dfs_items, esz * 4 * n_items, hipMemcpyHostToDevice)) != hipSuccess)
         return fail(hip_fail(e, "hipMemcpy(items)", __LINE__));
     {
-        rt_status fst = f32 ? upload_flat<float>(s.get()) : upload_flat<double>(s.get());
+        rt_status fst = f32 ? upload_flat<float>(s.get(), dfs_items) : upload_flat<double>(s.get(), dfs_items);
         if (fst != RT_OK) return fail(fst);
     }
     if (n_bounds) {

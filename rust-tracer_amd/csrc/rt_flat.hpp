@@ -66,9 +66,11 @@ template <typename T> struct FlatView {
 };
 
 // Pre-forms the per-item terms on the device (exact IEEE ops, the products the CPU path forms per ray).
+// shadow_order[i] = index of the item that sits at position i of the SHADOW array: shadow rays are any-hit, so their scan
+// order is free, and the host puts the largest spheres first (they occlude most rays, so fully shadowed waves leave early).
 template <typename T>
-__global__ void k_build_flat(const Item<T> *__restrict__ items, unsigned n, unsigned n_padded, V3<T> eye, Quad<T> *__restrict__ prim,
-                             T *__restrict__ prim_rr, Quad<T> *__restrict__ shad)
+__global__ void k_build_flat(const Item<T> *__restrict__ items, const unsigned *__restrict__ shadow_order, unsigned n, unsigned n_padded,
+                             V3<T> eye, Quad<T> *__restrict__ prim, T *__restrict__ prim_rr, Quad<T> *__restrict__ shad)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_padded) return;
@@ -78,7 +80,8 @@ __global__ void k_build_flat(const Item<T> *__restrict__ items, unsigned n, unsi
         const V3<T> v = { it.cx - eye.x, it.cy - eye.y, it.cz - eye.z };
         vx = v.x; vy = v.y; vz = v.z; vv = dot(v, v);
         rr = it.r * it.r;
-        cx = it.cx; cy = it.cy; cz = it.cz; srr = rr;
+        const Item<T> sh = items[shadow_order[i]];
+        cx = sh.cx; cy = sh.cy; cz = sh.cz; srr = sh.r * sh.r;
     } else {
         // primary pad: b = 0, disc = (0 - 1) + 0 < 0 for every ray -> can never hit, never NaN
         vx = T(0); vy = T(0); vz = T(0); vv = T(1); rr = T(0);
