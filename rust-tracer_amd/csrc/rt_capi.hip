@@ -180,7 +180,7 @@ rt::FlatView<T> flat_view_of(const rt_scene *s)
 template <typename T>
 rt_status upload_flat(rt_scene *s, const void *host_items)
 {
-    s->n_padded = (s->n_items + 3u) & ~3u;
+    s->n_padded = (s->n_items + 7u) & ~7u;     // the scan consumes 4 items per step, unrolled twice
     // any-hit scan order of the shadow pass: radius descending (stable), see k_build_flat
     std::vector<unsigned> order(s->n_items);
     for (unsigned i = 0; i < s->n_items; ++i) order[i] = i;

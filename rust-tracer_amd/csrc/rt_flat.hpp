@@ -24,8 +24,11 @@
 
 namespace rt {
 
-constexpr int kFlatBlockW = 16, kFlatBlockH = 32;      // pixels per 256-thread workgroup (2 per lane)
-constexpr int kFlatR = 2;
+#ifndef RT_FLAT_R
+#define RT_FLAT_R 2
+#endif
+constexpr int kFlatR = RT_FLAT_R;                              // pixels (rays) per lane: rows y, y+16, ...
+constexpr int kFlatBlockW = 16, kFlatBlockH = 16 * kFlatR;     // pixels per 256-thread workgroup
 
 template <typename T> struct alignas(sizeof(T) * 4) Quad { T x, y, z, w; };
 
@@ -57,7 +60,7 @@ template <> struct P2<double> {
 };
 
 template <typename T> struct FlatView {
-    const Quad<T> *prim;    // pair-interleaved {vx0,vx1,vy0,vy1},{vz0,vz1,vv0,vv1}; DFS order, padded to a multiple of 4 items
+    const Quad<T> *prim;    // pair-interleaved {vx0,vx1,vy0,vy1},{vz0,vz1,vv0,vv1}; DFS order, padded to a multiple of 8 items
     const T *prim_rr;       // rr per item, padded (pad items have vv = +big, rr = 0: disc < 0, never a hit)
     const Quad<T> *shad;    // pair-interleaved {cx0,cx1,cy0,cy1},{cz0,cz1,rr0,rr1} (pad items carry rr = -1e30: disc < 0)
     const Item<T> *items;   // centres for the normal of the winning item
@@ -165,11 +168,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_flat2(FlatView<T> sc, 
             for (int r = 0; r < kFlatR; ++r) { best[r] = inf<T>(); best_i[r] = 0; }
 
             for (unsigned base = 0; base < n; base += CHUNK) {
-                const unsigned cnt = min((unsigned)CHUNK, n - base);          // multiple of 4
+                const unsigned cnt = min((unsigned)CHUNK, n - base);          // multiple of 8
                 __syncthreads();
                 for (unsigned j = threadIdx.x; j < cnt; j += kBlockThreads) s_q[j] = sc.prim[base + j];
                 for (unsigned j = threadIdx.x; j < cnt; j += kBlockThreads) s_rr[j] = sc.prim_rr[base + j];
                 __syncthreads();
+                __builtin_assume(cnt % 8 == 0);
+#pragma unroll 2
                 for (unsigned j = 0; j < cnt; j += 4) {
                     // items j, j+1 in quads qa/qb; items j+2, j+3 in qc/qd; rr of all four in one quad
                     const Quad<T> qa = s_q[j], qb = s_q[j + 1], qc = s_q[j + 2], qd = s_q[j + 3];
@@ -187,10 +192,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_flat2(FlatView<T> sc, 
                         b[r][0] = b01.lo(); b[r][1] = b01.hi(); b[r][2] = b23.lo(); b[r][3] = b23.hi();
                         disc[r][0] = d01.lo(); disc[r][1] = d01.hi(); disc[r][2] = d23.lo(); disc[r][3] = d23.hi();
                     }
-                    T m = max3(disc[0][0], disc[0][1], disc[0][2]);
-                    m = max3(m, disc[0][3], disc[1][0]);
-                    m = max3(m, disc[1][1], disc[1][2]);
-                    m = fmax(m, disc[1][3]);
+                    T m = fmax(max3(disc[0][0], disc[0][1], disc[0][2]), disc[0][3]);
+#pragma unroll
+                    for (int r = 1; r < kFlatR; ++r) m = max3(max3(m, disc[r][0], disc[r][1]), disc[r][2], disc[r][3]);
                     if (!(m < T(0.0))) {                                      // rare: some lane's line meets one of the 4 items
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {                         // item order: first in DFS order wins ties
@@ -244,11 +248,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_flat2(FlatView<T> sc, 
 #pragma unroll
             for (int r = 0; r < kFlatR; ++r) { pending[r] = need_shadow[r]; occluded[r] = false; }
             for (unsigned base = 0; base < n; base += CHUNK) {
-                if (!__syncthreads_or((pending[0] || pending[1]) ? 1 : 0)) break;
+                bool any_pending = false;
+#pragma unroll
+                for (int r = 0; r < kFlatR; ++r) any_pending = any_pending || pending[r];
+                if (!__syncthreads_or(any_pending ? 1 : 0)) break;
                 const unsigned cnt = min((unsigned)CHUNK, n - base);
                 for (unsigned j = threadIdx.x; j < cnt; j += kBlockThreads) s_q[j] = sc.shad[base + j];
                 __syncthreads();
-                if (pending[0] || pending[1]) {
+                if (any_pending) {
+                    __builtin_assume(cnt % 8 == 0);
+#pragma unroll 2
                     for (unsigned j = 0; j < cnt; j += 4) {
                         const Quad<T> qa = s_q[j], qb = s_q[j + 1], qc = s_q[j + 2], qd = s_q[j + 3];
                         const P2<T> x01(qa.x, qa.y), y01(qa.z, qa.w), z01(qb.x, qb.y), r01(qb.z, qb.w);
@@ -270,9 +279,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_flat2(FlatView<T> sc, 
                             disc[r][0] = d01.lo(); disc[r][1] = d01.hi(); disc[r][2] = d23.lo(); disc[r][3] = d23.hi();
                         }
                         // a finished (or absent) ray must not keep re-entering the slow path
-                        const T m0 = pending[0] ? fmax(max3(disc[0][0], disc[0][1], disc[0][2]), disc[0][3]) : T(-1.0);
-                        const T m1 = pending[1] ? fmax(max3(disc[1][0], disc[1][1], disc[1][2]), disc[1][3]) : T(-1.0);
-                        if (!(fmax(m0, m1) < T(0.0))) {
+                        T m = T(-1.0);
+#pragma unroll
+                        for (int r = 0; r < kFlatR; ++r)
+                            if (pending[r]) m = max3(max3(m, disc[r][0], disc[r][1]), disc[r][2], disc[r][3]);
+                        if (!(m < T(0.0))) {
 #pragma unroll
                             for (int r = 0; r < kFlatR; ++r) {
 #pragma unroll
@@ -283,7 +294,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_flat2(FlatView<T> sc, 
                                     }
                                 }
                             }
-                            if (!(pending[0] || pending[1])) break;
+                            any_pending = false;
+#pragma unroll
+                            for (int r = 0; r < kFlatR; ++r) any_pending = any_pending || pending[r];
+                            if (!any_pending) break;
                         }
                     }
                 }
@@ -316,7 +330,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_flat2(FlatView<T> sc, 
 
     if (counters) {
         counters += blockIdx.x % kCounterStripes;
-        const unsigned long long prim = wave_sum(((inside[0] ? 1u : 0u) + (inside[1] ? 1u : 0u)) * spp * spp);
+        unsigned n_inside = 0;
+#pragma unroll
+        for (int r = 0; r < kFlatR; ++r) n_inside += inside[r] ? 1u : 0u;
+        const unsigned long long prim = wave_sum(n_inside * spp * spp);
         const unsigned long long hits = wave_sum(c_hits), sh = wave_sum(c_shadow), oc = wave_sum(c_occ);
         if (lane == 0) {
             atomicAdd(&counters->primary, prim);

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_sq.json from tools/profile_sq.sh: per-launch averages of the SQ counters of the render kernels plus
+derived figures (kernel duration from the counter rows' timestamps).  usage: summarize_sq.py <gpurun_out> <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNELS = [("k_render_skip<float, false", "k_render_skip"), ("k_render_flat2<float", "k_render_flat2")]
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    out = collections.defaultdict(dict)
+    for part in ("sq1", "sq2"):
+        for f in glob.glob(os.path.join(src, "%s_%s" % (part, tag), "*", "*_counter_collection.csv")):
+            agg = collections.defaultdict(list)
+            dur = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                for pat, name in KERNELS:
+                    if pat in r["Kernel_Name"]:
+                        agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
+                        dur[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            for (k, c), v in agg.items():
+                out[k][c] = sum(v) / len(v)
+            for k, v in dur.items():
+                out[k]["duration_ns_while_counting_" + part] = sum(v) / len(v)
+    for k, d in out.items():
+        if "SQ_INSTS_VALU" in d and "duration_ns_while_counting_sq1" in d:
+            cyc = d["duration_ns_while_counting_sq1"] * 2.4          # shader cycles at 2.4 GHz
+            d["derived_valu_issue_fraction_at_4_cycles_per_inst"] = d["SQ_INSTS_VALU"] * 4 / 1024 / cyc
+            d["derived_avg_waves_per_simd"] = d["SQ_WAVE_CYCLES"] * 4 / cyc / 1024
+            d["derived_valu_insts_per_wave"] = d["SQ_INSTS_VALU"] / d["SQ_WAVES"]
+    json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_sq.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
