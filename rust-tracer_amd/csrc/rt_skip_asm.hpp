@@ -19,7 +19,7 @@
 // by s_waitcnt lgkmcnt(0) before its registers are read.  Fixed SGPRs s40-s61 are declared clobbered.
 //
 // The C++ loops in rt_skip.hpp remain the reference implementation (f64, and every launch that counts tests);
-// tools/ab.py checks this variant's frames against them, and the parity tests run it against the oracle.
+// tools/ab.py checks this variant's frames against them, and the parity tests compare it with the CPU restatement.
 #pragma once
 #include "rt_kernels.hpp"
 
