@@ -81,6 +81,7 @@ class FrameSharder:
         self.shards = [torch.zeros(self.shard_px * 4, dtype=torch.uint8, device=tdev) for _ in range(2)]
         self.shard = self.shards[0]
         self.frame = None
+        self.side = torch.cuda.Stream(device=tdev) if (rank == 0 and self.collective) else None   # rank 0's blits run here
         if rank == 0:
             self.frame = torch.zeros(self.options.height * self.options.width * 4, dtype=torch.uint8, device=tdev)
             regions, offsets, _ = gathered_tile_table(self.options, world)
@@ -132,23 +133,37 @@ class FrameSharder:
             for _ in range(steps):
                 self.render_frame()
             return
+        torch = self.torch
+        main = torch.cuda.current_stream(self.device)
         works = [None, None]
+
+        def finish(slot):
+            """frame in `slot` has been gathered: blit it.  Rank 0 does that on its side stream, so the blit overlaps the
+            next render instead of queueing behind it (Work.wait() only orders the stream it is called on)."""
+            w, works[slot] = works[slot], None
+            if self.side is not None:
+                with torch.cuda.stream(self.side):
+                    w.wait()
+                    self.blit(slot=slot)
+            else:
+                w.wait()
+
         for k in range(steps):
             slot = k & 1
-            if works[slot] is not None:          # frame k-2 used this shard buffer: its gather must have finished
-                works[slot].wait()
-                works[slot] = None
+            if works[slot] is not None:          # (non-root) frame k-2 used this shard buffer: its gather must be done
+                finish(slot)
+            if self.side is not None:
+                main.wait_stream(self.side)      # gathered[slot] is about to be overwritten: frame k-2's blit read it
             self.render_shard(slot=slot)
             works[slot] = self.gather(slot=slot, async_op=True)
             prev = slot ^ 1
             if k > 0 and works[prev] is not None:
-                works[prev].wait()               # frame k-1 has arrived (this only orders the stream, the host runs on)
-                works[prev] = None
-                self.blit(slot=prev)
-        last = (steps - 1) & 1
-        if steps > 0 and works[last] is not None:
-            works[last].wait()
-            self.blit(slot=last)
+                finish(prev)
+        for slot in ((steps - 2) & 1, (steps - 1) & 1):
+            if steps > 0 and works[slot] is not None:
+                finish(slot)
+        if self.side is not None:
+            main.wait_stream(self.side)          # the caller synchronises the main stream only
 
     def frame_host(self):
         self.torch.cuda.synchronize(self.device)
