@@ -89,6 +89,13 @@ def main():
     WIDTH, HEIGHT, SPP, LEVEL = WORKLOADS[args.workload]
     N_ITEMS = (4 ** LEVEL - 1) // 3
 
+    # Exactly ONE line may reach stdout.  RCCL prints a version banner on stdout (NCCL_DEBUG=VERSION is set on the GPU
+    # boxes) whenever a communicator exists, so fd 1 is pointed at stderr for the whole run and the JSON line is written
+    # to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import rust_tracer_amd as rta
     from rust_tracer_amd.dist import FrameSharder
@@ -201,7 +208,7 @@ def main():
                            "valu": flat_valu(flat)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
