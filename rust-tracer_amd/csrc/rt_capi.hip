@@ -5,6 +5,7 @@
 #include "rt_kernels.hpp"
 #include "rt_skip.hpp"
 #include "rt_flat.hpp"
+#include "rt_flat_wf.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -48,6 +49,9 @@ struct Context {
     void *d_sample_gdot = nullptr;    // SPLIT path: per-sample n.light [spp*spp][n_px] (REAL)
     uint8_t *d_sample_state = nullptr;
     size_t sample_cap = 0;            // bytes of d_sample_gdot
+    void *d_queue1 = nullptr, *d_queue2 = nullptr;   // flat wavefront pipeline: shadow-ray queues, Quad<REAL> per sample
+    size_t queue_cap = 0;             // bytes of each queue
+    rt::FlatQueues *d_queues = nullptr;
     bool busy = false;       // leased to a caller right now
     bool inflight = false;   // released by an asynchronous caller; reusable once ev1 has completed
 
@@ -59,6 +63,9 @@ struct Context {
         if (d_out) (void)hipFree(d_out);
         if (d_sample_gdot) (void)hipFree(d_sample_gdot);
         if (d_sample_state) (void)hipFree(d_sample_state);
+        if (d_queue1) (void)hipFree(d_queue1);
+        if (d_queue2) (void)hipFree(d_queue2);
+        if (d_queues) (void)hipFree(d_queues);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -352,6 +359,68 @@ int skip_variant(uint64_t waves)
 // spp > 1 runs sample-parallel (one thread per sample + a resolve pass) unless spp*spp exceeds grid.y's limit.
 bool use_split(unsigned spp) { return spp > 1 && (unsigned long long)spp * spp <= 65535ull; }
 
+// (Re)allocates the context's per-sample buffers {n.light, state} for `samples` samples of REAL size `esz`.
+rt_status ensure_sample_buffers(Context *c, size_t samples, size_t esz)
+{
+    const size_t need = samples * esz;
+    if (c->sample_cap >= need) return RT_OK;
+    if (c->d_sample_gdot) HIP_TRY(hipFree(c->d_sample_gdot));
+    if (c->d_sample_state) HIP_TRY(hipFree(c->d_sample_state));
+    c->d_sample_gdot = nullptr; c->d_sample_state = nullptr; c->sample_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_sample_gdot, need));
+    HIP_TRY(hipMalloc(&c->d_sample_state, samples));
+    c->sample_cap = need;
+    return RT_OK;
+}
+
+// RT_FLAT_VARIANT=2 selects the fused flat kernel (k_render_flat2) for A/B runs; the default is the wavefront pipeline.
+int flat_variant()
+{
+    const char *e = getenv("RT_FLAT_VARIANT");
+    return e ? atoi(e) : 3;
+}
+
+// rt_flat_wf.hpp: primary+shade -> shadow pass over the largest spheres -> shadow pass over the rest -> ordered resolve.
+template <typename T, int CHUNK>
+rt_status launch_flat_wavefront(const rt_scene *s, Context *c, hipStream_t stream, unsigned w, unsigned h, unsigned spp, const rt::TileDev *d_tab32,
+                                unsigned nt, uint32_t blocks32, const rt::TileDev *d_tab16, uint32_t blocks16, uint64_t total_px, uint8_t *d_out,
+                                rt::Counters *cnt, unsigned frame_w)
+{
+    const size_t ns = (size_t)spp * spp, samples = ns * total_px;
+    if (ns > 65535 || samples > 0xFFFFFFFFull) {
+        snprintf(g_err, sizeof g_err, "flat traversal: too many samples for one pass");
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    rt_status st = ensure_sample_buffers(c, samples, sizeof(T));
+    if (st != RT_OK) return st;
+    const size_t qbytes = samples * sizeof(rt::Quad<T>);
+    if (c->queue_cap < qbytes) {
+        if (c->d_queue1) HIP_TRY(hipFree(c->d_queue1));
+        if (c->d_queue2) HIP_TRY(hipFree(c->d_queue2));
+        c->d_queue1 = c->d_queue2 = nullptr; c->queue_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_queue1, qbytes));
+        HIP_TRY(hipMalloc(&c->d_queue2, qbytes));
+        c->queue_cap = qbytes;
+    }
+    if (!c->d_queues) HIP_TRY(hipMalloc(&c->d_queues, sizeof(rt::FlatQueues)));
+    HIP_TRY(hipMemsetAsync(c->d_queues, 0, sizeof(rt::FlatQueues), stream));
+    rt::SampleBuf<T> sb{ static_cast<T *>(c->d_sample_gdot), c->d_sample_state, (unsigned)total_px };
+    rt::Quad<T> *q1 = static_cast<rt::Quad<T> *>(c->d_queue1), *q2 = static_cast<rt::Quad<T> *>(c->d_queue2);
+    const dim3 b(rt::kBlockThreads);
+    const rt::FlatView<T> view = flat_view_of<T>(s);
+    hipLaunchKernelGGL((rt::k_flat_primary<T, CHUNK>), dim3(blocks32, (unsigned)ns), b, 0, stream, view, w, h, spp, d_tab32, nt, sb, q1, c->d_queues, cnt);
+    HIP_TRY(hipGetLastError());
+    const unsigned rays_per_block = rt::kBlockThreads * rt::kFlatR;
+    const dim3 gshadow((unsigned)((samples + rays_per_block - 1) / rays_per_block));      // worst case; surplus workgroups leave at once
+    hipLaunchKernelGGL((rt::k_flat_shadow<T, CHUNK>), gshadow, b, 0, stream, view, 0u, (unsigned)CHUNK, q1, &c->d_queues->n1, q2, &c->d_queues->n2, sb, cnt);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL((rt::k_flat_shadow<T, CHUNK>), gshadow, b, 0, stream, view, (unsigned)CHUNK, 0xFFFFFFFFu, q2, &c->d_queues->n2,
+                       (rt::Quad<T> *)nullptr, (unsigned *)nullptr, sb, cnt);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL((rt::k_resolve_samples<T>), dim3(blocks16), b, 0, stream, sb, spp, d_tab16, nt, d_out, frame_w);
+    return RT_OK;
+}
+
 template <typename T, bool COUNT, int VAR>
 rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t stream, unsigned w, unsigned h, unsigned spp,
                           const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt, unsigned frame_w)
@@ -362,14 +431,10 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
         hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, false>), grid, b, 0, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb, frame_w);
         return RT_OK;
     }
-    const size_t ns = (size_t)spp * spp, need = ns * total_px * sizeof(T);
-    if (c->sample_cap < need) {
-        if (c->d_sample_gdot) HIP_TRY(hipFree(c->d_sample_gdot));
-        if (c->d_sample_state) HIP_TRY(hipFree(c->d_sample_state));
-        c->d_sample_gdot = nullptr; c->d_sample_state = nullptr; c->sample_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_sample_gdot, need));
-        HIP_TRY(hipMalloc(&c->d_sample_state, ns * total_px));
-        c->sample_cap = need;
+    const size_t ns = (size_t)spp * spp;
+    {
+        rt_status bst = ensure_sample_buffers(c, ns * total_px, sizeof(T));
+        if (bst != RT_OK) return bst;
     }
     sb.gdot = static_cast<T *>(c->d_sample_gdot);
     sb.state = c->d_sample_state;
@@ -420,11 +485,17 @@ rt_status check_traversal(const rt_scene *s, rt_traversal trav)
 // The render kernels of one pass.  c may be NULL when the pass needs no per-call device state (no counters, no
 // sample buffers): then nothing but the kernel itself is enqueued.
 rt_status launch_render(rt_scene *s, Context *c, const rt_options *o, rt_traversal trav, const rt::TileDev *d_tab, unsigned nt,
-                        uint32_t total_blocks, uint64_t total_px, uint8_t *d_out, unsigned frame_w, hipStream_t stream, rt::Counters *cnt)
+                        uint32_t total_blocks, uint64_t total_px, uint8_t *d_out, unsigned frame_w, hipStream_t stream, rt::Counters *cnt,
+                        const rt::TileDev *d_tab16 = nullptr, uint32_t blocks16 = 0)
 {
     const dim3 grid(total_blocks), block(rt::kBlockThreads);
     const unsigned w = o->width, h = o->height, spp = o->samples_per_pixel;
-    if (trav == RT_TRAVERSAL_FLAT) {
+    if (trav == RT_TRAVERSAL_FLAT && d_tab16) {                     // wavefront pipeline (needs a context and the 16x16 table)
+        rt_status fst = s->precision == RT_F32
+            ? launch_flat_wavefront<float, 1024>(s, c, stream, w, h, spp, d_tab, nt, total_blocks, d_tab16, blocks16, total_px, d_out, cnt, frame_w)
+            : launch_flat_wavefront<double, 512>(s, c, stream, w, h, spp, d_tab, nt, total_blocks, d_tab16, blocks16, total_px, d_out, cnt, frame_w);
+        if (fst != RT_OK) return fst;
+    } else if (trav == RT_TRAVERSAL_FLAT) {
         if (s->precision == RT_F32)
             hipLaunchKernelGGL((rt::k_render_flat2<float, 1024>), grid, block, 0, stream, flat_view_of<float>(s), w, h, spp, d_tab, nt, d_out, cnt, frame_w);
         else
@@ -440,19 +511,25 @@ rt_status launch_render(rt_scene *s, Context *c, const rt_options *o, rt_travers
 // Enqueues every kernel of one pass on `stream` through a leased context.  d_out must hold 4 * total_px bytes
 // (tile-major) or the whole frame (frame_w != 0).
 rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversal trav, const std::vector<rt::TileDev> &tab,
-                       uint32_t total_blocks, uint64_t total_px, uint8_t *d_out, unsigned frame_w, hipStream_t stream, bool want_counters)
+                       uint32_t total_blocks, uint64_t total_px, uint8_t *d_out, unsigned frame_w, hipStream_t stream, bool want_counters,
+                       const std::vector<rt::TileDev> *tab16 = nullptr, uint32_t blocks16 = 0)
 {
-    const rt::TileDev *d_tab = nullptr;
+    const rt::TileDev *d_tab = nullptr, *d_tab16 = nullptr;
     {
         rt_status ust = device_table(s, c, tab, stream, &d_tab);
         if (ust != RT_OK) return ust;
+        if (tab16) {
+            // the per-context upload buffer holds ONE table: the second table must come from the scene's cache
+            if ((ust = device_table(s, nullptr, *tab16, stream, &d_tab16)) != RT_OK) return ust;
+            if (!d_tab16) { snprintf(g_err, sizeof g_err, "flat traversal: tile-table cache exhausted"); return RT_ERR_OUT_OF_MEMORY; }
+        }
     }
     if (want_counters) {
         HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(rt::Counters) * rt::kCounterStripes, stream));
         HIP_TRY(hipEventRecord(c->ev0, stream));
     }
     rt_status st = launch_render(s, c, o, trav, d_tab, (unsigned)tab.size(), total_blocks, total_px, d_out, frame_w, stream,
-                                 want_counters ? c->d_counters : nullptr);
+                                 want_counters ? c->d_counters : nullptr, d_tab16, blocks16);
     if (st != RT_OK) return st;
     HIP_TRY(hipEventRecord(c->ev1, stream));
     return RT_OK;
@@ -652,8 +729,16 @@ static rt_status render_device(rt_scene *s, const rt_options *o, rt_traversal tr
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     uint8_t *out = static_cast<uint8_t *>(out_device);
+    // the flat wavefront pipeline resolves per pixel with the 16x16-block table
+    const bool wavefront = flat2 && flat_variant() != 2;
+    std::vector<rt::TileDev> tab16;
+    uint32_t blocks16 = 0;
+    if (wavefront) {
+        uint64_t px16 = 0;
+        if ((st = build_tile_table(o, tiles, n, tab16, &px16, &blocks16)) != RT_OK) return st;
+    }
     const bool split = trav == RT_TRAVERSAL_SKIP && use_split(o->samples_per_pixel);
-    if (!stats && !split) {
+    if (!stats && !split && !wavefront) {
         // Fast path: a cached tile table and no per-call device state -> the call enqueues exactly one kernel.
         const rt::TileDev *d_tab = nullptr;
         if ((st = device_table(s, nullptr, tab, stream, &d_tab)) != RT_OK) return st;
@@ -662,7 +747,7 @@ static rt_status render_device(rt_scene *s, const rt_options *o, rt_traversal tr
     Context *c = nullptr;
     if ((st = acquire(s, &c)) != RT_OK) return st;
     Lease lease{ s, c };
-    st = enqueue_pass(s, c, o, trav, tab, total_blocks, total_px, out, frame_w, stream, stats != nullptr);
+    st = enqueue_pass(s, c, o, trav, tab, total_blocks, total_px, out, frame_w, stream, stats != nullptr, wavefront ? &tab16 : nullptr, blocks16);
     if (st != RT_OK) return st;
     if (stats) return read_stats(s, c, stream, trav, stats);
     // Asynchronous return: the context's buffers are still in use by the enqueued work, so it goes back to the pool
@@ -706,7 +791,14 @@ rt_status rt_render_tiles(rt_scene *s, const rt_options *o, rt_traversal trav, c
         HIP_TRY(hipMalloc(&c->d_out, bytes));
         c->out_cap = bytes;
     }
-    st = enqueue_pass(s, c, o, trav, tab, total_blocks, total_px, c->d_out, 0u, c->stream, stats != nullptr);
+    std::vector<rt::TileDev> tab16;
+    uint32_t blocks16 = 0;
+    const bool wavefront = flat2 && flat_variant() != 2;
+    if (wavefront) {
+        uint64_t px16 = 0;
+        if ((st = build_tile_table(o, tiles, n, tab16, &px16, &blocks16)) != RT_OK) return st;
+    }
+    st = enqueue_pass(s, c, o, trav, tab, total_blocks, total_px, c->d_out, 0u, c->stream, stats != nullptr, wavefront ? &tab16 : nullptr, blocks16);
     if (st != RT_OK) return st;
     HIP_TRY(hipMemcpyAsync(rgba_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
     if (stats) return read_stats(s, c, c->stream, trav, stats);

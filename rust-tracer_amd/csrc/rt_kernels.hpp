@@ -18,6 +18,16 @@ struct TileDev {
     uint32_t blks_x;       // blocks per tile row
 };
 
+// Outcome of one sample, stored by the sample-parallel paths and consumed by k_resolve_samples in the reference's
+// accumulation order: the four exits of Renderer::raytrace (render.rs:190-213) and n.light where it is needed.
+enum SampleState : uint8_t { kMiss = 0, kAmbient = 1, kLit = 2, kShadowed = 3 };
+
+template <typename T> struct SampleBuf {
+    T *gdot;             // [spp*spp][n_px]  n.light of the sample (meaningful for kLit / kShadowed)
+    uint8_t *state;      // [spp*spp][n_px]
+    unsigned n_px;
+};
+
 // Counter slots are striped (kCounterStripes copies, picked by block index, summed on the host): tens of thousands of
 // waves adding to ONE address serialise at ~88 atomics/us, which made a stats pass 15x slower than the render itself.
 constexpr unsigned kCounterStripes = 256;

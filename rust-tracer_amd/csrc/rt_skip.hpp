@@ -99,14 +99,6 @@ template <> __device__ __forceinline__ Node<float> as_node<float>(const i32x8 &r
 // SPLIT = true : one thread traces ONE sample (blockIdx.y = ssx * spp + ssy) and stores the sample's outcome
 //   {state, n.light}; k_resolve_samples then accumulates each pixel's samples in the reference's order.  A frame's
 //   run time is bounded by its slowest wave, and a wave that walks 16 samples one after the other is 16x slower.
-enum SampleState : uint8_t { kMiss = 0, kAmbient = 1, kLit = 2, kShadowed = 3 };     // the four exits of render.rs:190-213
-
-template <typename T> struct SampleBuf {
-    T *gdot;             // [spp*spp][n_px]  n.light of the sample (meaningful for kLit / kShadowed)
-    uint8_t *state;      // [spp*spp][n_px]
-    unsigned n_px;
-};
-
 template <typename T, bool COUNT, int VAR, bool SPLIT>
 __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, unsigned width, unsigned height, unsigned spp,
                                                               const TileDev *__restrict__ tiles, unsigned n_tiles,
