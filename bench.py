@@ -65,11 +65,14 @@ def flat_valu(m):
     """Useful un-fused f32 ops of the flat scan (8 per primary test with the pre-formed terms, 16 per shadow test,
     primitive.rs:56-58) over the kernel time, against the packed un-fused VALU peak."""
     st = m["my_stats"]
-    ops = (st["primary"] * 8 + st["shadow"] * 16) * N_ITEMS
+    shadow_tests = st["tests_executed"] - st["primary"] * N_ITEMS       # what the any-hit passes really ran
+    ops = st["primary"] * N_ITEMS * 8 + shadow_tests * 16
     t = m["kern_ms"] * 1e-3
-    return {"ops_per_test": "8 primary / 16 shadow", "achieved_Tops": round(ops / t / 1e12, 2),
-            "peak_Tops": round(VALU_PEAK_OPS / 1e12, 1), "frac": round(ops / t / VALU_PEAK_OPS, 4),
-            "note": "shadow rays count all 21845 items although the any-hit scan stops early, so this is an upper bound"}
+    return {"ops_per_test": "8 primary / 16 shadow", "tests_executed": st["tests_executed"],
+            "achieved_Tops": round(ops / t / 1e12, 2), "peak_Tops": round(VALU_PEAK_OPS / 1e12, 1),
+            "frac": round(ops / t / VALU_PEAK_OPS, 4),
+            "note": "un-fused f32 ops of the tests the pipeline executed (queue lengths x pass lengths) over the time of "
+                    "all its kernels, against the packed (v_pk_mul/add) un-fused VALU peak"}
 
 
 def main():
@@ -151,7 +154,7 @@ def main():
         if dist is not None:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return {"elapsed": float(tt.item()), "kern_ms": kern_ms, "primary": primary, "shadow": shadow,
-                "my_tests": st["sphere_tests"] + st["bound_tests"], "my_stats": st}
+                "my_tests": st["sphere_tests"] + st["bound_tests"], "my_stats": st}     # algorithmic tests
 
     def roofline(m, kernel, note):
         alg = m["my_tests"] * BYTES_PER_TEST
@@ -180,9 +183,10 @@ def main():
                      "counted by the kernel and equal to the CPU path's) / hipEvent duration of k_render_skip; records "
                      "arrive through the scalar cache / L2 (the whole scene is < 1 MB), so this is a logical rate, not "
                      "HBM traffic (SURVEY.md H3)")
-        flat_note = ("algorithmic bytes = 16 B x (primary + shadow rays) x n_spheres items of rank 0's launch / hipEvent "
-                     "duration of k_render_flat2; every record staged to LDS is re-used by all rays of a workgroup, so the "
-                     "logical rate exceeds the HBM peak; the binding limit is un-fused f32 VALU issue (see valu)")
+        flat_note = ("algorithmic bytes = 16 B x (primary + shadow rays) x n_spheres items of rank 0's pass / hipEvent "
+                     "duration of its kernels (k_flat_primary + 2 x k_flat_shadow + k_resolve_samples); every record staged "
+                     "to LDS is re-used by all rays of a workgroup, so the logical rate exceeds the HBM peak; the binding "
+                     "limit is un-fused f32 VALU issue (see valu)")
         out = {
             "metric": "Mrays/sec + ms/frame, 1920x1080 20k-sphere scene" if args.workload == "1080p" else
                       "Mrays/sec + ms/frame, %dx%d spp %d L%d (non-headline workload %s)" % (WIDTH, HEIGHT, SPP, LEVEL, args.workload),
@@ -198,13 +202,13 @@ def main():
                        "primary_rays": m["primary"], "shadow_rays": m["shadow"], "traversal": args.traversal,
                        "parallelism": "tiles/%d" % world},
             "mprimary_per_s": round(m["primary"] / (ms_per_step * 1e-3) / 1e6, 3),
-            "roofline": roofline(m, "k_render_skip" if args.traversal == "skip" else "k_render_flat2",
+            "roofline": roofline(m, "k_render_skip" if args.traversal == "skip" else "k_flat_primary",
                                  skip_note if args.traversal == "skip" else flat_note),
         }
         if flat is not None:
             fms = flat["elapsed"] / max(2, min(5, args.steps)) * 1e3
             out["flat"] = {"ms_per_step": round(fms, 4), "value": round(rays / (fms * 1e-3) / 1e6, 3), "unit": "Mrays/s",
-                           "roofline": roofline(flat, "k_render_flat2", flat_note),
+                           "roofline": roofline(flat, "k_flat_primary", flat_note),
                            "valu": flat_valu(flat)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -81,6 +81,9 @@ typedef struct rt_stats {
     uint64_t sphere_tests;  /* ray x item tests (FLAT: rays * n_items; SKIP: Sphere::intersect calls the
                                reference's traversal makes, shadow rays stopping at their first hit)        */
     uint64_t bound_tests;   /* bound.distance_from_ray calls (group.rs:73); 0 for FLAT          */
+    uint64_t tests_executed;/* ray x record tests the kernels actually ran: SKIP = sphere_tests + bound_tests;
+                               FLAT = primary * n_items + (shadow rays) * first chunk + (survivors) * rest --
+                               the any-hit passes stop early, so FLAT's figure is below sphere_tests         */
     double device_ms;       /* hipEvent time of all kernels of this call on its stream       */
 } rt_stats;
 

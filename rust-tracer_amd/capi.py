@@ -32,7 +32,8 @@ class Range(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("primary", C.c_uint64), ("hits", C.c_uint64), ("shadow", C.c_uint64), ("occluded", C.c_uint64),
-                ("sphere_tests", C.c_uint64), ("bound_tests", C.c_uint64), ("device_ms", C.c_double)]
+                ("sphere_tests", C.c_uint64), ("bound_tests", C.c_uint64), ("tests_executed", C.c_uint64),
+                ("device_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

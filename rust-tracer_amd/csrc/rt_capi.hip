@@ -373,13 +373,6 @@ rt_status ensure_sample_buffers(Context *c, size_t samples, size_t esz)
     return RT_OK;
 }
 
-// RT_FLAT_VARIANT=2 selects the fused flat kernel (k_render_flat2) for A/B runs; the default is the wavefront pipeline.
-int flat_variant()
-{
-    const char *e = getenv("RT_FLAT_VARIANT");
-    return e ? atoi(e) : 3;
-}
-
 // rt_flat_wf.hpp: primary+shade -> shadow pass over the largest spheres -> shadow pass over the rest -> ordered resolve.
 template <typename T, int CHUNK>
 rt_status launch_flat_wavefront(const rt_scene *s, Context *c, hipStream_t stream, unsigned w, unsigned h, unsigned spp, const rt::TileDev *d_tab32,
@@ -488,7 +481,7 @@ rt_status launch_render(rt_scene *s, Context *c, const rt_options *o, rt_travers
                         uint32_t total_blocks, uint64_t total_px, uint8_t *d_out, unsigned frame_w, hipStream_t stream, rt::Counters *cnt,
                         const rt::TileDev *d_tab16 = nullptr, uint32_t blocks16 = 0)
 {
-    const dim3 grid(total_blocks), block(rt::kBlockThreads);
+    const dim3 grid(total_blocks);
     const unsigned w = o->width, h = o->height, spp = o->samples_per_pixel;
     if (trav == RT_TRAVERSAL_FLAT && d_tab16) {                     // wavefront pipeline (needs a context and the 16x16 table)
         rt_status fst = s->precision == RT_F32
@@ -496,10 +489,8 @@ rt_status launch_render(rt_scene *s, Context *c, const rt_options *o, rt_travers
             : launch_flat_wavefront<double, 512>(s, c, stream, w, h, spp, d_tab, nt, total_blocks, d_tab16, blocks16, total_px, d_out, cnt, frame_w);
         if (fst != RT_OK) return fst;
     } else if (trav == RT_TRAVERSAL_FLAT) {
-        if (s->precision == RT_F32)
-            hipLaunchKernelGGL((rt::k_render_flat2<float, 1024>), grid, block, 0, stream, flat_view_of<float>(s), w, h, spp, d_tab, nt, d_out, cnt, frame_w);
-        else
-            hipLaunchKernelGGL((rt::k_render_flat2<double, 512>), grid, block, 0, stream, flat_view_of<double>(s), w, h, spp, d_tab, nt, d_out, cnt, frame_w);
+        snprintf(g_err, sizeof g_err, "flat traversal launched without its resolve table");
+        return RT_ERR_INVALID_ARGUMENT;
     } else {
         rt_status lst = launch_skip(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w);
         if (lst != RT_OK) return lst;
@@ -551,8 +542,20 @@ rt_status read_stats(rt_scene *s, Context *c, hipStream_t stream, rt_traversal t
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     st->primary = h.primary; st->hits = h.hits; st->shadow = h.shadow; st->occluded = h.occluded;
-    if (trav == RT_TRAVERSAL_FLAT) { st->sphere_tests = (h.primary + h.shadow) * (uint64_t)s->n_items; st->bound_tests = 0; }
-    else { st->sphere_tests = h.sphere_tests; st->bound_tests = h.bound_tests; }
+    if (trav == RT_TRAVERSAL_FLAT) {
+        st->sphere_tests = (h.primary + h.shadow) * (uint64_t)s->n_items;
+        st->bound_tests = 0;
+        st->tests_executed = st->sphere_tests;
+        if (c->d_queues) {                                          // the shadow queues' lengths say what actually ran
+            rt::FlatQueues q{};
+            HIP_TRY(hipMemcpy(&q, c->d_queues, sizeof q, hipMemcpyDeviceToHost));
+            const uint64_t chunk = s->precision == RT_F32 ? 1024 : 512, n = s->n_items;
+            st->tests_executed = h.primary * n + (uint64_t)q.n1 * std::min<uint64_t>(chunk, n) + (uint64_t)q.n2 * (n > chunk ? n - chunk : 0);
+        }
+    } else {
+        st->sphere_tests = h.sphere_tests; st->bound_tests = h.bound_tests;
+        st->tests_executed = h.sphere_tests + h.bound_tests;
+    }
     if (getenv("RT_DEBUG_STEPS"))
         fprintf(stderr, "[rtrace_hip] wave_steps %llu max_wave_steps %llu longest wave: %llu cycles, %.2f us, %.0f MHz\n", h.wave_steps,
                 h.max_wave_steps, h.max_wave_cycles, h.max_wave_ref100mhz / 100.0,
@@ -730,7 +733,7 @@ static rt_status render_device(rt_scene *s, const rt_options *o, rt_traversal tr
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     uint8_t *out = static_cast<uint8_t *>(out_device);
     // the flat wavefront pipeline resolves per pixel with the 16x16-block table
-    const bool wavefront = flat2 && flat_variant() != 2;
+    const bool wavefront = flat2;
     std::vector<rt::TileDev> tab16;
     uint32_t blocks16 = 0;
     if (wavefront) {
@@ -793,7 +796,7 @@ rt_status rt_render_tiles(rt_scene *s, const rt_options *o, rt_traversal trav, c
     }
     std::vector<rt::TileDev> tab16;
     uint32_t blocks16 = 0;
-    const bool wavefront = flat2 && flat_variant() != 2;
+    const bool wavefront = flat2;
     if (wavefront) {
         uint64_t px16 = 0;
         if ((st = build_tile_table(o, tiles, n, tab16, &px16, &blocks16)) != RT_OK) return st;

@@ -18,7 +18,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHORT = [("k_render_skip<float, false", "k_render_skip"), ("k_render_flat2<float", "k_render_flat2"),
+SHORT = [("k_render_skip<float, false", "k_render_skip"), ("k_render_flat2<float", "k_render_flat2"), ("k_flat_primary<float", "k_flat_primary"), ("k_flat_shadow<float", "k_flat_shadow"),
          ("k_render_fused<float", "k_render_fused"), ("k_blit_tiles", "k_blit_tiles"), ("k_build_streams<float>", "k_build_streams"),
          ("k_resolve_samples<float>", "k_resolve_samples")]
 
@@ -55,7 +55,7 @@ def main():
     json.dump(pmc, open(os.path.join(prof, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     tpath = os.path.join(prof, "roofline_traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
-    for k in ("k_render_skip", "k_render_flat2"):
+    for k in ("k_render_skip", "k_flat_primary", "k_flat_shadow"):
         if k in pmc and "hbm_bytes_per_launch" in pmc[k]:
             traffic["%s_n%d" % (k, n)] = pmc[k]["hbm_bytes_per_launch"]
     traffic["_source"] = "tools/summarize_profile.py from rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, tag " + tag

@@ -9,7 +9,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = [("k_render_skip<float, false", "k_render_skip"), ("k_render_flat2<float", "k_render_flat2")]
+KERNELS = [("k_render_skip<float, false", "k_render_skip"), ("k_flat_primary<float", "k_flat_primary"), ("k_flat_shadow<float", "k_flat_shadow")]
 
 
 def main():
