@@ -40,9 +40,10 @@ rt_status hip_fail(hipError_t e, const char *what, int line)
 struct Context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    rt::TileDev *d_tiles = nullptr;
-    rt::TileDev *h_tiles = nullptr;   // pinned: the H2D copy of the table is truly asynchronous
-    size_t tiles_cap = 0;
+    // two upload slots (a flat pass uses two tables); pinned host side: the H2D copy is truly asynchronous
+    rt::TileDev *d_tiles[2] = { nullptr, nullptr };
+    rt::TileDev *h_tiles[2] = { nullptr, nullptr };
+    size_t tiles_cap[2] = { 0, 0 };
     rt::Counters *d_counters = nullptr;
     uint8_t *d_out = nullptr;
     size_t out_cap = 0;
@@ -57,8 +58,10 @@ struct Context {
 
     ~Context()
     {
-        if (d_tiles) (void)hipFree(d_tiles);
-        if (h_tiles) (void)hipHostFree(h_tiles);
+        for (int k = 0; k < 2; ++k) {
+            if (d_tiles[k]) (void)hipFree(d_tiles[k]);
+            if (h_tiles[k]) (void)hipHostFree(h_tiles[k]);
+        }
         if (d_counters) (void)hipFree(d_counters);
         if (d_out) (void)hipFree(d_out);
         if (d_sample_gdot) (void)hipFree(d_sample_gdot);
@@ -296,26 +299,27 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
 constexpr size_t kMaxCachedTables = 32;
 
 // Device copy of `tab`: from the scene's cache when seen before (or cacheable now), else through the context.
-rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, const rt::TileDev **out);
+rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, const rt::TileDev **out,
+                       int slot = 0);
 
 // Copies the tile table through the context's pinned buffer; truly asynchronous on `stream`.
-rt_status upload_tiles(Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream)
+rt_status upload_tiles(Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, int slot)
 {
     const size_t tab_bytes = tab.size() * sizeof(rt::TileDev);
-    if (c->tiles_cap < tab.size()) {
-        if (c->d_tiles) HIP_TRY(hipFree(c->d_tiles));
-        if (c->h_tiles) HIP_TRY(hipHostFree(c->h_tiles));
-        c->d_tiles = nullptr; c->h_tiles = nullptr; c->tiles_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_tiles, tab_bytes));
-        HIP_TRY(hipHostMalloc(&c->h_tiles, tab_bytes, hipHostMallocDefault));
-        c->tiles_cap = tab.size();
+    if (c->tiles_cap[slot] < tab.size()) {
+        if (c->d_tiles[slot]) HIP_TRY(hipFree(c->d_tiles[slot]));
+        if (c->h_tiles[slot]) HIP_TRY(hipHostFree(c->h_tiles[slot]));
+        c->d_tiles[slot] = nullptr; c->h_tiles[slot] = nullptr; c->tiles_cap[slot] = 0;
+        HIP_TRY(hipMalloc(&c->d_tiles[slot], tab_bytes));
+        HIP_TRY(hipHostMalloc(&c->h_tiles[slot], tab_bytes, hipHostMallocDefault));
+        c->tiles_cap[slot] = tab.size();
     }
-    memcpy(c->h_tiles, tab.data(), tab_bytes);
-    HIP_TRY(hipMemcpyAsync(c->d_tiles, c->h_tiles, tab_bytes, hipMemcpyHostToDevice, stream));
+    memcpy(c->h_tiles[slot], tab.data(), tab_bytes);
+    HIP_TRY(hipMemcpyAsync(c->d_tiles[slot], c->h_tiles[slot], tab_bytes, hipMemcpyHostToDevice, stream));
     return RT_OK;
 }
 
-rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, const rt::TileDev **out)
+rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, const rt::TileDev **out, int slot)
 {
     const size_t bytes = tab.size() * sizeof(rt::TileDev);
     {
@@ -334,8 +338,8 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
         }
     }
     if (!c) { *out = nullptr; return RT_OK; }                       // cache full and no context to upload through
-    rt_status st = upload_tiles(c, tab, stream);
-    if (st == RT_OK) *out = c->d_tiles;
+    rt_status st = upload_tiles(c, tab, stream, slot);
+    if (st == RT_OK) *out = c->d_tiles[slot];
     return st;
 }
 
@@ -510,9 +514,7 @@ rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversa
         rt_status ust = device_table(s, c, tab, stream, &d_tab);
         if (ust != RT_OK) return ust;
         if (tab16) {
-            // the per-context upload buffer holds ONE table: the second table must come from the scene's cache
-            if ((ust = device_table(s, nullptr, *tab16, stream, &d_tab16)) != RT_OK) return ust;
-            if (!d_tab16) { snprintf(g_err, sizeof g_err, "flat traversal: tile-table cache exhausted"); return RT_ERR_OUT_OF_MEMORY; }
+            if ((ust = device_table(s, c, *tab16, stream, &d_tab16, 1)) != RT_OK) return ust;
         }
     }
     if (want_counters) {

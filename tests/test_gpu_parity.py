@@ -532,3 +532,17 @@ def test_tangent_ray_zero_discriminant(precision, trav):
     assert util.ray_stats(st) == util.ray_stats(rst)
     assert data.reshape(64, 64, 4)[32, 32, 3] in (0, 255)   # the pixel is a hit (lit or shadowed), not background
     assert tuple(data.reshape(64, 64, 4)[32, 32, :3]) != (34, 10, 10)
+
+
+@pytest.mark.parametrize("trav", [SKIP, FLAT], ids=["skip", "flat"])
+def test_more_distinct_tile_lists_than_the_table_cache_holds(trav):
+    # the reference calls render_region once per bucket: 48 different single-bucket lists on one scene must all work
+    # (the device tile-table cache holds 32; beyond that tables are uploaded per call)
+    s, o = util.scene_pair_default()
+    d = s.device()
+    regs = bucket_list(512, 384)
+    assert len(regs) == 48
+    ref, _, _ = o.render(512, 384, 1, nthreads=4)
+    for (l, t, r, b) in regs + regs[:8]:
+        data, _ = d.render_tiles((512, 384, 1), [(l, t, r, b)], trav, want_stats=False)
+        np.testing.assert_array_equal(data.reshape(t - b, r - l, 4), ref[b:t, l:r])
