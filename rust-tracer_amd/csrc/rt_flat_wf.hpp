@@ -1,20 +1,21 @@
-// rt_flat_wf.hpp -- RT_TRAVERSAL_FLAT as a wavefront pipeline (the default flat path).
+// rt_flat_wf.hpp -- RT_TRAVERSAL_FLAT as a wavefront pipeline.
 //
-// The fused flat kernel (rt_flat.hpp) keeps a whole wave scanning all 21,845 items for as long as ONE of its lanes still
-// has a shadow ray pending, although only 64 % of the pixels cast a shadow ray and 55 % of those rays are occluded -- most
-// of them by one of the largest spheres.  Because an any-hit query may visit the items in any order, the shadow array is
-// sorted by radius (89 % of the occluded rays are settled by its first 1,024 items) and the work is cut into passes with
-// the rays re-packed densely in between, so every lane of every wave carries a ray that still needs work:
+// A single kernel that does primary scan, shade and shadow scan per pixel keeps a whole wave scanning all 21,845 items for
+// as long as ONE of its lanes still has a shadow ray pending, although only 64 % of the pixels cast a shadow ray and 55 % of
+// those rays are occluded -- most of them by one of the largest spheres (that first version took 15.2 ms at 1080p).  Because
+// an any-hit query may visit the items in any order, the shadow array is sorted by radius (89 % of the occluded rays are
+// settled by its first 1,024 items) and the work is cut into passes with the rays re-packed densely in between, so every
+// lane of every wave carries a ray that still needs work:
 //
-//   k_flat_primary   one thread per pixel pair x one sample: primary-ray generation, nearest-hit scan through LDS (same
-//                    loop as the fused kernel), shade; stores the sample's {state, n.light}; rays that need a shadow
-//                    test are appended to queue 1 (one atomic per wave: __ballot + popcount + mbcnt)
+//   k_flat_primary   one thread per pixel pair x one sample: primary-ray generation, nearest-hit scan through LDS, shade;
+//                    stores the sample's {state, n.light}; rays that need a shadow test are appended to queue 1 (one
+//                    atomic per wave: __ballot + popcount + mbcnt)
 //   k_flat_shadow    pass A: queue 1 against the first LDS chunk (the 1,024 largest spheres); occluded rays record
 //                    kShadowed, survivors are appended to queue 2.   pass B: queue 2 against the remaining chunks.
 //   k_resolve_samples (rt_skip.hpp) accumulates each pixel's samples in the reference's order and quantises.
 //
-// Results are bit-identical to the fused kernel and to the reference: every ray still performs the same individually
-// rounded arithmetic against every item it needs (any-hit = a boolean OR over the items, order-free).
+// Results are bit-identical to the reference: every ray performs the same individually rounded arithmetic against every
+// item it needs (nearest hit: all items in DFS order; any-hit: a boolean OR over the items, order-free).
 #pragma once
 #include "rt_flat.hpp"
 #include "rt_skip.hpp"

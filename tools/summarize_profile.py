@@ -18,8 +18,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHORT = [("k_render_skip<float, false", "k_render_skip"), ("k_render_flat2<float", "k_render_flat2"), ("k_flat_primary<float", "k_flat_primary"), ("k_flat_shadow<float", "k_flat_shadow"),
-         ("k_render_fused<float", "k_render_fused"), ("k_blit_tiles", "k_blit_tiles"), ("k_build_streams<float>", "k_build_streams"),
+SHORT = [("k_render_skip<float, false", "k_render_skip"), ("k_flat_primary<float", "k_flat_primary"), ("k_flat_shadow<float", "k_flat_shadow"),
+         ("k_blit_tiles", "k_blit_tiles"), ("k_build_streams<float>", "k_build_streams"),
          ("k_resolve_samples<float>", "k_resolve_samples")]
 
 
