@@ -57,6 +57,32 @@ def assemble_host(options, world, gathered):
     return frame
 
 
+def run_pipeline(steps, ops):
+    """The frame schedule of the multi-GPU path, double-buffered: render(k) -> async gather(k) -> [gather(k-1) done: blit(k-1)].
+    Frame k uses buffer slot k & 1; a slot is only re-rendered after the gather that read it has completed, and only
+    re-gathered after the blit that read its gathered copy has been ordered (op_before_reuse)."""
+    works = [None, None]
+
+    def finish(slot):
+        w, works[slot] = works[slot], None
+        ops.op_blit_after(w, slot)
+
+    for k in range(steps):
+        slot = k & 1
+        if works[slot] is not None:              # frame k-2 used this slot and nobody has waited for its gather yet
+            finish(slot)
+        ops.op_before_reuse(slot)
+        ops.op_render(slot)
+        works[slot] = ops.op_gather_async(slot)
+        prev = slot ^ 1
+        if k > 0 and works[prev] is not None:
+            finish(prev)
+    for slot in ((steps - 2) & 1, (steps - 1) & 1):
+        if steps > 0 and works[slot] is not None:
+            finish(slot)
+    ops.op_drain()
+
+
 class FrameSharder:
     """One per process (= per GPU).  world == 1: a step renders the buckets straight into the row-major frame.
     world > 1: a step renders this rank's buckets tile-major, one RCCL gather brings the u8 shards to rank 0, and rank 0
@@ -126,6 +152,32 @@ class FrameSharder:
             self.gather(slot=0)
             self.blit(slot=0)
 
+    # ---- the operations run_pipeline() schedules (a CPU stand-in with the same five methods is used by the gloo tests) ----
+    def op_render(self, slot):
+        self.render_shard(slot=slot)
+
+    def op_gather_async(self, slot):
+        return self.gather(slot=slot, async_op=True)
+
+    def op_blit_after(self, work, slot):
+        """Frame in `slot` has been gathered once `work` is done: blit it.  Rank 0 does that on its side stream, so the blit
+        overlaps the next render instead of queueing behind it (Work.wait() only orders the stream it is called on)."""
+        if self.side is not None:
+            with self.torch.cuda.stream(self.side):
+                work.wait()
+                self.blit(slot=slot)
+        else:
+            work.wait()
+
+    def op_before_reuse(self, slot):
+        """gathered[slot] is about to be overwritten by the next gather: the blit that read it must be ordered before."""
+        if self.side is not None:
+            self.torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+    def op_drain(self):
+        if self.side is not None:
+            self.torch.cuda.current_stream(self.device).wait_stream(self.side)    # the caller synchronises the main stream only
+
     def run(self, steps):
         """`steps` complete frames.  world > 1: software-pipelined, gather(k) overlaps render(k+1); every frame has been
         blitted on rank 0 when this returns (the caller still synchronises the device)."""
@@ -133,37 +185,7 @@ class FrameSharder:
             for _ in range(steps):
                 self.render_frame()
             return
-        torch = self.torch
-        main = torch.cuda.current_stream(self.device)
-        works = [None, None]
-
-        def finish(slot):
-            """frame in `slot` has been gathered: blit it.  Rank 0 does that on its side stream, so the blit overlaps the
-            next render instead of queueing behind it (Work.wait() only orders the stream it is called on)."""
-            w, works[slot] = works[slot], None
-            if self.side is not None:
-                with torch.cuda.stream(self.side):
-                    w.wait()
-                    self.blit(slot=slot)
-            else:
-                w.wait()
-
-        for k in range(steps):
-            slot = k & 1
-            if works[slot] is not None:          # (non-root) frame k-2 used this shard buffer: its gather must be done
-                finish(slot)
-            if self.side is not None:
-                main.wait_stream(self.side)      # gathered[slot] is about to be overwritten: frame k-2's blit read it
-            self.render_shard(slot=slot)
-            works[slot] = self.gather(slot=slot, async_op=True)
-            prev = slot ^ 1
-            if k > 0 and works[prev] is not None:
-                finish(prev)
-        for slot in ((steps - 2) & 1, (steps - 1) & 1):
-            if steps > 0 and works[slot] is not None:
-                finish(slot)
-        if self.side is not None:
-            main.wait_stream(self.side)          # the caller synchronises the main stream only
+        run_pipeline(steps, self)
 
     def frame_host(self):
         self.torch.cuda.synchronize(self.device)

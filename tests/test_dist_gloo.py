@@ -68,6 +68,100 @@ def _worker(rank, world, port, w, h, spp, q):
         dist.destroy_process_group()
 
 
+class _CpuOps:
+    """The five operations run_pipeline() schedules, on CPU tensors over gloo.  Every frame k is rendered with a
+    different pattern (the oracle tile XOR k), so a slot mix-up in the schedule shows up as a wrong frame."""
+
+    def __init__(self, rank, world, opts, oracle_scene, log):
+        import torch
+        self.torch, self.rank, self.world, self.opts, self.o, self.log = torch, rank, world, opts, oracle_scene, log
+        self.bl, self.per_rank, self.shard_px = rdist.shard_layout(opts, world)
+        self.shards = [torch.zeros(self.shard_px * 4, dtype=torch.uint8) for _ in range(2)]
+        self.gathered = [[torch.zeros(self.shard_px * 4, dtype=torch.uint8) for _ in range(world)] for _ in range(2)]
+        self.frames = []
+        self.k_render = 0
+        self.slot_frame = [None, None]
+        self.tiles = {}
+
+    def op_render(self, slot):
+        k = self.k_render
+        self.k_render += 1
+        self.slot_frame[slot] = k
+        idx, offs, _ = self.per_rank[self.rank]
+        sh = np.zeros(self.shard_px * 4, dtype=np.uint8)
+        for i, off in zip(idx, offs):
+            if i not in self.tiles:
+                self.tiles[i] = self.o.render_region(self.opts.width, self.opts.height, self.opts.samples_per_pixel, *self.bl[i])[0].reshape(-1)
+            sh[off * 4:off * 4 + self.tiles[i].size] = self.tiles[i] ^ np.uint8(k & 0xFF)
+        self.shards[slot].copy_(self.torch.from_numpy(sh))
+        self.log.append(("render", k, slot))
+
+    def op_gather_async(self, slot):
+        import torch.distributed as dist
+        self.log.append(("gather", self.slot_frame[slot], slot))
+        return dist.gather(self.shards[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, async_op=True)
+
+    def op_blit_after(self, work, slot):
+        work.wait()
+        if self.rank == 0:
+            k = self.slot_frame[slot] if False else None
+            self.frames.append(rdist.assemble_host(self.opts, self.world, self.torch.stack(self.gathered[slot]).numpy()))
+        self.log.append(("blit", slot))
+
+    def op_before_reuse(self, slot):
+        pass
+
+    def op_drain(self):
+        self.log.append(("drain",))
+
+
+def _pipeline_worker(rank, world, port, steps, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import oracle
+    import rust_tracer_amd as rta
+    from rust_tracer_amd import dist as rdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        opts = rta.RenderOptions(256, 192, 1)
+        o = oracle.Scene.default()
+        log = []
+        ops = _CpuOps(rank, world, opts, o, log)
+        rdist.run_pipeline(steps, ops)
+        ok = True
+        if rank == 0:
+            ref, _, _ = o.render(256, 192, 1, nthreads=2)
+            ok = len(ops.frames) == steps and all(np.array_equal(f, ref ^ np.uint8(k & 0xFF)) for k, f in enumerate(ops.frames))
+        n_render = sum(1 for e in log if e[0] == "render")
+        n_blit = sum(1 for e in log if e[0] == "blit")
+        q.put((rank, bool(ok), n_render, n_blit, log[-1] == ("drain",)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("steps", [1, 2, 5])
+def test_world_size_2_pipelined_schedule_delivers_every_frame_in_order(steps):
+    # the schedule bench.py runs for N > 1 (FrameSharder.run -> run_pipeline), with CPU stand-ins for the device operations:
+    # both ranks execute it, frames differ from each other, rank 0 must assemble frame k from frame k's shards
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, steps, q)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(180) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    for rank, ok, n_render, n_blit, drained in res:
+        assert ok and n_render == steps and n_blit == steps and drained, (rank, ok, n_render, n_blit, drained)
+
+
 @pytest.mark.parametrize("size", [(320, 200, 1), (192, 128, 2)])
 def test_world_size_2_gather_assembles_the_identical_frame(size):
     import torch.multiprocessing as mp
