@@ -546,3 +546,26 @@ def test_more_distinct_tile_lists_than_the_table_cache_holds(trav):
     for (l, t, r, b) in regs + regs[:8]:
         data, _ = d.render_tiles((512, 384, 1), [(l, t, r, b)], trav, want_stats=False)
         np.testing.assert_array_equal(data.reshape(t - b, r - l, 4), ref[b:t, l:r])
+
+
+@pytest.mark.parametrize("variant", [0, 1, 5, 7])
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_every_skip_loop_flavour_on_deep_random_scenes(variant, seed):
+    # RT_SKIP_VARIANT picks the traversal-loop flavour explicitly (0/1 C++ loops, 5 assembly, 7 assembly + successor
+    # prefetch; the default picks 5 or 7 by pass size).  Deeper, wider random trees with loose bounds and an eye inside
+    # some bounds: culling decides pixels, many lanes retire at different items in the shadow walk.
+    import ctypes
+    libc = ctypes.CDLL(None)
+    items, bounds, ranges = util.random_nested_scene(seed, depth=4, fan=4, leaf_items=2)
+    s, o = util.scene_pair_ranges(items, bounds, ranges, eye=(0.05, -0.1, -2.2))
+    regs = bucket_list(192, 160, 2)
+    ref, rst, _ = o.render(192, 160, 2, os.cpu_count() or 1, HIER_EXIT)
+    libc.setenv(b"RT_SKIP_VARIANT", str(variant).encode(), 1)
+    try:
+        plain, _ = s.device().render_tiles((192, 160, 2), regs, SKIP, want_stats=False)
+        counted, st = s.device().render_tiles((192, 160, 2), regs, SKIP, want_stats=True)
+    finally:
+        libc.unsetenv(b"RT_SKIP_VARIANT")
+    np.testing.assert_array_equal(util.stitch((192, 160), regs, plain), ref)
+    np.testing.assert_array_equal(counted, plain)
+    assert util.all_stats(st) == util.all_stats(rst)
