@@ -55,6 +55,55 @@ def normalized(v, precision=capi.RT_F32):
     return np.array([x * rc, y * rc, z * rc], dtype=R)
 
 
+def build_hierarchy(spheres, leaf_size=4, precision=capi.RT_F32):
+    """Bounding-sphere hierarchy for an arbitrary sphere list (scenes other than the pyramid, e.g. BASELINE
+    config 5 with exactly 100,000 spheres).  Not in the reference -- its only scene builder is `pyramid` -- but the result
+    is an ordinary `TypedGroup` tree in the flat description the C ABI takes: median splits along the longest axis until
+    at most `leaf_size` spheres remain; every group's bound encloses its whole subtree (centre = box centre, radius =
+    max(|c_i - centre| + r_i), inflated by 1e-4 so that it also encloses after rounding to REAL).
+
+    Returns (items REAL[n,4] in the tree's DFS order, bounds REAL[g,4], ranges int32[g,2], order int64[n]) where
+    items == spheres[order]."""
+    R = _real(precision)
+    sp = np.asarray(spheres, dtype=np.float64).reshape(-1, 4)
+    if sp.shape[0] == 0:
+        raise ValueError("build_hierarchy needs at least one sphere")
+    order, bounds, ranges = [], [], []
+
+    def bound_of(idx):
+        c, r = sp[idx, :3], sp[idx, 3]
+        lo, hi = (c - r[:, None]).min(axis=0), (c + r[:, None]).max(axis=0)
+        centre = (lo + hi) * 0.5
+        radius = float((np.linalg.norm(c - centre, axis=1) + r).max()) * (1.0 + 1e-4) + 1e-30
+        return (centre[0], centre[1], centre[2], radius)
+
+    # iterative pre-order build (no recursion limit for 100k+ spheres): "open" emits a group and schedules its halves,
+    # "close" fixes the group's item range once its subtree has been emitted
+    todo = [("open", np.arange(sp.shape[0]))]
+    while todo:
+        kind, idx = todo.pop()
+        if kind == "close":
+            gi, first = idx
+            ranges[gi] = (first, len(order) - first)
+            continue
+        gi = len(bounds)
+        bounds.append(bound_of(idx))
+        ranges.append(None)
+        todo.append(("close", (gi, len(order))))
+        if idx.size <= leaf_size:
+            order.extend(int(i) for i in idx)
+            continue
+        c = sp[idx, :3]
+        axis = int(np.argmax(c.max(axis=0) - c.min(axis=0)))
+        srt = idx[np.argsort(c[:, axis], kind="stable")]
+        half = srt.size // 2
+        todo.append(("open", srt[half:]))      # popped second -> visited after the first half (pre-order)
+        todo.append(("open", srt[:half]))
+    order = np.asarray(order, dtype=np.int64)
+    return (sp[order].astype(R), np.asarray(bounds, dtype=np.float64).astype(R),
+            np.asarray(ranges, dtype=np.int32).reshape(-1, 2), order)
+
+
 class Scene:
     """Scene{group, directional_light, eye} (render.rs:138-142) with the group flattened to DFS arrays."""
 
@@ -80,6 +129,12 @@ class Scene:
         items = np.asarray(spheres, dtype=np.float64).reshape(-1, 4)
         return cls(items, normalized(light, precision), eye, np.asarray(bound, dtype=np.float64).reshape(1, 4),
                    np.array([[0, items.shape[0]]], dtype=np.int32), precision)
+
+    @classmethod
+    def from_spheres_auto(cls, spheres, light=(-1.0, -3.0, 2.0), eye=(0.0, 0.0, -4.0), leaf_size=4, precision=capi.RT_F32):
+        """Arbitrary sphere list with an automatically built bounding-sphere hierarchy (build_hierarchy)."""
+        items, bounds, ranges, _ = build_hierarchy(spheres, leaf_size, precision)
+        return cls(items, normalized(light, precision), eye, bounds, ranges, precision)
 
     @classmethod
     def three_spheres(cls, precision=capi.RT_F32):

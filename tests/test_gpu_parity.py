@@ -569,3 +569,23 @@ def test_every_skip_loop_flavour_on_deep_random_scenes(variant, seed):
     np.testing.assert_array_equal(util.stitch((192, 160), regs, plain), ref)
     np.testing.assert_array_equal(counted, plain)
     assert util.all_stats(st) == util.all_stats(rst)
+
+
+def test_100k_arbitrary_spheres_with_auto_built_hierarchy():
+    # BASELINE config 5 asks for "100k spheres"; the pyramid only offers 87,381 -- SURVEY.md 8f.4: an arbitrary list of
+    # exactly 100,000 spheres with an automatically built bounding-sphere hierarchy (65,535 groups, depth 16)
+    rng = np.random.default_rng(5)
+    n = 100000
+    sp = np.concatenate([rng.uniform([-3, -2, 0], [3, 2, 6], (n, 3)), rng.uniform(0.01, 0.03, (n, 1))], axis=1)
+    sp = sp.astype(np.float32).astype(np.float64)
+    s = rta.Scene.from_spheres_auto(sp)
+    assert s.items.shape[0] == n
+    o = oracle.Scene.from_ranges(s.items.astype(np.float64), s.bounds.astype(np.float64), s.ranges)
+    regs = bucket_list(512, 384)
+    skip, st = s.device().render_tiles((512, 384, 1), regs, SKIP)
+    ref, rst, _ = o.render(512, 384, 1, os.cpu_count() or 1, HIER_EXIT)
+    np.testing.assert_array_equal(util.stitch((512, 384), regs, skip), ref)
+    assert util.all_stats(st) == util.all_stats(rst)
+    flat, fst = s.device().render_tiles((512, 384, 1), regs, FLAT)      # eye outside every bound: flat == hierarchy (H2)
+    np.testing.assert_array_equal(flat, skip)
+    assert util.ray_stats(fst) == util.ray_stats(st)

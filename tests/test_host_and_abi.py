@@ -127,3 +127,24 @@ def test_rgba_buffer_blit_requires_containment():
     big = rta.RGBABuffer(rta.ImageRegion(0, 64, 64, 0))
     with pytest.raises(ValueError):
         big.set_pixels_from_buffer(rta.RGBABuffer(rta.ImageRegion(32, 96, 96, 32)))
+
+
+def test_auto_hierarchy_is_a_valid_enclosing_nesting():
+    # arbitrary sphere lists.  The built bounds must enclose their subtrees (in REAL) and nest, so the
+    # oracle accepts the same description and flat == hierarchy for an eye outside the root bound (H2).
+    rng = np.random.default_rng(3)
+    sp = np.concatenate([rng.uniform([-2, -1.5, 0], [2, 1.5, 4], (3000, 3)), rng.uniform(0.02, 0.08, (3000, 1))], axis=1)
+    sp = sp.astype(np.float32).astype(np.float64)
+    items, bounds, ranges, order = rta.build_hierarchy(sp, leaf_size=4)
+    np.testing.assert_array_equal(items, sp[order].astype(np.float32))
+    assert sorted(order.tolist()) == list(range(3000))
+    assert ranges[0].tolist() == [0, 3000]
+    for gi in range(len(bounds)):
+        f, c = ranges[gi]
+        it, b = items[f:f + c].astype(np.float64), bounds[gi].astype(np.float64)
+        assert (np.linalg.norm(it[:, :3] - b[:3], axis=1) + it[:, 3] <= b[3]).all(), gi
+    o = oracle.Scene.from_ranges(items.astype(np.float64), bounds.astype(np.float64), ranges)
+    assert o.counts() == (len(bounds), 3000)
+    a, _ = o.render_region(160, 120, 1, 0, 120, 160, 0, oracle.MODE_HIERARCHY)
+    b, _ = o.render_region(160, 120, 1, 0, 120, 160, 0, oracle.MODE_FLAT)
+    np.testing.assert_array_equal(a, b)
