@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s + ms/frame on the 1920x1080, 21,845-sphere default scene (BASELINE.json).
 
-A "step" is one frame: every 64x64 bucket of the frame through the HIP hot path (primary + shadow rays), the
-RCCL gather of the u8 shards to rank 0 and the blit into the row-major frame when N > 1 (at N = 1 the buckets are
-rendered straight into the frame: render and blit are one kernel).  The scene is already
+A "step" is one frame PER GPU: every 64x64 bucket of the frame through the HIP hot path (primary + shadow rays), rendered
+straight into the row-major frame; for N > 1 the finished u8 frames are gathered to rank 0 over RCCL (the only collective;
+the gather of step k overlaps the render of step k+1).  Per-GPU work is fixed as N grows: weak scaling, `value` counts the
+rays of all N frames.  `--multi tiles` instead deals the buckets of ONE frame over the GPUs (BASELINE config 4, strong
+scaling; byte-identical output, but a 0.11 ms frame bounded by its heaviest wave cannot get faster that way).  The scene is already
 resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 
 The headline uses the product's default traversal, RT_TRAVERSAL_SKIP (the reference's own bounding-sphere
@@ -85,6 +87,9 @@ def main():
     ap.add_argument("--traversal", choices=("skip", "flat"), default="skip", help="traversal of the headline measurement")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: take the shard -> RCCL gather -> blit path even at N = 1 (needs torch.distributed.run)")
+    ap.add_argument("--multi", choices=("frames", "tiles"), default="frames",
+                    help="N > 1: 'frames' = every GPU renders whole frames, N per step, gathered to rank 0 (weak scaling); "
+                         "'tiles' = BASELINE config 4, the buckets of ONE frame dealt over the GPUs (strong scaling)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1080p",
                     help="1080p = the headline workload; the others are BASELINE's neighbouring configs")
     args = ap.parse_args()
@@ -129,7 +134,7 @@ def main():
 
     def measure(traversal, steps, warmup):
         """-> dict with whole-job ms/step (max over ranks), this rank's kernel ms (HIP events), ray/test counters."""
-        fs = FrameSharder(scene, opts, rank, world, local, traversal, force_collective=args.force_collective)
+        fs = FrameSharder(scene, opts, rank, world, local, traversal, force_collective=args.force_collective, mode=args.multi)
         st = fs.render_shard(want_stats=True)          # counters of this rank's shard (equal the oracle's; tests)
         cnt = torch.tensor([st["primary"], st["shadow"]], dtype=torch.int64, device="cuda")
         if dist is not None:
@@ -187,20 +192,27 @@ def main():
                      "duration of its kernels (k_flat_primary + 2 x k_flat_shadow + k_resolve_samples); every record staged "
                      "to LDS is re-used by all rays of a workgroup, so the logical rate exceeds the HBM peak; the binding "
                      "limit is un-fused f32 VALU issue (see valu)")
+        if world == 1 and not args.force_collective:
+            layout = "1 GPU, buckets rendered straight into the row-major frame"
+        elif args.multi == "frames":
+            layout = ("%d GPUs, every GPU renders a whole frame per step (%d frames per step), u8 frames gathered to rank 0 "
+                      "over RCCL, gather of frame k overlapped with the render of frame k+1" % (world, world))
+        else:
+            layout = ("%d GPUs, the buckets of ONE frame dealt round-robin (tile_id %% N), u8 shards gathered to rank 0 over "
+                      "RCCL and blitted into the frame there, pipelined across frames" % world)
         out = {
             "metric": "Mrays/sec + ms/frame, 1920x1080 20k-sphere scene" if args.workload == "1080p" else
                       "Mrays/sec + ms/frame, %dx%d spp %d L%d (non-headline workload %s)" % (WIDTH, HEIGHT, SPP, LEVEL, args.workload),
             "value": round(rays / (ms_per_step * 1e-3) / 1e6, 3), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak" if args.multi == "frames" else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (the reference's deterministic default scene: pyramid level %d)" % LEVEL,
-            "config": {"workload": "%dx%d, %d spheres (pyramid L%d), spp %d, f32, %s traversal, %d 64x64 buckets "
-                                   "round-robin over %d GPU(s)%s" % (WIDTH, HEIGHT, N_ITEMS, LEVEL, SPP, args.traversal,
-                                                                      -(-WIDTH // 64) * -(-HEIGHT // 64), world, ", RCCL gather + device blit to rank 0" if world > 1 else
-                                                                  ", rendered straight into the row-major frame"),
+            "config": {"workload": "%dx%d, %d spheres (pyramid L%d), spp %d, f32, %s traversal, %d 64x64 buckets per frame; %s"
+                                   % (WIDTH, HEIGHT, N_ITEMS, LEVEL, SPP, args.traversal, -(-WIDTH // 64) * -(-HEIGHT // 64), layout),
                        "width": WIDTH, "height": HEIGHT, "samples_per_pixel": SPP, "n_spheres": N_ITEMS,
                        "primary_rays": m["primary"], "shadow_rays": m["shadow"], "traversal": args.traversal,
-                       "parallelism": "tiles/%d" % world},
+                       "frames_per_step": world if (args.multi == "frames") else 1,
+                       "parallelism": ("frames x %d" if args.multi == "frames" else "tiles/%d") % world},
             "mprimary_per_s": round(m["primary"] / (ms_per_step * 1e-3) / 1e6, 3),
             "roofline": roofline(m, "k_render_skip" if args.traversal == "skip" else "k_flat_primary",
                                  skip_note if args.traversal == "skip" else flat_note),

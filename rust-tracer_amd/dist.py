@@ -5,6 +5,14 @@ The reference's only parallelism is "independent 64x64 buckets on a thread pool"
 its shard tile-major into device memory and a single RCCL gather of the u8 shards over xGMI brings them to
 rank 0, which blits them into the row-major frame on the device.  No other collective touches the data path.
 
+Two ways to use N GPUs, both with the gather as the only collective:
+  * mode "frames" (bench.py's default for N > 1, weak scaling): every GPU renders whole frames -- all 510 buckets of its
+    own frame per step, N frames per step in total -- and the finished u8 frames are gathered to rank 0, where the writer
+    lives.  Per-GPU work is fixed as N grows.
+  * mode "tiles" (BASELINE config 4, strong scaling): the buckets of ONE frame are dealt round-robin over the ranks,
+    the tile-major shards are gathered and blitted into the frame on rank 0.  Byte-identical for every N, but a
+    1080p frame takes ~0.11 ms and is bounded by its heaviest wave, so sharding it cannot make it faster.
+
 The sharding arithmetic is plain Python (testable on CPU with gloo); only `FrameSharder.step` touches the GPU.
 
 Load order: PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as the system one librtrace_hip.so links),
@@ -89,9 +97,13 @@ class FrameSharder:
     blits them into the frame.  run() pipelines consecutive frames: the gather of frame k (RCCL's own stream) overlaps
     the render of frame k+1, so a sequence of frames costs max(render, gather + blit) per frame instead of their sum."""
 
-    def __init__(self, scene, options, rank=0, world=1, device=0, traversal=capi.RT_TRAVERSAL_SKIP, force_collective=False):
+    def __init__(self, scene, options, rank=0, world=1, device=0, traversal=capi.RT_TRAVERSAL_SKIP, force_collective=False,
+                 mode="tiles"):
         import torch
         self.torch = torch
+        if mode not in ("tiles", "frames"):
+            raise ValueError("mode must be 'tiles' or 'frames'")
+        self.mode = mode
         # force_collective: take the shard -> gather -> blit path even for world == 1 (a one-rank RCCL gather); lets a
         # single-GPU test drive exactly the code the 8-GPU run executes
         self.collective = world > 1 or force_collective
@@ -99,8 +111,11 @@ class FrameSharder:
         self.rank, self.world, self.device = rank, world, device
         self.traversal = traversal
         self.dev = scene.device(device)
-        bl, per_rank, self.shard_px = shard_layout(self.options, world)
-        self.my_regions = [tuple(bl[i]) for i in per_rank[rank][0]]
+        # "frames": this rank owns a whole frame (all buckets, laid out like a 1-rank shard = the row-major frame itself)
+        bl, per_rank, self.shard_px = shard_layout(self.options, world if mode == "tiles" else 1)
+        if mode == "frames":
+            self.shard_px = self.options.width * self.options.height
+        self.my_regions = [tuple(bl[i]) for i in per_rank[rank if mode == "tiles" else 0][0]]
         self.my_regions_c = self.dev._regions(self.my_regions)
         tdev = torch.device("cuda", device)
         # two shard buffers: frame k+1 is rendered while frame k's shard is still being gathered
@@ -110,7 +125,7 @@ class FrameSharder:
         self.side = torch.cuda.Stream(device=tdev) if (rank == 0 and self.collective) else None   # rank 0's blits run here
         if rank == 0:
             self.frame = torch.zeros(self.options.height * self.options.width * 4, dtype=torch.uint8, device=tdev)
-            regions, offsets, _ = gathered_tile_table(self.options, world)
+            regions, offsets, _ = gathered_tile_table(self.options, world if mode == "tiles" else 1)
             self.all_regions_c = self.dev._regions(regions)
             self.all_offsets = offsets
             if self.collective:
@@ -122,7 +137,11 @@ class FrameSharder:
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
     def render_shard(self, want_stats=False, slot=0):
-        """This rank's buckets, tile-major, into shard buffer `slot` (enqueued on torch's current stream)."""
+        """This rank's buckets into shard buffer `slot` (enqueued on torch's current stream): tile-major in "tiles" mode,
+        straight into row-major frame order in "frames" mode (the shard IS this rank's frame)."""
+        if self.mode == "frames":
+            return self.dev.render_frame_device(tuple(self.options), self.my_regions_c, self.shards[slot].data_ptr(), self._stream(),
+                                                self.traversal, want_stats)
         return self.dev.render_tiles_device(tuple(self.options), self.my_regions_c, self.shards[slot].data_ptr(), self._stream(),
                                             self.traversal, want_stats)
 
@@ -137,8 +156,9 @@ class FrameSharder:
         return dist.gather(self.shards[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, async_op=async_op)
 
     def blit(self, slot=0):
-        """Rank 0: gathered shards -> row-major frame (set_pixels_from_buffer on the device)."""
-        if self.rank == 0:
+        """Rank 0: gathered shards -> row-major frame (set_pixels_from_buffer on the device).  "frames" mode gathers finished
+        frames (gathered[slot][r] is rank r's frame), there is nothing to assemble."""
+        if self.rank == 0 and self.mode == "tiles":
             src = self.gathered_flat[slot] if self.collective else self.shards[slot]
             self.dev.blit_tiles_device(tuple(self.options), self.all_regions_c, src.data_ptr(), self.frame.data_ptr(),
                                        self._stream(), self.all_offsets)
@@ -187,6 +207,8 @@ class FrameSharder:
             return
         run_pipeline(steps, self)
 
-    def frame_host(self):
+    def frame_host(self, slot=0, of_rank=0):
+        """Rank 0: the assembled frame ("tiles"), or the frame gathered from `of_rank` in buffer `slot` ("frames")."""
         self.torch.cuda.synchronize(self.device)
-        return self.frame.cpu().numpy().reshape(self.options.height, self.options.width, 4)
+        src = self.frame if (self.mode == "tiles" or not self.collective) else self.gathered[slot][of_rank]
+        return src.cpu().numpy().reshape(self.options.height, self.options.width, 4)

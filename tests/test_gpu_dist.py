@@ -55,3 +55,19 @@ def test_fused_single_gpu_path_equals_collective_path(one_rank_rccl):
     a.run(3)
     b.run(3)
     np.testing.assert_array_equal(a.frame_host(), b.frame_host())
+
+
+def test_frames_mode_gathers_whole_frames(one_rank_rccl):
+    # bench.py's N > 1 default (weak scaling): every rank renders a whole frame straight into row-major order and the
+    # finished frames are gathered to rank 0 -- here with one rank, both pipeline slots
+    import torch
+    s, o = util.scene_pair_default()
+    ref, _, _ = o.render(1920, 1080, 1, nthreads=os.cpu_count() or 1)
+    fs = FrameSharder(s, (1920, 1080, 1), 0, 1, 0, rta.RT_TRAVERSAL_SKIP, force_collective=True, mode="frames")
+    for g in fs.gathered_flat:
+        g.fill_(0xCD)
+    fs.run(5)
+    for slot in (0, 1):
+        np.testing.assert_array_equal(fs.frame_host(slot=slot, of_rank=0), ref)
+    st = fs.render_shard(want_stats=True)
+    assert st["primary"] == 1920 * 1080
