@@ -148,3 +148,19 @@ def test_auto_hierarchy_is_a_valid_enclosing_nesting():
     a, _ = o.render_region(160, 120, 1, 0, 120, 160, 0, oracle.MODE_HIERARCHY)
     b, _ = o.render_region(160, 120, 1, 0, 120, 160, 0, oracle.MODE_FLAT)
     np.testing.assert_array_equal(a, b)
+
+
+def test_header_is_plain_c_and_the_library_links_from_c(tmp_path):
+    # the boundary is a C ABI: a C99 translation unit (no C++, no HIP headers) includes the header and links the library
+    import subprocess
+    exe = str(tmp_path / "abi_check")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_check.c"), "-o", exe, "-L", os.path.dirname(capi.LIB_PATH),
+                           "-lrtrace_hip", "-Wl,-rpath," + os.path.dirname(capi.LIB_PATH)])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "sizeof rt_options 6 rt_region 8 rt_range 8 rt_stats %d" % ctypes.sizeof(capi.Stats) in out.stdout
+    # the ctypes mirror has the same field offsets as the C struct
+    offs = " ".join("%s %d" % (n, getattr(capi.Stats, n).offset) for n, _ in capi.Stats._fields_)
+    assert "offsets stats: " + offs in out.stdout
+    assert ctypes.sizeof(capi.Options) == 6 and ctypes.sizeof(capi.Region) == 8 and ctypes.sizeof(capi.Range) == 8
