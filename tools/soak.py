@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Soak / fuzz run for the hand-written traversal loops (GPU box): bitwise stability over many launches, and random nested
+scenes where every loop flavour must agree with the counted C++ flavour (which the parity tests pin to the CPU path).
+usage: soak.py [seconds]"""
+import ctypes
+import os
+import sys
+import time
+import zlib
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import rust_tracer_amd as rta
+from tests import util
+
+libc = ctypes.CDLL(None)
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+t_end = time.time() + budget
+stream = torch.cuda.current_stream().cuda_stream
+
+# 1. bitwise stability of the default path, many launches back to back
+s = rta.Scene.default()
+d = s.device()
+for (w, h, spp) in ((1920, 1080, 1), (1024, 768, 4)):
+    regs = d._regions([tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))])
+    out = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    d.render_frame_device((w, h, spp), regs, out.data_ptr(), stream, rta.RT_TRAVERSAL_SKIP)
+    torch.cuda.synchronize()
+    want = zlib.crc32(out.cpu().numpy().tobytes())
+    n = 0
+    while time.time() < t_end - budget * 0.75 + (0 if spp == 1 else budget * 0.125):
+        for _ in range(200):
+            d.render_frame_device((w, h, spp), regs, out.data_ptr(), stream, rta.RT_TRAVERSAL_SKIP)
+        torch.cuda.synchronize()
+        assert zlib.crc32(out.cpu().numpy().tobytes()) == want, "frame changed after %d launches" % n
+        n += 200
+    print("stable: %dx%d spp %d, %d launches" % (w, h, spp, n), flush=True)
+
+# 2. random nested scenes: flavours 0/5/7 (no counters) vs flavour 1 with counters
+seed = 1000
+checked = 0
+while time.time() < t_end:
+    rng = np.random.default_rng(seed)
+    depth, fan, leaf = int(rng.integers(2, 6)), int(rng.integers(2, 5)), int(rng.integers(1, 4))
+    items, bounds, ranges = util.random_nested_scene(seed, depth=depth, fan=fan, leaf_items=leaf)
+    eye = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-4.5, -1.0)))
+    sc = rta.Scene(items, rta.normalized((-1, -3, 2)), eye, bounds, ranges)
+    dv = sc.device()
+    w, h, spp = int(rng.integers(3, 9)) * 32, int(rng.integers(3, 9)) * 24, int(rng.integers(1, 3))
+    regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
+    libc.setenv(b"RT_SKIP_VARIANT", b"1", 1)
+    ref, st = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=True)
+    for v in (0, 5, 7):
+        libc.setenv(b"RT_SKIP_VARIANT", str(v).encode(), 1)
+        got, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
+        assert np.array_equal(got, ref), "seed %d: flavour %d differs" % (seed, v)
+    libc.unsetenv(b"RT_SKIP_VARIANT")
+    dv.close()
+    checked += 1
+    seed += 1
+print("fuzz: %d random scenes, all flavours identical" % checked)
