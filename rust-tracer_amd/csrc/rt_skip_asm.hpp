@@ -107,7 +107,10 @@ namespace rt {
         "s_cmp_eq_u64 vcc, 0\n\t" \
         "s_cselect_b32 s49, s45, s49\n\t" \
         "v_cndmask_b32_e64 %[resume], %[resume], %[t5], s[56:57]\n\t" \
-        "s_branch 6f\n" \
+        "s_cmp_ge_u32 s49, %[n]\n\t"  /* own copy of the loop tail: one taken branch per BOUND step */ \
+        "s_cbranch_scc1 7f\n\t" \
+        NEXT \
+        "s_branch 1b\n" \
         "5:\n\t" \
   /* ---- ITEM (primitive.rs:78-83) ---- */ \
         "v_mov_b32_e32 %[t5], s46\n\t" \
@@ -218,7 +221,10 @@ __device__ __forceinline__ void skip_primary_asm(const void *nodes, unsigned n, 
         "s_cmp_eq_u64 vcc, 0\n\t" \
         "s_cselect_b32 s49, s45, s49\n\t" \
         "v_cndmask_b32_e64 %[resume], %[resume], %[t5], s[56:57]\n\t" \
-        "s_branch 6f\n" \
+        "s_cmp_ge_u32 s49, %[n]\n\t"  /* own copy of the loop tail: one taken branch per BOUND step */ \
+        "s_cbranch_scc1 10f\n\t" \
+        NEXT \
+        "s_branch 1b\n" \
         "5:\n\t" \
   /* ---- ITEM: any hit ends those rays; hand them to the caller ---- */ \
         "s_cmp_eq_u64 vcc, 0\n\t" \
