@@ -72,7 +72,7 @@ namespace rt {
         "v_cmp_ge_u32_e64 s[52:53], s48, %[resume]\n\t"  /* active = i >= resume */ \
         "v_cmp_le_f32_e32 vcc, 0, %[disc]\n\t"  /* disc >= 0 */ \
         "s_and_b64 vcc, vcc, s[52:53]\n\t"  /* lanes that need the exact distance */ \
-        "s_cbranch_vccz 4f\n\t"  /* no active lane can hit this node: go (= vcc) is already empty */ \
+        "s_cbranch_vccz 3f\n\t"  /* no active lane can hit this node */ \
   /* ---- correctly rounded root ---- */ \
         "v_sqrt_f32_e32 %[root], %[disc]\n\t" \
         "v_cmp_lt_f32_e64 s[60:61], |%[disc]|, %[tiny]\n\t" \
@@ -121,6 +121,14 @@ namespace rt {
         "s_cbranch_scc1 7f\n\t" \
         NEXT \
         "s_branch 1b\n" \
+        "3:\n\t"  /* nobody can hit: an ITEM changes nothing; a BOUND puts every active lane to sleep and the wave jumps */ \
+        "s_add_u32 s49, s48, 1\n\t" \
+        "s_cmp_eq_u32 s45, 0\n\t" \
+        "s_cbranch_scc1 6b\n\t" \
+        "v_mov_b32_e32 %[t5], s45\n\t" \
+        "s_mov_b32 s49, s45\n\t" \
+        "v_cndmask_b32_e64 %[resume], %[resume], %[t5], s[52:53]\n\t" \
+        "s_branch 6b\n" \
         "9:\n\t"  /* root with the 2^32 / 2^-16 scaling for tiny lanes */ \
         "v_mul_f32_e32 %[t0], 0x4f800000, %[disc]\n\t" \
         "v_cndmask_b32_e64 %[t5], %[disc], %[t0], s[60:61]\n\t" \
@@ -189,7 +197,7 @@ __device__ __forceinline__ void skip_primary_asm(const void *nodes, unsigned n, 
         "v_cmp_ge_u32_e64 s[52:53], s48, %[resume]\n\t"  /* active = i >= resume */ \
         "v_cmp_le_f32_e32 vcc, 0, %[disc]\n\t" \
         "s_and_b64 vcc, vcc, s[52:53]\n\t"  /* candidates: active, disc >= 0 */ \
-        "s_cbranch_vccz 4f\n\t" \
+        "s_cbranch_vccz 3f\n\t"  /* no active lane can hit this node */ \
         "v_cmp_gt_f32_e64 s[54:55], 0, %[b]\n\t"  /* b < 0: t2 may still be negative */ \
         "s_and_b64 s[54:55], s[54:55], vcc\n\t" \
         "s_cbranch_scc0 4f\n\t"  /* nobody needs the root: hit = candidates */ \
@@ -237,6 +245,14 @@ __device__ __forceinline__ void skip_primary_asm(const void *nodes, unsigned n, 
         "s_cbranch_scc1 10f\n\t" \
         NEXT \
         "s_branch 1b\n" \
+        "3:\n\t"  /* nobody can hit: an ITEM changes nothing; a BOUND puts every active lane to sleep and the wave jumps */ \
+        "s_add_u32 s49, s48, 1\n\t" \
+        "s_cmp_eq_u32 s45, 0\n\t" \
+        "s_cbranch_scc1 6b\n\t" \
+        "v_mov_b32_e32 %[t5], s45\n\t" \
+        "s_mov_b32 s49, s45\n\t" \
+        "v_cndmask_b32_e64 %[resume], %[resume], %[t5], s[52:53]\n\t" \
+        "s_branch 6b\n" \
         "9:\n\t"  /* root with the 2^32 / 2^-16 scaling for tiny lanes */ \
         "v_mul_f32_e32 %[t0], 0x4f800000, %[disc]\n\t" \
         "v_cndmask_b32_e64 %[t5], %[disc], %[t0], s[60:61]\n\t" \
