@@ -103,9 +103,12 @@ template <typename T, bool COUNT, int VAR, bool SPLIT>
 __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, unsigned width, unsigned height, unsigned spp,
                                                               const TileDev *__restrict__ tiles, unsigned n_tiles,
                                                               uint8_t *__restrict__ out, Counters *__restrict__ counters,
-                                                              SampleBuf<T> sb, unsigned frame_w)
+                                                              SampleBuf<T> sb, unsigned frame_w,
+                                                              const uint32_t *__restrict__ order, uint32_t *__restrict__ lane_cost)
 {
-    const unsigned gblock = blockIdx.x;                                      // 16x16 pixel block index
+    // 16x16 pixel block index.  `order` (optional) is a permutation of the pass's blocks, most expensive first: a pass
+    // is as long as its last wave, so the long chains must not be the ones dispatched last (rt_capi.hip, block_order).
+    const unsigned gblock = order ? order[blockIdx.x] : blockIdx.x;
     unsigned lo = 0, hi = n_tiles - 1;
     while (lo < hi) {
         unsigned mid = (lo + hi + 1) >> 1;
@@ -323,10 +326,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
         const size_t px = out_index(tile, x, y, frame_w);
         const unsigned rgba = scale_u8(g.x) | (scale_u8(g.y) << 8) | (scale_u8(g.z) << 16) | (scale_u8(alpha) << 24);
         reinterpret_cast<unsigned *>(out)[px] = rgba;
+        if (COUNT) { if (lane_cost) lane_cost[px] = c_items + c_bounds; }   // the scene's cost map is rendered through this
     }
 
     if (COUNT) {
-        counters += (blockIdx.x + blockIdx.y) % kCounterStripes;
+        counters += (gblock + blockIdx.y) % kCounterStripes;
         const unsigned long long prim = wave_sum(inside ? (SPLIT ? 1u : spp * spp) : 0u);
         const unsigned long long hits = wave_sum(c_hits), sh = wave_sum(c_shadow), oc = wave_sum(c_occ);
         const unsigned long long its = wave_sum(c_items), bds = wave_sum(c_bounds);

@@ -571,6 +571,37 @@ def test_every_skip_loop_flavour_on_deep_random_scenes(variant, seed):
     assert util.all_stats(st) == util.all_stats(rst)
 
 
+@pytest.mark.parametrize("size", [(1920, 1080, 1), (200, 1000, 1), (333, 77, 2)])
+def test_block_dispatch_order_never_changes_a_pixel(size):
+    # The library dispatches a pass's 16x16 blocks most-expensive-first (cost map rendered once per scene).  Same pixels
+    # and same counters with the ordering switched off, for landscape, portrait (rows beyond the square cost map are
+    # clamped) and ragged sizes, and for tile lists given in a scrambled order.
+    import ctypes
+    libc = ctypes.CDLL(None)
+    w, h, spp = size
+    scene = rta.Scene.default(6)
+    d = scene.device()
+    regs = bucket_list(w, h, spp)
+    rng = np.random.default_rng(5)
+    scrambled = [regs[i] for i in rng.permutation(len(regs))]
+    out = {}
+    for flag in (b"0", b"1"):
+        libc.setenv(b"RT_BLOCK_ORDER", flag, 1)
+        try:
+            a, sa = d.render_tiles((w, h, spp), regs, SKIP, want_stats=True)
+            b, _ = d.render_tiles((w, h, spp), scrambled, SKIP, want_stats=False)
+        finally:
+            libc.unsetenv(b"RT_BLOCK_ORDER")
+        out[flag] = (util.stitch((w, h), regs, a), util.stitch((w, h), scrambled, b), util.all_stats(sa))
+    np.testing.assert_array_equal(out[b"0"][0], out[b"1"][0])
+    np.testing.assert_array_equal(out[b"0"][1], out[b"1"][1])
+    np.testing.assert_array_equal(out[b"1"][0], out[b"1"][1])
+    assert out[b"0"][2] == out[b"1"][2]
+    o = oracle.Scene.default(level=6)
+    ref, _, _ = o.render(w, h, spp, os.cpu_count() or 1, HIER_EXIT)
+    np.testing.assert_array_equal(out[b"1"][0], ref)
+
+
 def test_100k_arbitrary_spheres_with_auto_built_hierarchy():
     # BASELINE config 5 asks for "100k spheres"; the pyramid only offers 87,381 -- SURVEY.md 8f.4: an arbitrary list of
     # exactly 100,000 spheres with an automatically built bounding-sphere hierarchy (65,535 groups, depth 16)
