@@ -142,18 +142,25 @@ def main():
         primary, shadow = (int(v) for v in cnt.tolist())
         fs.run(warmup)
         barrier()
+        # N = 1: the timed region is `steps` launches of the render kernel back to back on torch's current stream, which is the
+        # stream handed to the C ABI -- two HIP events on that stream bracket exactly those launches, inside the timed region
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        if not fs.collective:
+            k0.record()
         fs.run(steps)                                  # N > 1: gather(k) on RCCL's stream overlaps render(k+1)
+        if not fs.collective:
+            k1.record()
         barrier()
         elapsed = time.perf_counter() - t0
-        # per-launch duration of the render kernel alone: `steps` launches back to back between two HIP events on the
-        # launch stream (nothing else enqueued in between; agrees with rocprofv3 --kernel-trace --stats)
-        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        k0.record()
-        for _ in range(steps):
-            fs.render_shard() if fs.collective else fs.render_frame()
-        k1.record()
-        torch.cuda.synchronize()
+        if fs.collective:
+            # N > 1: the main stream also carries the waits on RCCL's stream, so the kernel alone is timed right after the
+            # timed region: `steps` launches back to back between two HIP events (agrees with rocprofv3 --kernel-trace --stats)
+            k0.record()
+            for _ in range(steps):
+                fs.render_shard()
+            k1.record()
+            torch.cuda.synchronize()
         kern_ms = k0.elapsed_time(k1) / steps
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         if dist is not None:

@@ -91,8 +91,8 @@ struct rt_scene {
     std::vector<std::unique_ptr<Context>> pool;
     // Immutable device copies of recently used tile tables (a scheduler re-submits the same bucket list every
     // frame): a hit means a pass enqueues nothing but its kernel.
-    // dev_order: the pass's 16x16 blocks, most expensive first (block_order below), or NULL.
-    struct CachedTable { std::vector<rt::TileDev> host; unsigned w = 0, h = 0; rt::TileDev *dev = nullptr; uint32_t *dev_order = nullptr; };
+    // dev_order: one descriptor per 16x16 block of the pass, most expensive first (block_order below), or NULL.
+    struct CachedTable { std::vector<rt::TileDev> host; unsigned w = 0, h = 0; rt::TileDev *dev = nullptr; rt::BlockDesc *dev_order = nullptr; uint32_t n_order = 0; };
     std::vector<CachedTable> tables;
     // Tests per primary ray (its shadow ray included) on a kCostRes x kCostRes grid over the camera's field of view,
     // rendered once per scene with the counting kernel.  It only ever decides the ORDER in which blocks are dispatched.
@@ -305,7 +305,7 @@ constexpr size_t kMaxCachedTables = 32;
 
 // Device copy of `tab`: from the scene's cache when seen before (or cacheable now), else through the context.
 rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, const rt::TileDev **out,
-                       int slot = 0, const rt_options *o = nullptr, const uint32_t **order_out = nullptr);
+                       int slot = 0, const rt_options *o = nullptr, rt::BlockList *order_out = nullptr);
 
 // Copies the tile table through the context's pinned buffer; truly asynchronous on `stream`.
 rt_status upload_tiles(Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, int slot)
@@ -345,8 +345,8 @@ rt_status render_cost_map(rt_scene *s, std::vector<uint32_t> &map)
     if (e == hipSuccess) e = hipMemsetAsync(d_cost, 0, (size_t)R * R * 4, stream);
     if (e == hipSuccess) {
         rt::SampleBuf<T> sb{ nullptr, nullptr, R * R };
-        hipLaunchKernelGGL((rt::k_render_skip<T, true, 1, false>), dim3((R / rt::kBlockW) * (R / rt::kBlockH)), dim3(rt::kBlockThreads), 0, stream,
-                           skip_view_of<T>(s), R, R, 1u, d_tile, 1u, d_out, d_cnt, sb, 0u, (const uint32_t *)nullptr, d_cost);
+        hipLaunchKernelGGL((rt::k_render_skip<T, true, 1, rt::kSkipLoop>), dim3((R / rt::kBlockW) * (R / rt::kBlockH)), dim3(rt::kBlockThreads), 0, stream,
+                           skip_view_of<T>(s), R, R, 1u, d_tile, 1u, d_out, d_cnt, sb, 0u, (const rt::BlockDesc *)nullptr, d_cost);
         e = hipGetLastError();
     }
     map.assign((size_t)R * R, 0u);
@@ -376,27 +376,34 @@ const std::vector<uint32_t> *cost_map_of(rt_scene *s)
 // ties in grid order.  The frame is as long as its last wave's chain of dependent node steps and the chains differ by
 // more than 10x across the image, so the long ones have to start first (measured at 1080p: 141 -> 115 us for the
 // same one-block tiles in raster vs. descending order).
-void block_order(const std::vector<uint32_t> &map, const std::vector<rt::TileDev> &tab, unsigned w, unsigned h, std::vector<uint32_t> &order)
+void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev> &tab, unsigned w, unsigned h, std::vector<rt::BlockDesc> &descs)
 {
     constexpr int R = (int)kCostRes;
     std::vector<uint32_t> cost;
+    std::vector<rt::BlockDesc> raster;
     for (const rt::TileDev &t : tab) {
         const unsigned bys = ((unsigned)(t.t - t.b) + rt::kBlockH - 1) / rt::kBlockH;
+        const uint32_t pitch = (uint32_t)t.r - t.l;
         for (unsigned by = 0; by < bys; ++by)
             for (unsigned bx = 0; bx < t.blks_x; ++bx) {
                 const unsigned x0 = t.l + bx * rt::kBlockW, y0 = t.b + by * rt::kBlockH;
-                const unsigned x1 = std::min<unsigned>(x0 + rt::kBlockW, t.r) - 1, y1 = std::min<unsigned>(y0 + rt::kBlockH, t.t) - 1;
-                auto col = [&](unsigned x) { return std::clamp((int)((uint64_t)x * R / w), 0, R - 1); };
-                auto row = [&](unsigned y) { return std::clamp((int)std::floor(((double)y - h / 2.0) * R / w + R / 2.0), 0, R - 1); };
+                raster.push_back(rt::BlockDesc{ (uint16_t)x0, (uint16_t)y0, t.r, t.t, pitch, t.out_px - t.b * pitch - t.l });
                 uint32_t m = 0;
-                for (int Y = row(y0); Y <= row(y1); ++Y)
-                    for (int X = col(x0); X <= col(x1); ++X) m = std::max(m, map[(size_t)Y * R + X]);
+                if (map) {
+                    const unsigned x1 = std::min<unsigned>(x0 + rt::kBlockW, t.r) - 1, y1 = std::min<unsigned>(y0 + rt::kBlockH, t.t) - 1;
+                    auto col = [&](unsigned x) { return std::clamp((int)((uint64_t)x * R / w), 0, R - 1); };
+                    auto row = [&](unsigned y) { return std::clamp((int)std::floor(((double)y - h / 2.0) * R / w + R / 2.0), 0, R - 1); };
+                    for (int Y = row(y0); Y <= row(y1); ++Y)
+                        for (int X = col(x0); X <= col(x1); ++X) m = std::max(m, (*map)[(size_t)Y * R + X]);
+                }
                 cost.push_back(m);
             }
     }
-    order.resize(cost.size());
+    std::vector<uint32_t> order(cost.size());
     for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&cost](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    descs.resize(order.size());
+    for (size_t i = 0; i < order.size(); ++i) descs[i] = raster[order[i]];
 }
 
 bool block_order_enabled()
@@ -406,18 +413,18 @@ bool block_order_enabled()
 }
 
 rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, const rt::TileDev **out, int slot,
-                       const rt_options *o, const uint32_t **order_out)
+                       const rt_options *o, rt::BlockList *order_out)
 {
     const size_t bytes = tab.size() * sizeof(rt::TileDev);
     const unsigned w = o ? o->width : 0u, h = o ? o->height : 0u;
-    if (order_out) *order_out = nullptr;
+    if (order_out) *order_out = rt::BlockList{};
     const std::vector<uint32_t> *map = (o && order_out) ? cost_map_of(s) : nullptr;     // before taking the lock: it renders
     {
         std::lock_guard<std::mutex> lk(s->mu);
         for (auto &t : s->tables)
             if ((!o || (t.w == w && t.h == h)) && t.host.size() == tab.size() && memcmp(t.host.data(), tab.data(), bytes) == 0) {
                 *out = t.dev;
-                if (order_out && block_order_enabled()) *order_out = t.dev_order;
+                if (order_out && block_order_enabled()) *order_out = rt::BlockList{ t.dev_order, t.n_order };
                 return RT_OK;
             }
         if (s->tables.size() < kMaxCachedTables) {
@@ -425,16 +432,17 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
             HIP_TRY(hipMalloc(&t.dev, bytes));
             hipError_t e = hipMemcpy(t.dev, tab.data(), bytes, hipMemcpyHostToDevice);    // blocking, once per table
             if (e != hipSuccess) { (void)hipFree(t.dev); return hip_fail(e, "hipMemcpy(tile table)", __LINE__); }
-            if (map) {
-                std::vector<uint32_t> order;
-                block_order(*map, tab, w, h, order);
-                e = hipMalloc(&t.dev_order, order.size() * sizeof(uint32_t));
-                if (e == hipSuccess) e = hipMemcpy(t.dev_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (o && order_out) {
+                std::vector<rt::BlockDesc> order;
+                block_order(map, tab, w, h, order);
+                e = hipMalloc(&t.dev_order, order.size() * sizeof(rt::BlockDesc));
+                if (e == hipSuccess) e = hipMemcpy(t.dev_order, order.data(), order.size() * sizeof(rt::BlockDesc), hipMemcpyHostToDevice);
                 if (e != hipSuccess) { (void)hipFree(t.dev); if (t.dev_order) (void)hipFree(t.dev_order); return hip_fail(e, "block order", __LINE__); }
+                t.n_order = (uint32_t)order.size();
             }
             t.host = tab; t.w = w; t.h = h;
             *out = t.dev;
-            if (order_out && block_order_enabled()) *order_out = t.dev_order;
+            if (order_out && block_order_enabled()) *order_out = rt::BlockList{ t.dev_order, t.n_order };
             s->tables.push_back(std::move(t));
             return RT_OK;
         }
@@ -446,8 +454,8 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
 }
 
 // Tuning variant of k_render_skip (rt_skip.hpp VAR bits); RT_SKIP_VARIANT overrides the default for A/B runs.
-constexpr int kSkipVariantDefault = 5;   // hand-written f32 traversal loops (4) + lean sqrt in the C++ loops (1); the prefetch (2)
-                                         // only pays for a lone wave and costs throughput under load
+constexpr int kSkipVariantDefault = 13;  // hand-written f32 traversal loops (4) with EXEC-narrowed updates (8) + lean sqrt in the C++
+                                         // loops (1); the prefetch (2) only pays for a lone wave and costs throughput under load
 
 // A pass of at most this many waves leaves the 8,192 wave slots of the chip under-filled for most of its duration: its
 // time is its longest wave's chain, and the prefetching loop flavour (VAR 2) shortens exactly that (measured: 1080p
@@ -458,7 +466,7 @@ int skip_variant(uint64_t waves)
 {
     // read per call so one process can interleave variants (A/B timing in tools/ab.py)
     const char *e = getenv("RT_SKIP_VARIANT");
-    if (e) return atoi(e) & 7;
+    if (e) return atoi(e) & 15;
     return kSkipVariantDefault | (waves <= kLatencyRegimeWaves ? 2 : 0);
 }
 
@@ -523,14 +531,39 @@ rt_status launch_flat_wavefront(const rt_scene *s, Context *c, hipStream_t strea
 template <typename T, bool COUNT, int VAR>
 rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t stream, unsigned w, unsigned h, unsigned spp,
                           const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt, unsigned frame_w,
-                          const uint32_t *order)
+                          rt::BlockList order)
 {
     const dim3 b(rt::kBlockThreads);
-    uint32_t *const no_cost = nullptr;
+    uint32_t *no_cost = nullptr;
+    // RT_WAVE_TRACE=<file> (diagnostic, tools/wave_timeline.py): the launch records every wave's start / end / placement and
+    // the records are written to <file> -- synchronous, one file per launch (overwritten).
+    const char *trace_path = COUNT ? nullptr : getenv("RT_WAVE_TRACE");
+    const dim3 rgrid(order.d ? order.n : grid.x);      // render workgroups: one per descriptor
+    const size_t trace_words = (size_t)rgrid.x * 4 * 4 * (use_split(spp) ? (size_t)spp * spp : 1);
+    struct Trace {
+        uint32_t *d = nullptr; const char *path; size_t words; hipStream_t stream;
+        ~Trace()
+        {
+            if (!d) return;
+            std::vector<uint32_t> h(words);
+            if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(h.data(), d, words * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+                if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), 4, words, f); fclose(f); }
+            }
+            (void)hipFree(d);
+        }
+    } tr{ nullptr, trace_path, trace_words, stream };
+    if (trace_path && hipMalloc(&tr.d, trace_words * 4) == hipSuccess) {
+        (void)hipMemsetAsync(tr.d, 0, trace_words * 4, stream);
+        no_cost = tr.d;
+    }
     rt::SampleBuf<T> sb{ nullptr, nullptr, (unsigned)total_px };
     if (!use_split(spp)) {
-        hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, false>), grid, b, 0, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb, frame_w,
-                           order, no_cost);
+        if (spp == 1)
+            hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipOne>), rgrid, b, 0, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
+                               frame_w, order.d, no_cost);
+        else
+            hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipLoop>), rgrid, b, 0, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
+                               frame_w, order.d, no_cost);
         return RT_OK;
     }
     const size_t ns = (size_t)spp * spp;
@@ -540,8 +573,8 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     }
     sb.gdot = static_cast<T *>(c->d_sample_gdot);
     sb.state = c->d_sample_state;
-    hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, true>), dim3(grid.x, (unsigned)ns), b, 0, stream, skip_view_of<T>(s), w, h, spp, d_tab,
-                       nt, d_out, cnt, sb, frame_w, order, no_cost);
+    hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipSplit>), dim3(rgrid.x, (unsigned)ns), b, 0, stream, skip_view_of<T>(s), w, h, spp, d_tab,
+                       nt, d_out, cnt, sb, frame_w, order.d, no_cost);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL((rt::k_resolve_samples<T>), grid, b, 0, stream, sb, spp, d_tab, nt, d_out, frame_w);
     return RT_OK;
@@ -550,21 +583,23 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
 template <typename T, bool COUNT>
 rt_status launch_skip_var(const rt_scene *s, Context *c, dim3 grid, hipStream_t stream, unsigned w, unsigned h, unsigned spp,
                           const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt, unsigned frame_w,
-                          const uint32_t *order)
+                          rt::BlockList order)
 {
-    switch (skip_variant((uint64_t)grid.x * 4 * (use_split(spp) ? (uint64_t)spp * spp : 1))) {
+    switch (skip_variant((uint64_t)(order.d ? order.n : grid.x) * 4 * (use_split(spp) ? (uint64_t)spp * spp : 1))) {
     case 1: return launch_skip_one<T, COUNT, 1>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     case 2: return launch_skip_one<T, COUNT, 2>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     case 3: return launch_skip_one<T, COUNT, 3>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     case 5: return launch_skip_one<T, COUNT, 5>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     case 7: return launch_skip_one<T, COUNT, 7>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+    case 13: return launch_skip_one<T, COUNT, 13>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+    case 15: return launch_skip_one<T, COUNT, 15>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     default: return launch_skip_one<T, COUNT, 0>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     }
 }
 
 rt_status launch_skip(const rt_scene *s, Context *c, dim3 grid, hipStream_t stream, unsigned w, unsigned h, unsigned spp,
                       const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt, unsigned frame_w,
-                      const uint32_t *order)
+                      rt::BlockList order)
 {
     if (s->precision == RT_F32)
         return cnt ? launch_skip_var<float, true>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order)
@@ -590,7 +625,7 @@ rt_status check_traversal(const rt_scene *s, rt_traversal trav)
 // sample buffers): then nothing but the kernel itself is enqueued.
 rt_status launch_render(rt_scene *s, Context *c, const rt_options *o, rt_traversal trav, const rt::TileDev *d_tab, unsigned nt,
                         uint32_t total_blocks, uint64_t total_px, uint8_t *d_out, unsigned frame_w, hipStream_t stream, rt::Counters *cnt,
-                        const rt::TileDev *d_tab16 = nullptr, uint32_t blocks16 = 0, const uint32_t *order = nullptr)
+                        const rt::TileDev *d_tab16 = nullptr, uint32_t blocks16 = 0, rt::BlockList order = rt::BlockList{})
 {
     const dim3 grid(total_blocks);
     const unsigned w = o->width, h = o->height, spp = o->samples_per_pixel;
@@ -617,7 +652,7 @@ rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversa
                        const std::vector<rt::TileDev> *tab16 = nullptr, uint32_t blocks16 = 0)
 {
     const rt::TileDev *d_tab = nullptr, *d_tab16 = nullptr;
-    const uint32_t *order = nullptr;
+    rt::BlockList order;
     {
         rt_status ust = trav == RT_TRAVERSAL_SKIP ? device_table(s, c, tab, stream, &d_tab, 0, o, &order) : device_table(s, c, tab, stream, &d_tab);
         if (ust != RT_OK) return ust;
@@ -854,7 +889,7 @@ static rt_status render_device(rt_scene *s, const rt_options *o, rt_traversal tr
     if (!stats && !split && !wavefront) {
         // Fast path: a cached tile table and no per-call device state -> the call enqueues exactly one kernel.
         const rt::TileDev *d_tab = nullptr;
-        const uint32_t *order = nullptr;
+        rt::BlockList order;
         if ((st = device_table(s, nullptr, tab, stream, &d_tab, 0, o, &order)) != RT_OK) return st;
         if (d_tab)
             return launch_render(s, nullptr, o, trav, d_tab, (unsigned)tab.size(), total_blocks, total_px, out, frame_w, stream, nullptr, nullptr, 0, order);

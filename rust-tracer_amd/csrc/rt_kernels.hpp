@@ -18,6 +18,18 @@ struct TileDev {
     uint32_t blks_x;       // blocks per tile row
 };
 
+// One 16x16 block of a pass, ready to use: where it is, where its tile ends, and where its pixels go in a tile-major
+// output (pixel (x, y) -> base + y * pitch + x, modulo 2^32; a row-major frame uses y * frame_w + x instead).  A pass hands
+// the render kernel one descriptor per workgroup IN DISPATCH ORDER (most expensive block first), so a workgroup finds its
+// work with one 16-byte scalar load instead of a binary search over the tile table (9 dependent loads for 510 buckets,
+// 13 for 8,160 one-block tiles) followed by an index lookup.
+struct BlockDesc {
+    uint16_t x0, y0, r, t;     // block origin; the tile's right / top edge (exclusive) for clipping
+    uint32_t pitch, base;
+};
+static_assert(sizeof(BlockDesc) == 16, "one s_load_dwordx4");
+struct BlockList { const BlockDesc *d = nullptr; uint32_t n = 0; };
+
 // Outcome of one sample, stored by the sample-parallel paths and consumed by k_resolve_samples in the reference's
 // accumulation order: the four exits of Renderer::raytrace (render.rs:190-213) and n.light where it is needed.
 enum SampleState : uint8_t { kMiss = 0, kAmbient = 1, kLit = 2, kShadowed = 3 };

@@ -91,6 +91,7 @@ template <> __device__ __forceinline__ Node<float> as_node<float>(const i32x8 &r
 // VAR bits (tuning variants, all bit-identical in output and counters):
 //   1 = sqrt_rn_lean (same value as the IEEE sqrt for every input, about half the instructions)
 //   4 = (f32, launches that do not count tests) the primary traversal loop hand-written in assembly, rt_skip_asm.hpp
+//   8 = (with 4) EXEC-narrowed register updates in the hand-written loops (rt_skip_asm.hpp, *_V2 pieces)
 //   2 = the records of both possible successors (i+1 and skip) are fetched with hand-placed scalar loads while node i
 //       is processed, so the dependent scalar-load latency leaves the wave's critical path
 //
@@ -99,32 +100,53 @@ template <> __device__ __forceinline__ Node<float> as_node<float>(const i32x8 &r
 // SPLIT = true : one thread traces ONE sample (blockIdx.y = ssx * spp + ssy) and stores the sample's outcome
 //   {state, n.light}; k_resolve_samples then accumulates each pixel's samples in the reference's order.  A frame's
 //   run time is bounded by its slowest wave, and a wave that walks 16 samples one after the other is 16x slower.
-template <typename T, bool COUNT, int VAR, bool SPLIT>
-__global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, unsigned width, unsigned height, unsigned spp,
+//
+// MODE: kSkipLoop = SPLIT false, any spp; kSkipSplit = SPLIT true; kSkipOne = SPLIT false with spp == 1 known at compile
+//   time (x + 0/1 == x, v * (1/(1*1)) == v and alpha * 1 == alpha bit for bit, so three IEEE divisions and the multiplies
+//   by 1.0 leave the per-wave prologue / epilogue -- a fifth of all VALU work of a 1080p frame is outside the loops).
+enum { kSkipLoop = 0, kSkipSplit = 1, kSkipOne = 2 };
+template <typename T, bool COUNT, int VAR, int MODE>
+__global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, unsigned width, unsigned height, unsigned spp_arg,
                                                               const TileDev *__restrict__ tiles, unsigned n_tiles,
                                                               uint8_t *__restrict__ out, Counters *__restrict__ counters,
                                                               SampleBuf<T> sb, unsigned frame_w,
-                                                              const uint32_t *__restrict__ order, uint32_t *__restrict__ lane_cost)
+                                                              const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost)
 {
-    // 16x16 pixel block index.  `order` (optional) is a permutation of the pass's blocks, most expensive first: a pass
-    // is as long as its last wave, so the long chains must not be the ones dispatched last (rt_capi.hip, block_order).
-    const unsigned gblock = order ? order[blockIdx.x] : blockIdx.x;
-    unsigned lo = 0, hi = n_tiles - 1;
-    while (lo < hi) {
-        unsigned mid = (lo + hi + 1) >> 1;
-        if (tiles[mid].blk_first <= gblock) lo = mid; else hi = mid - 1;
+    constexpr bool SPLIT = MODE == kSkipSplit, ONE = MODE == kSkipOne;
+    const unsigned spp = ONE ? 1u : spp_arg;
+    // `order` (optional): one descriptor per workgroup in dispatch order, most expensive block first -- a pass is as long
+    // as its last wave, so the long chains must not be the ones dispatched last (rt_capi.hip, block_order).  Without it
+    // the workgroup finds its block in the tile table.
+    unsigned bx0, by0, tile_r, tile_t, pitch, base;
+    if (order) {
+        const BlockDesc bd = order[blockIdx.x];
+        bx0 = bd.x0; by0 = bd.y0; tile_r = bd.r; tile_t = bd.t; pitch = bd.pitch; base = bd.base;
+    } else {
+        unsigned lo = 0, hi = n_tiles - 1;
+        while (lo < hi) {
+            unsigned mid = (lo + hi + 1) >> 1;
+            if (tiles[mid].blk_first <= blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        const TileDev tile = tiles[lo];
+        const unsigned lb = blockIdx.x - tile.blk_first;
+        bx0 = tile.l + (lb % tile.blks_x) * kBlockW; by0 = tile.b + (lb / tile.blks_x) * kBlockH;
+        tile_r = tile.r; tile_t = tile.t;
+        pitch = (unsigned)tile.r - tile.l;
+        base = tile.out_px - tile.b * pitch - tile.l;
     }
-    const TileDev tile = tiles[lo];
-    const unsigned lb = gblock - tile.blk_first;
-    const unsigned bx = lb % tile.blks_x, by = lb / tile.blks_x;
+    const unsigned gblock = blockIdx.x;
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned x = tile.l + bx * kBlockW + (wave & 1) * 8 + (lane & 7);
-    const unsigned y = tile.b + by * kBlockH + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = x < tile.r && y < tile.t;
+    const unsigned x = bx0 + (wave & 1) * 8 + (lane & 7);
+    const unsigned y = by0 + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = x < tile_r && y < tile_t;
     if (__ballot(inside) == 0) return;          // waves are independent here: no LDS, no barrier
 
     unsigned long long t_start = 0, r_start = 0;
     if (COUNT) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
+    // diagnostic (RT_WAVE_TRACE, tools/wave_timeline.py): launches that do not count may be handed a trace buffer instead of
+    // the cost map -- every wave records when it ran (100 MHz clock) and where
+    const bool trace = !COUNT && lane_cost != nullptr;
+    if (trace) r_start = __builtin_amdgcn_s_memrealtime();
 
     const T ssf = T(spp);
     const T total_recip = T(1.0) / (ssf * ssf);
@@ -145,8 +167,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     const unsigned ss_first = SPLIT ? blockIdx.y / spp : 0u, ss_last = SPLIT ? ss_first + 1 : spp;
     for (unsigned ssx = ss_first; ssx < ss_last; ++ssx) {
         for (unsigned ssy = SPLIT ? blockIdx.y % spp : 0u; ssy < (SPLIT ? blockIdx.y % spp + 1 : spp); ++ssy) {
-            const T xres = T(x) + T(ssx) / ssf;
-            const T yres = T(y) + T(ssy) / ssf;
+            const T xres = ONE ? T(x) : T(x) + T(ssx) / ssf;
+            const T yres = ONE ? T(y) : T(y) + T(ssy) / ssf;
             V3<T> dir = { xres - half_w, (fh - yres) - half_h, fw };
             dir = normalized(dir);
 
@@ -156,7 +178,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             unsigned resume = inside ? 0u : kNever;
             unsigned i = 0;
             if constexpr ((VAR & 4) && !COUNT && sizeof(T) == 4) {
-                skip_primary_asm<(VAR & 2) != 0>(sc.prim, n, dir.x, dir.y, dir.z, resume, best, best_item);
+                skip_primary_asm<(VAR & 2) != 0, (VAR & 8) != 0>(sc.prim, n, dir.x, dir.y, dir.z, resume, best, best_item);
             } else {
             Node<T> nd = sc.prim[0];                                    // wave-uniform record -> SGPRs
             for (;;) {
@@ -242,7 +264,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                 if (__ballot(need_shadow) != 0) {
                     while (i < n) {
                         unsigned fin;
-                        i = skip_shadow_asm<(VAR & 2) != 0>(sc.shad, n, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
+                        i = skip_shadow_asm<(VAR & 2) != 0, (VAR & 8) != 0>(sc.shad, n, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
                         if (i >= n) break;
                         if (fin) { occluded = true; resume = kNever; }
                         // some lane retired at item i: go straight to the next node any lane still wants
@@ -313,7 +335,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                 }
             }
             if (SPLIT && inside) {
-                const size_t p = (size_t)blockIdx.y * sb.n_px + (size_t)tile.out_px + (size_t)(y - tile.b) * (tile.r - tile.l) + (x - tile.l);
+                const size_t p = (size_t)blockIdx.y * sb.n_px + (size_t)(base + y * pitch + x);
                 sb.gdot[p] = gdot;
                 sb.state[p] = state;
             }
@@ -321,14 +343,23 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     }
 
     if (!SPLIT && inside) {
-        g = mulf(g, total_recip);
-        alpha *= total_recip;
-        const size_t px = out_index(tile, x, y, frame_w);
+        if (!ONE) {
+            g = mulf(g, total_recip);
+            alpha *= total_recip;
+        }
+        const size_t px = frame_w ? (size_t)y * frame_w + x : (size_t)(base + y * pitch + x);
         const unsigned rgba = scale_u8(g.x) | (scale_u8(g.y) << 8) | (scale_u8(g.z) << 16) | (scale_u8(alpha) << 24);
         reinterpret_cast<unsigned *>(out)[px] = rgba;
         if (COUNT) { if (lane_cost) lane_cost[px] = c_items + c_bounds; }   // the scene's cost map is rendered through this
     }
 
+    if (trace && lane == 0) {
+        uint32_t *rec = lane_cost + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 4;     // in dispatch order
+        rec[0] = (uint32_t)r_start;
+        rec[1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        rec[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16);  // HW_ID | XCC_ID << 16
+        rec[3] = gblock;
+    }
     if (COUNT) {
         counters += (gblock + blockIdx.y) % kCounterStripes;
         const unsigned long long prim = wave_sum(inside ? (SPLIT ? 1u : spp * spp) : 0u);

@@ -51,11 +51,44 @@ namespace rt {
     "s_cselect_b64 s[46:47], s[70:71], s[78:79]\n\t"
 #define RT_SKIP_CLOBBERS                                                                                                       \
     "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", \
-        "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74",   \
+        "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74",   \
         "s75", "s76", "s77", "s78", "s79"
 
-#define RT_PRIMARY_ASM(TOP, NEXT) \
+
+// Node-update flavours.  V1 selects with v_cndmask (a VGPR copy of the SGPR operand + one select per register); V2 narrows
+// EXEC to the lanes that change and moves (one VALU op fewer per BOUND and per ITEM step), and leaves `resume` alone when the
+// wave jumps over a subtree nobody enters: the lanes that culled it are awake again at `skip` either way (resume <= i < skip).
+#define RT_BOUND_UPD_V1                                                   \
+        "s_andn2_b64 s[56:57], s[52:53], vcc\n\t"                         \
+        "v_mov_b32_e32 %[t5], s45\n\t"                                    \
+        "s_cmp_eq_u64 vcc, 0\n\t"                                         \
+        "s_cselect_b32 s49, s45, s49\n\t"                                 \
+        "v_cndmask_b32_e64 %[resume], %[resume], %[t5], s[56:57]\n\t"
+#define RT_BOUND_UPD_V2                                                   \
+        "s_cmp_eq_u64 vcc, 0\n\t"                                         \
+        "s_cselect_b32 s49, s45, s49\n\t"                                 \
+        "s_andn2_b64 exec, s[52:53], vcc\n\t"  /* lanes that may not enter */ \
+        "v_mov_b32_e32 %[resume], s45\n\t"                                \
+        "s_mov_b64 exec, s[62:63]\n\t"
+#define RT_ITEM_UPD_V1                                                    \
+        "v_mov_b32_e32 %[t5], s46\n\t"                                    \
+        "v_cndmask_b32_e32 %[best], %[best], %[t4], vcc\n\t"              \
+        "v_cndmask_b32_e32 %[bitem], %[bitem], %[t5], vcc\n"
+#define RT_ITEM_UPD_V2                                                    \
+        "s_mov_b64 exec, vcc\n\t"                                         \
+        "v_mov_b32_e32 %[best], %[t4]\n\t"                                \
+        "v_mov_b32_e32 %[bitem], s46\n\t"                                 \
+        "s_mov_b64 exec, s[62:63]\n"
+#define RT_MISS_BOUND_V1                                                  \
+        "v_mov_b32_e32 %[t5], s45\n\t"                                    \
+        "s_mov_b32 s49, s45\n\t"                                          \
+        "v_cndmask_b32_e64 %[resume], %[resume], %[t5], s[52:53]\n\t"
+#define RT_MISS_BOUND_V2                                                  \
+        "s_mov_b32 s49, s45\n\t"
+
+#define RT_PRIMARY_ASM(TOP, NEXT, BOUND_UPD, ITEM_UPD, MISS_BOUND) \
         "s_mov_b32 s48, 0\n\t" \
+        "s_mov_b64 s[62:63], exec\n\t" \
         "s_load_dwordx8 s[40:47], %[base], 0x0\n\t" \
         "s_waitcnt lgkmcnt(0)\n" \
         "1:\n\t" \
@@ -102,20 +135,14 @@ namespace rt {
         "s_cmp_eq_u32 s45, 0\n\t" \
         "s_cbranch_scc1 5f\n\t" \
   /* ---- BOUND (group.rs:73): lanes that may not enter sleep until `skip`; jump if nobody enters ---- */ \
-        "s_andn2_b64 s[56:57], s[52:53], vcc\n\t" \
-        "v_mov_b32_e32 %[t5], s45\n\t" \
-        "s_cmp_eq_u64 vcc, 0\n\t" \
-        "s_cselect_b32 s49, s45, s49\n\t" \
-        "v_cndmask_b32_e64 %[resume], %[resume], %[t5], s[56:57]\n\t" \
+        BOUND_UPD \
         "s_cmp_ge_u32 s49, %[n]\n\t"  /* own copy of the loop tail: one taken branch per BOUND step */ \
         "s_cbranch_scc1 7f\n\t" \
         NEXT \
         "s_branch 1b\n" \
         "5:\n\t" \
   /* ---- ITEM (primitive.rs:78-83) ---- */ \
-        "v_mov_b32_e32 %[t5], s46\n\t" \
-        "v_cndmask_b32_e32 %[best], %[best], %[t4], vcc\n\t" \
-        "v_cndmask_b32_e32 %[bitem], %[bitem], %[t5], vcc\n" \
+        ITEM_UPD \
         "6:\n\t" \
         "s_cmp_ge_u32 s49, %[n]\n\t" \
         "s_cbranch_scc1 7f\n\t" \
@@ -125,9 +152,7 @@ namespace rt {
         "s_add_u32 s49, s48, 1\n\t" \
         "s_cmp_eq_u32 s45, 0\n\t" \
         "s_cbranch_scc1 6b\n\t" \
-        "v_mov_b32_e32 %[t5], s45\n\t" \
-        "s_mov_b32 s49, s45\n\t" \
-        "v_cndmask_b32_e64 %[resume], %[resume], %[t5], s[52:53]\n\t" \
+        MISS_BOUND \
         "s_branch 6b\n" \
         "9:\n\t"  /* root with the 2^32 / 2^-16 scaling for tiny lanes */ \
         "v_mul_f32_e32 %[t0], 0x4f800000, %[disc]\n\t" \
@@ -151,7 +176,7 @@ namespace rt {
 
 // Primary-ray traversal: s.group.intersect(&mut h, r) for all 64 rays of the wave.  nodes: Node<float>[n + 1].
 // resume: 0 for lanes with a ray, 0xFFFFFFFF for lanes without.  Returns hit.distance / item index per lane.
-template <bool PF>
+template <bool PF, bool V2>
 __device__ __forceinline__ void skip_primary_asm(const void *nodes, unsigned n, float dx, float dy, float dz, unsigned resume,
                                                  float &best_out, unsigned &item_out)
 {
@@ -164,15 +189,18 @@ __device__ __forceinline__ void skip_primary_asm(const void *nodes, unsigned n, 
       [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [b] "=&v"(b), [disc] "=&v"(disc), [root] "=&v"(root)                   \
     : [base] "s"(nodes), [n] "s"(n), [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz), [tiny] "s"(tiny)                               \
     : RT_SKIP_CLOBBERS
-    if constexpr (PF) asm volatile(RT_PRIMARY_ASM(RT_TOP_PF, RT_NEXT_PF) RT_PRIMARY_OPERANDS);
-    else asm volatile(RT_PRIMARY_ASM(RT_TOP_PLAIN, RT_NEXT_PLAIN) RT_PRIMARY_OPERANDS);
+    if constexpr (PF && V2) asm volatile(RT_PRIMARY_ASM(RT_TOP_PF, RT_NEXT_PF, RT_BOUND_UPD_V2, RT_ITEM_UPD_V2, RT_MISS_BOUND_V2) RT_PRIMARY_OPERANDS);
+    else if constexpr (PF) asm volatile(RT_PRIMARY_ASM(RT_TOP_PF, RT_NEXT_PF, RT_BOUND_UPD_V1, RT_ITEM_UPD_V1, RT_MISS_BOUND_V1) RT_PRIMARY_OPERANDS);
+    else if constexpr (V2) asm volatile(RT_PRIMARY_ASM(RT_TOP_PLAIN, RT_NEXT_PLAIN, RT_BOUND_UPD_V2, RT_ITEM_UPD_V2, RT_MISS_BOUND_V2) RT_PRIMARY_OPERANDS);
+    else asm volatile(RT_PRIMARY_ASM(RT_TOP_PLAIN, RT_NEXT_PLAIN, RT_BOUND_UPD_V1, RT_ITEM_UPD_V1, RT_MISS_BOUND_V1) RT_PRIMARY_OPERANDS);
 #undef RT_PRIMARY_OPERANDS
     best_out = best;
     item_out = bitem;
 }
 
-#define RT_SHADOW_ASM(TOP, NEXT) \
+#define RT_SHADOW_ASM(TOP, NEXT, BOUND_UPD, MISS_BOUND) \
         "s_mov_b32 s48, %[start]\n\t" \
+        "s_mov_b64 s[62:63], exec\n\t" \
         "s_lshl_b32 s50, s48, 5\n\t" \
         "s_load_dwordx8 s[40:47], %[base], s50\n\t" \
         "s_waitcnt lgkmcnt(0)\n" \
@@ -224,11 +252,7 @@ __device__ __forceinline__ void skip_primary_asm(const void *nodes, unsigned n, 
         "s_cmp_eq_u32 s45, 0\n\t" \
         "s_cbranch_scc1 5f\n\t" \
   /* ---- BOUND: a lane that misses the bound sleeps until `skip`; jump if nobody enters ---- */ \
-        "s_andn2_b64 s[56:57], s[52:53], vcc\n\t" \
-        "v_mov_b32_e32 %[t5], s45\n\t" \
-        "s_cmp_eq_u64 vcc, 0\n\t" \
-        "s_cselect_b32 s49, s45, s49\n\t" \
-        "v_cndmask_b32_e64 %[resume], %[resume], %[t5], s[56:57]\n\t" \
+        BOUND_UPD \
         "s_cmp_ge_u32 s49, %[n]\n\t"  /* own copy of the loop tail: one taken branch per BOUND step */ \
         "s_cbranch_scc1 10f\n\t" \
         NEXT \
@@ -249,9 +273,7 @@ __device__ __forceinline__ void skip_primary_asm(const void *nodes, unsigned n, 
         "s_add_u32 s49, s48, 1\n\t" \
         "s_cmp_eq_u32 s45, 0\n\t" \
         "s_cbranch_scc1 6b\n\t" \
-        "v_mov_b32_e32 %[t5], s45\n\t" \
-        "s_mov_b32 s49, s45\n\t" \
-        "v_cndmask_b32_e64 %[resume], %[resume], %[t5], s[52:53]\n\t" \
+        MISS_BOUND \
         "s_branch 6b\n" \
         "9:\n\t"  /* root with the 2^32 / 2^-16 scaling for tiny lanes */ \
         "v_mul_f32_e32 %[t0], 0x4f800000, %[disc]\n\t" \
@@ -280,7 +302,7 @@ __device__ __forceinline__ void skip_primary_asm(const void *nodes, unsigned n, 
 // wave).  hit.distance is INF throughout, so a node is "hit" iff disc >= 0 and t2 = b + root >= 0 -- and t2 >= 0 is
 // certain when b >= 0, so the root is only formed when some candidate lane has b < 0.
 // Returns the index it stopped at (>= n: stream finished); fin = 1 in the lanes that hit the ITEM at that index.
-template <bool PF>
+template <bool PF, bool V2>
 __device__ __forceinline__ unsigned skip_shadow_asm(const void *nodes, unsigned n, unsigned start, float ox, float oy, float oz, float lx,
                                                    float ly, float lz, unsigned &resume_io, unsigned &fin_out)
 {
@@ -294,8 +316,10 @@ __device__ __forceinline__ unsigned skip_shadow_asm(const void *nodes, unsigned 
     : [base] "s"(nodes), [n] "s"(n), [start] "s"(start), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [lx] "s"(lx), [ly] "s"(ly), \
       [lz] "s"(lz), [tiny] "s"(tiny)                                                                                           \
     : RT_SKIP_CLOBBERS
-    if constexpr (PF) asm volatile(RT_SHADOW_ASM(RT_TOP_PF, RT_NEXT_PF) RT_SHADOW_OPERANDS);
-    else asm volatile(RT_SHADOW_ASM(RT_TOP_PLAIN, RT_NEXT_PLAIN) RT_SHADOW_OPERANDS);
+    if constexpr (PF && V2) asm volatile(RT_SHADOW_ASM(RT_TOP_PF, RT_NEXT_PF, RT_BOUND_UPD_V2, RT_MISS_BOUND_V2) RT_SHADOW_OPERANDS);
+    else if constexpr (PF) asm volatile(RT_SHADOW_ASM(RT_TOP_PF, RT_NEXT_PF, RT_BOUND_UPD_V1, RT_MISS_BOUND_V1) RT_SHADOW_OPERANDS);
+    else if constexpr (V2) asm volatile(RT_SHADOW_ASM(RT_TOP_PLAIN, RT_NEXT_PLAIN, RT_BOUND_UPD_V2, RT_MISS_BOUND_V2) RT_SHADOW_OPERANDS);
+    else asm volatile(RT_SHADOW_ASM(RT_TOP_PLAIN, RT_NEXT_PLAIN, RT_BOUND_UPD_V1, RT_MISS_BOUND_V1) RT_SHADOW_OPERANDS);
 #undef RT_SHADOW_OPERANDS
     resume_io = resume;
     fin_out = fin;

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-wave timeline of one k_render_skip launch (RT_WAVE_TRACE, rt_capi.hip).  Every wave records its start and
+end on the 100 MHz clock plus HW_ID / XCC_ID; this prints how the launch's time is made up: when the last wave was
+dispatched, how long the longest waves ran, how busy the SIMDs were over time.
+usage: wave_timeline.py [w h spp level]      env: RT_SKIP_VARIANT as usual"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import rust_tracer_amd as rta
+
+libc = ctypes.CDLL(None)
+
+
+def main():
+    w, h, spp, level = (int(a) for a in sys.argv[1:5]) if len(sys.argv) > 4 else (1920, 1080, 1, 8)
+    path = os.path.join(ROOT, "gpurun_out", "wave_trace.bin")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    scene = rta.Scene.default(level)
+    dev = scene.device(0)
+    opts = (w, h, spp)
+    regs_c = dev._regions([tuple(r) for r in rta.buckets(rta.RenderOptions(*opts))])
+    out = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        dev.render_frame_device(opts, regs_c, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    libc.setenv(b"RT_WAVE_TRACE", path.encode(), 1)
+    dev.render_frame_device(opts, regs_c, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    libc.unsetenv(b"RT_WAVE_TRACE")
+    rec = np.fromfile(path, dtype=np.uint32).reshape(-1, 4)
+    ran = rec[:, 1] != 0
+    r = rec[ran]
+    t0 = r[:, 0].min()
+    start = (r[:, 0] - t0).astype(np.int64) * 10          # ns
+    end = (r[:, 1] - t0).astype(np.int64) * 10
+    dur = end - start
+    print("%dx%d spp %d L%d: %d waves ran (of %d slots), span %.1f us" % (w, h, spp, level, len(r), len(rec), end.max() / 1e3))
+    print("wave duration us: median %.2f  p90 %.2f  p99 %.2f  max %.2f ; sum %.0f us = %.1f us x 1024 SIMDs" % (
+        np.median(dur) / 1e3, np.percentile(dur, 90) / 1e3, np.percentile(dur, 99) / 1e3, dur.max() / 1e3, dur.sum() / 1e3, dur.sum() / 1e3 / 1024))
+    print("last wave dispatched at %.1f us; first wave ends at %.1f us" % (start.max() / 1e3, end.min() / 1e3))
+    order = np.argsort(-dur)[:10]
+    print("10 longest waves: (start, end, dur us, dispatch index)")
+    idx = np.nonzero(ran)[0]
+    for k in order:
+        print("   %.1f  %.1f  %.1f   #%d" % (start[k] / 1e3, end[k] / 1e3, dur[k] / 1e3, idx[k]))
+    # waves in flight over time
+    T = int(end.max() // 1000) + 1
+    print("time(us)  waves in flight   started so far")
+    for t in range(0, T, max(1, T // 25)):
+        ns = t * 1000
+        print("  %4d     %6d           %6d" % (t, int(((start <= ns) & (end > ns)).sum()), int((start <= ns).sum())))
+    hw = r[:, 2] & 0xFFFF
+    xcc = r[:, 2] >> 16
+    simd = (hw >> 4) & 3
+    cu = (hw >> 8) & 15
+    se = (hw >> 13) & 7
+    slot = ((xcc.astype(np.int64) * 8 + se) * 16 + cu) * 4 + simd
+    busy = np.bincount(slot, weights=dur)
+    busy = busy[busy > 0]
+    print("SIMDs used %d; per-SIMD sum of wave time us: min %.1f median %.1f max %.1f" % (len(busy), busy.min() / 1e3, np.median(busy) / 1e3, busy.max() / 1e3))
+    last_end = np.zeros(slot.max() + 1)
+    np.maximum.at(last_end, slot, end)
+    le = last_end[last_end > 0]
+    print("per-SIMD time of last wave end us: min %.1f median %.1f max %.1f" % (le.min() / 1e3, np.median(le) / 1e3, le.max() / 1e3))
+
+
+if __name__ == "__main__":
+    main()
