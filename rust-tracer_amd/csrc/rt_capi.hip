@@ -376,6 +376,10 @@ const std::vector<uint32_t> *cost_map_of(rt_scene *s)
 // ties in grid order.  The frame is as long as its last wave's chain of dependent node steps and the chains differ by
 // more than 10x across the image, so the long ones have to start first (measured at 1080p: 141 -> 115 us for the
 // same one-block tiles in raster vs. descending order).
+constexpr size_t kNarrowMax = 64;
+constexpr uint64_t kNarrowPercent = 60;
+constexpr size_t kNarrowPassBlocks = 16384;
+
 void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev> &tab, unsigned w, unsigned h, std::vector<rt::BlockDesc> &descs)
 {
     constexpr int R = (int)kCostRes;
@@ -402,8 +406,35 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
     std::vector<uint32_t> order(cost.size());
     for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&cost](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-    descs.resize(order.size());
-    for (size_t i = 0; i < order.size(); ++i) descs[i] = raster[order[i]];
+    // The most expensive blocks go out as four narrow workgroups each (rt_kernels.hpp, kBlockNarrow): those whose cost
+    // estimate is at least kNarrowPercent of the pass's maximum, at most kNarrowMax and 1/128 of the pass (RT_NARROW_MAX
+    // overrides the cap for A/B runs -- the table is built once per tile list, so one value per process).
+    size_t n_narrow = 0;
+    if (getenv("RT_DEBUG_COST") && !cost.empty()) {
+        fprintf(stderr, "[rtrace_hip] block costs, descending:");
+        for (size_t i = 0; i < order.size(); i = i < 64 ? i + 4 : i * 2) fprintf(stderr, " #%zu=%u", i, cost[order[i]]);
+        fprintf(stderr, "\n");
+    }
+    if (map && !cost.empty()) {
+        const char *e = getenv("RT_NARROW_MAX");
+        // a pass of more blocks than kNarrowPassBlocks is throughput-bound: narrowing only adds work there (3840x2160 + 2 %)
+        const size_t cap = e ? (size_t)atoi(e) : order.size() > kNarrowPassBlocks ? 0 : std::min<size_t>(kNarrowMax, order.size() / 128);
+        const uint64_t top = cost[order[0]];
+        while (n_narrow < order.size() && n_narrow < cap && cost[order[n_narrow]] > 0 && (uint64_t)cost[order[n_narrow]] * 100 >= top * kNarrowPercent)
+            ++n_narrow;
+    }
+    descs.clear();
+    descs.reserve(order.size() + 3 * n_narrow);
+    for (size_t i = 0; i < order.size(); ++i) {
+        const rt::BlockDesc &d = raster[order[i]];
+        if (i >= n_narrow) { descs.push_back(d); continue; }
+        for (unsigned q = 0; q < 4; ++q) {
+            rt::BlockDesc n = d;
+            n.x0 = (uint16_t)(d.x0 + (q & 1) * 8); n.y0 = (uint16_t)(d.y0 + (q >> 1) * 8);
+            n.pitch |= rt::kBlockNarrow;
+            if (n.x0 < d.r && n.y0 < d.t) descs.push_back(n);
+        }
+    }
 }
 
 bool block_order_enabled()
@@ -454,20 +485,15 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
 }
 
 // Tuning variant of k_render_skip (rt_skip.hpp VAR bits); RT_SKIP_VARIANT overrides the default for A/B runs.
-constexpr int kSkipVariantDefault = 13;  // hand-written f32 traversal loops (4) with EXEC-narrowed updates (8) + lean sqrt in the C++
-                                         // loops (1); the prefetch (2) only pays for a lone wave and costs throughput under load
-
-// A pass of at most this many waves leaves the 8,192 wave slots of the chip under-filled for most of its duration: its
-// time is its longest wave's chain, and the prefetching loop flavour (VAR 2) shortens exactly that (measured: 1080p
-// 125 -> 118 us, 960x540 132 -> 115 us; but 3840x2160 260 -> 304 us, so larger passes keep the plain flavour).
-constexpr uint64_t kLatencyRegimeWaves = 6 * 8192;
+constexpr int kSkipVariantDefault = 21;  // the generated rotating f32 traversal loops (16 + 4) + lean sqrt in the C++ loops (1)
 
 int skip_variant(uint64_t waves)
 {
     // read per call so one process can interleave variants (A/B timing in tools/ab.py)
     const char *e = getenv("RT_SKIP_VARIANT");
-    if (e) return atoi(e) & 15;
-    return kSkipVariantDefault | (waves <= kLatencyRegimeWaves ? 2 : 0);
+    if (e) return atoi(e) & 31;
+    (void)waves;
+    return kSkipVariantDefault;
 }
 
 // spp > 1 runs sample-parallel (one thread per sample + a resolve pass) unless spp*spp exceeds grid.y's limit.
@@ -593,6 +619,7 @@ rt_status launch_skip_var(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     case 7: return launch_skip_one<T, COUNT, 7>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     case 13: return launch_skip_one<T, COUNT, 13>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     case 15: return launch_skip_one<T, COUNT, 15>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+    case 21: return launch_skip_one<T, COUNT, 21>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     default: return launch_skip_one<T, COUNT, 0>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     }
 }

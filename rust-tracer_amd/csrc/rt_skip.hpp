@@ -15,6 +15,7 @@
 #pragma once
 #include "rt_kernels.hpp"
 #include "rt_skip_asm.hpp"
+#include "rt_skip_rot.hpp"
 
 namespace rt {
 
@@ -26,6 +27,7 @@ namespace rt {
 template <typename T> struct alignas(sizeof(T) * 8) Node {
     T a0, a1, a2, a3, a4;
     uint32_t skip, item;
+    uint32_t skip_off;      // skip as a byte offset into the stream (rt_skip_rot.hpp)
 };
 static_assert(sizeof(Node<float>) == 32 && sizeof(Node<double>) == 64, "node records are one aligned scalar-load unit");
 
@@ -55,15 +57,26 @@ __global__ void k_build_streams(const RawNode<T> *__restrict__ raw, unsigned n, 
     const T rr = r.r * r.r;                                           // primitive.rs:58
     Node<T> p; p.a0 = v.x; p.a1 = v.y; p.a2 = v.z; p.a3 = dot(v, v); p.a4 = rr; p.skip = r.skip; p.item = r.item;
     Node<T> s; s.a0 = r.cx; s.a1 = r.cy; s.a2 = r.cz; s.a3 = rr; s.a4 = T(0); s.skip = r.skip; s.item = r.item;
+    p.skip_off = s.skip_off = r.skip * (unsigned)sizeof(Node<T>);
     prim[i] = p;
     shad[i] = s;
 }
 
+// Minimum over the wave's 64 lanes, in every lane's return value (wave-uniform).  DPP row shifts + the two row broadcasts:
+// a dozen VALU ops.  (__shfl_xor compiles to ds_bpermute_b32 -- six dependent LDS round trips sat on the shadow walk's
+// critical path every time a ray retired.)
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o, 64));
-    return v;
+    const int id = -1;      // 0xFFFFFFFF: the identity of an unsigned min
+#define RT_DPP_MIN(CTRL, ROWS) v = min(v, (unsigned)__builtin_amdgcn_update_dpp(id, (int)v, CTRL, ROWS, 0xf, false))
+    RT_DPP_MIN(0x111, 0xf);     // row_shr:1
+    RT_DPP_MIN(0x112, 0xf);     // row_shr:2
+    RT_DPP_MIN(0x114, 0xf);     // row_shr:4
+    RT_DPP_MIN(0x118, 0xf);     // row_shr:8   -> lane 15 of each row holds the row's minimum
+    RT_DPP_MIN(0x142, 0xa);     // row_bcast:15 into rows 1 and 3
+    RT_DPP_MIN(0x143, 0xc);     // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
+#undef RT_DPP_MIN
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 constexpr unsigned kNever = 0xFFFFFFFFu;
@@ -92,6 +105,7 @@ template <> __device__ __forceinline__ Node<float> as_node<float>(const i32x8 &r
 //   1 = sqrt_rn_lean (same value as the IEEE sqrt for every input, about half the instructions)
 //   4 = (f32, launches that do not count tests) the primary traversal loop hand-written in assembly, rt_skip_asm.hpp
 //   8 = (with 4) EXEC-narrowed register updates in the hand-written loops (rt_skip_asm.hpp, *_V2 pieces)
+//  16 = (f32, launches that do not count tests) the generated rotating loops, rt_skip_rot.hpp
 //   2 = the records of both possible successors (i+1 and skip) are fetched with hand-placed scalar loads while node i
 //       is processed, so the dependent scalar-load latency leaves the wave's critical path
 //
@@ -118,9 +132,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     // as its last wave, so the long chains must not be the ones dispatched last (rt_capi.hip, block_order).  Without it
     // the workgroup finds its block in the tile table.
     unsigned bx0, by0, tile_r, tile_t, pitch, base;
+    bool narrow = false;
     if (order) {
         const BlockDesc bd = order[blockIdx.x];
-        bx0 = bd.x0; by0 = bd.y0; tile_r = bd.r; tile_t = bd.t; pitch = bd.pitch; base = bd.base;
+        bx0 = bd.x0; by0 = bd.y0; tile_r = bd.r; tile_t = bd.t; pitch = bd.pitch & 0xFFFFu; base = bd.base;
+        narrow = (bd.pitch & kBlockNarrow) != 0;
     } else {
         unsigned lo = 0, hi = n_tiles - 1;
         while (lo < hi) {
@@ -136,9 +152,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     }
     const unsigned gblock = blockIdx.x;
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned x = bx0 + (wave & 1) * 8 + (lane & 7);
-    const unsigned y = by0 + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = x < tile_r && y < tile_t;
+    const unsigned x = bx0 + (narrow ? (wave & 1) * 4 + (lane & 3) : (wave & 1) * 8 + (lane & 7));
+    const unsigned y = by0 + (narrow ? (wave >> 1) * 4 + ((lane >> 2) & 3) : (wave >> 1) * 8 + (lane >> 3));
+    const bool inside = x < tile_r && y < tile_t && !(narrow && lane >= 16);
     if (__ballot(inside) == 0) return;          // waves are independent here: no LDS, no barrier
 
     unsigned long long t_start = 0, r_start = 0;
@@ -177,7 +193,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             unsigned best_item = 0;
             unsigned resume = inside ? 0u : kNever;
             unsigned i = 0;
-            if constexpr ((VAR & 4) && !COUNT && sizeof(T) == 4) {
+            if constexpr ((VAR & 16) && !COUNT && sizeof(T) == 4) {
+                skip_primary_rot(sc.prim, n * 32u, dir.x, dir.y, dir.z, resume, best, best_item);
+            } else if constexpr ((VAR & 4) && !COUNT && sizeof(T) == 4) {
                 skip_primary_asm<(VAR & 2) != 0, (VAR & 8) != 0>(sc.prim, n, dir.x, dir.y, dir.z, resume, best, best_item);
             } else {
             Node<T> nd = sc.prim[0];                                    // wave-uniform record -> SGPRs
@@ -260,7 +278,19 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             bool occluded = false;
             resume = need_shadow ? 0u : kNever;
             i = 0;
-            if constexpr ((VAR & 4) && !COUNT && sizeof(T) == 4) {
+            if constexpr ((VAR & 16) && !COUNT && sizeof(T) == 4) {
+                if (__ballot(need_shadow) != 0) {
+                    const unsigned nb = n * 32u;                    // positions in bytes
+                    while (i < nb) {
+                        unsigned fin;
+                        i = skip_shadow_rot(sc.shad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
+                        if (i >= nb) break;
+                        if (fin) { occluded = true; resume = kNever; }
+                        i = (unsigned)__builtin_amdgcn_readfirstlane(
+                            (int)wave_min_u32(resume == kNever ? kNever : (resume > i ? resume : i + 32u)));
+                    }
+                }
+            } else if constexpr ((VAR & 4) && !COUNT && sizeof(T) == 4) {
                 if (__ballot(need_shadow) != 0) {
                     while (i < n) {
                         unsigned fin;
