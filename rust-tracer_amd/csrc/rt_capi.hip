@@ -84,6 +84,7 @@ struct rt_scene {
     void *d_items = nullptr;       // Item<REAL>[n_items], DFS order
     void *d_prim = nullptr, *d_shad = nullptr;   // Node<REAL>[n_nodes]: skip-pointer streams (RT_TRAVERSAL_SKIP)
     uint32_t n_nodes = 0;
+    bool fused = false;            // every BOUND is followed by an ITEM with the same centre (rt_skip.hpp, Node)
     void *d_fprim = nullptr, *d_fprim_rr = nullptr, *d_fshad = nullptr;   // pre-formed per-item terms (RT_TRAVERSAL_FLAT)
     uint32_t n_padded = 0;
     double light[3] = { 0, 0, 0 }, eye[3] = { 0, 0, 0 };   // exact copies of the REAL values
@@ -281,17 +282,24 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
     rt_status st = build_raw_stream<T>(static_cast<const T *>(items), s->n_items, static_cast<const T *>(bounds), ranges, s->n_bounds, raw);
     if (st != RT_OK) return st;
     s->n_nodes = (uint32_t)raw.size();
+    // fused: every BOUND directly followed by an ITEM with the same centre, bit for bit (then the values v, b, b*b - vv a
+    // ray forms for the two are the same bits).  f32 only: the assembly loops are the only users.
+    bool fused = sizeof(T) == 4 && !raw.empty();
+    for (size_t i = 0; fused && i < raw.size(); ++i)
+        if (raw[i].skip != 0u)
+            fused = i + 1 < raw.size() && raw[i + 1].skip == 0u && memcmp(&raw[i].cx, &raw[i + 1].cx, 3 * sizeof(T)) == 0;
+    s->fused = fused;
     rt::RawNode<T> *d_raw = nullptr;
     HIP_TRY(hipMalloc(&d_raw, sizeof(rt::RawNode<T>) * raw.size()));
     hipError_t e = hipMemcpy(d_raw, raw.data(), sizeof(rt::RawNode<T>) * raw.size(), hipMemcpyHostToDevice);
-    // one zeroed pad node at [n]: the traversal prefetches nodes[i + 1] without a bounds check
-    if (e == hipSuccess) e = hipMalloc(&s->d_prim, sizeof(rt::Node<T>) * (raw.size() + 1));
-    if (e == hipSuccess) e = hipMalloc(&s->d_shad, sizeof(rt::Node<T>) * (raw.size() + 1));
-    if (e == hipSuccess) e = hipMemset(s->d_prim, 0, sizeof(rt::Node<T>) * (raw.size() + 1));
-    if (e == hipSuccess) e = hipMemset(s->d_shad, 0, sizeof(rt::Node<T>) * (raw.size() + 1));
+    // two zeroed pad nodes at [n], [n + 1]: the traversal prefetches the next node (one or two on) without a bounds check
+    if (e == hipSuccess) e = hipMalloc(&s->d_prim, sizeof(rt::Node<T>) * (raw.size() + 2));
+    if (e == hipSuccess) e = hipMalloc(&s->d_shad, sizeof(rt::Node<T>) * (raw.size() + 2));
+    if (e == hipSuccess) e = hipMemset(s->d_prim, 0, sizeof(rt::Node<T>) * (raw.size() + 2));
+    if (e == hipSuccess) e = hipMemset(s->d_shad, 0, sizeof(rt::Node<T>) * (raw.size() + 2));
     if (e == hipSuccess) {
         const rt::V3<T> eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
-        hipLaunchKernelGGL((rt::k_build_streams<T>), dim3((s->n_nodes + 255) / 256), dim3(256), 0, nullptr, d_raw, s->n_nodes, eye,
+        hipLaunchKernelGGL((rt::k_build_streams<T>), dim3((s->n_nodes + 255) / 256), dim3(256), 0, nullptr, d_raw, s->n_nodes, eye, s->fused,
                            static_cast<rt::Node<T> *>(s->d_prim), static_cast<rt::Node<T> *>(s->d_shad));
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -484,16 +492,15 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
     return st;
 }
 
-// Tuning variant of k_render_skip (rt_skip.hpp VAR bits); RT_SKIP_VARIANT overrides the default for A/B runs.
-constexpr int kSkipVariantDefault = 21;  // the generated rotating f32 traversal loops (16 + 4) + lean sqrt in the C++ loops (1)
-
-int skip_variant(uint64_t waves)
+// Variant of k_render_skip (rt_skip.hpp VAR bits): the generated assembly loops, fused where the scene allows it.
+// RT_SKIP_VARIANT overrides for A/B runs (read per call so one process can interleave variants, tools/ab.py); the fused bit
+// is dropped for scenes that are not fused.
+int skip_variant(const rt_scene *s)
 {
-    // read per call so one process can interleave variants (A/B timing in tools/ab.py)
-    const char *e = getenv("RT_SKIP_VARIANT");
-    if (e) return atoi(e) & 31;
-    (void)waves;
-    return kSkipVariantDefault;
+    int v = 1 | 2 | 4;
+    if (const char *e = getenv("RT_SKIP_VARIANT")) v = atoi(e) & 7;
+    if (!s->fused || !(v & 2)) v &= ~4;
+    return v;
 }
 
 // spp > 1 runs sample-parallel (one thread per sample + a resolve pass) unless spp*spp exceeds grid.y's limit.
@@ -611,16 +618,13 @@ rt_status launch_skip_var(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
                           const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt, unsigned frame_w,
                           rt::BlockList order)
 {
-    switch (skip_variant((uint64_t)(order.d ? order.n : grid.x) * 4 * (use_split(spp) ? (uint64_t)spp * spp : 1))) {
-    case 1: return launch_skip_one<T, COUNT, 1>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+    switch (skip_variant(s)) {
+    case 0: return launch_skip_one<T, COUNT, 0>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     case 2: return launch_skip_one<T, COUNT, 2>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     case 3: return launch_skip_one<T, COUNT, 3>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
-    case 5: return launch_skip_one<T, COUNT, 5>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+    case 6: return launch_skip_one<T, COUNT, 6>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     case 7: return launch_skip_one<T, COUNT, 7>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
-    case 13: return launch_skip_one<T, COUNT, 13>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
-    case 15: return launch_skip_one<T, COUNT, 15>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
-    case 21: return launch_skip_one<T, COUNT, 21>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
-    default: return launch_skip_one<T, COUNT, 0>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+    default: return launch_skip_one<T, COUNT, 1>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     }
 }
 

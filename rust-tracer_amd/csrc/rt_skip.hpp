@@ -14,7 +14,6 @@
 // reference performs for its ray -- including the reference's behaviour when a ray starts inside a bound.
 #pragma once
 #include "rt_kernels.hpp"
-#include "rt_skip_asm.hpp"
 #include "rt_skip_rot.hpp"
 
 namespace rt {
@@ -23,11 +22,17 @@ namespace rt {
 // v = centre - eye, vv = dot(v, v), rr = radius * radius -- the ray-independent sub-expressions of
 // primitive.rs:56-58, computed on the device with the same individually rounded operations.
 // SHADOW stream (per-lane origin): a = {cx, cy, cz, rr, -}.
-// skip != 0: BOUND node, skip = index of the first node after the group's subtree.  skip == 0: ITEM node.
+// skip_off != 0: BOUND node; skip_off = byte offset of the first node after the group's subtree.  skip_off == 0: ITEM node.
+// A scene is FUSED when every BOUND is directly followed by an ITEM with the same centre, bit for bit (the reference's
+// pyramid: a group's first child is the sphere its bound is built around, group.rs:37-41).  Its BOUND nodes also carry that
+// sphere's rr and item index, so the assembly loops can test it inside the BOUND step (rt_skip_rot.hpp).
 template <typename T> struct alignas(sizeof(T) * 8) Node {
     T a0, a1, a2, a3, a4;
-    uint32_t skip, item;
-    uint32_t skip_off;      // skip as a byte offset into the stream (rt_skip_rot.hpp)
+    uint32_t own_rr;        // f32 bits of rr of the group's own sphere (fused scenes, BOUND nodes; f32 streams only)
+    uint32_t item;          // ITEM: index into the DFS items.  Fused BOUND: the index of the group's own sphere.
+    uint32_t skip_off;
+    __device__ __forceinline__ bool is_bound() const { return skip_off != 0u; }
+    __device__ __forceinline__ unsigned skip() const { return skip_off / (unsigned)sizeof(Node); }   // as a node index
 };
 static_assert(sizeof(Node<float>) == 32 && sizeof(Node<double>) == 64, "node records are one aligned scalar-load unit");
 
@@ -47,7 +52,7 @@ template <typename T> struct SkipView {
 
 // Derives both streams from the raw one: exact IEEE ops, no contraction (same products the CPU path forms).
 template <typename T>
-__global__ void k_build_streams(const RawNode<T> *__restrict__ raw, unsigned n, V3<T> eye, Node<T> *__restrict__ prim,
+__global__ void k_build_streams(const RawNode<T> *__restrict__ raw, unsigned n, V3<T> eye, bool fused, Node<T> *__restrict__ prim,
                                 Node<T> *__restrict__ shad)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,9 +60,14 @@ __global__ void k_build_streams(const RawNode<T> *__restrict__ raw, unsigned n, 
     const RawNode<T> r = raw[i];
     const V3<T> v = { r.cx - eye.x, r.cy - eye.y, r.cz - eye.z };      // primitive.rs:56
     const T rr = r.r * r.r;                                           // primitive.rs:58
-    Node<T> p; p.a0 = v.x; p.a1 = v.y; p.a2 = v.z; p.a3 = dot(v, v); p.a4 = rr; p.skip = r.skip; p.item = r.item;
-    Node<T> s; s.a0 = r.cx; s.a1 = r.cy; s.a2 = r.cz; s.a3 = rr; s.a4 = T(0); s.skip = r.skip; s.item = r.item;
+    Node<T> p; p.a0 = v.x; p.a1 = v.y; p.a2 = v.z; p.a3 = dot(v, v); p.a4 = rr; p.own_rr = 0u; p.item = r.item;
+    Node<T> s; s.a0 = r.cx; s.a1 = r.cy; s.a2 = r.cz; s.a3 = rr; s.a4 = T(0); s.own_rr = 0u; s.item = r.item;
     p.skip_off = s.skip_off = r.skip * (unsigned)sizeof(Node<T>);
+    if (fused && r.skip != 0u) {                                      // the ITEM behind this BOUND has the same centre
+        const RawNode<T> own = raw[i + 1];
+        p.own_rr = s.own_rr = __float_as_uint((float)(own.r * own.r));   // fused streams are f32: the cast is the identity
+        p.item = s.item = own.item;
+    }
     prim[i] = p;
     shad[i] = s;
 }
@@ -81,33 +91,10 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 
 constexpr unsigned kNever = 0xFFFFFFFFu;
 
-// Hand-placed scalar loads (hipcc sinks an ordinary speculative load below the work it should overlap).  hipcc does
-// not count an asm load: the value may only be used after sload_wait() on it (cdna guide 5.7 item 1).
-typedef int __attribute__((ext_vector_type(8))) i32x8;
-__device__ __forceinline__ i32x8 sload8(const void *base, unsigned byte_off)
-{
-    i32x8 r;
-    asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(r) : "s"(base), "s"(byte_off) : "memory");
-    return r;
-}
-__device__ __forceinline__ void sload_wait(i32x8 &a, i32x8 &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b) : : "memory"); }
-
-template <typename T> __device__ __forceinline__ Node<T> as_node(const i32x8 &r);
-template <> __device__ __forceinline__ Node<float> as_node<float>(const i32x8 &r)
-{
-    Node<float> n;
-    n.a0 = __int_as_float(r[0]); n.a1 = __int_as_float(r[1]); n.a2 = __int_as_float(r[2]); n.a3 = __int_as_float(r[3]);
-    n.a4 = __int_as_float(r[4]); n.skip = (unsigned)r[5]; n.item = (unsigned)r[6];
-    return n;
-}
-
-// VAR bits (tuning variants, all bit-identical in output and counters):
-//   1 = sqrt_rn_lean (same value as the IEEE sqrt for every input, about half the instructions)
-//   4 = (f32, launches that do not count tests) the primary traversal loop hand-written in assembly, rt_skip_asm.hpp
-//   8 = (with 4) EXEC-narrowed register updates in the hand-written loops (rt_skip_asm.hpp, *_V2 pieces)
-//  16 = (f32, launches that do not count tests) the generated rotating loops, rt_skip_rot.hpp
-//   2 = the records of both possible successors (i+1 and skip) are fetched with hand-placed scalar loads while node i
-//       is processed, so the dependent scalar-load latency leaves the wave's critical path
+// VAR bits (all bit-identical in output and counters):
+//   1 = sqrt_rn_lean in the C++ loops (same value as the IEEE sqrt for every input, about half the instructions)
+//   2 = (f32, launches that do not count tests) the generated assembly traversal loops, rt_skip_rot.hpp
+//   4 = (with 2; fused scenes only) their fused flavour
 //
 // SPLIT = false: one thread renders its pixel completely (all spp*spp samples in the reference's order) -- used for
 //   spp == 1, where it is a single pass.
@@ -193,23 +180,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             unsigned best_item = 0;
             unsigned resume = inside ? 0u : kNever;
             unsigned i = 0;
-            if constexpr ((VAR & 16) && !COUNT && sizeof(T) == 4) {
-                skip_primary_rot(sc.prim, n * 32u, dir.x, dir.y, dir.z, resume, best, best_item);
-            } else if constexpr ((VAR & 4) && !COUNT && sizeof(T) == 4) {
-                skip_primary_asm<(VAR & 2) != 0, (VAR & 8) != 0>(sc.prim, n, dir.x, dir.y, dir.z, resume, best, best_item);
+            if constexpr ((VAR & 2) && !COUNT && sizeof(T) == 4) {
+                if constexpr ((VAR & 4) != 0) skip_primary_rot_fused(sc.prim, n * 32u, dir.x, dir.y, dir.z, resume, best, best_item);
+                else skip_primary_rot(sc.prim, n * 32u, dir.x, dir.y, dir.z, resume, best, best_item);
             } else {
             Node<T> nd = sc.prim[0];                                    // wave-uniform record -> SGPRs
             for (;;) {
-                i32x8 pf_next, pf_skip;
-                if constexpr ((VAR & 2) && sizeof(T) == 4) {            // both successors; the array has a pad node at [n]
-                    pf_next = sload8(sc.prim, (i + 1) * 32u);
-                    pf_skip = sload8(sc.prim, nd.skip * 32u);
-                }
                 const bool active = i >= resume;
                 // Sphere::distance_from_ray with the ray-independent parts pre-formed (primitive.rs:55-72)
                 const T b = (nd.a0 * dir.x + nd.a1 * dir.y) + nd.a2 * dir.z;
                 const T disc = (b * b - nd.a3) + nd.a4;
-                const bool is_bound = nd.skip != 0u;
                 unsigned ni;
                 {
                     const bool pos = !(disc < T(0.0));
@@ -222,11 +202,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                             d = t1 > T(0.0) ? t1 : t2;
                         }
                     }
-                    if (is_bound) {                                     // BOUND  group.rs:73
+                    if (nd.is_bound()) {                                // BOUND  group.rs:73
                         const bool cull = active && (d >= best);
-                        if (cull) resume = nd.skip;
+                        if (cull) resume = nd.skip();
                         if (COUNT) c_bounds += active ? 1u : 0u;
-                        ni = (__ballot(active && !cull) == 0) ? nd.skip : i + 1;
+                        ni = (__ballot(active && !cull) == 0) ? nd.skip() : i + 1;
                     } else {                                            // ITEM   primitive.rs:78-83
                         if (active && !(d >= best)) { best = d; best_item = nd.item; }
                         if (COUNT) c_items += active ? 1u : 0u;
@@ -234,14 +214,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                     }
                 }
                 if (COUNT) ++c_steps;
-                // the asm loads must have landed before their registers can be reused, also on the way out
-                if constexpr ((VAR & 2) && sizeof(T) == 4) sload_wait(pf_next, pf_skip);
                 if (ni >= n) break;
-                if constexpr ((VAR & 2) && sizeof(T) == 4) {
-                    nd = as_node<T>(ni == i + 1 ? pf_next : pf_skip);   // ni is i+1 or nd.skip, nothing else
-                } else {
-                    nd = sc.prim[ni];
-                }
+                nd = sc.prim[ni];
                 i = ni;
             }
             }
@@ -278,38 +252,23 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             bool occluded = false;
             resume = need_shadow ? 0u : kNever;
             i = 0;
-            if constexpr ((VAR & 16) && !COUNT && sizeof(T) == 4) {
+            if constexpr ((VAR & 2) && !COUNT && sizeof(T) == 4) {
                 if (__ballot(need_shadow) != 0) {
-                    const unsigned nb = n * 32u;                    // positions in bytes
+                    const unsigned nb = n * 32u;                    // the assembly loops count in bytes
                     while (i < nb) {
                         unsigned fin;
-                        i = skip_shadow_rot(sc.shad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
+                        if constexpr ((VAR & 4) != 0) i = skip_shadow_rot_fused(sc.shad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
+                        else i = skip_shadow_rot(sc.shad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
                         if (i >= nb) break;
                         if (fin) { occluded = true; resume = kNever; }
+                        // some lane retired at the ITEM at i: go straight to the next node any lane still wants
                         i = (unsigned)__builtin_amdgcn_readfirstlane(
                             (int)wave_min_u32(resume == kNever ? kNever : (resume > i ? resume : i + 32u)));
-                    }
-                }
-            } else if constexpr ((VAR & 4) && !COUNT && sizeof(T) == 4) {
-                if (__ballot(need_shadow) != 0) {
-                    while (i < n) {
-                        unsigned fin;
-                        i = skip_shadow_asm<(VAR & 2) != 0, (VAR & 8) != 0>(sc.shad, n, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
-                        if (i >= n) break;
-                        if (fin) { occluded = true; resume = kNever; }
-                        // some lane retired at item i: go straight to the next node any lane still wants
-                        i = (unsigned)__builtin_amdgcn_readfirstlane(
-                            (int)wave_min_u32(resume == kNever ? kNever : (resume > i ? resume : i + 1)));
                     }
                 }
             } else if (__ballot(need_shadow) != 0) {
                 Node<T> nd = sc.shad[0];
                 for (;;) {
-                    i32x8 pf_next, pf_skip;
-                    if constexpr ((VAR & 2) && sizeof(T) == 4) {
-                        pf_next = sload8(sc.shad, (i + 1) * 32u);
-                        pf_skip = sload8(sc.shad, nd.skip * 32u);
-                    }
                     const bool active = i >= resume;
                     const V3<T> v = { nd.a0 - sp.x, nd.a1 - sp.y, nd.a2 - sp.z };
                     const T b = dot(v, sdir);
@@ -320,11 +279,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                         if (pos) hit = !((b + ((VAR & 1) ? sqrt_rn_lean(disc) : rsqrt_exact(disc))) < T(0.0));
                     }
                     unsigned ni;
-                    if (nd.skip != 0u) {
+                    if (nd.is_bound()) {
                         const bool cull = active && !hit;
-                        if (cull) resume = nd.skip;
+                        if (cull) resume = nd.skip();
                         if (COUNT) c_bounds += active ? 1u : 0u;
-                        ni = (__ballot(active && hit) == 0) ? nd.skip : i + 1;
+                        ni = (__ballot(active && hit) == 0) ? nd.skip() : i + 1;
                     } else {
                         const bool fin = active && hit;
                         if (COUNT) c_items += active ? 1u : 0u;
@@ -338,15 +297,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                         }
                     }
                     if (COUNT) ++c_steps;
-                    if constexpr ((VAR & 2) && sizeof(T) == 4) sload_wait(pf_next, pf_skip);
                     if (ni >= n) break;                                 // also ni == kNever: every lane retired
-                    if constexpr ((VAR & 2) && sizeof(T) == 4) {
-                        if (ni == i + 1) nd = as_node<T>(pf_next);
-                        else if (ni == nd.skip) nd = as_node<T>(pf_skip);
-                        else nd = sc.shad[ni];                          // wave_min jump after a lane retired
-                    } else {
-                        nd = sc.shad[ni];
-                    }
+                    nd = sc.shad[ni];
                     i = ni;
                 }
             }
