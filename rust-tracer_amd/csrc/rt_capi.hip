@@ -436,12 +436,14 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
     for (size_t i = 0; i < order.size(); ++i) {
         const rt::BlockDesc &d = raster[order[i]];
         if (i >= n_narrow) { descs.push_back(d); continue; }
-        for (unsigned q = 0; q < 4; ++q) {
-            rt::BlockDesc n = d;
-            n.x0 = (uint16_t)(d.x0 + (q & 1) * 8); n.y0 = (uint16_t)(d.y0 + (q >> 1) * 8);
-            n.pitch |= rt::kBlockNarrow;
-            if (n.x0 < d.r && n.y0 < d.t) descs.push_back(n);
-        }
+        const unsigned level = 1u, step = 16u >> level, cnt = 1u << level;     // level 2 (2x2 pixels per wave) measured slower
+        for (unsigned qy = 0; qy < cnt; ++qy)
+            for (unsigned qx = 0; qx < cnt; ++qx) {
+                rt::BlockDesc n = d;
+                n.x0 = (uint16_t)(d.x0 + qx * step); n.y0 = (uint16_t)(d.y0 + qy * step);
+                n.pitch |= level << rt::kBlockNarrowShift;
+                if (n.x0 < d.r && n.y0 < d.t) descs.push_back(n);      // parts outside a clipped edge tile have no pixels
+            }
     }
 }
 
@@ -500,6 +502,7 @@ int skip_variant(const rt_scene *s)
     int v = 1 | 2 | 4;
     if (const char *e = getenv("RT_SKIP_VARIANT")) v = atoi(e) & 7;
     if (!s->fused || !(v & 2)) v &= ~4;
+    if ((v & 3) == 3 && s->precision == RT_F32 && getenv("RT_WAVE_TRACE")) v |= 8;      // diagnostic build of the assembly variants
     return v;
 }
 
@@ -570,7 +573,7 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     uint32_t *no_cost = nullptr;
     // RT_WAVE_TRACE=<file> (diagnostic, tools/wave_timeline.py): the launch records every wave's start / end / placement and
     // the records are written to <file> -- synchronous, one file per launch (overwritten).
-    const char *trace_path = COUNT ? nullptr : getenv("RT_WAVE_TRACE");
+    const char *trace_path = (VAR & 8) ? getenv("RT_WAVE_TRACE") : nullptr;
     const dim3 rgrid(order.d ? order.n : grid.x);      // render workgroups: one per descriptor
     const size_t trace_words = (size_t)rgrid.x * 4 * 4 * (use_split(spp) ? (size_t)spp * spp : 1);
     struct Trace {
@@ -624,6 +627,8 @@ rt_status launch_skip_var(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     case 3: return launch_skip_one<T, COUNT, 3>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     case 6: return launch_skip_one<T, COUNT, 6>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     case 7: return launch_skip_one<T, COUNT, 7>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+    case 11: return launch_skip_one<T, COUNT, 11>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+    case 15: return launch_skip_one<T, COUNT, 15>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     default: return launch_skip_one<T, COUNT, 1>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     }
 }

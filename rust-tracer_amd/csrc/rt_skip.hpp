@@ -95,6 +95,7 @@ constexpr unsigned kNever = 0xFFFFFFFFu;
 //   1 = sqrt_rn_lean in the C++ loops (same value as the IEEE sqrt for every input, about half the instructions)
 //   2 = (f32, launches that do not count tests) the generated assembly traversal loops, rt_skip_rot.hpp
 //   4 = (with 2; fused scenes only) their fused flavour
+//   8 = wave trace (diagnostic, RT_WAVE_TRACE): every wave records when and where it ran into `lane_cost`
 //
 // SPLIT = false: one thread renders its pixel completely (all spp*spp samples in the reference's order) -- used for
 //   spp == 1, where it is a single pass.
@@ -119,11 +120,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     // as its last wave, so the long chains must not be the ones dispatched last (rt_capi.hip, block_order).  Without it
     // the workgroup finds its block in the tile table.
     unsigned bx0, by0, tile_r, tile_t, pitch, base;
-    bool narrow = false;
+    unsigned level = 0;             // 0: 8x8 pixels per wave; 1: 4x4 (16 live lanes); 2: 2x2 (4 live lanes)
     if (order) {
         const BlockDesc bd = order[blockIdx.x];
         bx0 = bd.x0; by0 = bd.y0; tile_r = bd.r; tile_t = bd.t; pitch = bd.pitch & 0xFFFFu; base = bd.base;
-        narrow = (bd.pitch & kBlockNarrow) != 0;
+        level = bd.pitch >> kBlockNarrowShift;
     } else {
         unsigned lo = 0, hi = n_tiles - 1;
         while (lo < hi) {
@@ -139,16 +140,19 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     }
     const unsigned gblock = blockIdx.x;
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned x = bx0 + (narrow ? (wave & 1) * 4 + (lane & 3) : (wave & 1) * 8 + (lane & 7));
-    const unsigned y = by0 + (narrow ? (wave >> 1) * 4 + ((lane >> 2) & 3) : (wave >> 1) * 8 + (lane >> 3));
-    const bool inside = x < tile_r && y < tile_t && !(narrow && lane >= 16);
+    const unsigned pw = 8u >> level, pbits = 3u - level;          // wave patch: pw x pw pixels in the first pw*pw lanes
+    const unsigned x = bx0 + (wave & 1) * pw + (lane & (pw - 1));
+    const unsigned y = by0 + (wave >> 1) * pw + ((lane >> pbits) & (pw - 1));
+    const bool inside = x < tile_r && y < tile_t && lane < pw * pw;
     if (__ballot(inside) == 0) return;          // waves are independent here: no LDS, no barrier
 
     unsigned long long t_start = 0, r_start = 0;
     if (COUNT) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
     // diagnostic (RT_WAVE_TRACE, tools/wave_timeline.py): launches that do not count may be handed a trace buffer instead of
     // the cost map -- every wave records when it ran (100 MHz clock) and where
-    const bool trace = !COUNT && lane_cost != nullptr;
+    // (a template bit, not a run-time test: hipcc treats s_memrealtime as a memory clobber and then fetches the wave-uniform
+    // node records of the C++ loops below with vector loads -- the f64 frame went from 151 to 248 us)
+    constexpr bool trace = !COUNT && (VAR & 8) != 0;
     if (trace) r_start = __builtin_amdgcn_s_memrealtime();
 
     const T ssf = T(spp);
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
         if (COUNT) { if (lane_cost) lane_cost[px] = c_items + c_bounds; }   // the scene's cost map is rendered through this
     }
 
-    if (trace && lane == 0) {
+    if (trace && lane_cost && lane == 0) {
         uint32_t *rec = lane_cost + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 4;     // in dispatch order
         rec[0] = (uint32_t)r_start;
         rec[1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
