@@ -28,7 +28,7 @@ def setvar(v):
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     w, h, spp, level = (int(a) for a in sys.argv[2:6]) if len(sys.argv) > 5 else (1920, 1080, 1, 8)
-    variants = [int(v) for v in os.environ.get("AB_VARIANTS", "0,1,2,3").split(",")]
+    variants = [int(v) for v in os.environ.get("AB_VARIANTS", "1,3,7").split(",")]
     scene = rta.Scene.default(level)
     dev = scene.device(0)
     opts = (w, h, spp)
