@@ -110,6 +110,14 @@ rt_status rt_scene_create(int device, rt_precision precision,
 
 rt_status rt_scene_destroy(rt_scene *scene);
 
+/* What rt_scene_create found out about the scene (diagnostic; selects nothing the caller has to know about).
+ *   RT_SCENE_HAS_BOUNDS      created with subtree bounds: RT_TRAVERSAL_SKIP is available
+ *   RT_SCENE_CONCENTRIC      every group bound is directly followed by an item with the same centre, bit for bit (the
+ *                            reference's pyramid, group.rs:37-41): the f32 traversal loops test that item inside the
+ *                            bound's step -- same tests, same order, same values, one node step fewer per entered group */
+enum { RT_SCENE_HAS_BOUNDS = 1u, RT_SCENE_CONCENTRIC = 2u };
+rt_status rt_scene_traits(const rt_scene *scene, uint32_t *traits);
+
 /* Renderer::render_region for a batch of regions in ONE device pass (a literal launch per 64x64 bucket would
  * starve 256 CUs).  rgba_out (HOST memory) receives the tiles back to back ("tile-major"):
  * tile i starts at 4 * sum_{j<i} area(j) and is its own row-major RGBABuffer (render.rs:74-109).

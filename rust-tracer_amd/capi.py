@@ -14,7 +14,7 @@ RT_TRAVERSAL_FLAT, RT_TRAVERSAL_SKIP = 0, 1
 ABI_VERSION = 1
 
 # every symbol include/rtrace_hip.h declares
-SYMBOLS = ("rt_abi_version", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render_tiles",
+SYMBOLS = ("rt_abi_version", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_scene_traits", "rt_render_tiles",
            "rt_render_tiles_device", "rt_render_frame_device", "rt_render_region", "rt_blit_tiles_device", "rt_selftest_sqrt", "rt_tiles_rgba_bytes", "rt_strerror", "rt_last_error_message")
 
 
@@ -63,6 +63,8 @@ lib.rt_render_region.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.POIN
 lib.rt_blit_tiles_device.argtypes = [C.c_void_p, C.POINTER(Options), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]
 lib.rt_selftest_sqrt.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+lib.rt_scene_traits.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+RT_SCENE_HAS_BOUNDS, RT_SCENE_CONCENTRIC = 1, 2
 lib.rt_tiles_rgba_bytes.restype = C.c_uint64
 lib.rt_tiles_rgba_bytes.argtypes = [C.c_void_p, C.c_uint32]
 lib.rt_strerror.restype = C.c_char_p

@@ -1028,6 +1028,13 @@ rt_status rt_blit_tiles_device(rt_scene *s, const rt_options *o, const rt_region
     return RT_OK;
 }
 
+rt_status rt_scene_traits(const rt_scene *s, uint32_t *traits)
+{
+    if (!s || !traits) { snprintf(g_err, sizeof g_err, "NULL argument"); return RT_ERR_INVALID_ARGUMENT; }
+    *traits = (s->n_nodes ? RT_SCENE_HAS_BOUNDS : 0u) | (s->fused ? RT_SCENE_CONCENTRIC : 0u);
+    return RT_OK;
+}
+
 rt_status rt_selftest_sqrt(int device, uint64_t *mismatches, uint32_t *first_bad_bits)
 {
     if (!mismatches || !first_bad_bits) return RT_ERR_INVALID_ARGUMENT;

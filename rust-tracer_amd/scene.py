@@ -164,6 +164,12 @@ class DeviceScene:
         capi.check(st, "rt_scene_create")
         self._h = h
 
+    def traits(self):
+        """rt_scene_traits -> bit set of capi.RT_SCENE_HAS_BOUNDS / capi.RT_SCENE_CONCENTRIC."""
+        t = C.c_uint32(0)
+        capi.check(capi.lib.rt_scene_traits(self._h, C.byref(t)), "rt_scene_traits")
+        return t.value
+
     def close(self):
         if getattr(self, "_h", None):
             capi.lib.rt_scene_destroy(self._h)

@@ -18,7 +18,8 @@ HIER_EXIT = oracle.MODE_HIERARCHY | oracle.MODE_ANYHIT_EXIT
 def test_random_scene(seed):
     rng = np.random.default_rng(seed)
     depth, fan, leaf = int(rng.integers(2, 6)), int(rng.integers(2, 5)), int(rng.integers(1, 4))
-    items, bounds, ranges = util.random_nested_scene(seed, depth=depth, fan=fan, leaf_items=leaf)
+    # every third scene is concentric (a group's first child sits at the centre of its bound): the fused traversal loops
+    items, bounds, ranges = util.random_nested_scene(seed, depth=depth, fan=fan, leaf_items=leaf, concentric=seed % 3 == 1)
     eye = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-4.5, -1.0)))
     light = (float(rng.uniform(-2, 2)), float(rng.uniform(-3, -0.5)), float(rng.uniform(-2, 2)))
     precision = rta.RT_F64 if seed % 5 == 0 else rta.RT_F32

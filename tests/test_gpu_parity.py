@@ -365,6 +365,7 @@ def test_skip_needs_bounds_and_rejects_bad_nesting():
 
 def test_lean_sqrt_is_correctly_rounded_for_every_f32():
     # the traversal loops use a lean correctly-rounded sqrt; it must equal the IEEE sqrt bit for bit on all 2^32 inputs
+    assert rta.Scene.default(4).device().traits() == rta.capi.RT_SCENE_HAS_BOUNDS | rta.capi.RT_SCENE_CONCENTRIC
     bad, first = rta.capi.selftest_sqrt(0)
     assert bad == 0, "first differing input bits: 0x%08x" % first
 
@@ -548,16 +549,19 @@ def test_more_distinct_tile_lists_than_the_table_cache_holds(trav):
         np.testing.assert_array_equal(data.reshape(t - b, r - l, 4), ref[b:t, l:r])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 5, 7])
+@pytest.mark.parametrize("variant", [0, 1, 3, 7])
+@pytest.mark.parametrize("concentric", [False, True], ids=["nested", "concentric"])
 @pytest.mark.parametrize("seed", [11, 12, 13])
-def test_every_skip_loop_flavour_on_deep_random_scenes(variant, seed):
-    # RT_SKIP_VARIANT picks the traversal-loop flavour explicitly (0/1 C++ loops, 5 assembly, 7 assembly + successor
-    # prefetch; the default picks 5 or 7 by pass size).  Deeper, wider random trees with loose bounds and an eye inside
-    # some bounds: culling decides pixels, many lanes retire at different items in the shadow walk.
+def test_every_skip_loop_flavour_on_deep_random_scenes(variant, concentric, seed):
+    # RT_SKIP_VARIANT picks the traversal-loop flavour explicitly (0/1 C++ loops, 3 generated assembly loops, 7 their fused
+    # flavour -- used for concentric scenes only, the library drops the bit otherwise; the default is 7).  Deeper, wider
+    # random trees with loose bounds and an eye inside some bounds: culling decides pixels, many lanes retire at different
+    # items in the shadow walk.
     import ctypes
     libc = ctypes.CDLL(None)
-    items, bounds, ranges = util.random_nested_scene(seed, depth=4, fan=4, leaf_items=2)
+    items, bounds, ranges = util.random_nested_scene(seed, depth=4, fan=4, leaf_items=2, concentric=concentric)
     s, o = util.scene_pair_ranges(items, bounds, ranges, eye=(0.05, -0.1, -2.2))
+    assert s.device().traits() == rta.capi.RT_SCENE_HAS_BOUNDS | (rta.capi.RT_SCENE_CONCENTRIC if concentric else 0)
     regs = bucket_list(192, 160, 2)
     ref, rst, _ = o.render(192, 160, 2, os.cpu_count() or 1, HIER_EXIT)
     libc.setenv(b"RT_SKIP_VARIANT", str(variant).encode(), 1)

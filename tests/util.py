@@ -54,9 +54,11 @@ def scene_pair_ranges(items, bounds, ranges, precision=rta.RT_F32, light=(-1.0, 
     return s, oracle.Scene.from_ranges(items, bounds, ranges, light, eye, PREC[precision])
 
 
-def random_nested_scene(seed, depth=3, fan=3, leaf_items=3):
+def random_nested_scene(seed, depth=3, fan=3, leaf_items=3, concentric=False):
     """A random laminar tree (items and sub-groups interleaved in random order) with tight-ish random bounds:
-    some bounds do NOT enclose their subtree, so culling really changes results and order matters."""
+    some bounds do NOT enclose their subtree, so culling really changes results and order matters.
+    concentric: every group's FIRST child is an item at the centre of the group's bound (like the reference's pyramid,
+    group.rs:37-41) -- the scene shape for which the f32 traversal loops fuse the bound's step with that item's."""
     rng = np.random.default_rng(seed)
     items, bounds, ranges = [], [], []
 
@@ -64,6 +66,8 @@ def random_nested_scene(seed, depth=3, fan=3, leaf_items=3):
         bi = len(bounds)
         bounds.append(None); ranges.append(None)
         first = len(items)
+        if concentric:
+            items.append((centre[0], centre[1], centre[2], float(rng.uniform(0.1, 0.5) * scale)))
         kids = ["item"] * leaf_items + (["group"] * fan if d > 0 else [])
         rng.shuffle(kids)
         for k in kids:

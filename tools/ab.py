@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B timing of kernel tuning variants, interleaved in ONE process (cdna guide rule 24).  Checks every variant's frame
 and counters against the first variant.  usage: ab.py [rounds] [w h spp level]
-env: AB_TRAVERSAL=skip|flat  AB_ENV=RT_SKIP_VARIANT|RT_FLAT_VARIANT  AB_VARIANTS=0,1,...  AB_LAUNCHES=5"""
+env: AB_TRAVERSAL=skip|flat  AB_ENV=RT_SKIP_VARIANT|RT_BLOCK_ORDER  AB_VARIANTS=1,3,7 (skip: 1 C++ loops, 3 generated assembly
+loops, 7 their fused flavour)  AB_LAUNCHES=5"""
 import ctypes
 import os
 import sys
