@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--multi", choices=("frames", "tiles"), default="frames",
                     help="N > 1: 'frames' = every GPU renders whole frames, N per step, gathered to rank 0 (weak scaling); "
                          "'tiles' = BASELINE config 4, the buckets of ONE frame dealt over the GPUs (strong scaling)")
+    ap.add_argument("--frames-per-gather", type=int, default=4,
+                    help="N > 1, 'frames' layout: frames a rank renders per RCCL gather (fewer, larger collectives)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1080p",
                     help="1080p = the headline workload; the others are BASELINE's neighbouring configs")
     args = ap.parse_args()
@@ -134,7 +136,8 @@ def main():
 
     def measure(traversal, steps, warmup):
         """-> dict with whole-job ms/step (max over ranks), this rank's kernel ms (HIP events), ray/test counters."""
-        fs = FrameSharder(scene, opts, rank, world, local, traversal, force_collective=args.force_collective, mode=args.multi)
+        fs = FrameSharder(scene, opts, rank, world, local, traversal, force_collective=args.force_collective, mode=args.multi,
+                          frames_per_gather=args.frames_per_gather)
         st = fs.render_shard(want_stats=True)          # counters of this rank's shard (equal the oracle's; tests)
         cnt = torch.tensor([st["primary"], st["shadow"]], dtype=torch.int64, device="cuda")
         if dist is not None:
@@ -203,7 +206,8 @@ def main():
             layout = "1 GPU, buckets rendered straight into the row-major frame"
         elif args.multi == "frames":
             layout = ("%d GPUs, every GPU renders a whole frame per step (%d frames per step), u8 frames gathered to rank 0 "
-                      "over RCCL, gather of frame k overlapped with the render of frame k+1" % (world, world))
+                      "over RCCL %d frames per rank at a time, each gather overlapped with the render of the next frames"
+                      % (world, world, args.frames_per_gather))
         else:
             layout = ("%d GPUs, the buckets of ONE frame dealt round-robin (tile_id %% N), u8 shards gathered to rank 0 over "
                       "RCCL and blitted into the frame there, pipelined across frames" % world)

@@ -98,12 +98,16 @@ class FrameSharder:
     the render of frame k+1, so a sequence of frames costs max(render, gather + blit) per frame instead of their sum."""
 
     def __init__(self, scene, options, rank=0, world=1, device=0, traversal=capi.RT_TRAVERSAL_SKIP, force_collective=False,
-                 mode="tiles"):
+                 mode="tiles", frames_per_gather=1):
         import torch
         self.torch = torch
         if mode not in ("tiles", "frames"):
             raise ValueError("mode must be 'tiles' or 'frames'")
         self.mode = mode
+        # "frames" mode may batch: a rank renders `batch` consecutive frames into one buffer and ONE gather moves them all
+        # (fewer, larger collectives: the per-call host cost of a gather is paid once per batch, the wire time is the same)
+        self.batch = max(1, int(frames_per_gather)) if mode == "frames" else 1
+        self._counts, self._next, self._slot_count = [], 0, [self.batch, self.batch]
         # force_collective: take the shard -> gather -> blit path even for world == 1 (a one-rank RCCL gather); lets a
         # single-GPU test drive exactly the code the 8-GPU run executes
         self.collective = world > 1 or force_collective
@@ -118,8 +122,9 @@ class FrameSharder:
         self.my_regions = [tuple(bl[i]) for i in per_rank[rank if mode == "tiles" else 0][0]]
         self.my_regions_c = self.dev._regions(self.my_regions)
         tdev = torch.device("cuda", device)
+        self.unit_bytes = self.shard_px * 4                      # one frame ("frames") / one shard ("tiles")
         # two shard buffers: frame k+1 is rendered while frame k's shard is still being gathered
-        self.shards = [torch.zeros(self.shard_px * 4, dtype=torch.uint8, device=tdev) for _ in range(2)]
+        self.shards = [torch.zeros(self.batch * self.unit_bytes, dtype=torch.uint8, device=tdev) for _ in range(2)]
         self.shard = self.shards[0]
         self.frame = None
         self.side = torch.cuda.Stream(device=tdev) if (rank == 0 and self.collective) else None   # rank 0's blits run here
@@ -130,17 +135,19 @@ class FrameSharder:
             self.all_offsets = offsets
             if self.collective:
                 # one buffer per in-flight frame for the blit; the gather lists are views of its rows
-                self.gathered_flat = [torch.zeros(world * self.shard_px * 4, dtype=torch.uint8, device=tdev) for _ in range(2)]
-                self.gathered = [list(g.view(world, self.shard_px * 4).unbind(0)) for g in self.gathered_flat]
+                self.gathered_flat = [torch.zeros(world * self.batch * self.unit_bytes, dtype=torch.uint8, device=tdev) for _ in range(2)]
+                self.gathered = [list(g.view(world, self.batch * self.unit_bytes).unbind(0)) for g in self.gathered_flat]
 
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
-    def render_shard(self, want_stats=False, slot=0):
+    def render_shard(self, want_stats=False, slot=0, index=0):
         """This rank's buckets into shard buffer `slot` (enqueued on torch's current stream): tile-major in "tiles" mode,
-        straight into row-major frame order in "frames" mode (the shard IS this rank's frame)."""
+        straight into row-major frame order in "frames" mode (the shard IS this rank's frame; `index` picks the frame of
+        the batch)."""
         if self.mode == "frames":
-            return self.dev.render_frame_device(tuple(self.options), self.my_regions_c, self.shards[slot].data_ptr(), self._stream(),
+            return self.dev.render_frame_device(tuple(self.options), self.my_regions_c,
+                                                self.shards[slot].data_ptr() + index * self.unit_bytes, self._stream(),
                                                 self.traversal, want_stats)
         return self.dev.render_tiles_device(tuple(self.options), self.my_regions_c, self.shards[slot].data_ptr(), self._stream(),
                                             self.traversal, want_stats)
@@ -150,10 +157,15 @@ class FrameSharder:
         return self.dev.render_frame_device(tuple(self.options), self.my_regions_c, self.frame.data_ptr(), self._stream(),
                                             self.traversal, want_stats)
 
-    def gather(self, slot=0, async_op=False):
-        """The one collective on the data path: equal-length u8 shards to rank 0 over RCCL."""
+    def gather(self, slot=0, async_op=False, count=None):
+        """The one collective on the data path: equal-length u8 shards to rank 0 over RCCL (`count` frames of a batch)."""
         import torch.distributed as dist
-        return dist.gather(self.shards[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, async_op=async_op)
+        count = self.batch if count is None else count
+        if count == self.batch:
+            return dist.gather(self.shards[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, async_op=async_op)
+        nb = count * self.unit_bytes                              # the last, partial batch of a run
+        return dist.gather(self.shards[slot][:nb], [g[:nb] for g in self.gathered[slot]] if self.rank == 0 else None, dst=0,
+                           async_op=async_op)
 
     def blit(self, slot=0):
         """Rank 0: gathered shards -> row-major frame (set_pixels_from_buffer on the device).  "frames" mode gathers finished
@@ -174,10 +186,14 @@ class FrameSharder:
 
     # ---- the operations run_pipeline() schedules (a CPU stand-in with the same five methods is used by the gloo tests) ----
     def op_render(self, slot):
-        self.render_shard(slot=slot)
+        count = self._counts[self._next] if self._next < len(self._counts) else self.batch
+        self._next += 1
+        self._slot_count[slot] = count
+        for j in range(count):
+            self.render_shard(slot=slot, index=j)
 
     def op_gather_async(self, slot):
-        return self.gather(slot=slot, async_op=True)
+        return self.gather(slot=slot, async_op=True, count=self._slot_count[slot])
 
     def op_blit_after(self, work, slot):
         """Frame in `slot` has been gathered once `work` is done: blit it.  Rank 0 does that on its side stream, so the blit
@@ -205,10 +221,17 @@ class FrameSharder:
             for _ in range(steps):
                 self.render_frame()
             return
-        run_pipeline(steps, self)
+        # `steps` frames in batches of self.batch (the last one may be partial); one pipeline step per batch
+        self._counts = [self.batch] * (steps // self.batch) + ([steps % self.batch] if steps % self.batch else [])
+        self._next = 0
+        run_pipeline(len(self._counts), self)
 
-    def frame_host(self, slot=0, of_rank=0):
-        """Rank 0: the assembled frame ("tiles"), or the frame gathered from `of_rank` in buffer `slot` ("frames")."""
+    def frame_host(self, slot=0, of_rank=0, index=0):
+        """Rank 0: the assembled frame ("tiles"), or frame `index` of the batch gathered from `of_rank` in buffer `slot`
+        ("frames")."""
         self.torch.cuda.synchronize(self.device)
-        src = self.frame if (self.mode == "tiles" or not self.collective) else self.gathered[slot][of_rank]
+        if self.mode == "tiles" or not self.collective:
+            src = self.frame
+        else:
+            src = self.gathered[slot][of_rank][index * self.unit_bytes:(index + 1) * self.unit_bytes]
         return src.cpu().numpy().reshape(self.options.height, self.options.width, 4)

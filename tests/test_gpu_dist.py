@@ -71,3 +71,28 @@ def test_frames_mode_gathers_whole_frames(one_rank_rccl):
         np.testing.assert_array_equal(fs.frame_host(slot=slot, of_rank=0), ref)
     st = fs.render_shard(want_stats=True)
     assert st["primary"] == 1920 * 1080
+
+
+def test_frames_mode_batched_gather_delivers_every_frame(one_rank_rccl):
+    # bench.py gathers several frames per collective for N > 1: 7 frames in batches of 3 (3 + 3 + 1, the last one a partial
+    # gather) -- every frame slot that was gathered must hold the oracle's frame, the untouched tail of the last batch's
+    # buffer must still hold the poison
+    import torch
+    s, o = util.scene_pair_default()
+    ref, _, _ = o.render(640, 360, 1, nthreads=os.cpu_count() or 1)
+    fs = FrameSharder(s, (640, 360, 1), 0, 1, 0, rta.RT_TRAVERSAL_SKIP, force_collective=True, mode="frames", frames_per_gather=3)
+    for g in fs.gathered_flat:
+        g.fill_(0xCD)
+    fs.run(7)
+    torch.cuda.synchronize()
+    # batches land in slots 0, 1, 0: slot 1 holds batch 2 (3 frames), slot 0 holds the final partial batch (1 frame) over
+    # batch 1's frames 2 and 3
+    for index in range(3):
+        np.testing.assert_array_equal(fs.frame_host(slot=1, of_rank=0, index=index), ref)
+        np.testing.assert_array_equal(fs.frame_host(slot=0, of_rank=0, index=index), ref)
+    fs2 = FrameSharder(s, (640, 360, 1), 0, 1, 0, rta.RT_TRAVERSAL_SKIP, force_collective=True, mode="frames", frames_per_gather=4)
+    for g in fs2.gathered_flat:
+        g.fill_(0xCD)
+    fs2.run(1)                                   # one partial batch: frames 1..3 of slot 0 were never gathered
+    np.testing.assert_array_equal(fs2.frame_host(slot=0, index=0), ref)
+    assert int(fs2.frame_host(slot=0, index=1).min()) == 0xCD and int(fs2.frame_host(slot=0, index=3).max()) == 0xCD
