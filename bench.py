@@ -181,9 +181,27 @@ def main():
                 traffic = json.load(open(tpath)).get("%s_n%d" % (kernel, world))
             except Exception:
                 traffic = None
-        return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
-                "kernel_ms": round(m["kern_ms"], 4), "tests_per_launch": m["my_tests"], "note": note}
+        out = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
+               "kernel_ms": round(m["kern_ms"], 4), "tests_per_launch": m["my_tests"], "note": note}
+        if traffic:
+            # the physical figure beside the logical one: measured HBM bytes per launch over the live kernel time
+            out["traffic_GBs"] = round(traffic / (m["kern_ms"] * 1e-3) / 1e9, 1)
+            out["traffic_frac_of_peak"] = round(traffic / (m["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        spath = os.path.join(ROOT, "profiles", "roofline_sq.json")
+        if os.path.exists(spath):
+            try:
+                sq = json.load(open(spath)).get("%s_n%d" % (kernel, world))
+            except Exception:
+                sq = None
+            if sq and sq.get("valu_insts"):
+                # what actually limits the kernel: VALU issue (one wave64 VALU instruction occupies a SIMD for 4 cycles)
+                cyc = m["kern_ms"] * 1e-3 * 2.4e9
+                out["valu_issue"] = {"valu_insts_per_launch": sq["valu_insts"], "salu_insts_per_launch": sq.get("salu_insts"),
+                                     "frac": round(sq["valu_insts"] * 4 / 1024 / cyc, 4),
+                                     "note": "SQ_INSTS_VALU per launch (profiles/, rocprofv3 --pmc) x 4 cycles / 1024 SIMDs "
+                                             "over the live kernel time at 2.4 GHz"}
+        return out
 
     head_trav = rta.RT_TRAVERSAL_SKIP if args.traversal == "skip" else rta.RT_TRAVERSAL_FLAT
     m = measure(head_trav, args.steps, args.warmup)

@@ -283,8 +283,8 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
     if (st != RT_OK) return st;
     s->n_nodes = (uint32_t)raw.size();
     // fused: every BOUND directly followed by an ITEM with the same centre, bit for bit (then the values v, b, b*b - vv a
-    // ray forms for the two are the same bits).  f32 only: the assembly loops are the only users.
-    bool fused = sizeof(T) == 4 && !raw.empty();
+    // ray forms for the two are the same bits).
+    bool fused = !raw.empty();
     for (size_t i = 0; fused && i < raw.size(); ++i)
         if (raw[i].skip != 0u)
             fused = i + 1 < raw.size() && raw[i + 1].skip == 0u && memcmp(&raw[i].cx, &raw[i + 1].cx, 3 * sizeof(T)) == 0;
@@ -502,7 +502,7 @@ int skip_variant(const rt_scene *s)
     int v = 1 | 2 | 4;
     if (const char *e = getenv("RT_SKIP_VARIANT")) v = atoi(e) & 7;
     if (!s->fused || !(v & 2)) v &= ~4;
-    if ((v & 3) == 3 && s->precision == RT_F32 && getenv("RT_WAVE_TRACE")) v |= 8;      // diagnostic build of the assembly variants
+    if ((v & 3) == 3 && getenv("RT_WAVE_TRACE")) v |= 8;      // diagnostic build of the assembly variants
     return v;
 }
 

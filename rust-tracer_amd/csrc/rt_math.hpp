@@ -47,7 +47,7 @@ template <typename T> __device__ __forceinline__ T dot(V3<T> a, V3<T> b) { retur
 // vec.rs:87-95: multiply by len.recip(), a true division
 template <typename T> __device__ __forceinline__ V3<T> normalized(V3<T> a)
 {
-    T len = rsqrt_exact(dot(a, a));
+    T len = sqrt_rn_lean(dot(a, a));       // == rsqrt_exact for every input (rt_selftest_sqrt), fewer instructions in f32
     return mulf(a, T(1.0) / len);
 }
 
@@ -74,6 +74,15 @@ template <typename T> __device__ __forceinline__ unsigned scale_u8(T v)
     if (r > T(255.0)) return 255u;
     if (!(r > T(0.0))) return 0u;          // Rust `as u8` saturates, NaN -> 0
     return (unsigned)r;                    // toward zero
+}
+// Same value without branches: v_cvt_u32_f32 truncates toward zero and saturates (r <= 0 and NaN -> 0, huge -> 2^32-1), and
+// every r > 255 truncates to >= 255.
+template <> __device__ __forceinline__ unsigned scale_u8<float>(float v)
+{
+    const float r = 0.5f + 255.0f * v;
+    unsigned u;
+    asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(u) : "v"(r));
+    return min(u, 255u);
 }
 
 }  // namespace rt

@@ -28,9 +28,9 @@ namespace rt {
 // sphere's rr and item index, so the assembly loops can test it inside the BOUND step (rt_skip_rot.hpp).
 template <typename T> struct alignas(sizeof(T) * 8) Node {
     T a0, a1, a2, a3, a4;
-    uint32_t own_rr;        // f32 bits of rr of the group's own sphere (fused scenes, BOUND nodes; f32 streams only)
     uint32_t item;          // ITEM: index into the DFS items.  Fused BOUND: the index of the group's own sphere.
     uint32_t skip_off;
+    T own_rr;               // rr of the group's own sphere (fused scenes, BOUND nodes)
     __device__ __forceinline__ bool is_bound() const { return skip_off != 0u; }
     __device__ __forceinline__ unsigned skip() const { return skip_off / (unsigned)sizeof(Node); }   // as a node index
 };
@@ -60,12 +60,12 @@ __global__ void k_build_streams(const RawNode<T> *__restrict__ raw, unsigned n, 
     const RawNode<T> r = raw[i];
     const V3<T> v = { r.cx - eye.x, r.cy - eye.y, r.cz - eye.z };      // primitive.rs:56
     const T rr = r.r * r.r;                                           // primitive.rs:58
-    Node<T> p; p.a0 = v.x; p.a1 = v.y; p.a2 = v.z; p.a3 = dot(v, v); p.a4 = rr; p.own_rr = 0u; p.item = r.item;
-    Node<T> s; s.a0 = r.cx; s.a1 = r.cy; s.a2 = r.cz; s.a3 = rr; s.a4 = T(0); s.own_rr = 0u; s.item = r.item;
+    Node<T> p; p.a0 = v.x; p.a1 = v.y; p.a2 = v.z; p.a3 = dot(v, v); p.a4 = rr; p.own_rr = T(0); p.item = r.item;
+    Node<T> s; s.a0 = r.cx; s.a1 = r.cy; s.a2 = r.cz; s.a3 = rr; s.a4 = T(0); s.own_rr = T(0); s.item = r.item;
     p.skip_off = s.skip_off = r.skip * (unsigned)sizeof(Node<T>);
     if (fused && r.skip != 0u) {                                      // the ITEM behind this BOUND has the same centre
         const RawNode<T> own = raw[i + 1];
-        p.own_rr = s.own_rr = __float_as_uint((float)(own.r * own.r));   // fused streams are f32: the cast is the identity
+        p.own_rr = s.own_rr = own.r * own.r;                          // primitive.rs:58
         p.item = s.item = own.item;
     }
     prim[i] = p;
@@ -93,7 +93,7 @@ constexpr unsigned kNever = 0xFFFFFFFFu;
 
 // VAR bits (all bit-identical in output and counters):
 //   1 = sqrt_rn_lean in the C++ loops (same value as the IEEE sqrt for every input, about half the instructions)
-//   2 = (f32, launches that do not count tests) the generated assembly traversal loops, rt_skip_rot.hpp
+//   2 = (launches that do not count tests) the generated assembly traversal loops, rt_skip_rot.hpp
 //   4 = (with 2; fused scenes only) their fused flavour
 //   8 = wave trace (diagnostic, RT_WAVE_TRACE): every wave records when and where it ran into `lane_cost`
 //
@@ -184,9 +184,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             unsigned best_item = 0;
             unsigned resume = inside ? 0u : kNever;
             unsigned i = 0;
-            if constexpr ((VAR & 2) && !COUNT && sizeof(T) == 4) {
-                if constexpr ((VAR & 4) != 0) skip_primary_rot_fused(sc.prim, n * 32u, dir.x, dir.y, dir.z, resume, best, best_item);
-                else skip_primary_rot(sc.prim, n * 32u, dir.x, dir.y, dir.z, resume, best, best_item);
+            if constexpr ((VAR & 2) && !COUNT) {
+                constexpr unsigned kStride = (unsigned)sizeof(Node<T>);    // the assembly loops count in bytes
+                if constexpr ((VAR & 4) != 0) skip_primary_rot_fused(sc.prim, n * kStride, dir.x, dir.y, dir.z, resume, best, best_item);
+                else skip_primary_rot(sc.prim, n * kStride, dir.x, dir.y, dir.z, resume, best, best_item);
             } else {
             Node<T> nd = sc.prim[0];                                    // wave-uniform record -> SGPRs
             for (;;) {
@@ -256,9 +257,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             bool occluded = false;
             resume = need_shadow ? 0u : kNever;
             i = 0;
-            if constexpr ((VAR & 2) && !COUNT && sizeof(T) == 4) {
+            if constexpr ((VAR & 2) && !COUNT) {
                 if (__ballot(need_shadow) != 0) {
-                    const unsigned nb = n * 32u;                    // the assembly loops count in bytes
+                    constexpr unsigned kStride = (unsigned)sizeof(Node<T>);
+                    const unsigned nb = n * kStride;                // the assembly loops count in bytes
                     while (i < nb) {
                         unsigned fin;
                         if constexpr ((VAR & 4) != 0) i = skip_shadow_rot_fused(sc.shad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                         if (fin) { occluded = true; resume = kNever; }
                         // some lane retired at the ITEM at i: go straight to the next node any lane still wants
                         i = (unsigned)__builtin_amdgcn_readfirstlane(
-                            (int)wave_min_u32(resume == kNever ? kNever : (resume > i ? resume : i + 32u)));
+                            (int)wave_min_u32(resume == kNever ? kNever : (resume > i ? resume : i + kStride)));
                     }
                 }
             } else if (__ballot(need_shadow) != 0) {

@@ -551,8 +551,9 @@ def test_more_distinct_tile_lists_than_the_table_cache_holds(trav):
 
 @pytest.mark.parametrize("variant", [0, 1, 3, 7])
 @pytest.mark.parametrize("concentric", [False, True], ids=["nested", "concentric"])
+@pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64], ids=["f32", "f64"])
 @pytest.mark.parametrize("seed", [11, 12, 13])
-def test_every_skip_loop_flavour_on_deep_random_scenes(variant, concentric, seed):
+def test_every_skip_loop_flavour_on_deep_random_scenes(variant, concentric, precision, seed):
     # RT_SKIP_VARIANT picks the traversal-loop flavour explicitly (0/1 C++ loops, 3 generated assembly loops, 7 their fused
     # flavour -- used for concentric scenes only, the library drops the bit otherwise; the default is 7).  Deeper, wider
     # random trees with loose bounds and an eye inside some bounds: culling decides pixels, many lanes retire at different
@@ -560,7 +561,7 @@ def test_every_skip_loop_flavour_on_deep_random_scenes(variant, concentric, seed
     import ctypes
     libc = ctypes.CDLL(None)
     items, bounds, ranges = util.random_nested_scene(seed, depth=4, fan=4, leaf_items=2, concentric=concentric)
-    s, o = util.scene_pair_ranges(items, bounds, ranges, eye=(0.05, -0.1, -2.2))
+    s, o = util.scene_pair_ranges(items, bounds, ranges, precision, eye=(0.05, -0.1, -2.2))
     assert s.device().traits() == rta.capi.RT_SCENE_HAS_BOUNDS | (rta.capi.RT_SCENE_CONCENTRIC if concentric else 0)
     regs = bucket_list(192, 160, 2)
     ref, rst, _ = o.render(192, 160, 2, os.cpu_count() or 1, HIER_EXIT)

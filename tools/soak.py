@@ -45,7 +45,8 @@ while time.time() < t_end:
     depth, fan, leaf = int(rng.integers(2, 6)), int(rng.integers(2, 5)), int(rng.integers(1, 4))
     items, bounds, ranges = util.random_nested_scene(seed, depth=depth, fan=fan, leaf_items=leaf, concentric=seed % 2 == 1)
     eye = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-4.5, -1.0)))
-    sc = rta.Scene(items, rta.normalized((-1, -3, 2)), eye, bounds, ranges)
+    prec = rta.RT_F64 if seed % 4 == 3 else rta.RT_F32
+    sc = rta.Scene(items, rta.normalized((-1, -3, 2), prec), eye, bounds, ranges, prec)
     dv = sc.device()
     w, h, spp = int(rng.integers(3, 9)) * 32, int(rng.integers(3, 9)) * 24, int(rng.integers(1, 3))
     regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]

@@ -35,6 +35,13 @@ def main():
             d["derived_avg_waves_per_simd"] = d["SQ_WAVE_CYCLES"] * 4 / cyc / 1024
             d["derived_valu_insts_per_wave"] = d["SQ_INSTS_VALU"] / d["SQ_WAVES"]
     json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_sq.json"), "w"), indent=1, sort_keys=True)
+    # what bench.py quotes beside its live timing (instruction counts per launch do not depend on the clock)
+    quote = {"_source": "tools/summarize_sq.py from rocprofv3 --pmc SQ_* passes, tag " + tag}
+    for k, d in out.items():
+        if "SQ_INSTS_VALU" in d:
+            quote[k + "_n1"] = {"valu_insts": d["SQ_INSTS_VALU"], "salu_insts": d.get("SQ_INSTS_SALU"), "smem_insts": d.get("SQ_INSTS_SMEM"),
+                                "waves": d.get("SQ_WAVES")}
+    json.dump(quote, open(os.path.join(ROOT, "profiles", "roofline_sq.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))
 
 
