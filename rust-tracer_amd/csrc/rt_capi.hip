@@ -93,7 +93,7 @@ struct rt_scene {
     // Immutable device copies of recently used tile tables (a scheduler re-submits the same bucket list every
     // frame): a hit means a pass enqueues nothing but its kernel.
     // dev_order: one descriptor per 16x16 block of the pass, most expensive first (block_order below), or NULL.
-    struct CachedTable { std::vector<rt::TileDev> host; unsigned w = 0, h = 0; rt::TileDev *dev = nullptr; rt::BlockDesc *dev_order = nullptr; uint32_t n_order = 0; };
+    struct CachedTable { std::vector<rt::TileDev> host; unsigned w = 0, h = 0, passes = 0; rt::TileDev *dev = nullptr; rt::BlockDesc *dev_order = nullptr; uint32_t n_order = 0; };
     std::vector<CachedTable> tables;
     // Tests per primary ray (its shadow ray included) on a kCostRes x kCostRes grid over the camera's field of view,
     // rendered once per scene with the counting kernel.  It only ever decides the ORDER in which blocks are dispatched.
@@ -309,6 +309,9 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
     return RT_OK;
 }
 
+// spp > 1 runs sample-parallel (one thread per sample + a resolve pass) unless spp*spp exceeds grid.y's limit.
+bool use_split(unsigned spp) { return spp > 1 && (unsigned long long)spp * spp <= 65535ull; }
+
 constexpr size_t kMaxCachedTables = 32;
 
 // Device copy of `tab`: from the scene's cache when seen before (or cacheable now), else through the context.
@@ -387,8 +390,11 @@ const std::vector<uint32_t> *cost_map_of(rt_scene *s)
 constexpr size_t kNarrowMax = 64;
 constexpr uint64_t kNarrowPercent = 60;
 constexpr size_t kNarrowPassBlocks = 16384;
+constexpr size_t kNarrowLevel2Blocks = 4096;
 
-void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev> &tab, unsigned w, unsigned h, std::vector<rt::BlockDesc> &descs)
+// `passes`: how many times the render kernel walks the list in one launch (one per sample in the sample-parallel path).
+void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev> &tab, unsigned w, unsigned h, unsigned passes,
+                 std::vector<rt::BlockDesc> &descs)
 {
     constexpr int R = (int)kCostRes;
     std::vector<uint32_t> cost;
@@ -426,17 +432,19 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
     if (map && !cost.empty()) {
         const char *e = getenv("RT_NARROW_MAX");
         // a pass of more blocks than kNarrowPassBlocks is throughput-bound: narrowing only adds work there (3840x2160 + 2 %)
-        const size_t cap = e ? (size_t)atoi(e) : order.size() > kNarrowPassBlocks ? 0 : std::min<size_t>(kNarrowMax, order.size() / 128);
+        const size_t cap = e ? (size_t)atoi(e) : order.size() * passes > kNarrowPassBlocks ? 0 : std::min<size_t>(kNarrowMax, order.size() / 128);
         const uint64_t top = cost[order[0]];
         while (n_narrow < order.size() && n_narrow < cap && cost[order[n_narrow]] > 0 && (uint64_t)cost[order[n_narrow]] * 100 >= top * kNarrowPercent)
             ++n_narrow;
     }
     descs.clear();
-    descs.reserve(order.size() + 3 * n_narrow);
+    descs.reserve(order.size() + 15 * n_narrow);
     for (size_t i = 0; i < order.size(); ++i) {
         const rt::BlockDesc &d = raster[order[i]];
         if (i >= n_narrow) { descs.push_back(d); continue; }
-        const unsigned level = 1u, step = 16u >> level, cnt = 1u << level;     // level 2 (2x2 pixels per wave) measured slower
+        // 4x4 pixels per wave; 2x2 in a pass so small that its waves all start at once anyway (800x600: 63 -> 52 us; at 1080p the
+        // sixteen-fold wave count of 2x2 costs more throughput than the shorter chains buy)
+        const unsigned level = order.size() * passes <= kNarrowLevel2Blocks ? 2u : 1u, step = 16u >> level, cnt = 1u << level;
         for (unsigned qy = 0; qy < cnt; ++qy)
             for (unsigned qx = 0; qx < cnt; ++qx) {
                 rt::BlockDesc n = d;
@@ -458,12 +466,13 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
 {
     const size_t bytes = tab.size() * sizeof(rt::TileDev);
     const unsigned w = o ? o->width : 0u, h = o ? o->height : 0u;
+    const unsigned passes = (o && use_split(o->samples_per_pixel)) ? (unsigned)o->samples_per_pixel * o->samples_per_pixel : 1u;
     if (order_out) *order_out = rt::BlockList{};
     const std::vector<uint32_t> *map = (o && order_out) ? cost_map_of(s) : nullptr;     // before taking the lock: it renders
     {
         std::lock_guard<std::mutex> lk(s->mu);
         for (auto &t : s->tables)
-            if ((!o || (t.w == w && t.h == h)) && t.host.size() == tab.size() && memcmp(t.host.data(), tab.data(), bytes) == 0) {
+            if ((!o || (t.w == w && t.h == h && t.passes == passes)) && t.host.size() == tab.size() && memcmp(t.host.data(), tab.data(), bytes) == 0) {
                 *out = t.dev;
                 if (order_out && block_order_enabled()) *order_out = rt::BlockList{ t.dev_order, t.n_order };
                 return RT_OK;
@@ -475,13 +484,13 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
             if (e != hipSuccess) { (void)hipFree(t.dev); return hip_fail(e, "hipMemcpy(tile table)", __LINE__); }
             if (o && order_out) {
                 std::vector<rt::BlockDesc> order;
-                block_order(map, tab, w, h, order);
+                block_order(map, tab, w, h, passes, order);
                 e = hipMalloc(&t.dev_order, order.size() * sizeof(rt::BlockDesc));
                 if (e == hipSuccess) e = hipMemcpy(t.dev_order, order.data(), order.size() * sizeof(rt::BlockDesc), hipMemcpyHostToDevice);
                 if (e != hipSuccess) { (void)hipFree(t.dev); if (t.dev_order) (void)hipFree(t.dev_order); return hip_fail(e, "block order", __LINE__); }
                 t.n_order = (uint32_t)order.size();
             }
-            t.host = tab; t.w = w; t.h = h;
+            t.host = tab; t.w = w; t.h = h; t.passes = passes;
             *out = t.dev;
             if (order_out && block_order_enabled()) *order_out = rt::BlockList{ t.dev_order, t.n_order };
             s->tables.push_back(std::move(t));
@@ -506,8 +515,6 @@ int skip_variant(const rt_scene *s)
     return v;
 }
 
-// spp > 1 runs sample-parallel (one thread per sample + a resolve pass) unless spp*spp exceeds grid.y's limit.
-bool use_split(unsigned spp) { return spp > 1 && (unsigned long long)spp * spp <= 65535ull; }
 
 // (Re)allocates the context's per-sample buffers {n.light, state} for `samples` samples of REAL size `esz`.
 rt_status ensure_sample_buffers(Context *c, size_t samples, size_t esz)

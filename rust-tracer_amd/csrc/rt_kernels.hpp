@@ -32,7 +32,7 @@ static_assert(sizeof(BlockDesc) == 16, "one s_load_dwordx4");
 // a block and each of the workgroup's four waves traces a 4x4 patch with 16 live lanes.  A wave walks the union of its rays'
 // nodes and the pass is as long as its longest wave, so the few most expensive blocks are dealt out as four such workgroups
 // each: their chains get ~17 % shorter (1080p: 74 -> 66 us with the ~30 heaviest blocks narrowed; narrowing hundreds costs
-// throughput, and 2x2 patches (level 2) cost more than they shorten).
+// throughput).  Level 2 (2x2 patches, sixteen workgroups per block) is used in passes too small to fill the chip.
 constexpr uint32_t kBlockNarrowShift = 16;       // pitch >> 16: 0 full, 1: 4x4 pixels per wave, 2: 2x2
 struct BlockList { const BlockDesc *d = nullptr; uint32_t n = 0; };
 
