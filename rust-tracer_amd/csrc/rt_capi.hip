@@ -311,6 +311,13 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
 
 // spp > 1 runs sample-parallel (one thread per sample + a resolve pass) unless spp*spp exceeds grid.y's limit.
 bool use_split(unsigned spp) { return spp > 1 && (unsigned long long)spp * spp <= 65535ull; }
+// spp 2 / 4 / 8: the samples of a pixel fill 4 / 16 / 64 lanes of a wave (rt_skip.hpp, kSkipPacked); RT_PACKED_SAMPLES=0
+// switches it off for A/B runs
+bool packed_samples(unsigned spp)
+{
+    const char *e = getenv("RT_PACKED_SAMPLES");
+    return (spp == 2 || spp == 4 || spp == 8) && !(e && e[0] == '0');
+}
 
 constexpr size_t kMaxCachedTables = 32;
 
@@ -432,7 +439,8 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
     if (map && !cost.empty()) {
         const char *e = getenv("RT_NARROW_MAX");
         // a pass of more blocks than kNarrowPassBlocks is throughput-bound: narrowing only adds work there (3840x2160 + 2 %)
-        const size_t cap = e ? (size_t)atoi(e) : order.size() * passes > kNarrowPassBlocks ? 0 : std::min<size_t>(kNarrowMax, order.size() / 128);
+        // (and only in single-pass launches: the packed sample-parallel mapping has its own, finer ray packets)
+        const size_t cap = passes > 1 ? 0 : e ? (size_t)atoi(e) : order.size() > kNarrowPassBlocks ? 0 : std::min<size_t>(kNarrowMax, order.size() / 128);
         const uint64_t top = cost[order[0]];
         while (n_narrow < order.size() && n_narrow < cap && cost[order[n_narrow]] > 0 && (uint64_t)cost[order[n_narrow]] * 100 >= top * kNarrowPercent)
             ++n_narrow;
@@ -444,7 +452,7 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
         if (i >= n_narrow) { descs.push_back(d); continue; }
         // 4x4 pixels per wave; 2x2 in a pass so small that its waves all start at once anyway (800x600: 63 -> 52 us; at 1080p the
         // sixteen-fold wave count of 2x2 costs more throughput than the shorter chains buy)
-        const unsigned level = order.size() * passes <= kNarrowLevel2Blocks ? 2u : 1u, step = 16u >> level, cnt = 1u << level;
+        const unsigned level = order.size() <= kNarrowLevel2Blocks ? 2u : 1u, step = 16u >> level, cnt = 1u << level;
         for (unsigned qy = 0; qy < cnt; ++qy)
             for (unsigned qx = 0; qx < cnt; ++qx) {
                 rt::BlockDesc n = d;
@@ -567,7 +575,7 @@ rt_status launch_flat_wavefront(const rt_scene *s, Context *c, hipStream_t strea
     hipLaunchKernelGGL((rt::k_flat_shadow<T, CHUNK>), gshadow, b, 0, stream, view, (unsigned)CHUNK, 0xFFFFFFFFu, q2, &c->d_queues->n2,
                        (rt::Quad<T> *)nullptr, (unsigned *)nullptr, sb, cnt);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL((rt::k_resolve_samples<T>), dim3(blocks16), b, 0, stream, sb, spp, d_tab16, nt, d_out, frame_w);
+    hipLaunchKernelGGL((rt::k_resolve_samples<T>), dim3(blocks16), b, 0, stream, sb, spp, d_tab16, nt, d_out, frame_w, false);
     return RT_OK;
 }
 
@@ -616,10 +624,15 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     }
     sb.gdot = static_cast<T *>(c->d_sample_gdot);
     sb.state = c->d_sample_state;
-    hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipSplit>), dim3(rgrid.x, (unsigned)ns), b, 0, stream, skip_view_of<T>(s), w, h, spp, d_tab,
-                       nt, d_out, cnt, sb, frame_w, order.d, no_cost);
+    const bool packed = packed_samples(spp);
+    if (packed)
+        hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipPacked>), dim3(rgrid.x, (unsigned)ns), b, 0, stream, skip_view_of<T>(s), w, h, spp,
+                           d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost);
+    else
+        hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipSplit>), dim3(rgrid.x, (unsigned)ns), b, 0, stream, skip_view_of<T>(s), w, h, spp,
+                           d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL((rt::k_resolve_samples<T>), grid, b, 0, stream, sb, spp, d_tab, nt, d_out, frame_w);
+    hipLaunchKernelGGL((rt::k_resolve_samples<T>), grid, b, 0, stream, sb, spp, d_tab, nt, d_out, frame_w, packed);
     return RT_OK;
 }
 

@@ -106,7 +106,12 @@ constexpr unsigned kNever = 0xFFFFFFFFu;
 // MODE: kSkipLoop = SPLIT false, any spp; kSkipSplit = SPLIT true; kSkipOne = SPLIT false with spp == 1 known at compile
 //   time (x + 0/1 == x, v * (1/(1*1)) == v and alpha * 1 == alpha bit for bit, so three IEEE divisions and the multiplies
 //   by 1.0 leave the per-wave prologue / epilogue -- a fifth of all VALU work of a 1080p frame is outside the loops).
-enum { kSkipLoop = 0, kSkipSplit = 1, kSkipOne = 2 };
+//   kSkipPacked = sample-parallel like kSkipSplit, for spp*spp in {4, 16, 64}: a wave's lanes enumerate the SAMPLES of a
+//   few neighbouring pixels (spp 4: 2x2 pixels x 16 samples) instead of one sample of 8x8 pixels; blockIdx.y picks the
+//   sub-block of the 16x16 block.  A wave walks the union of its rays' nodes, and 64 rays through four pixels share far more
+//   of their walk than 64 rays spread over 64 pixels (`make image`: 0.39 -> see DESIGN.md); samples are stored
+//   [pixel][sample], so a wave's stores are one contiguous run.
+enum { kSkipLoop = 0, kSkipSplit = 1, kSkipOne = 2, kSkipPacked = 3 };
 template <typename T, bool COUNT, int VAR, int MODE>
 __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, unsigned width, unsigned height, unsigned spp_arg,
                                                               const TileDev *__restrict__ tiles, unsigned n_tiles,
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                                                               SampleBuf<T> sb, unsigned frame_w,
                                                               const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost)
 {
-    constexpr bool SPLIT = MODE == kSkipSplit, ONE = MODE == kSkipOne;
+    constexpr bool PACKED = MODE == kSkipPacked, SPLIT = MODE == kSkipSplit || PACKED, ONE = MODE == kSkipOne;
     const unsigned spp = ONE ? 1u : spp_arg;
     // `order` (optional): one descriptor per workgroup in dispatch order, most expensive block first -- a pass is as long
     // as its last wave, so the long chains must not be the ones dispatched last (rt_capi.hip, block_order).  Without it
@@ -140,10 +145,25 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     }
     const unsigned gblock = blockIdx.x;
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned pw = 8u >> level, pbits = 3u - level;          // wave patch: pw x pw pixels in the first pw*pw lanes
-    const unsigned x = bx0 + (wave & 1) * pw + (lane & (pw - 1));
-    const unsigned y = by0 + (wave >> 1) * pw + ((lane >> pbits) & (pw - 1));
-    const bool inside = x < tile_r && y < tile_t && lane < pw * pw;
+    unsigned x, y, sample = 0;
+    bool inside;
+    if (PACKED) {
+        // spp 2 / 4 / 8: 4 / 16 / 64 samples per pixel, so a wave holds 4x4 / 2x2 / 1 pixels and the workgroup a sub-block of
+        // 8x8 / 4x4 / 2x2 pixels -- spp x spp sub-blocks per 16x16 block, picked by blockIdx.y
+        const unsigned ns = spp * spp, lg = 31u - (unsigned)__builtin_clz(ns);
+        const unsigned ppw = 8u >> (lg >> 1), pb = 3u - (lg >> 1);          // wave patch: ppw x ppw pixels
+        const unsigned pi = lane >> lg;
+        sample = lane & (ns - 1u);
+        x = bx0 + (blockIdx.y % spp) * 2u * ppw + (wave & 1) * ppw + (pi & (ppw - 1u));
+        y = by0 + (blockIdx.y / spp) * 2u * ppw + (wave >> 1) * ppw + (pi >> pb);
+        inside = x < tile_r && y < tile_t;
+    } else {
+        const unsigned pw = 8u >> level, pbits = 3u - level;      // wave patch: pw x pw pixels in the first pw*pw lanes
+        x = bx0 + (wave & 1) * pw + (lane & (pw - 1));
+        y = by0 + (wave >> 1) * pw + ((lane >> pbits) & (pw - 1));
+        inside = x < tile_r && y < tile_t && lane < pw * pw;
+        sample = blockIdx.y;
+    }
     if (__ballot(inside) == 0) return;          // waves are independent here: no LDS, no barrier
 
     unsigned long long t_start = 0, r_start = 0;
@@ -171,9 +191,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     T alpha = T(0.0);
     unsigned c_hits = 0, c_shadow = 0, c_occ = 0, c_items = 0, c_bounds = 0, c_steps = 0;
 
-    const unsigned ss_first = SPLIT ? blockIdx.y / spp : 0u, ss_last = SPLIT ? ss_first + 1 : spp;
+    const unsigned ss_first = SPLIT ? sample / spp : 0u, ss_last = SPLIT ? ss_first + 1 : spp;
     for (unsigned ssx = ss_first; ssx < ss_last; ++ssx) {
-        for (unsigned ssy = SPLIT ? blockIdx.y % spp : 0u; ssy < (SPLIT ? blockIdx.y % spp + 1 : spp); ++ssy) {
+        for (unsigned ssy = SPLIT ? sample % spp : 0u; ssy < (SPLIT ? sample % spp + 1 : spp); ++ssy) {
             const T xres = ONE ? T(x) : T(x) + T(ssx) / ssf;
             const T yres = ONE ? T(y) : T(y) + T(ssy) / ssf;
             V3<T> dir = { xres - half_w, (fh - yres) - half_h, fw };
@@ -323,7 +343,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                 }
             }
             if (SPLIT && inside) {
-                const size_t p = (size_t)blockIdx.y * sb.n_px + (size_t)(base + y * pitch + x);
+                const size_t px_i = (size_t)(base + y * pitch + x);
+                const size_t p = PACKED ? px_i * (spp * spp) + sample : (size_t)sample * sb.n_px + px_i;
                 sb.gdot[p] = gdot;
                 sb.state[p] = state;
             }
@@ -372,7 +393,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
 // in the reference's order (ssx outer, ssy inner; each term added on its own, never pre-summed), then quantised.
 template <typename T>
 __global__ __launch_bounds__(kBlockThreads) void k_resolve_samples(SampleBuf<T> sb, unsigned spp, const TileDev *__restrict__ tiles,
-                                                                  unsigned n_tiles, uint8_t *__restrict__ out, unsigned frame_w)
+                                                                  unsigned n_tiles, uint8_t *__restrict__ out, unsigned frame_w,
+                                                                  bool packed)      // samples stored [pixel][sample], not [sample][pixel]
 {
     unsigned lo = 0, hi = n_tiles - 1;
     while (lo < hi) {
@@ -394,7 +416,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_resolve_samples(SampleBuf<T> 
     T alpha = T(0.0);
     const unsigned ns = spp * spp;
     for (unsigned k = 0; k < ns; ++k) {
-        const size_t q = (size_t)k * sb.n_px + p;
+        const size_t q = packed ? p * ns + k : (size_t)k * sb.n_px + p;
         const uint8_t st = sb.state[q];
         const T gdot = sb.gdot[q];
         if (st == kMiss) g = add(g, BACKGROUND);                                        // render.rs:191
