@@ -164,3 +164,15 @@ def test_header_is_plain_c_and_the_library_links_from_c(tmp_path):
     offs = " ".join("%s %d" % (n, getattr(capi.Stats, n).offset) for n, _ in capi.Stats._fields_)
     assert "offsets stats: " + offs in out.stdout
     assert ctypes.sizeof(capi.Options) == 6 and ctypes.sizeof(capi.Region) == 8 and ctypes.sizeof(capi.Range) == 8
+
+
+def test_generated_traversal_loops_are_up_to_date(tmp_path):
+    # csrc/rt_skip_rot.hpp is the output of tools/gen_skip_asm.py: the committed header must be what the generator writes
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_skip_asm", os.path.join(ROOT, "tools", "gen_skip_asm.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(gen.OUT).read()
+    gen.OUT = str(tmp_path / "rt_skip_rot.hpp")
+    gen.main()
+    assert open(gen.OUT).read() == committed
