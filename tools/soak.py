@@ -60,4 +60,6 @@ while time.time() < t_end:
     dv.close()
     checked += 1
     seed += 1
+    if checked % 2000 == 0:
+        print("fuzz: %d scenes so far" % checked, flush=True)        # a long run must not look hung
 print("fuzz: %d random scenes, all flavours identical" % checked)
