@@ -632,3 +632,32 @@ def test_100k_arbitrary_spheres_with_auto_built_hierarchy():
     for (l, t, r, b) in ((192, 256, 256, 192), (320, 128, 384, 64)):
         fref, _ = o.render_region(512, 384, 1, l, t, r, b, oracle.MODE_FLAT)
         np.testing.assert_array_equal(frame[b:t, l:r], fref)
+
+
+@pytest.mark.parametrize("narrow_max", [b"0", b"64"])
+def test_narrow_blocks_on_ragged_tiles(narrow_max):
+    # The most expensive 16x16 blocks of a pass go out as four (or, in a small pass, sixteen) narrow workgroups.  Here the
+    # expensive part of the image is covered by ragged 50x50 tiles (their last block row / column is clipped to 2 pixels), and
+    # up to 64 of the 256 blocks are narrowed: every pixel and every counter must equal the CPU path's, and the un-narrowed
+    # launch's.
+    import ctypes
+    libc = ctypes.CDLL(None)
+    s, o = rta.Scene.default(), oracle.Scene.default()      # a fresh device scene: its table cache has not seen this tile list
+    w, h = 1920, 1080
+    regs = [(x, y + 50, x + 50, y) for y in range(440, 640, 50) for x in range(860, 1060, 50)]
+    libc.setenv(b"RT_NARROW_MAX", narrow_max, 1)
+    try:
+        d = s.device()
+        plain, _ = d.render_tiles((w, h, 1), regs, SKIP, want_stats=False)
+        counted, st = d.render_tiles((w, h, 1), regs, SKIP, want_stats=True)
+    finally:
+        libc.unsetenv(b"RT_NARROW_MAX")
+    np.testing.assert_array_equal(counted, plain)
+    off, tot = 0, None
+    for (l, t, r, b) in regs:
+        ref, rst = o.render_region(w, h, 1, l, t, r, b, HIER_EXIT)
+        n = (r - l) * (t - b) * 4
+        np.testing.assert_array_equal(plain[off:off + n].reshape(t - b, r - l, 4), ref)
+        off += n
+        tot = util.all_stats(rst) if tot is None else tuple(a + c for a, c in zip(tot, util.all_stats(rst)))
+    assert util.all_stats(st) == tot
