@@ -281,6 +281,11 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
     std::vector<rt::RawNode<T>> raw;
     rt_status st = build_raw_stream<T>(static_cast<const T *>(items), s->n_items, static_cast<const T *>(bounds), ranges, s->n_bounds, raw);
     if (st != RT_OK) return st;
+    // the traversal loops address the streams with 32-bit byte offsets (two pad nodes included)
+    if (((uint64_t)raw.size() + 2) * sizeof(rt::Node<T>) > 0xFFFFFFFFull) {
+        snprintf(g_err, sizeof g_err, "rt_scene_create: %zu stream nodes exceed the 4 GiB the traversal streams can address", raw.size());
+        return RT_ERR_UNSUPPORTED;
+    }
     s->n_nodes = (uint32_t)raw.size();
     // fused: every BOUND directly followed by an ITEM with the same centre, bit for bit (then the values v, b, b*b - vv a
     // ray forms for the two are the same bits).
