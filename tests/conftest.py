@@ -29,7 +29,7 @@ def golden_dir():
 
 @pytest.fixture(autouse=True)
 def _check_both_launch_flavours(request, monkeypatch):
-    """The kernels have two flavours: with ray/test counters (C++ traversal loops) and without (hand-written f32
+    """The kernels have two flavours: with ray/test counters (C++ traversal loops) and without (generated assembly
     loops, the flavour bench.py and the async entry points use).  Every -m gpu test that renders with counters is
     made to render once more without them, and the bytes must be identical -- so all oracle comparisons cover both."""
     if request.node.get_closest_marker("gpu") is None:

@@ -477,7 +477,7 @@ def test_many_async_calls_in_flight_reuse_nothing_they_should_not():
 
 
 def test_repeated_and_concurrent_launches_are_bitwise_stable():
-    # the hand-written traversal loops must give the same bytes on every launch, also with several frames in flight on
+    # the assembly traversal loops must give the same bytes on every launch, also with several frames in flight on
     # different streams (different co-residency / timing): guards against an instruction-hazard slip in the assembly
     import torch
     s, o = util.scene_pair_default()
@@ -522,7 +522,7 @@ def test_config5_4096x4096_level9_spp4_selected_buckets():
 def test_tangent_ray_zero_discriminant(precision, trav):
     # pixel (32, 32) of a 64x64 image looks exactly along +z; for a sphere at (0.5, 0, -2) r 0.5 and the eye at (0, 0, -4)
     # the discriminant is EXACTLY 0 (4 - 4.25 + 0.25): the tangent hit goes through the small-input branch of the exact
-    # square root (the scaled path of the hand-written loops)
+    # square root (the scaled path of the assembly loops)
     spheres = [(0.5, 0.0, -2.0, 0.5), (-3.0, 2.0, 1.0, 0.75)]
     s, o = util.scene_pair_spheres(spheres, (0.0, 0.0, 0.0, 6.0), precision)
     d, pos = o.intersect((0, 0, -4, 0, 0, 1))
