@@ -661,3 +661,27 @@ def test_narrow_blocks_on_ragged_tiles(narrow_max):
         off += n
         tot = util.all_stats(rst) if tot is None else tuple(a + c for a, c in zip(tot, util.all_stats(rst)))
     assert util.all_stats(st) == tot
+
+
+@pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64], ids=["f32", "f64"])
+@pytest.mark.parametrize("spp", [2, 3, 4, 5, 8])
+def test_every_sample_count_on_a_ragged_image(spp, precision):
+    # spp 2 / 4 / 8 take the packed sample-parallel mapping (a wave = the samples of a few neighbouring pixels, samples stored
+    # [pixel][sample]); 3 and 5 the plain one (a wave = one sample of 8x8 pixels).  150x70 leaves clipped buckets, blocks and
+    # sub-blocks on both edges.  Pixels, alpha and every counter against the CPU path; the switch RT_PACKED_SAMPLES=0 must not
+    # change a byte.
+    import ctypes
+    libc = ctypes.CDLL(None)
+    s, o = util.scene_pair_default(precision)
+    w, h = 150, 70
+    regs = bucket_list(w, h, spp)
+    ref, rst, _ = o.render(w, h, spp, os.cpu_count() or 1, HIER_EXIT)
+    data, st = s.device().render_tiles((w, h, spp), regs, SKIP)
+    np.testing.assert_array_equal(util.stitch((w, h), regs, data), ref)
+    assert util.all_stats(st) == util.all_stats(rst)
+    libc.setenv(b"RT_PACKED_SAMPLES", b"0", 1)
+    try:
+        plain, _ = s.device().render_tiles((w, h, spp), regs, SKIP, want_stats=False)
+    finally:
+        libc.unsetenv(b"RT_PACKED_SAMPLES")
+    np.testing.assert_array_equal(plain, data)
