@@ -750,6 +750,7 @@ rt_status read_stats(rt_scene *s, Context *c, hipStream_t stream, rt_traversal t
         h.max_wave_steps = std::max(h.max_wave_steps, k.max_wave_steps);
         h.max_wave_cycles = std::max(h.max_wave_cycles, k.max_wave_cycles);
         h.max_wave_ref100mhz = std::max(h.max_wave_ref100mhz, k.max_wave_ref100mhz);
+        h.wave_item_steps += k.wave_item_steps;
     }
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -769,8 +770,8 @@ rt_status read_stats(rt_scene *s, Context *c, hipStream_t stream, rt_traversal t
         st->tests_executed = h.sphere_tests + h.bound_tests;
     }
     if (getenv("RT_DEBUG_STEPS"))
-        fprintf(stderr, "[rtrace_hip] wave_steps %llu max_wave_steps %llu longest wave: %llu cycles, %.2f us, %.0f MHz\n", h.wave_steps,
-                h.max_wave_steps, h.max_wave_cycles, h.max_wave_ref100mhz / 100.0,
+        fprintf(stderr, "[rtrace_hip] wave_steps %llu (%llu at ITEM nodes) max_wave_steps %llu longest wave: %llu cycles, %.2f us, %.0f MHz\n",
+                h.wave_steps, h.wave_item_steps, h.max_wave_steps, h.max_wave_cycles, h.max_wave_ref100mhz / 100.0,
                 h.max_wave_ref100mhz ? 100.0 * h.max_wave_cycles / h.max_wave_ref100mhz : 0.0);
     st->device_ms = ms;
     return RT_OK;

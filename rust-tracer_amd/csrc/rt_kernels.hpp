@@ -62,6 +62,7 @@ struct Counters {          // same meaning as the reference-side ray statistics
     unsigned long long sphere_tests, bound_tests;   // per-ray tests executed (SKIP traversal counts them exactly)
     unsigned long long wave_steps, max_wave_steps;  // SKIP: node visits summed over waves / of the busiest wave (diagnostic)
     unsigned long long max_wave_cycles, max_wave_ref100mhz;   // diagnostic: s_memtime / s_memrealtime span of the longest wave
+    unsigned long long wave_item_steps;                       // diagnostic: node visits that were ITEM nodes
 };
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned v)

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
 
     V3<T> g = { T(0.0), T(0.0), T(0.0) };
     T alpha = T(0.0);
-    unsigned c_hits = 0, c_shadow = 0, c_occ = 0, c_items = 0, c_bounds = 0, c_steps = 0;
+    unsigned c_hits = 0, c_shadow = 0, c_occ = 0, c_items = 0, c_bounds = 0, c_steps = 0, c_isteps = 0;
 
     const unsigned ss_first = SPLIT ? sample / spp : 0u, ss_last = SPLIT ? ss_first + 1 : spp;
     for (unsigned ssx = ss_first; ssx < ss_last; ++ssx) {
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                         ni = (__ballot(active && !cull) == 0) ? nd.skip() : i + 1;
                     } else {                                            // ITEM   primitive.rs:78-83
                         if (active && !(d >= best)) { best = d; best_item = nd.item; }
-                        if (COUNT) c_items += active ? 1u : 0u;
+                        if (COUNT) { c_items += active ? 1u : 0u; ++c_isteps; }
                         ni = i + 1;
                     }
                 }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                         ni = (__ballot(active && hit) == 0) ? nd.skip() : i + 1;
                     } else {
                         const bool fin = active && hit;
-                        if (COUNT) c_items += active ? 1u : 0u;
+                        if (COUNT) { c_items += active ? 1u : 0u; ++c_isteps; }
                         if (fin) { occluded = true; resume = kNever; }
                         if (__ballot(fin) != 0) {
                             // some lane retired: go straight to the next node any lane still wants
@@ -382,6 +382,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             atomicAdd(&counters->sphere_tests, its);
             atomicAdd(&counters->bound_tests, bds);
             atomicAdd(&counters->wave_steps, (unsigned long long)c_steps);
+            atomicAdd(&counters->wave_item_steps, (unsigned long long)c_isteps);
             atomicMax(&counters->max_wave_steps, (unsigned long long)c_steps);
             atomicMax(&counters->max_wave_cycles, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start));
             atomicMax(&counters->max_wave_ref100mhz, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r_start));
