@@ -54,34 +54,7 @@ def scene_pair_ranges(items, bounds, ranges, precision=rta.RT_F32, light=(-1.0, 
     return s, oracle.Scene.from_ranges(items, bounds, ranges, light, eye, PREC[precision])
 
 
-def random_nested_scene(seed, depth=3, fan=3, leaf_items=3, concentric=False):
-    """A random laminar tree (items and sub-groups interleaved in random order) with tight-ish random bounds:
-    some bounds do NOT enclose their subtree, so culling really changes results and order matters.
-    concentric: every group's FIRST child is an item at the centre of the group's bound (like the reference's pyramid,
-    group.rs:37-41) -- the scene shape for which the f32 traversal loops fuse the bound's step with that item's."""
-    rng = np.random.default_rng(seed)
-    items, bounds, ranges = [], [], []
-
-    def rec(d, centre, scale):
-        bi = len(bounds)
-        bounds.append(None); ranges.append(None)
-        first = len(items)
-        if concentric:
-            items.append((centre[0], centre[1], centre[2], float(rng.uniform(0.1, 0.5) * scale)))
-        kids = ["item"] * leaf_items + (["group"] * fan if d > 0 else [])
-        rng.shuffle(kids)
-        for k in kids:
-            c = centre + rng.uniform(-scale, scale, 3)
-            if k == "item":
-                items.append((c[0], c[1], c[2], float(rng.uniform(0.08, 0.35) * scale)))
-            else:
-                rec(d - 1, c, scale * 0.55)
-        bounds[bi] = (centre[0], centre[1], centre[2], float(scale * rng.uniform(1.2, 2.6)))
-        ranges[bi] = (first, len(items) - first)
-
-    rec(depth, np.array([0.0, 0.0, 0.0]), 1.2)
-    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
-    return f32(items), f32(bounds), np.asarray(ranges, dtype=np.int32)
+from tests.scenes import random_nested_scene  # noqa: E402,F401  (pure numpy; tools/soak.py uses it without the oracle)
 
 
 def all_stats(st):

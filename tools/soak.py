@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import rust_tracer_amd as rta
-from tests import util
+from tests import scenes as util        # numpy-only scene generators (the oracle is not loaded by this tool)
 
 libc = ctypes.CDLL(None)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
