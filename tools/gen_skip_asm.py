@@ -332,8 +332,12 @@ def emit_transitions(a, P, name, c, lab):
     emit_next(a, P, name)
 
 
-def candidates(a, P, hit_label):
+def live_mask(a, P):
+    """Issued before the terms: it depends on nothing they compute, and the chain disc -> compare -> branch stays short."""
     a.op("v_cmp_ge_u32_e64 %s, %s, %%[resume]" % (P.ACT, P.I), "active = i >= resume")
+
+
+def candidates(a, P, hit_label):
     P.cand_cmp(a)
     a.op("s_and_b64 vcc, vcc, %s" % P.ACT, "live lanes whose line meets the sphere")
     a.op("s_cbranch_vccnz %s" % hit_label)
@@ -360,6 +364,7 @@ def primary_copy(a, P, name, fused):
     a.op("s_cbranch_scc1 %s" % lab("item"))
     # ---------------- BOUND step (group.rs:73) ----------------
     bound_top(a, P, c, n, s, fused)
+    live_mask(a, P)
     P.primary_terms(a, c)
     candidates(a, P, lab("bhit"))
     emit_transitions(a, P, name, c, lab)   # nobody can hit the bound: jump (the lanes that culled it are awake again at `skip`)
@@ -387,6 +392,7 @@ def primary_copy(a, P, name, fused):
     a.label(lab("item"))
     a.op("s_add_u32 %s, %s, %d" % (P.NX, P.I, P.stride))
     P.load(a, n, P.NX)
+    live_mask(a, P)
     P.primary_terms(a, c)
     candidates(a, P, lab("ihit"))
     emit_next(a, P, name)                  # nobody can hit: an ITEM changes nothing
@@ -418,6 +424,7 @@ def shadow_copy(a, P, name, fused):
     a.op("s_cbranch_scc1 %s" % lab("item"))
     # ---------------- BOUND step: hit.distance is INF, so a bound culls iff the ray misses it ----------------
     bound_top(a, P, c, n, s, fused)
+    live_mask(a, P)
     P.shadow_terms(a, c)
     candidates(a, P, lab("bhit"))
     emit_transitions(a, P, name, c, lab)
@@ -447,6 +454,7 @@ def shadow_copy(a, P, name, fused):
     a.label(lab("item"))
     a.op("s_add_u32 %s, %s, %d" % (P.NX, P.I, P.stride))
     P.load(a, n, P.NX)
+    live_mask(a, P)
     P.shadow_terms(a, c)
     candidates(a, P, lab("ihit"))
     emit_next(a, P, name)
