@@ -1,0 +1,203 @@
+// valu_issue_probe.hip -- how many cycles does one wave64 vector instruction occupy a gfx950 SIMD for?
+//
+// Decides the VALU-issue roof of the render kernels (bench.py roofline.valu_issue): round 1 assumed 4 cycles per
+// wave64 VALU instruction whatever the occupancy; MI355X_MICROARCH.md says 2 cycles once a SIMD holds >= 2 waves.  This
+// program measures it for the instruction forms the traversal loops are made of, at 1 / 2 / 4 / 8 waves per SIMD on all
+// 1,024 SIMDs at once:
+//      independent v_mul_f32 / v_add_f32 (VGPR operands), the SGPR-operand form the loops use (node terms are SGPRs),
+//      v_fma_f32 (the guide's calibration row), packed v_pk_mul_f32 / v_pk_add_f32 (VGPR pairs, and an SGPR pair broadcast with
+//      op_sel_hi), v_cmp_*_e64 writing an SGPR pair, v_cndmask, v_sqrt_f32, a dependent v_add_f32 chain, a 50/50 VALU/SALU mix and
+//      the 10 VALU + 12 SALU mix of the commonest traversal step.
+// Every wave runs ITERS x 64 instructions of one kind between two s_memtime stamps (shader-clock cycles) and two
+// s_memrealtime stamps (100 MHz); with W co-resident waves per SIMD that all overlap, cycles per instruction per SIMD =
+// median wave cycles / (W x instructions per wave).  The HW_ID of every wave is recorded to check that the waves really sat
+// W to a SIMD.
+//
+//   hipcc -O2 --offload-arch=gfx950 -o valu_issue_probe tools/valu_issue_probe.hip && ./valu_issue_probe > profiles/r02_valu_issue_probe.json
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <vector>
+
+#define CHECK(x)                                                                                     \
+    do {                                                                                             \
+        hipError_t e_ = (x);                                                                         \
+        if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); }   \
+    } while (0)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+enum Kind { K_MUL, K_ADD, K_MUL_SGPR, K_FMA, K_PK_MUL, K_PK_ADD, K_PK_MUL_SGPR, K_CMP_E64, K_CNDMASK, K_SQRT, K_DEP_ADD, K_VALU_SALU,
+            K_STEP_MIX, K_PK_FMA, K_COUNT };
+
+static const char *kNames[K_COUNT] = {
+    "v_mul_f32 (VGPR x VGPR, independent)", "v_add_f32 (independent)", "v_mul_f32 (SGPR x VGPR, independent)", "v_fma_f32 (independent)",
+    "v_pk_mul_f32 (VGPR pairs, independent)", "v_pk_add_f32 (VGPR pairs, independent)", "v_pk_mul_f32 (SGPR pair x VGPR pair, op_sel_hi:[0,1])",
+    "v_cmp_lt_f32_e64 -> SGPR pair", "v_cndmask_b32 (vcc)", "v_sqrt_f32 (independent)", "v_add_f32 (dependent chain)",
+    "alternating v_mul_f32 / s_add_u32", "traversal-step mix: 10 VALU + 12 SALU per 22", "v_pk_fma_f32 (VGPR pairs, independent)" };
+// vector instructions per 64-instruction block (the rest are scalar)
+static const int kValuPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 32, 30, 64 };
+static const int kInstPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 66, 64 };
+
+#define R8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#define R64(M) R8(M) R8(M) R8(M) R8(M) R8(M) R8(M) R8(M) R8(M)
+
+#define I_MUL(k) "v_mul_f32_e32 %" #k ", %8, %" #k "\n"
+#define I_ADD(k) "v_add_f32_e32 %" #k ", %8, %" #k "\n"
+#define I_MULS(k) "v_mul_f32_e32 %" #k ", %9, %" #k "\n"
+#define I_FMA(k) "v_fma_f32 %" #k ", %8, %" #k ", %8\n"
+#define I_PKMUL(k) "v_pk_mul_f32 %" #k ", %8, %" #k "\n"
+#define I_PKADD(k) "v_pk_add_f32 %" #k ", %8, %" #k "\n"
+#define I_PKFMA(k) "v_pk_fma_f32 %" #k ", %8, %" #k ", %8\n"
+#define I_PKMULS(k) "v_pk_mul_f32 %" #k ", %9, %" #k " op_sel_hi:[0,1]\n"
+#define I_CMP(k) "v_cmp_lt_f32_e64 s[20:21], %8, %" #k "\n"
+#define I_CND(k) "v_cndmask_b32_e32 %" #k ", %8, %" #k ", vcc\n"
+#define I_SQRT(k) "v_sqrt_f32_e32 %" #k ", %" #k "\n"
+#define I_DEP(k) "v_add_f32_e32 %0, %8, %0\n"
+#define I_VS(k) "v_mul_f32_e32 %" #k ", %8, %" #k "\n" "s_add_u32 s20, s20, 1\n"
+// the commonest traversal step (a BOUND no live lane can hit), as rt_skip_rot.hpp has it, with the loads and branches
+// replaced by scalar ALU instructions of the same count: 10 VALU + 12 SALU
+#define I_STEP(k)                                                                                                    \
+    "s_cmp_eq_u32 s22, 0\n" "s_add_u32 s20, s20, 32\n" "s_add_u32 s21, s21, 1\n" "s_add_u32 s23, s23, 1\n"            \
+    "v_cmp_ge_u32_e64 s[24:25], s20, %0\n"                                                                            \
+    "v_mul_f32_e32 %1, %9, %5\n" "v_mul_f32_e32 %2, %9, %6\n" "v_mul_f32_e32 %3, %9, %7\n"                            \
+    "v_add_f32_e32 %1, %1, %2\n" "v_add_f32_e32 %4, %1, %3\n" "v_mul_f32_e32 %1, %4, %4\n"                            \
+    "v_subrev_f32_e32 %2, %9, %1\n" "v_add_f32_e32 %3, %9, %2\n" "v_cmp_le_f32_e32 vcc, 0, %3\n"                      \
+    "s_and_b64 vcc, vcc, s[24:25]\n" "s_mov_b32 s26, s21\n" "s_cmp_ge_u32 s26, s27\n" "s_mov_b32 s28, s26\n"           \
+    "s_add_u32 s29, s29, 1\n" "s_add_u32 s30, s30, 1\n" "s_add_u32 s31, s31, 1\n" "s_nop 0\n"
+#define R3(M) M(0) M(1) M(2)
+
+struct Rec { unsigned long long cycles, ref100; unsigned hw_id, xcc; };
+
+template <int KIND>
+__global__ __launch_bounds__(1024) void k_probe(int iters, Rec *rec, float *sink, float seed)
+{
+    float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7;
+    v2f p0 = { seed, seed }, p1 = p0 + 1.f, p2 = p0 + 2.f, p3 = p0 + 3.f, p4 = p0 + 4.f, p5 = p0 + 5.f, p6 = p0 + 6.f, p7 = p0 + 7.f;
+    const float one = 1.0f + seed * 0.f;
+    const v2f one2 = { one, one };
+    const float sone = __builtin_amdgcn_readfirstlane(one);
+    unsigned long long sone2;
+    { unsigned u = __float_as_uint(sone); sone2 = ((unsigned long long)u << 32) | u; }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (KIND == K_MUL)
+            asm volatile(R64(I_MUL) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone));
+        else if constexpr (KIND == K_ADD)
+            asm volatile(R64(I_ADD) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone));
+        else if constexpr (KIND == K_MUL_SGPR)
+            asm volatile(R64(I_MULS) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone));
+        else if constexpr (KIND == K_FMA)
+            asm volatile(R64(I_FMA) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone));
+        else if constexpr (KIND == K_PK_MUL)
+            asm volatile(R64(I_PKMUL) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(one2), "s"(sone2));
+        else if constexpr (KIND == K_PK_ADD)
+            asm volatile(R64(I_PKADD) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(one2), "s"(sone2));
+        else if constexpr (KIND == K_PK_FMA)
+            asm volatile(R64(I_PKFMA) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(one2), "s"(sone2));
+        else if constexpr (KIND == K_PK_MUL_SGPR)
+            asm volatile(R64(I_PKMULS) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(one2), "s"(sone2));
+        else if constexpr (KIND == K_CMP_E64)
+            asm volatile(R64(I_CMP) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone) : "s20", "s21");
+        else if constexpr (KIND == K_CNDMASK)
+            asm volatile(R64(I_CND) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone) : "vcc");
+        else if constexpr (KIND == K_SQRT)
+            asm volatile(R64(I_SQRT) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone));
+        else if constexpr (KIND == K_DEP_ADD)
+            asm volatile(R64(I_DEP) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone));
+        else if constexpr (KIND == K_VALU_SALU)
+            asm volatile(R8(I_VS) R8(I_VS) R8(I_VS) R8(I_VS)
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone) : "s20", "scc");
+        else if constexpr (KIND == K_STEP_MIX)
+            asm volatile(R3(I_STEP)
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone)
+                         : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "vcc", "scc");
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        rec[wave].cycles = t1 - t0;
+        rec[wave].ref100 = r1 - r0;
+        rec[wave].hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        rec[wave].xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+    const float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
+    if (s == 12345.678f) sink[0] = s;          // keeps every accumulator alive without a store in practice
+}
+
+template <int KIND>
+void run_kind(int n_cu, Rec *d_rec, float *d_sink, bool first)
+{
+    const int iters = 2000;
+    for (int W : { 1, 2, 4, 8 }) {
+        // W waves per SIMD: one workgroup of 256*W threads per CU (its waves go round-robin over the 4 SIMDs); W = 8 takes two
+        // 1,024-thread workgroups per CU
+        const int block = std::min(1024, 256 * W), per_cu = (256 * W) / block, grid = n_cu * per_cu;
+        const int waves = grid * block / 64;
+        CHECK(hipMemset(d_rec, 0, sizeof(Rec) * waves));
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_probe<KIND>, dim3(grid), dim3(block), 0, nullptr, 50, d_rec, d_sink, 1.0f);      // warm-up: clocks, code
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_probe<KIND>, dim3(grid), dim3(block), 0, nullptr, iters, d_rec, d_sink, 1.0f);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<Rec> rec(waves);
+        CHECK(hipMemcpy(rec.data(), d_rec, sizeof(Rec) * waves, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> cyc(waves), ref(waves);
+        std::map<unsigned long long, int> per_simd;
+        for (int i = 0; i < waves; ++i) {
+            cyc[i] = rec[i].cycles; ref[i] = rec[i].ref100;
+            // HW_ID (gfx9): simd_id [5:4], cu_id [11:8], sh_id [12], se_id [15:13]; XCC_ID [3:0]
+            per_simd[((unsigned long long)(rec[i].xcc & 0xf) << 16) | (rec[i].hw_id & 0xfff0u & ~0xc0u)]++;
+        }
+        std::sort(cyc.begin(), cyc.end()); std::sort(ref.begin(), ref.end());
+        int occ_min = 1 << 30, occ_max = 0;
+        for (auto &kv : per_simd) { occ_min = std::min(occ_min, kv.second); occ_max = std::max(occ_max, kv.second); }
+        const double med = (double)cyc[waves / 2], med_ref = (double)ref[waves / 2];
+        const double inst = (double)iters * kInstPerBlock[KIND], valu = (double)iters * kValuPerBlock[KIND];
+        printf("%s    {\"kind\": \"%s\", \"waves_per_simd\": %d, \"simds_seen\": %zu, \"waves_on_a_simd_min_max\": [%d, %d], "
+               "\"wave_cycles_median\": %.0f, \"wave_cycles_min_max\": [%llu, %llu], \"cycles_per_instruction_per_simd\": %.3f, "
+               "\"cycles_per_valu_instruction_per_simd\": %.3f, \"shader_clock_MHz\": %.0f, \"kernel_ms\": %.4f}",
+               first && W == 1 ? "" : ",\n", kNames[KIND], W, per_simd.size(), occ_min, occ_max, med, cyc.front(), cyc.back(),
+               med / (W * inst), med / (W * valu), med_ref > 0 ? med / med_ref * 100.0 : 0.0, ms);
+        CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+    }
+}
+
+int main()
+{
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int n_cu = prop.multiProcessorCount;
+    Rec *d_rec = nullptr; float *d_sink = nullptr;
+    CHECK(hipMalloc(&d_rec, sizeof(Rec) * n_cu * 2 * 16));
+    CHECK(hipMalloc(&d_sink, 64));
+    printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"compute_units\": %d, \"clock_rate_kHz\": %d,\n"
+           " \"method\": \"every wave runs 2000 x 64 instructions of one kind between s_memtime stamps; W waves per SIMD on every SIMD at once; "
+           "cycles per instruction per SIMD = median wave cycles / (W x instructions per wave)\",\n \"results\": [\n",
+           prop.name, prop.gcnArchName, n_cu, prop.clockRate);
+    run_kind<K_MUL>(n_cu, d_rec, d_sink, true);
+    run_kind<K_ADD>(n_cu, d_rec, d_sink, false);
+    run_kind<K_MUL_SGPR>(n_cu, d_rec, d_sink, false);
+    run_kind<K_FMA>(n_cu, d_rec, d_sink, false);
+    run_kind<K_PK_MUL>(n_cu, d_rec, d_sink, false);
+    run_kind<K_PK_ADD>(n_cu, d_rec, d_sink, false);
+    run_kind<K_PK_FMA>(n_cu, d_rec, d_sink, false);
+    run_kind<K_PK_MUL_SGPR>(n_cu, d_rec, d_sink, false);
+    run_kind<K_CMP_E64>(n_cu, d_rec, d_sink, false);
+    run_kind<K_CNDMASK>(n_cu, d_rec, d_sink, false);
+    run_kind<K_SQRT>(n_cu, d_rec, d_sink, false);
+    run_kind<K_DEP_ADD>(n_cu, d_rec, d_sink, false);
+    run_kind<K_VALU_SALU>(n_cu, d_rec, d_sink, false);
+    run_kind<K_STEP_MIX>(n_cu, d_rec, d_sink, false);
+    printf("\n ]}\n");
+    CHECK(hipFree(d_rec)); CHECK(hipFree(d_sink));
+    return 0;
+}
