@@ -26,13 +26,14 @@
 #ifndef RTRACE_HIP_H
 #define RTRACE_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define RTRACE_HIP_ABI_VERSION 1
+#define RTRACE_HIP_ABI_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -118,9 +119,22 @@ rt_status rt_scene_destroy(rt_scene *scene);
 enum { RT_SCENE_HAS_BOUNDS = 1u, RT_SCENE_CONCENTRIC = 2u };
 rt_status rt_scene_traits(const rt_scene *scene, uint32_t *traits);
 
+/* Host memory for RGBABuffer storage (render.rs:74-90 allocates it with vec![0; area * 4]) that the device can reach
+ * directly.  rt_render_tiles / rt_render_region recognise such memory by address (any pointer inside the range) and then
+ * the render kernel stores its pixels straight into it over PCIe: no device-side copy of the frame, no staging, no CPU copy.
+ * Pageable memory (a plain Vec<u8>) works everywhere too, but every byte then takes a bounce through pinned staging and a CPU
+ * copy (about 3x slower for a 1080p frame).
+ *   rt_host_alloc / rt_host_free        pinned, device-mapped allocation
+ *   rt_host_register / rt_host_unregister   pin memory the caller already owns (e.g. the writer's frame, render.rs:323);
+ *                                       the caller keeps it alive and unregisters before freeing it */
+rt_status rt_host_alloc(size_t bytes, void **out);
+rt_status rt_host_free(void *p);
+rt_status rt_host_register(void *p, size_t bytes);
+rt_status rt_host_unregister(void *p);
+
 /* Renderer::render_region for a batch of regions in ONE device pass (a literal launch per 64x64 bucket would
- * starve 256 CUs).  rgba_out (HOST memory) receives the tiles back to back ("tile-major"):
- * tile i starts at 4 * sum_{j<i} area(j) and is its own row-major RGBABuffer (render.rs:74-109).
+ * starve 256 CUs).  rgba_out (HOST memory, see rt_host_alloc) receives the tiles back to back
+ * ("tile-major"): tile i starts at 4 * sum_{j<i} area(j) and is its own row-major RGBABuffer (render.rs:74-109).
  * A single region {0, height, width, 0} therefore yields the row-major frame.  stats may be NULL. */
 rt_status rt_render_tiles(rt_scene *scene, const rt_options *options, rt_traversal traversal,
                           const rt_region *tiles, uint32_t n_tiles,
@@ -141,7 +155,10 @@ rt_status rt_render_frame_device(rt_scene *scene, const rt_options *options, rt_
                                  const rt_region *tiles, uint32_t n_tiles,
                                  void *frame_rgba_device, void *hip_stream, rt_stats *stats);
 
-/* Single-bucket convenience == rt_render_tiles(..., region, 1, ...): the exact shape of the reference call. */
+/* Single bucket: the exact shape of the reference call (render.rs:283-294), made from up to RTRACEMAXPROCS pool threads
+ * at once.  Concurrent calls on one scene are merged into shared device passes (whoever finds no pass running leads the
+ * next one and renders every request waiting at that moment), so RTRACEMAXPROCS keeps its meaning: more scheduler threads,
+ * more buckets per pass.  A lone caller gets one pass per call.  With stats != NULL the call runs on its own. */
 rt_status rt_render_region(rt_scene *scene, const rt_options *options, rt_traversal traversal,
                            const rt_region *region, uint8_t *rgba_out, rt_stats *stats);
 

@@ -2,6 +2,7 @@
 
 There is no CPU fallback here: if librtrace_hip.so is missing the import of this module raises, and if no
 gfx950 device is visible every render call raises RtError(RT_ERR_NO_DEVICE)."""
+import contextlib
 import ctypes as C
 import os
 
@@ -11,11 +12,12 @@ LIB_PATH = os.path.join(HERE, "librtrace_hip.so")
 RT_OK, RT_ERR_INVALID_ARGUMENT, RT_ERR_INVALID_REGION, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_OUT_OF_MEMORY, RT_ERR_UNSUPPORTED = range(7)
 RT_F32, RT_F64 = 0, 1
 RT_TRAVERSAL_FLAT, RT_TRAVERSAL_SKIP = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/rtrace_hip.h declares
 SYMBOLS = ("rt_abi_version", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_scene_traits", "rt_render_tiles",
-           "rt_render_tiles_device", "rt_render_frame_device", "rt_render_region", "rt_blit_tiles_device", "rt_selftest_sqrt", "rt_tiles_rgba_bytes", "rt_strerror", "rt_last_error_message")
+           "rt_render_tiles_device", "rt_render_frame_device", "rt_render_region", "rt_blit_tiles_device", "rt_selftest_sqrt", "rt_tiles_rgba_bytes", "rt_strerror", "rt_last_error_message",
+           "rt_host_alloc", "rt_host_free", "rt_host_register", "rt_host_unregister")
 
 
 class Options(C.Structure):      # rt_options / RenderOptions render.rs:33-38
@@ -62,6 +64,10 @@ lib.rt_render_frame_device.argtypes = lib.rt_render_tiles_device.argtypes
 lib.rt_render_region.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.POINTER(Region), C.c_void_p, C.POINTER(Stats)]
 lib.rt_blit_tiles_device.argtypes = [C.c_void_p, C.POINTER(Options), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]
+lib.rt_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+lib.rt_host_free.argtypes = [C.c_void_p]
+lib.rt_host_register.argtypes = [C.c_void_p, C.c_size_t]
+lib.rt_host_unregister.argtypes = [C.c_void_p]
 lib.rt_selftest_sqrt.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
 lib.rt_scene_traits.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
 RT_SCENE_HAS_BOUNDS, RT_SCENE_CONCENTRIC = 1, 2
@@ -90,8 +96,60 @@ def device_count():
     return n.value if st == RT_OK else 0
 
 
+class HostBuffer:
+    """rt_host_alloc'd bytes as a numpy uint8 array (`.array`): RGBABuffer storage the render kernel writes directly."""
+
+    def __init__(self, nbytes):
+        import numpy as np
+        p = C.c_void_p()
+        check(lib.rt_host_alloc(nbytes, C.byref(p)), "rt_host_alloc")
+        self._p = p
+        self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p.value))
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            lib.rt_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def selftest_sqrt(device=0):
     """rt_selftest_sqrt -> (mismatches, first_bad_bits) over all 2^32 f32 bit patterns."""
     bad, first = C.c_uint64(0), C.c_uint32(0)
     check(lib.rt_selftest_sqrt(device, C.byref(bad), C.byref(first)), "rt_selftest_sqrt")
     return bad.value, first.value
+
+
+# ---- csrc/rt_debug.h: diagnostic controls (not part of the drop-in ABI; the library reads no environment variable) ----
+(DEBUG_SKIP_VARIANT, DEBUG_BLOCK_ORDER, DEBUG_NARROW_MAX, DEBUG_PACKED_SAMPLES, DEBUG_PRINT_STEPS, DEBUG_PRINT_COSTS,
+ DEBUG_HOST_COPY, DEBUG_COALESCE) = range(8)
+lib.rt_debug_set.argtypes = [C.c_int, C.c_longlong]
+lib.rt_debug_wave_trace.argtypes = [C.c_char_p]
+lib.rt_debug_count.restype = C.c_longlong
+lib.rt_debug_count.argtypes = [C.c_int]
+DEBUG_COUNT_REGION_CALLS, DEBUG_COUNT_REGION_PASSES = 0, 1
+
+
+def debug_set(key, value=-1):
+    """rt_debug_set; value < 0 restores the default."""
+    check(lib.rt_debug_set(key, value), "rt_debug_set")
+
+
+@contextlib.contextmanager
+def debug(key, value):
+    """with capi.debug(capi.DEBUG_SKIP_VARIANT, 3): ...  -- the control is back at its default afterwards."""
+    debug_set(key, value)
+    try:
+        yield
+    finally:
+        debug_set(key, -1)
+
+
+def wave_trace(path):
+    check(lib.rt_debug_wave_trace(path.encode() if path else None), "rt_debug_wave_trace")

@@ -45,7 +45,8 @@ const char *USAGE =
     "        --devices <N>                   number of GPUs; buckets are dealt round-robin [default: 1]\n"
     "        --traversal <skip|flat>         hierarchy walk (default) or flat DFS scan; identical pixels\n"
     "        --level <N>                     pyramid level of the default scene [default: 8]\n"
-    "        --stats                         print ray counters and device time on stderr\n\n"
+    "        --stats                         print ray counters and device time on stderr\n"
+    "        --strict-64                     panic like the reference unless width and height are multiples of 64\n\n"
     "ARGS:\n"
     "    <output>    Either a file with .tga extension, or - to write file to stdout\n";
 
@@ -99,7 +100,7 @@ int main(int argc, char **argv)
 
     std::string width = "1024", height = "1024", ssp = "1", numcores = "1", output;
     std::string device = "0", devices = "1", traversal = "skip", level = "8";
-    bool have_output = false, stats = false;
+    bool have_output = false, stats = false, strict64 = false;
     auto take = [&](int &i, const std::string &arg, const char *name, std::string &dst) -> bool {
         const std::string flag = std::string("--") + name;
         if (arg == flag) {
@@ -115,6 +116,7 @@ int main(int argc, char **argv)
         if (a == "-h" || a == "--help") { fputs(USAGE, stdout); return 0; }
         if (a == "-V" || a == "--version") { puts("rtrace 0.2.0"); return 0; }
         if (a == "--stats") { stats = true; continue; }
+        if (a == "--strict-64") { strict64 = true; continue; }
         if (take(i, a, "width", width) || take(i, a, "height", height) || take(i, a, "samples-per-pixel", ssp) ||
             take(i, a, "num-cores", numcores) || take(i, a, "device", device) || take(i, a, "devices", devices) ||
             take(i, a, "traversal", traversal) || take(i, a, "level", level))
@@ -161,6 +163,8 @@ int main(int argc, char **argv)
     try {
         const Scene scene = Scene::with_level(parse_or_panic<uint32_t>(level));          // Arc::new(Default::default())  main.rs:23
         Backend be;
+        be.strict_64 = strict64;
+        be.want_stats = stats;
         if (traversal == "flat") be.traversal = RT_TRAVERSAL_FLAT;
         else if (traversal == "skip") be.traversal = RT_TRAVERSAL_SKIP;
         else { fprintf(stderr, "error: --traversal must be skip or flat\n"); return 1; }

@@ -7,6 +7,7 @@
 namespace rtrace {
 
 static constexpr uint16_t CHUNK_SIZE = 64;                        // render.rs:264
+static constexpr size_t kMaxBucketsPerCall = 64, kMinBucketsPerCall = 16;      // per device call (a pass of < 16 buckets leaves most CUs idle)
 
 static void check(rt_status st, const char *what)
 {
@@ -38,12 +39,14 @@ void PPMStdoutRGBABufferWriter::write_buffer_with_header()
     if (!width_ || !height_) throw std::runtime_error("begin() called");
     fprintf(out, "%s\n%u %u\n255\n", rgb_ ? "P6" : "P5", (unsigned)*width_, (unsigned)*height_);
     const std::vector<uint8_t> &buf = image_->buffer();
-    std::vector<uint8_t> line;
-    line.reserve(buf.size() / 4 * 3);
-    for (size_t po = 0; po < buf.size(); po += RGBABuffer::components()) {
-        const uint8_t *b = &buf[po];
-        if (rgb_) { line.push_back(b[0]); line.push_back(b[1]); line.push_back(b[2]); }
-        else line.push_back((uint8_t)(((float)b[0] + (float)b[1] + (float)b[2]) / 3.0f));      // render.rs:399
+    const size_t n_px = buf.size() / RGBABuffer::components();
+    std::vector<uint8_t> line(n_px * (rgb_ ? 3 : 1));
+    const uint8_t *b = buf.data();
+    uint8_t *w = line.data();
+    if (rgb_) {
+        for (size_t i = 0; i < n_px; ++i, b += 4, w += 3) { w[0] = b[0]; w[1] = b[1]; w[2] = b[2]; }      // alpha dropped, render.rs:392-396
+    } else {
+        for (size_t i = 0; i < n_px; ++i, b += 4) w[i] = (uint8_t)(((float)b[0] + (float)b[1] + (float)b[2]) / 3.0f);      // render.rs:399
     }
     if (fwrite(line.data(), 1, line.size(), out) != line.size()) throw std::runtime_error("called `Result::unwrap()` on an `Err` value: write");
     fflush(out);
@@ -65,6 +68,8 @@ std::vector<ImageRegion> Renderer::buckets(const RenderOptions &o)
 RenderStats Renderer::render(const RenderOptions &o, const Backend &be, RGBABufferWriter &writer, ThreadPool &pool)
 {
     if (be.devices.empty()) throw std::runtime_error("no device scene: the HIP backend has no CPU fallback");
+    if (be.strict_64 && (o.width % CHUNK_SIZE != 0 || o.height % CHUNK_SIZE != 0))                 // render.rs:265-266
+        throw std::runtime_error("TODO: handle chunk sizes");
     writer.begin(o.width, o.height);
 
     const std::vector<ImageRegion> all = buckets(o);
@@ -78,7 +83,11 @@ RenderStats Renderer::render(const RenderOptions &o, const Backend &be, RGBABuff
         std::vector<ImageRegion> mine;
         for (size_t i = d; i < all.size(); i += ndev) mine.push_back(all[i]);
         const size_t calls = std::max<size_t>(1, (pool.size() + ndev - 1) / ndev);
-        const size_t per = be.buckets_per_call ? be.buckets_per_call : std::max<size_t>(1, (mine.size() + calls - 1) / calls);
+        // at most kMaxBucketsPerCall per device call: enough to fill 256 CUs (64 buckets = 1,024 workgroups), few enough that
+        // finished buckets keep reaching the writer during a long render (tiles in completion order, the once-per-second
+        // rewrite of the file: render.rs:301-307, 427-432) even with RTRACEMAXPROCS = 1
+        const size_t per = be.buckets_per_call ? be.buckets_per_call
+                                               : std::clamp((mine.size() + calls - 1) / calls, kMinBucketsPerCall, kMaxBucketsPerCall);
         for (size_t i = 0; i < mine.size(); i += per)
             batches.push_back(Batch{ d, std::vector<ImageRegion>(mine.begin() + i, mine.begin() + std::min(mine.size(), i + per)) });
     }
@@ -99,10 +108,12 @@ RenderStats Renderer::render(const RenderOptions &o, const Backend &be, RGBABuff
                 for (const ImageRegion &r : b.regs) px += r.area();
                 std::vector<uint8_t> rgba(px * 4);
                 rt_stats st{};
+                // counters are opt-in: a counted launch runs the counting flavour of the kernels (same bytes, ~3x slower)
                 check(rt_render_tiles(be.devices[b.dev]->handle(), &opts, be.traversal,
-                                      reinterpret_cast<const rt_region *>(b.regs.data()), (uint32_t)b.regs.size(), rgba.data(), &st),
+                                      reinterpret_cast<const rt_region *>(b.regs.data()), (uint32_t)b.regs.size(), rgba.data(),
+                                      be.want_stats ? &st : nullptr),
                       "rt_render_tiles");
-                {
+                if (be.want_stats) {
                     std::lock_guard<std::mutex> lk(stats_mu);
                     total.primary += st.primary; total.hits += st.hits; total.shadow += st.shadow; total.occluded += st.occluded;
                     total.sphere_tests += st.sphere_tests; total.bound_tests += st.bound_tests; total.device_ms += st.device_ms;
@@ -127,8 +138,14 @@ RenderStats Renderer::render(const RenderOptions &o, const Backend &be, RGBABuff
             if (m.err && !first_err) first_err = m.err;
             --open;
         } else if (!first_err) {
-            writer.write_rgba_buffer(*m.buf);
-            count -= 1;
+            // a failing writer (ftruncate / fwrite) must not unwind past the pool jobs: they hold references to this frame's
+            // locals and may be blocked in chan.send -- remember the failure and keep draining until every batch has ended
+            try {
+                writer.write_rgba_buffer(*m.buf);
+                count -= 1;
+            } catch (...) {
+                first_err = std::current_exception();
+            }
         }
     }
     if (first_err) std::rethrow_exception(first_err);             // the reference panics here

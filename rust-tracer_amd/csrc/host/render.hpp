@@ -125,7 +125,9 @@ struct RenderStats {
 struct Backend {                                                  // additions that do not exist in the reference
     std::vector<std::shared_ptr<DeviceScene>> devices;            // buckets are dealt round-robin over these
     rt_traversal traversal = RT_TRAVERSAL_SKIP;
-    size_t buckets_per_call = 0;                                  // 0 = split each device's buckets evenly over the pool
+    size_t buckets_per_call = 0;                                  // 0 = split each device's buckets evenly over the pool (<= 64 per call)
+    bool want_stats = false;                                      // collect RenderStats (ray / test counters, device time)
+    bool strict_64 = false;                                       // reproduce assert!(w % 64 == 0 && h % 64 == 0), render.rs:265-266
 };
 
 struct Renderer {

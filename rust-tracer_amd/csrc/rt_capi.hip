@@ -2,6 +2,7 @@
 // validation, device copies of the Scene, tile tables, streams, launches, read-back.  No pixel arithmetic
 // happens on the host and there is NO CPU fallback: without a device every render entry point fails.
 #include "../../include/rtrace_hip.h"
+#include "rt_debug.h"
 #include "rt_kernels.hpp"
 #include "rt_skip.hpp"
 #include "rt_flat.hpp"
@@ -10,18 +11,29 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 namespace {
 
 thread_local char g_err[512] = "";
+
+// Diagnostic controls (rt_debug.h): process-wide, -1 = default.  The library reads no environment variable.
+std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
+std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = { {0}, {0} };
+std::atomic<bool> g_trace_on{ false };
+std::mutex g_trace_mu;
+std::string g_trace_path;
+inline long long knob(int key) { return g_knob[key].load(std::memory_order_relaxed); }
 
 rt_status hip_fail(hipError_t e, const char *what, int line)
 {
@@ -47,6 +59,9 @@ struct Context {
     rt::Counters *d_counters = nullptr;
     uint8_t *d_out = nullptr;
     size_t out_cap = 0;
+    uint8_t *h_out = nullptr;         // pinned staging for pageable destinations (rt_render_tiles), same size as d_out
+    size_t h_out_cap = 0;
+    std::vector<hipEvent_t> chunk_ev; // one per staged chunk in flight
     void *d_sample_gdot = nullptr;    // SPLIT path: per-sample n.light [spp*spp][n_px] (REAL)
     uint8_t *d_sample_state = nullptr;
     size_t sample_cap = 0;            // bytes of d_sample_gdot
@@ -64,6 +79,8 @@ struct Context {
         }
         if (d_counters) (void)hipFree(d_counters);
         if (d_out) (void)hipFree(d_out);
+        if (h_out) (void)hipHostFree(h_out);
+        for (hipEvent_t e : chunk_ev) (void)hipEventDestroy(e);
         if (d_sample_gdot) (void)hipFree(d_sample_gdot);
         if (d_sample_state) (void)hipFree(d_sample_state);
         if (d_queue1) (void)hipFree(d_queue1);
@@ -99,32 +116,51 @@ struct rt_scene {
     // rendered once per scene with the counting kernel.  It only ever decides the ORDER in which blocks are dispatched.
     std::once_flag cost_once;
     std::vector<uint32_t> cost_map;
+    // Concurrent rt_render_region callers (the reference's pool threads, render.rs:283-294) are merged into shared passes:
+    // whoever finds no pass running becomes its leader and renders every request that is waiting at that moment.
+    struct RegionReq { rt_options o; rt_traversal trav; rt_region region; uint8_t *out; rt_status st = RT_OK; bool taken = false, done = false; char err[256] = "";
+                       std::condition_variable cv; };      // signalled when the request is done, or when its owner should lead
+    std::mutex comb_mu;
+    std::vector<RegionReq *> comb_pending;
+    int comb_leaders = 0;              // passes being led right now (<= kMaxRegionLeaders)
 };
 
 namespace {
 
-constexpr size_t kMaxContexts = 3;   // enough to keep the device fed; each may hold per-sample buffers (GBs at 4096^2 x 16)
+// Contexts released by asynchronous callers and still in flight: enough to keep the device fed; each may hold per-sample
+// buffers (GBs at 4096^2 x 16).  Synchronous callers (one per host thread) each hold their own while they run.
+constexpr size_t kMaxAsyncContexts = 3;
+
+void release(rt_scene *s, Context *c, bool inflight);
 
 rt_status acquire(rt_scene *s, Context **out)
 {
-    std::lock_guard<std::mutex> lk(s->mu);
-    for (auto &c : s->pool) {
-        if (c->busy) continue;
-        if (c->inflight) {
-            if (hipEventQuery(c->ev1) != hipSuccess) { (void)hipGetLastError(); continue; }
-            c->inflight = false;
-        }
-        c->busy = true; *out = c.get(); return RT_OK;
-    }
-    // A caller that keeps enqueuing asynchronous passes without ever synchronising must not grow the pool (and its
-    // per-sample buffers) without bound: past kMaxContexts, wait for the oldest pass still in flight and reuse its context.
-    if (s->pool.size() >= kMaxContexts) {
+    Context *victim = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
         for (auto &c : s->pool) {
-            if (c->busy || !c->inflight) continue;
-            HIP_TRY(hipEventSynchronize(c->ev1));
-            c->inflight = false;
+            if (c->busy) continue;
+            if (c->inflight) {
+                if (hipEventQuery(c->ev1) != hipSuccess) { (void)hipGetLastError(); continue; }
+                c->inflight = false;
+            }
             c->busy = true; *out = c.get(); return RT_OK;
         }
+        // A caller that keeps enqueuing asynchronous passes without ever synchronising must not grow the pool (and its
+        // per-sample buffers) without bound: past kMaxAsyncContexts, take the oldest pass still in flight and wait for it
+        // OUTSIDE the lock (other threads of the scene, the one-kernel fast path included, go on meanwhile).
+        size_t inflight = 0;
+        for (auto &c : s->pool) inflight += (!c->busy && c->inflight) ? 1 : 0;
+        if (inflight >= kMaxAsyncContexts)
+            for (auto &c : s->pool)
+                if (!c->busy && c->inflight) { c->busy = true; victim = c.get(); break; }
+    }
+    if (victim) {
+        hipError_t e = hipEventSynchronize(victim->ev1);
+        if (e != hipSuccess) { release(s, victim, true); return hip_fail(e, "hipEventSynchronize(context)", __LINE__); }
+        victim->inflight = false;
+        *out = victim;
+        return RT_OK;
     }
     std::unique_ptr<Context> c(new (std::nothrow) Context());
     if (!c) return RT_ERR_OUT_OF_MEMORY;
@@ -134,6 +170,7 @@ rt_status acquire(rt_scene *s, Context **out)
     HIP_TRY(hipMalloc(&c->d_counters, sizeof(rt::Counters) * rt::kCounterStripes));
     c->busy = true;
     *out = c.get();
+    std::lock_guard<std::mutex> lk(s->mu);
     s->pool.push_back(std::move(c));
     return RT_OK;
 }
@@ -316,22 +353,23 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
 
 // spp > 1 runs sample-parallel (one thread per sample + a resolve pass) unless spp*spp exceeds grid.y's limit.
 bool use_split(unsigned spp) { return spp > 1 && (unsigned long long)spp * spp <= 65535ull; }
-// spp 2 / 4 / 8: the samples of a pixel fill 4 / 16 / 64 lanes of a wave (rt_skip.hpp, kSkipPacked); RT_PACKED_SAMPLES=0
-// switches it off for A/B runs
+// spp 2 / 4 / 8: the samples of a pixel fill 4 / 16 / 64 lanes of a wave (rt_skip.hpp, kSkipPacked)
 bool packed_samples(unsigned spp)
 {
-    const char *e = getenv("RT_PACKED_SAMPLES");
-    return (spp == 2 || spp == 4 || spp == 8) && !(e && e[0] == '0');
+    return (spp == 2 || spp == 4 || spp == 8) && knob(RT_DEBUG_PACKED_SAMPLES) != 0;
 }
 
 constexpr size_t kMaxCachedTables = 32;
 
 // Device copy of `tab`: from the scene's cache when seen before (or cacheable now), else through the context.
 rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, const rt::TileDev **out,
-                       int slot = 0, const rt_options *o = nullptr, rt::BlockList *order_out = nullptr);
+                       int slot = 0, const rt_options *o = nullptr, rt::BlockList *order_out = nullptr, bool cacheable = true);
 
-// Copies the tile table through the context's pinned buffer; truly asynchronous on `stream`.
-rt_status upload_tiles(Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, int slot)
+// Copies the tile table through the context's pinned buffer; truly asynchronous on `stream`.  A table of one or two tiles
+// is read by the kernel straight from the pinned copy instead (one PCIe read per workgroup beats a copy operation on the stream).
+constexpr size_t kZeroCopyTableTiles = 2;
+
+rt_status upload_tiles(Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, int slot, const rt::TileDev **out)
 {
     const size_t tab_bytes = tab.size() * sizeof(rt::TileDev);
     if (c->tiles_cap[slot] < tab.size()) {
@@ -343,7 +381,13 @@ rt_status upload_tiles(Context *c, const std::vector<rt::TileDev> &tab, hipStrea
         c->tiles_cap[slot] = tab.size();
     }
     memcpy(c->h_tiles[slot], tab.data(), tab_bytes);
+    if (tab.size() <= kZeroCopyTableTiles) {
+        void *alias = nullptr;
+        if (hipHostGetDevicePointer(&alias, c->h_tiles[slot], 0) == hipSuccess) { *out = static_cast<const rt::TileDev *>(alias); return RT_OK; }
+        (void)hipGetLastError();
+    }
     HIP_TRY(hipMemcpyAsync(c->d_tiles[slot], c->h_tiles[slot], tab_bytes, hipMemcpyHostToDevice, stream));
+    *out = c->d_tiles[slot];
     return RT_OK;
 }
 
@@ -433,19 +477,19 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
     for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&cost](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
     // The most expensive blocks go out as four narrow workgroups each (rt_kernels.hpp, kBlockNarrow): those whose cost
-    // estimate is at least kNarrowPercent of the pass's maximum, at most kNarrowMax and 1/128 of the pass (RT_NARROW_MAX
-    // overrides the cap for A/B runs -- the table is built once per tile list, so one value per process).
+    // estimate is at least kNarrowPercent of the pass's maximum, at most kNarrowMax and 1/128 of the pass (rt_debug.h can
+    // override the cap for A/B runs -- the table is built once per tile list, when it is first seen).
     size_t n_narrow = 0;
-    if (getenv("RT_DEBUG_COST") && !cost.empty()) {
+    if (knob(RT_DEBUG_PRINT_COSTS) > 0 && !cost.empty()) {
         fprintf(stderr, "[rtrace_hip] block costs, descending:");
         for (size_t i = 0; i < order.size(); i = i < 64 ? i + 4 : i * 2) fprintf(stderr, " #%zu=%u", i, cost[order[i]]);
         fprintf(stderr, "\n");
     }
     if (map && !cost.empty()) {
-        const char *e = getenv("RT_NARROW_MAX");
+        const long long e = knob(RT_DEBUG_NARROW_MAX);
         // a pass of more blocks than kNarrowPassBlocks is throughput-bound: narrowing only adds work there (3840x2160 + 2 %)
         // (and only in single-pass launches: the packed sample-parallel mapping has its own, finer ray packets)
-        const size_t cap = passes > 1 ? 0 : e ? (size_t)atoi(e) : order.size() > kNarrowPassBlocks ? 0 : std::min<size_t>(kNarrowMax, order.size() / 128);
+        const size_t cap = passes > 1 ? 0 : e >= 0 ? (size_t)e : order.size() > kNarrowPassBlocks ? 0 : std::min<size_t>(kNarrowMax, order.size() / 128);
         const uint64_t top = cost[order[0]];
         while (n_narrow < order.size() && n_narrow < cap && cost[order[n_narrow]] > 0 && (uint64_t)cost[order[n_narrow]] * 100 >= top * kNarrowPercent)
             ++n_narrow;
@@ -468,21 +512,17 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
     }
 }
 
-bool block_order_enabled()
-{
-    const char *e = getenv("RT_BLOCK_ORDER");       // read per call: A/B timing interleaves both in one process
-    return !(e && e[0] == '0');
-}
+bool block_order_enabled() { return knob(RT_DEBUG_BLOCK_ORDER) != 0; }     // read per call: A/B timing interleaves both
 
 rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, const rt::TileDev **out, int slot,
-                       const rt_options *o, rt::BlockList *order_out)
+                       const rt_options *o, rt::BlockList *order_out, bool cacheable)
 {
     const size_t bytes = tab.size() * sizeof(rt::TileDev);
     const unsigned w = o ? o->width : 0u, h = o ? o->height : 0u;
     const unsigned passes = (o && use_split(o->samples_per_pixel)) ? (unsigned)o->samples_per_pixel * o->samples_per_pixel : 1u;
     if (order_out) *order_out = rt::BlockList{};
-    const std::vector<uint32_t> *map = (o && order_out) ? cost_map_of(s) : nullptr;     // before taking the lock: it renders
-    {
+    const std::vector<uint32_t> *map = (o && order_out && cacheable) ? cost_map_of(s) : nullptr;     // before taking the lock: it renders
+    if (cacheable) {
         std::lock_guard<std::mutex> lk(s->mu);
         for (auto &t : s->tables)
             if ((!o || (t.w == w && t.h == h && t.passes == passes)) && t.host.size() == tab.size() && memcmp(t.host.data(), tab.data(), bytes) == 0) {
@@ -511,21 +551,19 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
         }
     }
     if (!c) { *out = nullptr; return RT_OK; }                       // cache full and no context to upload through
-    rt_status st = upload_tiles(c, tab, stream, slot);
-    if (st == RT_OK) *out = c->d_tiles[slot];
-    return st;
+    return upload_tiles(c, tab, stream, slot, out);
 }
 
 // Variant of k_render_skip (rt_skip.hpp VAR bits): the generated assembly loops, fused where the scene allows it.
-// RT_SKIP_VARIANT overrides for A/B runs (read per call so one process can interleave variants, tools/ab.py); the fused bit
+// rt_debug.h overrides it for A/B runs (read per call so one process can interleave variants, tools/ab.py); the fused bit
 // is dropped for scenes that are not fused.
 int skip_variant(const rt_scene *s)
 {
     int v = 1 | 2 | 4;
-    if (const char *e = getenv("RT_SKIP_VARIANT")) v = atoi(e) & 7;
+    if (const long long o = knob(RT_DEBUG_SKIP_VARIANT); o >= 0) v = (int)o & 7;
     if (v & 2) v |= 1;                                  // the assembly loops imply the lean sqrt in what C++ remains
     if (!s->fused || !(v & 2)) v &= ~4;
-    if ((v & 3) == 3 && getenv("RT_WAVE_TRACE")) v |= 8;      // diagnostic build of the assembly variants
+    if ((v & 3) == 3 && g_trace_on.load(std::memory_order_relaxed)) v |= 8;      // diagnostic build of the assembly variants
     return v;
 }
 
@@ -592,9 +630,11 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
 {
     const dim3 b(rt::kBlockThreads);
     uint32_t *no_cost = nullptr;
-    // RT_WAVE_TRACE=<file> (diagnostic, tools/wave_timeline.py): the launch records every wave's start / end / placement and
-    // the records are written to <file> -- synchronous, one file per launch (overwritten).
-    const char *trace_path = (VAR & 8) ? getenv("RT_WAVE_TRACE") : nullptr;
+    // rt_debug_wave_trace(<file>) (diagnostic, tools/wave_timeline.py): the launch records every wave's start / end /
+    // placement and the records are written to <file> -- synchronous, one file per launch (overwritten).
+    std::string trace_file;
+    if (VAR & 8) { std::lock_guard<std::mutex> lk(g_trace_mu); trace_file = g_trace_path; }
+    const char *trace_path = trace_file.empty() ? nullptr : trace_file.c_str();
     const dim3 rgrid(order.d ? order.n : grid.x);      // render workgroups: one per descriptor
     const size_t trace_words = (size_t)rgrid.x * 4 * 4 * (use_split(spp) ? (size_t)spp * spp : 1);
     struct Trace {
@@ -682,7 +722,7 @@ rt_status check_traversal(const rt_scene *s, rt_traversal trav)
         return RT_ERR_INVALID_ARGUMENT;
     }
     if (trav == RT_TRAVERSAL_SKIP && s->n_nodes == 0) {
-        snprintf(g_err, sizeof g_err, "RT_TRAVERSAL_SKIP needs a scene created with subtree bounds");
+        snprintf(g_err, sizeof g_err, "the hierarchy (skip) traversal needs a scene created with subtree bounds");
         return RT_ERR_UNSUPPORTED;
     }
     return RT_OK;
@@ -716,15 +756,16 @@ rt_status launch_render(rt_scene *s, Context *c, const rt_options *o, rt_travers
 // (tile-major) or the whole frame (frame_w != 0).
 rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversal trav, const std::vector<rt::TileDev> &tab,
                        uint32_t total_blocks, uint64_t total_px, uint8_t *d_out, unsigned frame_w, hipStream_t stream, bool want_counters,
-                       const std::vector<rt::TileDev> *tab16 = nullptr, uint32_t blocks16 = 0)
+                       const std::vector<rt::TileDev> *tab16 = nullptr, uint32_t blocks16 = 0, bool cacheable = true)
 {
     const rt::TileDev *d_tab = nullptr, *d_tab16 = nullptr;
     rt::BlockList order;
     {
-        rt_status ust = trav == RT_TRAVERSAL_SKIP ? device_table(s, c, tab, stream, &d_tab, 0, o, &order) : device_table(s, c, tab, stream, &d_tab);
+        rt_status ust = trav == RT_TRAVERSAL_SKIP ? device_table(s, c, tab, stream, &d_tab, 0, o, &order, cacheable)
+                                                  : device_table(s, c, tab, stream, &d_tab, 0, nullptr, nullptr, cacheable);
         if (ust != RT_OK) return ust;
         if (tab16) {
-            if ((ust = device_table(s, c, *tab16, stream, &d_tab16, 1)) != RT_OK) return ust;
+            if ((ust = device_table(s, c, *tab16, stream, &d_tab16, 1, nullptr, nullptr, cacheable)) != RT_OK) return ust;
         }
     }
     if (want_counters) {
@@ -769,7 +810,7 @@ rt_status read_stats(rt_scene *s, Context *c, hipStream_t stream, rt_traversal t
         st->sphere_tests = h.sphere_tests; st->bound_tests = h.bound_tests;
         st->tests_executed = h.sphere_tests + h.bound_tests;
     }
-    if (getenv("RT_DEBUG_STEPS"))
+    if (knob(RT_DEBUG_PRINT_STEPS) > 0)
         fprintf(stderr, "[rtrace_hip] wave_steps %llu (%llu at ITEM nodes) max_wave_steps %llu longest wave: %llu cycles, %.2f us, %.0f MHz\n",
                 h.wave_steps, h.wave_item_steps, h.max_wave_steps, h.max_wave_cycles, h.max_wave_ref100mhz / 100.0,
                 h.max_wave_ref100mhz ? 100.0 * h.max_wave_cycles / h.max_wave_ref100mhz : 0.0);
@@ -803,6 +844,26 @@ bool items_valid(const void *p, uint32_t n, bool need_positive_radius)
 extern "C" {
 
 int rt_abi_version(void) { return RTRACE_HIP_ABI_VERSION; }
+
+rt_status rt_debug_set(int key, long long value)
+{
+    if (key < 0 || key >= RT_DEBUG_KEYS) { snprintf(g_err, sizeof g_err, "rt_debug_set: unknown key %d", key); return RT_ERR_INVALID_ARGUMENT; }
+    g_knob[key].store(value < 0 ? -1 : value, std::memory_order_relaxed);
+    return RT_OK;
+}
+
+long long rt_debug_count(int counter)
+{
+    return counter >= 0 && counter < RT_DEBUG_COUNTERS ? g_count[counter].load(std::memory_order_relaxed) : -1;
+}
+
+rt_status rt_debug_wave_trace(const char *path)
+{
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    g_trace_path = path ? path : "";
+    g_trace_on.store(!g_trace_path.empty(), std::memory_order_relaxed);
+    return RT_OK;
+}
 
 const char *rt_last_error_message(void) { return g_err; }
 
@@ -966,7 +1027,14 @@ static rt_status render_device(rt_scene *s, const rt_options *o, rt_traversal tr
     if ((st = acquire(s, &c)) != RT_OK) return st;
     Lease lease{ s, c };
     st = enqueue_pass(s, c, o, trav, tab, total_blocks, total_px, out, frame_w, stream, stats != nullptr, wavefront ? &tab16 : nullptr, blocks16);
-    if (st != RT_OK) return st;
+    if (st != RT_OK) {
+        // some kernels of the pass may already be enqueued and using the context's buffers: it goes back to the pool marked
+        // in flight behind everything that is on the stream now
+        (void)hipEventRecord(c->ev1, stream);
+        (void)hipGetLastError();
+        lease.inflight = true;
+        return st;
+    }
     if (stats) return read_stats(s, c, stream, trav, stats);
     // Asynchronous return: the context's buffers are still in use by the enqueued work, so it goes back to the pool
     // marked in-flight and is only reused once its end event has completed.
@@ -986,10 +1054,42 @@ rt_status rt_render_frame_device(rt_scene *s, const rt_options *o, rt_traversal 
     return render_device(s, o, trav, tiles, n, frame_rgba_device, o ? (unsigned)o->width : 0u, hip_stream, stats);
 }
 
-rt_status rt_render_tiles(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n,
-                          uint8_t *rgba_out, rt_stats *stats)
+// How the bytes of a pass get into the caller's HOST buffer.
+//   pinned   (rt_host_alloc / rt_host_register memory, or any hipHostMalloc'd / registered range): the render kernel stores
+//            straight into it over PCIe (no device copy of the frame, no separate D2H) or, as an alternative, renders
+//            into device memory followed by ONE asynchronous D2H at full link speed;
+//   pageable (Vec<u8>, malloc): the runtime has to bounce through pinned memory and a CPU copy whatever we do; one
+//            hipMemcpyAsync to the caller's pointer, or our own pinned staging in 1 MiB chunks with the CPU copy of chunk k
+//            overlapping the DMA of chunk k+1.
+//   scattered (the merged rt_render_region passes: every tile has its own destination): the kernel stores into the context's
+//            pinned staging and the CPU hands each caller its 16 KB.
+enum HostCopy { kCopyAuto = 0, kCopyDirect = 1, kCopyStaged = 2, kCopyZero = 3, kCopyZeroStaged = 4 };
+
+struct HostDest { bool pinned = false; uint8_t *dev_alias = nullptr; bool bad = false; };
+
+static HostDest classify_host_pointer(const void *p)
 {
-    if (!check_common(s, o, tiles, n, rgba_out)) return RT_ERR_INVALID_ARGUMENT;
+    HostDest d;
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return d; }      // plain pageable memory
+    if (a.type == hipMemoryTypeHost) {
+        d.pinned = true;
+        void *alias = nullptr;
+        if (hipHostGetDevicePointer(&alias, const_cast<void *>(p), 0) == hipSuccess) d.dev_alias = static_cast<uint8_t *>(alias);
+        else (void)hipGetLastError();
+    } else if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeArray) {
+        d.bad = true;
+    }
+    return d;
+}
+
+constexpr size_t kStageChunk = 1u << 20;
+
+// rt_render_tiles for a list of tiles whose bytes go to host memory.  `scatter` (optional, n entries): tile i's bytes go to
+// scatter[i] instead of lying back to back at rgba_out (the coalesced rt_render_region path).
+static rt_status render_tiles_host(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n,
+                                   uint8_t *rgba_out, uint8_t *const *scatter, rt_stats *stats, bool cacheable)
+{
     rt_status st = check_traversal(s, trav);
     if (st != RT_OK) return st;
     std::vector<rt::TileDev> tab;
@@ -999,15 +1099,47 @@ rt_status rt_render_tiles(rt_scene *s, const rt_options *o, rt_traversal trav, c
                                     flat2 ? rt::kFlatBlockH : rt::kBlockH);
     if (st != RT_OK) return st;
     HIP_TRY(hipSetDevice(s->device));
+    HostDest dest;
+    if (!scatter) {
+        dest = classify_host_pointer(rgba_out);
+        if (dest.bad) {
+            snprintf(g_err, sizeof g_err, "rt_render_tiles: rgba_out is device memory; use rt_render_tiles_device");
+            return RT_ERR_INVALID_ARGUMENT;
+        }
+    }
+    long long mode = knob(RT_DEBUG_HOST_COPY);
+    if (mode <= 0) mode = dest.pinned ? (dest.dev_alias ? kCopyZero : kCopyDirect) : kCopyDirect;
+    if (scatter) mode = kCopyZeroStaged;
+    if (mode == kCopyZero && !dest.dev_alias) mode = kCopyDirect;
+    if (mode == kCopyStaged && dest.pinned) mode = kCopyDirect;          // staging a pinned destination is pointless
+
     Context *c = nullptr;
     if ((st = acquire(s, &c)) != RT_OK) return st;
     Lease lease{ s, c };
     const size_t bytes = (size_t)total_px * 4;
-    if (c->out_cap < bytes) {
-        if (c->d_out) HIP_TRY(hipFree(c->d_out));
-        c->d_out = nullptr; c->out_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_out, bytes));
-        c->out_cap = bytes;
+    uint8_t *d_target = nullptr;
+    if (mode == kCopyStaged || mode == kCopyZeroStaged) {
+        if (c->h_out_cap < bytes) {
+            if (c->h_out) HIP_TRY(hipHostFree(c->h_out));
+            c->h_out = nullptr; c->h_out_cap = 0;
+            HIP_TRY(hipHostMalloc(&c->h_out, std::max(bytes, (size_t)1 << 20), hipHostMallocDefault));
+            c->h_out_cap = std::max(bytes, (size_t)1 << 20);
+        }
+    }
+    if (mode == kCopyZero) {
+        d_target = dest.dev_alias;
+    } else if (mode == kCopyZeroStaged) {
+        void *alias = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&alias, c->h_out, 0));
+        d_target = static_cast<uint8_t *>(alias);
+    } else {
+        if (c->out_cap < bytes) {
+            if (c->d_out) HIP_TRY(hipFree(c->d_out));
+            c->d_out = nullptr; c->out_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_out, bytes));
+            c->out_cap = bytes;
+        }
+        d_target = c->d_out;
     }
     std::vector<rt::TileDev> tab16;
     uint32_t blocks16 = 0;
@@ -1016,11 +1148,92 @@ rt_status rt_render_tiles(rt_scene *s, const rt_options *o, rt_traversal trav, c
         uint64_t px16 = 0;
         if ((st = build_tile_table(o, tiles, n, tab16, &px16, &blocks16)) != RT_OK) return st;
     }
-    st = enqueue_pass(s, c, o, trav, tab, total_blocks, total_px, c->d_out, 0u, c->stream, stats != nullptr, wavefront ? &tab16 : nullptr, blocks16);
+    st = enqueue_pass(s, c, o, trav, tab, total_blocks, total_px, d_target, 0u, c->stream, stats != nullptr, wavefront ? &tab16 : nullptr, blocks16,
+                      cacheable);
+    if (st != RT_OK) { (void)hipStreamSynchronize(c->stream); (void)hipGetLastError(); return st; }
+    if (mode == kCopyDirect) {
+        HIP_TRY(hipMemcpyAsync(rgba_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    } else if (mode == kCopyStaged) {
+        const size_t chunks = (bytes + kStageChunk - 1) / kStageChunk;
+        while (c->chunk_ev.size() < chunks) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->chunk_ev.push_back(e);
+        }
+        for (size_t k = 0; k < chunks; ++k) {
+            const size_t off = k * kStageChunk, len = std::min(kStageChunk, bytes - off);
+            HIP_TRY(hipMemcpyAsync(c->h_out + off, c->d_out + off, len, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipEventRecord(c->chunk_ev[k], c->stream));
+        }
+        // the CPU copy of chunk k runs while the DMA engine moves chunk k + 1
+        size_t tile = 0, tile_off = 0;                    // scatter cursor: current tile and bytes of it already delivered
+        for (size_t k = 0; k < chunks; ++k) {
+            HIP_TRY(hipEventSynchronize(c->chunk_ev[k]));
+            const size_t off = k * kStageChunk, len = std::min(kStageChunk, bytes - off);
+            if (!scatter) { memcpy(rgba_out + off, c->h_out + off, len); continue; }
+            size_t pos = off;
+            while (pos < off + len) {
+                const size_t tbytes = (size_t)(tiles[tile].r - tiles[tile].l) * (tiles[tile].t - tiles[tile].b) * 4;
+                const size_t take = std::min(tbytes - tile_off, off + len - pos);
+                memcpy(scatter[tile] + tile_off, c->h_out + pos, take);
+                pos += take; tile_off += take;
+                if (tile_off == tbytes) { ++tile; tile_off = 0; }
+            }
+        }
+    }
+    rt_status rst = RT_OK;
+    if (stats) rst = read_stats(s, c, c->stream, trav, stats);          // synchronises the stream
+    else HIP_TRY(hipStreamSynchronize(c->stream));
+    if (rst == RT_OK && mode == kCopyZeroStaged) {
+        size_t off = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const size_t tbytes = (size_t)(tiles[i].r - tiles[i].l) * (tiles[i].t - tiles[i].b) * 4;
+            memcpy(scatter ? scatter[i] : rgba_out + off, c->h_out + off, tbytes);
+            off += tbytes;
+        }
+    }
+    return rst;
+}
+
+rt_status rt_render_tiles(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n,
+                          uint8_t *rgba_out, rt_stats *stats)
+{
+    if (!check_common(s, o, tiles, n, rgba_out)) return RT_ERR_INVALID_ARGUMENT;
+    return render_tiles_host(s, o, trav, tiles, n, rgba_out, nullptr, stats, true);
+}
+
+rt_status rt_host_alloc(size_t bytes, void **out)
+{
+    if (!out || bytes == 0) { snprintf(g_err, sizeof g_err, "rt_host_alloc: NULL argument or 0 bytes"); return RT_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    int ndev = 0;
+    rt_status st = rt_device_count(&ndev);
     if (st != RT_OK) return st;
-    HIP_TRY(hipMemcpyAsync(rgba_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
-    if (stats) return read_stats(s, c, c->stream, trav, stats);
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocPortable | hipHostMallocMapped));
+    return RT_OK;
+}
+
+rt_status rt_host_free(void *p)
+{
+    if (!p) return RT_OK;
+    HIP_TRY(hipHostFree(p));
+    return RT_OK;
+}
+
+rt_status rt_host_register(void *p, size_t bytes)
+{
+    if (!p || bytes == 0) { snprintf(g_err, sizeof g_err, "rt_host_register: NULL argument or 0 bytes"); return RT_ERR_INVALID_ARGUMENT; }
+    int ndev = 0;
+    rt_status st = rt_device_count(&ndev);
+    if (st != RT_OK) return st;
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+    return RT_OK;
+}
+
+rt_status rt_host_unregister(void *p)
+{
+    if (!p) return RT_OK;
+    HIP_TRY(hipHostUnregister(p));
     return RT_OK;
 }
 
@@ -1094,10 +1307,78 @@ rt_status rt_selftest_sqrt(int device, uint64_t *mismatches, uint32_t *first_bad
     return RT_OK;
 }
 
+constexpr int kMaxRegionLeaders = 2;
+
+// Renders every request of `batch` in ONE pass and delivers each tile to its caller's buffer.
+static void run_region_batch(rt_scene *s, const std::vector<rt_scene::RegionReq *> &batch)
+{
+    std::vector<rt_region> regs(batch.size());
+    std::vector<uint8_t *> outs(batch.size());
+    for (size_t i = 0; i < batch.size(); ++i) { regs[i] = batch[i]->region; outs[i] = batch[i]->out; }
+    g_count[RT_DEBUG_COUNT_REGION_CALLS].fetch_add((long long)batch.size(), std::memory_order_relaxed);
+    g_count[RT_DEBUG_COUNT_REGION_PASSES].fetch_add(1, std::memory_order_relaxed);
+    g_err[0] = '\0';
+    rt_status st = RT_OK;
+    if (batch.size() == 1) {
+        st = render_tiles_host(s, &batch[0]->o, batch[0]->trav, regs.data(), 1, outs[0], outs.data(), nullptr, false);
+    } else {
+        st = render_tiles_host(s, &batch[0]->o, batch[0]->trav, regs.data(), (uint32_t)regs.size(), outs[0], outs.data(), nullptr, false);
+        if (st == RT_ERR_INVALID_REGION) {
+            // one caller's bad region must not fail its neighbours: everyone on their own
+            for (rt_scene::RegionReq *r : batch) {
+                g_err[0] = '\0';
+                r->st = render_tiles_host(s, &r->o, r->trav, &r->region, 1, r->out, &r->out, nullptr, false);
+                snprintf(r->err, sizeof r->err, "%s", g_err);
+            }
+            return;
+        }
+    }
+    for (rt_scene::RegionReq *r : batch) { r->st = st; snprintf(r->err, sizeof r->err, "%s", g_err); }
+}
+
 rt_status rt_render_region(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *region, uint8_t *rgba_out,
                            rt_stats *stats)
 {
-    return rt_render_tiles(s, o, trav, region, 1, rgba_out, stats);
+    if (!check_common(s, o, region, 1, rgba_out)) return RT_ERR_INVALID_ARGUMENT;
+    if (stats || knob(RT_DEBUG_COALESCE) == 0) return render_tiles_host(s, o, trav, region, 1, rgba_out, &rgba_out, stats, false);
+    // Group commit: the reference calls this from up to RTRACEMAXPROCS pool threads at once (render.rs:283-294), and one
+    // 64x64 bucket per device pass would leave 255 of 256 CUs idle.  A caller that finds no pass running leads the next
+    // one and renders every request waiting at that moment (same options and traversal) together; the others sleep until
+    // their bytes are in their buffer.  A lone caller degenerates to one pass per call.
+    rt_scene::RegionReq me;
+    me.o = *o; me.trav = trav; me.region = *region; me.out = rgba_out;
+    const long long k = knob(RT_DEBUG_COALESCE);
+    const int max_leaders = k > 0 ? (int)std::min<long long>(k, 8) : kMaxRegionLeaders;
+    std::unique_lock<std::mutex> lk(s->comb_mu);
+    s->comb_pending.push_back(&me);
+    while (!me.done) {
+        // up to max_leaders passes at once: while one leader waits for its kernel or hands out bytes, the next batch is
+        // already being set up and rendered on another stream.  Sleepers are woken one by one (their request is done, or it
+        // is their turn to lead), never all at once.
+        if (me.taken || s->comb_leaders >= max_leaders) { me.cv.wait(lk); continue; }
+        ++s->comb_leaders;
+        std::vector<rt_scene::RegionReq *> batch, rest;
+        const rt_scene::RegionReq *head = s->comb_pending.front();
+        for (rt_scene::RegionReq *r : s->comb_pending) {
+            const bool same = r->trav == head->trav && r->o.width == head->o.width && r->o.height == head->o.height &&
+                              r->o.samples_per_pixel == head->o.samples_per_pixel;
+            (same ? batch : rest).push_back(r);
+            if (same) r->taken = true;
+        }
+        s->comb_pending.swap(rest);
+        lk.unlock();
+        run_region_batch(s, batch);
+        lk.lock();
+        --s->comb_leaders;
+        if (!s->comb_pending.empty()) s->comb_pending.front()->cv.notify_one();      // someone whose request is still waiting leads next
+        for (rt_scene::RegionReq *r : batch) {
+            r->done = true;
+            if (r != &me) r->cv.notify_one();
+        }
+    }
+    lk.unlock();
+    if (me.st != RT_OK) snprintf(g_err, sizeof g_err, "%s", me.err);
+    return me.st;
 }
 
 }  // extern "C"

@@ -1,0 +1,49 @@
+/*
+ * rt_debug.h -- diagnostic controls of librtrace_hip.so.  NOT part of the drop-in ABI (include/rtrace_hip.h): nothing a
+ * renderer needs is here, and the library reads no environment variable.  The parity tests and tools/ use these to pick a
+ * traversal-loop flavour or switch an optimisation off and prove that no byte and no counter changes.
+ *
+ * Every control is process-wide and atomic; set it between calls, not during one.
+ */
+#ifndef RTRACE_HIP_DEBUG_H
+#define RTRACE_HIP_DEBUG_H
+
+#include "../../include/rtrace_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_debug_key {
+    RT_DEBUG_SKIP_VARIANT = 0,   /* k_render_skip VAR bits (rt_skip.hpp): 0/1 C++ loops, 3 generated assembly loops, 7 their fused
+                                    flavour (dropped for scenes that are not concentric).  Default 7 */
+    RT_DEBUG_BLOCK_ORDER = 1,    /* 0: dispatch a pass's blocks in raster order instead of most-expensive-first.  Default 1 */
+    RT_DEBUG_NARROW_MAX = 2,     /* cap on the number of blocks dealt out as narrow workgroups (read when a tile list is first seen) */
+    RT_DEBUG_PACKED_SAMPLES = 3, /* 0: spp 2/4/8 use the plain sample-parallel mapping.  Default 1 */
+    RT_DEBUG_PRINT_STEPS = 4,    /* 1: a counted call prints its node-step statistics on stderr */
+    RT_DEBUG_PRINT_COSTS = 5,    /* 1: print the block cost estimates when a dispatch order is built */
+    RT_DEBUG_HOST_COPY = 6,      /* how rt_render_tiles returns bytes to host memory: 0 the library's choice, 1 one copy to the
+                                    caller's pointer, 2 pinned staging + CPU copy, 3 the kernel stores into pinned host memory */
+    RT_DEBUG_COALESCE = 7,       /* 0: concurrent rt_render_region calls are not merged into shared passes; n > 0: at most n merged passes in flight.  Default 2 */
+    RT_DEBUG_KEYS = 8
+} rt_debug_key;
+
+/* value < 0 restores the default. */
+rt_status rt_debug_set(int key, long long value);
+
+/* Process-wide event counts since load (diagnostic): how the merged rt_render_region passes went. */
+typedef enum rt_debug_counter {
+    RT_DEBUG_COUNT_REGION_CALLS = 0,    /* rt_render_region calls that went through the merging path */
+    RT_DEBUG_COUNT_REGION_PASSES = 1,   /* device passes they were rendered in */
+    RT_DEBUG_COUNTERS = 2
+} rt_debug_counter;
+long long rt_debug_count(int counter);
+
+/* Per-wave timeline (tools/wave_timeline.py): while a path is set, every launch of the assembly loops records each wave's
+ * start / end / placement and writes the records to the file (synchronous, overwritten per launch).  NULL switches it off. */
+rt_status rt_debug_wave_trace(const char *path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTRACE_HIP_DEBUG_H */

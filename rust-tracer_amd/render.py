@@ -4,8 +4,8 @@
 
 Same names, argument meaning and error behaviour (the reference panics; here ValueError / RtError).  The one
 deliberate difference: edge buckets are clipped instead of asserting w % 64 == 0 && h % 64 == 0
-(render.rs:265-266), because BASELINE's 800x600 and 1920x1080 configs are not multiples of 64.
-Pixels come only from the HIP kernels; this module moves bytes."""
+(render.rs:265-266), because BASELINE's 800x600 and 1920x1080 configs are not multiples of 64 (SURVEY.md H5);
+`strict_64=True` brings the assertion back.  Pixels come only from the HIP kernels; this module moves bytes."""
 import queue
 import sys
 import threading
@@ -70,11 +70,13 @@ class RGBABufferWriter:                                            # trait, rend
 
 class PPMStdoutRGBABufferWriter(RGBABufferWriter):                 # render.rs:319-434
     """P6 (rgb=True) or P5 writer.  `out` is a path (file sink: progressive whole-file rewrite at most once per
-    second, render.rs:427-432), or '-' / a binary file object (written once at close, like the Drop impl)."""
+    second, render.rs:427-432), or '-' / a binary file object (written once at close, like the Drop impl).
+    `clock` (seconds, monotonic) is injectable so that a test can watch the progressive rewrites."""
 
-    def __init__(self, write_rgb, out):
+    def __init__(self, write_rgb, out, clock=time.monotonic):
         self.rgb = write_rgb
         self.out = out
+        self.clock = clock
         self.width = self.height = None
         self.image = None
         self.last_written_at = None
@@ -90,8 +92,9 @@ class PPMStdoutRGBABufferWriter(RGBABufferWriter):                 # render.rs:3
     def write_rgba_buffer(self, buffer):
         self.image.set_pixels_from_buffer(buffer)
         self.buffer_dirty = True
-        if self.output_is_file() and (self.last_written_at is None or self.last_written_at + 1.0 <= time.monotonic()):
-            self.last_written_at = time.monotonic()
+        now = self.clock()
+        if self.output_is_file() and (self.last_written_at is None or self.last_written_at + 1.0 <= now):      # render.rs:427-432
+            self.last_written_at = now
             self.write_buffer_with_header()
 
     def encode(self):
@@ -132,33 +135,48 @@ def buckets(options, chunk=CHUNK_SIZE):
     return out
 
 
+# Buckets handed to the device per call.  Large enough to fill 256 CUs (64 buckets = 1,024 workgroups), small enough that
+# finished buckets keep reaching the writer while the rest of a long render is still running -- the reference's observable
+# behaviour (tiles arrive in completion order, the file is rewritten once per second, render.rs:301-307, 427-432) --
+# even with RTRACEMAXPROCS = 1.
+MAX_BUCKETS_PER_CALL = 64
+
+
 class Renderer:
     @staticmethod
-    def render_region(o, scene, buf, device=0, traversal=capi.RT_TRAVERSAL_FLAT):
-        """Renderer::render_region(o, scene, buf) render.rs:218 -- fills buf for buf.region() on the GPU."""
-        data, stats = scene.device(device).render_tiles(tuple(o), [tuple(buf.region())], traversal)
-        buf.buf[...] = data.reshape(buf.buf.shape)
+    def render_region(o, scene, buf, device=0, traversal=None):
+        """Renderer::render_region(o, scene, buf) render.rs:218 -- fills buf for buf.region() on the GPU.
+        traversal: None = the reference's hierarchy walk when the scene has bounds (else the flat scan)."""
+        _, stats = scene.device(device).render_region(tuple(o), tuple(buf.region()), traversal, want_stats=True,
+                                                      out=buf.buf.reshape(-1))
         return stats
 
     @staticmethod
-    def render(o, scene, writer, pool=1, device=0, traversal=capi.RT_TRAVERSAL_FLAT, tiles_per_call=None):
+    def render(o, scene, writer, pool=1, device=0, traversal=None, tiles_per_call=None, strict_64=False):
         """Renderer::render(o, scene, writer, pool) render.rs:260-310.
 
         `pool` keeps the meaning of the reference's ThreadPool size (RTRACEMAXPROCS / --num-cores): the number of
         host scheduler threads.  Each thread hands the device a BATCH of buckets per call (one launch per 64x64
-        bucket would starve 256 CUs, H4); finished buckets reach the writer through a bounded queue of 4
-        (sync_channel(4), render.rs:271) in completion order.  Returns accumulated ray statistics."""
+        bucket would starve 256 CUs, H4), at most MAX_BUCKETS_PER_CALL; finished buckets reach the writer through a
+        bounded queue of 4 (sync_channel(4), render.rs:271) in completion order.  Returns accumulated ray statistics.
+        strict_64: reproduce `assert!(w % 64 == 0 && h % 64 == 0)` (render.rs:265-266) instead of clipping edge buckets."""
+        if strict_64 and (o.width % CHUNK_SIZE or o.height % CHUNK_SIZE):
+            raise ValueError("TODO: handle chunk sizes")                 # the assert!s custom message
         bl = buckets(o)
         writer.begin(o.width, o.height)
         dev = scene.device(device)
+        traversal = dev.default_traversal() if traversal is None else traversal
         pool = max(1, int(pool))
-        per = tiles_per_call or max(1, -(-len(bl) // pool))
+        per = tiles_per_call or max(1, min(MAX_BUCKETS_PER_CALL, -(-len(bl) // pool)))
         batches = [bl[i:i + per] for i in range(0, len(bl), per)]
         q = queue.Queue(maxsize=4)
         total = {"primary": 0, "hits": 0, "shadow": 0, "occluded": 0, "sphere_tests": 0, "device_ms": 0.0}
         lock = threading.Lock()
+        stop = threading.Event()
 
         def work(batch):
+            if stop.is_set():
+                return
             data, st = dev.render_tiles(tuple(o), [tuple(r) for r in batch], traversal)
             with lock:
                 for k in total:
@@ -166,21 +184,34 @@ class Renderer:
             off = 0
             for r in batch:
                 n = r.area() * 4
-                q.put(RGBABuffer(r, data[off:off + n]))
+                item = RGBABuffer(r, data[off:off + n])
+                while not stop.is_set():                           # a failed render must not leave workers blocked in put()
+                    try:
+                        q.put(item, timeout=0.05)
+                        break
+                    except queue.Full:
+                        pass
                 off += n
 
         count = len(bl)
+        failure = None
         with ThreadPoolExecutor(max_workers=pool) as ex:
             futs = [ex.submit(work, b) for b in batches]
-            while count:
-                try:
-                    writer.write_rgba_buffer(q.get(timeout=0.1))
-                    count -= 1
-                except queue.Empty:
-                    for f in futs:
-                        if f.done() and f.exception() is not None:
-                            raise f.exception()
-            for f in futs:
-                f.result()
+            try:
+                while count:
+                    try:
+                        writer.write_rgba_buffer(q.get(timeout=0.05))
+                        count -= 1
+                    except queue.Empty:
+                        for f in futs:
+                            if f.done() and f.exception() is not None:
+                                raise f.exception()
+            except BaseException as e:                             # worker or writer failure: release the workers, then re-raise
+                failure = e
+                stop.set()
+        if failure is not None:
+            raise failure
+        for f in futs:
+            f.result()
         assert count == 0, "We really should have processed all chunks here"      # render.rs:308-309
         return total

@@ -188,20 +188,43 @@ class DeviceScene:
             arr[i] = capi.Region(l, t, r, b)
         return arr
 
-    def render_tiles(self, options, regions, traversal=capi.RT_TRAVERSAL_FLAT, want_stats=True):
-        """rt_render_tiles: regions = [(l, t, r, b), ...] -> (uint8[total_px*4] tile-major, stats dict | None)."""
-        arr = self._regions(regions)
-        nbytes = capi.lib.rt_tiles_rgba_bytes(arr, len(regions))
-        out = np.empty(max(int(nbytes), 1), dtype=np.uint8)
+    def render_tiles(self, options, regions, traversal=None, want_stats=True, out=None):
+        """rt_render_tiles: regions = [(l, t, r, b), ...] -> (uint8[total_px*4] tile-major, stats dict | None).
+        out: optional uint8 array to render into (e.g. capi.HostBuffer(n).array: pinned, written by the kernel directly)."""
+        traversal = self.default_traversal() if traversal is None else traversal
+        arr = regions if isinstance(regions, C.Array) else self._regions(regions)
+        nbytes = capi.lib.rt_tiles_rgba_bytes(arr, len(arr))
+        if out is None:
+            out = np.empty(max(int(nbytes), 1), dtype=np.uint8)
+        elif out.dtype != np.uint8 or not out.flags.c_contiguous or out.size < nbytes:
+            raise ValueError("out must be a contiguous uint8 array of at least %d bytes" % nbytes)
         st = capi.Stats()
         o = capi.Options(*options)
-        rc = capi.lib.rt_render_tiles(self._h, C.byref(o), traversal, arr, len(regions), out.ctypes.data,
+        rc = capi.lib.rt_render_tiles(self._h, C.byref(o), traversal, arr, len(arr), out.ctypes.data,
                                       C.byref(st) if want_stats else None)
         capi.check(rc, "rt_render_tiles")
-        return out[:int(nbytes)], (st.as_dict() if want_stats else None)
+        return out.reshape(-1)[:int(nbytes)], (st.as_dict() if want_stats else None)
 
-    def render_tiles_device(self, options, regions, out_ptr, stream=0, traversal=capi.RT_TRAVERSAL_FLAT, want_stats=False):
+    def render_region(self, options, region, traversal=None, want_stats=False, out=None):
+        """rt_render_region: one bucket (l, t, r, b) -> (uint8[h, w, 4], stats dict | None); the literal render.rs:283-294 call."""
+        traversal = self.default_traversal() if traversal is None else traversal
+        l, t, r, b = region
+        reg = capi.Region(l, t, r, b)
+        if out is None:
+            out = np.empty((t - b) * (r - l) * 4, dtype=np.uint8)
+        st = capi.Stats()
+        o = capi.Options(*options)
+        rc = capi.lib.rt_render_region(self._h, C.byref(o), traversal, C.byref(reg), out.ctypes.data, C.byref(st) if want_stats else None)
+        capi.check(rc, "rt_render_region")
+        return out.reshape(t - b, r - l, 4), (st.as_dict() if want_stats else None)
+
+    def default_traversal(self):
+        """The reference's hierarchy walk whenever the scene has bounds; the flat scan otherwise."""
+        return capi.RT_TRAVERSAL_SKIP if self.scene.bounds is not None and len(self.scene.bounds) else capi.RT_TRAVERSAL_FLAT
+
+    def render_tiles_device(self, options, regions, out_ptr, stream=0, traversal=None, want_stats=False):
         """rt_render_tiles_device: enqueue on `stream` (hipStream_t as int), output to device pointer `out_ptr`."""
+        traversal = self.default_traversal() if traversal is None else traversal
         arr = regions if isinstance(regions, C.Array) else self._regions(regions)
         st = capi.Stats()
         o = capi.Options(*options)

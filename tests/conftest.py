@@ -15,6 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The test modules import the package (and the oracle) at module scope, and both need their built libraries: on a fresh
+# checkout (the .so files are git-ignored) build them here, before collection, instead of failing with an ImportError.
+if not (os.path.exists(os.path.join(ROOT, "rust-tracer_amd", "librtrace_hip.so")) and
+        os.path.exists(os.path.join(ROOT, "oracle", "librt_oracle.so")) and
+        os.path.exists(os.path.join(ROOT, "rust-tracer_amd", "rtrace"))):
+    import __graft_entry__
+    __graft_entry__.build()
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -39,8 +47,8 @@ def _check_both_launch_flavours(request, monkeypatch):
     import rust_tracer_amd as rta
     orig = rta.DeviceScene.render_tiles
 
-    def both(self, options, regions, traversal=rta.RT_TRAVERSAL_FLAT, want_stats=True):
-        data, st = orig(self, options, regions, traversal, want_stats)
+    def both(self, options, regions, traversal=None, want_stats=True, out=None):
+        data, st = orig(self, options, regions, traversal, want_stats, out)
         if want_stats:
             plain, _ = orig(self, options, regions, traversal, False)
             assert np.array_equal(plain, data), "the launch without counters renders different bytes"

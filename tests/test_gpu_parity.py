@@ -33,7 +33,7 @@ def test_device_present():
 def test_config1_three_spheres_single_tile(precision):
     # BASELINE config 1: single 64x64 tile, 3 spheres, 1 light
     s, o = util.scene_pair_spheres(util.THREE_SPHERES, util.THREE_BOUND, precision)
-    data, st = s.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)])
+    data, st = s.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)], traversal=FLAT)
     for mode in (oracle.MODE_HIERARCHY, oracle.MODE_FLAT):
         ref, rst = o.render_region(64, 64, 1, 0, 64, 64, 0, mode)
         np.testing.assert_array_equal(data.reshape(64, 64, 4), ref)
@@ -44,7 +44,7 @@ def test_config1_three_spheres_single_tile(precision):
 def test_default_scene_single_tile_and_counters():
     # SURVEY 8(d) row 1 companion: default scene 64x64 spp 1 -> 4096 / 2487 / 1923 / 909
     s, o = util.scene_pair_default()
-    data, st = s.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)])
+    data, st = s.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)], traversal=FLAT)
     ref, rst = o.render_region(64, 64, 1, 0, 64, 64, 0)
     np.testing.assert_array_equal(data.reshape(64, 64, 4), ref)
     assert util.ray_stats(st) == (4096, 2487, 1923, 909) == util.ray_stats(rst)
@@ -55,7 +55,7 @@ def test_reference_test_shape_64x128_spp2_two_buckets():
     s, o = util.scene_pair_default()
     regs = bucket_list(64, 128, 2)
     assert len(regs) == 2
-    data, st = s.device().render_tiles((64, 128, 2), regs)
+    data, st = s.device().render_tiles((64, 128, 2), regs, traversal=FLAT)
     ref, rst, n = o.render(64, 128, 2, nthreads=2)
     assert n == 2
     np.testing.assert_array_equal(util.stitch((64, 128), regs, data), ref)
@@ -69,7 +69,7 @@ def test_golden_make_image_1024x768_spp4(golden_dir):
     s, o = util.scene_pair_default()
     regs = bucket_list(1024, 768, 4)
     assert len(regs) == 192
-    data, st = s.device().render_tiles((1024, 768, 4), regs)
+    data, st = s.device().render_tiles((1024, 768, 4), regs, traversal=FLAT)
     frame = util.stitch((1024, 768), regs, data)
     assert int((frame[:, :, :3] != ref_rgb).any(axis=2).sum()) == 0
     off = 0
@@ -87,7 +87,7 @@ def test_config2_800x600_clipped_edge_buckets():
     s, o = util.scene_pair_default()
     regs = bucket_list(800, 600)
     assert len(regs) == 130
-    data, st = s.device().render_tiles((800, 600, 1), regs)
+    data, st = s.device().render_tiles((800, 600, 1), regs, traversal=FLAT)
     ref, rst, _ = o.render(800, 600, 1, nthreads=os.cpu_count() or 1)
     np.testing.assert_array_equal(util.stitch((800, 600), regs, data), ref)
     assert util.ray_stats(st) == (480000, 359528, 275032, 136797) == util.ray_stats(rst)
@@ -98,7 +98,7 @@ def test_config3_1920x1080_f32():
     s, o = util.scene_pair_default()
     regs = bucket_list(1920, 1080)
     assert len(regs) == 510
-    data, st = s.device().render_tiles((1920, 1080, 1), regs)
+    data, st = s.device().render_tiles((1920, 1080, 1), regs, traversal=FLAT)
     ref, rst, _ = o.render(1920, 1080, 1, nthreads=os.cpu_count() or 1)
     np.testing.assert_array_equal(util.stitch((1920, 1080), regs, data), ref)
     assert util.ray_stats(st) == (2073600, 1777280, 1337403, 730313) == util.ray_stats(rst)
@@ -109,7 +109,7 @@ def test_config3_1920x1080_f64_type_alias_swap():
     # f64 is a separate golden (P7), pinned only by the oracle's own f64 instantiation ("parity unpinned")
     s, o = util.scene_pair_default(rta.RT_F64)
     regs = bucket_list(1920, 1080)
-    data, st = s.device().render_tiles((1920, 1080, 1), regs)
+    data, st = s.device().render_tiles((1920, 1080, 1), regs, traversal=FLAT)
     ref, rst, _ = o.render(1920, 1080, 1, nthreads=os.cpu_count() or 1)
     np.testing.assert_array_equal(util.stitch((1920, 1080), regs, data), ref)
     assert util.ray_stats(st) == util.ray_stats(rst)
@@ -119,9 +119,9 @@ def test_whole_frame_as_one_region_equals_buckets():
     # a pixel does not depend on its tile (render.rs:217): one region == 130 stitched buckets
     s, _ = util.scene_pair_default()
     d = s.device()
-    one, st1 = d.render_tiles((800, 600, 1), full(800, 600))
+    one, st1 = d.render_tiles((800, 600, 1), full(800, 600), traversal=FLAT)
     regs = bucket_list(800, 600)
-    many, st2 = d.render_tiles((800, 600, 1), regs)
+    many, st2 = d.render_tiles((800, 600, 1), regs, traversal=FLAT)
     np.testing.assert_array_equal(one.reshape(600, 800, 4), util.stitch((800, 600), regs, many))
     assert util.ray_stats(st1) == util.ray_stats(st2)
 
@@ -129,7 +129,7 @@ def test_whole_frame_as_one_region_equals_buckets():
 def test_tile_order_and_duplicates_are_honoured():
     s, o = util.scene_pair_default()
     regs = [(64, 128, 128, 64), (0, 64, 64, 0), (64, 128, 128, 64), (130, 77, 131, 76)]
-    data, st = s.device().render_tiles((256, 192, 2), regs)
+    data, st = s.device().render_tiles((256, 192, 2), regs, traversal=FLAT)
     off = 0
     for (l, t, r, b) in regs:
         ref, _ = o.render_region(256, 192, 2, l, t, r, b)
@@ -145,7 +145,7 @@ def test_ragged_regions(region):
     # ImageRegion{l:2,t:18,r:34,b:2}-like odd rectangles, 1x1, single row, single column
     s, o = util.scene_pair_default()
     l, t, r, b = region
-    data, st = s.device().render_tiles((200, 150, 1), [region])
+    data, st = s.device().render_tiles((200, 150, 1), [region], traversal=FLAT)
     ref, rst = o.render_region(200, 150, 1, l, t, r, b)
     np.testing.assert_array_equal(data.reshape(ref.shape), ref)
     assert util.ray_stats(st) == util.ray_stats(rst)
@@ -156,14 +156,14 @@ def test_tie_break_first_in_dfs_order_wins(precision):
     # primitive.rs:79 strict `>=` reject: of two items at exactly equal distance the first one keeps the hit
     for spheres in (util.TIE_SPHERES, util.TIE_SPHERES[::-1]):
         s, o = util.scene_pair_spheres(spheres, util.TIE_BOUND, precision)
-        data, st = s.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)])
+        data, st = s.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)], traversal=FLAT)
         ref, rst = o.render_region(64, 64, 1, 0, 64, 64, 0)
         np.testing.assert_array_equal(data.reshape(64, 64, 4), ref)
         assert util.ray_stats(st) == util.ray_stats(rst)
     a, _ = util.scene_pair_spheres(util.TIE_SPHERES, util.TIE_BOUND, precision)
     b, _ = util.scene_pair_spheres(util.TIE_SPHERES[::-1], util.TIE_BOUND, precision)
-    da, _ = a.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)])
-    db, _ = b.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)])
+    da, _ = a.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)], traversal=FLAT)
+    db, _ = b.device().render_tiles((64, 64, 1), [(0, 64, 64, 0)], traversal=FLAT)
     col_a, col_b = da.reshape(64, 64, 4)[:, 32], db.reshape(64, 64, 4)[:, 32]
     assert (col_a != col_b).any(), "the tie column must depend on item order, or the scene does not exercise the rule"
 
@@ -173,7 +173,7 @@ def test_pyramid_level9_87381_items_chunk_boundaries():
     s, o = util.scene_pair_default(level=9)
     assert s.items.shape[0] == 87381
     regs = bucket_list(192, 128, 2)
-    data, st = s.device().render_tiles((192, 128, 2), regs)
+    data, st = s.device().render_tiles((192, 128, 2), regs, traversal=FLAT)
     ref, rst, _ = o.render(192, 128, 2, nthreads=os.cpu_count() or 1)
     np.testing.assert_array_equal(util.stitch((192, 128), regs, data), ref)
     assert util.ray_stats(st) == util.ray_stats(rst)
@@ -185,7 +185,7 @@ def test_item_counts_around_the_lds_chunk(n_items):
     sp = np.concatenate([rng.uniform(-1.5, 1.5, (n_items, 3)), rng.uniform(0.02, 0.12, (n_items, 1))], axis=1)
     sp = sp.astype(np.float32).astype(np.float64)
     s, o = util.scene_pair_spheres(sp, (0, 0, 0, 3.0))
-    data, st = s.device().render_tiles((96, 80, 1), [(0, 80, 96, 0)])
+    data, st = s.device().render_tiles((96, 80, 1), [(0, 80, 96, 0)], traversal=FLAT)
     ref, rst = o.render_region(96, 80, 1, 0, 80, 96, 0, oracle.MODE_FLAT)
     np.testing.assert_array_equal(data.reshape(ref.shape), ref)
     assert util.ray_stats(st) == util.ray_stats(rst)
@@ -194,8 +194,8 @@ def test_item_counts_around_the_lds_chunk(n_items):
 def test_idempotent_and_stats_optional():
     s, _ = util.scene_pair_default()
     d = s.device()
-    a, _ = d.render_tiles((320, 200, 1), full(320, 200))
-    b, none = d.render_tiles((320, 200, 1), full(320, 200), want_stats=False)
+    a, _ = d.render_tiles((320, 200, 1), full(320, 200), traversal=FLAT)
+    b, none = d.render_tiles((320, 200, 1), full(320, 200), want_stats=False, traversal=FLAT)
     assert none is None
     np.testing.assert_array_equal(a, b)
 
@@ -208,7 +208,7 @@ def test_concurrent_callers_share_one_scene():
     out = [None] * len(regs)
 
     def work(i):
-        out[i], _ = d.render_tiles((256, 256, 1), [regs[i]])
+        out[i], _ = d.render_tiles((256, 256, 1), [regs[i]], traversal=FLAT)
 
     th = [threading.Thread(target=work, args=(i,)) for i in range(len(regs))]
     [t.start() for t in th]
@@ -223,7 +223,7 @@ def test_renderer_surface_writes_reference_ppm(tmp_path):
     opts = rta.RenderOptions(256, 192, 2)
     path = str(tmp_path / "out.tga")
     w = rta.PPMStdoutRGBABufferWriter(True, path)
-    rta.Renderer.render(opts, s, w, pool=3)
+    rta.Renderer.render(opts, s, w, pool=3, traversal=FLAT)
     w.close()
     ref, _, _ = o.render(256, 192, 2, nthreads=4)
     oracle.write_ppm(str(tmp_path / "ref.ppm"), ref)
@@ -234,13 +234,13 @@ def test_error_codes_instead_of_panics():
     s, _ = util.scene_pair_default()
     d = s.device()
     with pytest.raises(rta.RtError) as e:
-        d.render_tiles((64, 64, 1), [(0, 65, 64, 0)])          # outside the image
+        d.render_tiles((64, 64, 1), [(0, 65, 64, 0)], traversal=FLAT)          # outside the image
     assert e.value.status == rta.capi.RT_ERR_INVALID_REGION
     with pytest.raises(rta.RtError) as e:
-        d.render_tiles((64, 64, 1), [(10, 20, 10, 0)])         # empty
+        d.render_tiles((64, 64, 1), [(10, 20, 10, 0)], traversal=FLAT)         # empty
     assert e.value.status == rta.capi.RT_ERR_INVALID_REGION
     with pytest.raises(rta.RtError) as e:
-        d.render_tiles((64, 64, 0), [(0, 64, 64, 0)])          # spp == 0
+        d.render_tiles((64, 64, 0), [(0, 64, 64, 0)], traversal=FLAT)          # spp == 0
     assert e.value.status == rta.capi.RT_ERR_INVALID_ARGUMENT
     with pytest.raises(rta.RtError) as e:
         rta.Scene.from_spheres([(0, 0, 0, -1.0)], (0, 0, 0, 3.0)).device()
@@ -554,23 +554,18 @@ def test_more_distinct_tile_lists_than_the_table_cache_holds(trav):
 @pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64], ids=["f32", "f64"])
 @pytest.mark.parametrize("seed", [11, 12, 13])
 def test_every_skip_loop_flavour_on_deep_random_scenes(variant, concentric, precision, seed):
-    # RT_SKIP_VARIANT picks the traversal-loop flavour explicitly (0/1 C++ loops, 3 generated assembly loops, 7 their fused
+    # rt_debug_set(RT_DEBUG_SKIP_VARIANT) picks the traversal-loop flavour explicitly (0/1 C++ loops, 3 generated assembly loops, 7 their fused
     # flavour -- used for concentric scenes only, the library drops the bit otherwise; the default is 7).  Deeper, wider
     # random trees with loose bounds and an eye inside some bounds: culling decides pixels, many lanes retire at different
     # items in the shadow walk.
-    import ctypes
-    libc = ctypes.CDLL(None)
     items, bounds, ranges = util.random_nested_scene(seed, depth=4, fan=4, leaf_items=2, concentric=concentric)
     s, o = util.scene_pair_ranges(items, bounds, ranges, precision, eye=(0.05, -0.1, -2.2))
     assert s.device().traits() == rta.capi.RT_SCENE_HAS_BOUNDS | (rta.capi.RT_SCENE_CONCENTRIC if concentric else 0)
     regs = bucket_list(192, 160, 2)
     ref, rst, _ = o.render(192, 160, 2, os.cpu_count() or 1, HIER_EXIT)
-    libc.setenv(b"RT_SKIP_VARIANT", str(variant).encode(), 1)
-    try:
+    with rta.capi.debug(rta.capi.DEBUG_SKIP_VARIANT, variant):
         plain, _ = s.device().render_tiles((192, 160, 2), regs, SKIP, want_stats=False)
         counted, st = s.device().render_tiles((192, 160, 2), regs, SKIP, want_stats=True)
-    finally:
-        libc.unsetenv(b"RT_SKIP_VARIANT")
     np.testing.assert_array_equal(util.stitch((192, 160), regs, plain), ref)
     np.testing.assert_array_equal(counted, plain)
     assert util.all_stats(st) == util.all_stats(rst)
@@ -581,8 +576,6 @@ def test_block_dispatch_order_never_changes_a_pixel(size):
     # The library dispatches a pass's 16x16 blocks most-expensive-first (cost map rendered once per scene).  Same pixels
     # and same counters with the ordering switched off, for landscape, portrait (rows beyond the square cost map are
     # clamped) and ragged sizes, and for tile lists given in a scrambled order.
-    import ctypes
-    libc = ctypes.CDLL(None)
     w, h, spp = size
     scene = rta.Scene.default(6)
     d = scene.device()
@@ -591,12 +584,9 @@ def test_block_dispatch_order_never_changes_a_pixel(size):
     scrambled = [regs[i] for i in rng.permutation(len(regs))]
     out = {}
     for flag in (b"0", b"1"):
-        libc.setenv(b"RT_BLOCK_ORDER", flag, 1)
-        try:
+        with rta.capi.debug(rta.capi.DEBUG_BLOCK_ORDER, int(flag)):
             a, sa = d.render_tiles((w, h, spp), regs, SKIP, want_stats=True)
             b, _ = d.render_tiles((w, h, spp), scrambled, SKIP, want_stats=False)
-        finally:
-            libc.unsetenv(b"RT_BLOCK_ORDER")
         out[flag] = (util.stitch((w, h), regs, a), util.stitch((w, h), scrambled, b), util.all_stats(sa))
     np.testing.assert_array_equal(out[b"0"][0], out[b"1"][0])
     np.testing.assert_array_equal(out[b"0"][1], out[b"1"][1])
@@ -634,24 +624,19 @@ def test_100k_arbitrary_spheres_with_auto_built_hierarchy():
         np.testing.assert_array_equal(frame[b:t, l:r], fref)
 
 
-@pytest.mark.parametrize("narrow_max", [b"0", b"64"])
+@pytest.mark.parametrize("narrow_max", [0, 64])
 def test_narrow_blocks_on_ragged_tiles(narrow_max):
     # The most expensive 16x16 blocks of a pass go out as four (or, in a small pass, sixteen) narrow workgroups.  Here the
     # expensive part of the image is covered by ragged 50x50 tiles (their last block row / column is clipped to 2 pixels), and
     # up to 64 of the 256 blocks are narrowed: every pixel and every counter must equal the CPU path's, and the un-narrowed
     # launch's.
-    import ctypes
-    libc = ctypes.CDLL(None)
     s, o = rta.Scene.default(), oracle.Scene.default()      # a fresh device scene: its table cache has not seen this tile list
     w, h = 1920, 1080
     regs = [(x, y + 50, x + 50, y) for y in range(440, 640, 50) for x in range(860, 1060, 50)]
-    libc.setenv(b"RT_NARROW_MAX", narrow_max, 1)
-    try:
+    with rta.capi.debug(rta.capi.DEBUG_NARROW_MAX, narrow_max):
         d = s.device()
         plain, _ = d.render_tiles((w, h, 1), regs, SKIP, want_stats=False)
         counted, st = d.render_tiles((w, h, 1), regs, SKIP, want_stats=True)
-    finally:
-        libc.unsetenv(b"RT_NARROW_MAX")
     np.testing.assert_array_equal(counted, plain)
     off, tot = 0, None
     for (l, t, r, b) in regs:
@@ -668,10 +653,8 @@ def test_narrow_blocks_on_ragged_tiles(narrow_max):
 def test_every_sample_count_on_a_ragged_image(spp, precision):
     # spp 2 / 4 / 8 take the packed sample-parallel mapping (a wave = the samples of a few neighbouring pixels, samples stored
     # [pixel][sample]); 3 and 5 the plain one (a wave = one sample of 8x8 pixels).  150x70 leaves clipped buckets, blocks and
-    # sub-blocks on both edges.  Pixels, alpha and every counter against the CPU path; the switch RT_PACKED_SAMPLES=0 must not
+    # sub-blocks on both edges.  Pixels, alpha and every counter against the CPU path; switching the packed mapping off (rt_debug.h) must not
     # change a byte.
-    import ctypes
-    libc = ctypes.CDLL(None)
     s, o = util.scene_pair_default(precision)
     w, h = 150, 70
     regs = bucket_list(w, h, spp)
@@ -679,9 +662,159 @@ def test_every_sample_count_on_a_ragged_image(spp, precision):
     data, st = s.device().render_tiles((w, h, spp), regs, SKIP)
     np.testing.assert_array_equal(util.stitch((w, h), regs, data), ref)
     assert util.all_stats(st) == util.all_stats(rst)
-    libc.setenv(b"RT_PACKED_SAMPLES", b"0", 1)
-    try:
+    with rta.capi.debug(rta.capi.DEBUG_PACKED_SAMPLES, 0):
         plain, _ = s.device().render_tiles((w, h, spp), regs, SKIP, want_stats=False)
-    finally:
-        libc.unsetenv(b"RT_PACKED_SAMPLES")
     np.testing.assert_array_equal(plain, data)
+
+
+# ---------------------------------------------------------------- host-buffer boundary (round 2)
+def test_host_buffers_pinned_registered_and_pageable_deliver_the_same_bytes():
+    # rt_render_tiles recognises rt_host_alloc'd / rt_host_register'd memory by address and lets the kernel store into it
+    # directly; pageable memory takes a copy.  Every copy strategy (csrc/rt_debug.h RT_DEBUG_HOST_COPY) must deliver the same bytes.
+    s, o = util.scene_pair_default()
+    d = s.device()
+    w, h = 320, 200
+    regs = bucket_list(w, h)
+    ref, _, _ = o.render(w, h, 1, nthreads=4)
+    n = w * h * 4
+    pinned = rta.capi.HostBuffer(n)
+    registered = np.zeros(n + 8192, dtype=np.uint8)
+    page = (registered.ctypes.data + 4095) & ~4095          # register whole pages
+    reg_view = registered[page - registered.ctypes.data:][:n]
+    rta.capi.check(rta.capi.lib.rt_host_register(reg_view.ctypes.data, n), "rt_host_register")
+    try:
+        for buf, modes in ((np.zeros(n, dtype=np.uint8), (0, 1, 2)), (pinned.array, (0, 1, 3)), (reg_view, (0, 1, 3))):
+            for mode in modes:
+                buf[:] = 0
+                with rta.capi.debug(rta.capi.DEBUG_HOST_COPY, mode if mode else -1):
+                    data, _ = d.render_tiles((w, h, 1), regs, SKIP, want_stats=False, out=buf)
+                np.testing.assert_array_equal(util.stitch((w, h), regs, data), ref)
+        # an interior pointer of a pinned range is recognised too
+        pinned.array[:] = 0
+        data, _ = d.render_tiles((w, h, 1), regs[1:], SKIP, want_stats=False, out=pinned.array[64 * 64 * 4:])
+        np.testing.assert_array_equal(data, util_tile_major(ref, regs[1:]))
+    finally:
+        rta.capi.check(rta.capi.lib.rt_host_unregister(reg_view.ctypes.data), "rt_host_unregister")
+        pinned.close()
+
+
+def util_tile_major(frame, regs):
+    return np.concatenate([np.ascontiguousarray(frame[b:t, l:r]).reshape(-1) for (l, t, r, b) in regs])
+
+
+def test_render_tiles_rejects_a_device_pointer():
+    import torch
+    s, _ = util.scene_pair_default()
+    dev = torch.zeros(64 * 64 * 4, dtype=torch.uint8, device="cuda")
+    o = rta.capi.Options(64, 64, 1)
+    reg = s.device()._regions([(0, 64, 64, 0)])
+    rc = rta.capi.lib.rt_render_tiles(s.device()._h, o, SKIP, reg, 1, dev.data_ptr(), None)
+    assert rc == rta.capi.RT_ERR_INVALID_ARGUMENT
+    assert b"rt_render_tiles_device" in rta.capi.lib.rt_last_error_message()
+
+
+@pytest.mark.parametrize("leaders", [0, 1, 2, 3])
+def test_concurrent_render_region_calls_are_merged_and_stay_exact(leaders):
+    # the literal render.rs:283-294 shape: one rt_render_region call per bucket from many pool threads at once.  The library
+    # merges concurrent callers into shared passes (leaders = passes in flight; 0 = no merging): every caller must get exactly
+    # its bucket's bytes, whatever it was merged with -- here two different images are rendered concurrently by 24 threads.
+    s, o = util.scene_pair_default()
+    d = s.device()
+    jobs = [((256, 192, 1), r) for r in bucket_list(256, 192)] + [((200, 130, 2), r) for r in bucket_list(200, 130, 2)]
+    refs = {(256, 192, 1): o.render(256, 192, 1, nthreads=4)[0], (200, 130, 2): o.render(200, 130, 2, nthreads=4)[0]}
+    out = [None] * len(jobs)
+    calls0 = rta.capi.lib.rt_debug_count(0)
+    nxt, lock = [0], threading.Lock()
+
+    def work():
+        while True:
+            with lock:
+                i = nxt[0]
+                nxt[0] += 1
+            if i >= len(jobs):
+                return
+            out[i], _ = d.render_region(jobs[i][0], jobs[i][1], SKIP)
+
+    with rta.capi.debug(rta.capi.DEBUG_COALESCE, leaders):
+        th = [threading.Thread(target=work) for _ in range(24)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    for (opts, (l, t, r, b)), got in zip(jobs, out):
+        np.testing.assert_array_equal(got, refs[opts][b:t, l:r])
+    assert rta.capi.lib.rt_debug_count(0) - calls0 == (len(jobs) if leaders else 0)
+
+
+def test_a_bad_region_fails_alone_in_a_merged_pass():
+    s, o = util.scene_pair_default()
+    d = s.device()
+    regs = bucket_list(256, 192) + [(0, 200, 64, 136)]          # the last one sticks out of the 256x192 image
+    res = [None] * len(regs)
+
+    def work(i):
+        try:
+            res[i] = d.render_region((256, 192, 1), regs[i], SKIP)[0]
+        except rta.RtError as e:
+            res[i] = e
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(regs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    ref = o.render(256, 192, 1, nthreads=4)[0]
+    for (l, t, r, b), got in zip(regs[:-1], res[:-1]):
+        np.testing.assert_array_equal(got, ref[b:t, l:r])
+    assert isinstance(res[-1], rta.RtError) and res[-1].status == rta.capi.RT_ERR_INVALID_REGION
+
+
+def test_renderer_defaults_to_the_hierarchy_and_strict_64_reproduces_the_assertion(tmp_path):
+    # Renderer.render(o, scene, writer) with no traversal given is the reference's hierarchy walk (render.rs:218 -> group.rs:72);
+    # strict_64 brings back assert!(w % 64 == 0 && h % 64 == 0) (render.rs:265-266)
+    s, o = util.scene_pair_ranges(util.INSIDE_ITEMS, util.INSIDE_BOUNDS, util.INSIDE_RANGES)
+    assert s.device().default_traversal() == SKIP
+    opts = rta.RenderOptions(128, 64, 1)
+    w = rta.PPMStdoutRGBABufferWriter(True, str(tmp_path / "a.tga"))
+    rta.Renderer.render(opts, s, w)
+    w.close()
+    ref, _, _ = o.render(128, 64, 1, 2, HIER_EXIT)
+    oracle.write_ppm(str(tmp_path / "ref.ppm"), ref)
+    assert open(str(tmp_path / "a.tga"), "rb").read() == open(str(tmp_path / "ref.ppm"), "rb").read()
+    buf = rta.RGBABuffer(rta.ImageRegion(0, 64, 64, 0))
+    rta.Renderer.render_region(opts, s, buf)
+    np.testing.assert_array_equal(buf.buf, ref[0:64, 0:64])
+    with pytest.raises(ValueError, match="TODO: handle chunk sizes"):
+        rta.Renderer.render(rta.RenderOptions(800, 600, 1), s, rta.PPMStdoutRGBABufferWriter(True, str(tmp_path / "b.tga")), strict_64=True)
+    assert rta.Scene.from_spheres(util.THREE_SPHERES, util.THREE_BOUND).device().default_traversal() == SKIP
+    assert rta.Scene(np.array(util.THREE_SPHERES), rta.normalized((-1, -3, 2), rta.RT_F32), (0, 0, -4)).device().default_traversal() == FLAT
+
+
+def test_progressive_output_partial_ppm_on_disk_mid_render(tmp_path):
+    # f.2 (render.rs:301-307, 422-433): buckets reach the writer in completion order while the rest of the frame is still to
+    # be rendered, and the file sink rewrites the whole image as they come (at most once per second: the clock is injected and
+    # jumps 2 s per bucket).  With RTRACEMAXPROCS = 1 the device gets 8 buckets per call, so when bucket k arrives the file must
+    # be a valid P6 holding exactly the first k buckets (bit-exact) and zeros everywhere else.
+    s, o = util.scene_pair_default()
+    opts = rta.RenderOptions(512, 384, 1)
+    ref, _, _ = o.render(512, 384, 1, nthreads=os.cpu_count() or 1)
+    path = str(tmp_path / "progressive.tga")
+    now = [0.0]
+    seen = []
+
+    class Spy(rta.PPMStdoutRGBABufferWriter):
+        def write_rgba_buffer(self, buffer):
+            now[0] += 2.0
+            super().write_rgba_buffer(buffer)
+            seen.append(tuple(buffer.region()))
+            data = open(path, "rb").read()
+            assert data.startswith(b"P6\n512 384\n255\n") and len(data) == 15 + 512 * 384 * 3
+            img = np.frombuffer(data[15:], dtype=np.uint8).reshape(384, 512, 3)
+            done = np.zeros((384, 512), dtype=bool)
+            for (l, t, r, b) in seen:
+                done[b:t, l:r] = True
+            assert np.array_equal(img[done], ref[:, :, :3][done])
+            assert (img[~done] == 0).all()
+
+    w = Spy(True, path, clock=lambda: now[0])
+    rta.Renderer.render(opts, s, w, pool=1, tiles_per_call=8)
+    assert len(seen) == 48 and len(set(seen)) == 48
+    w.close()
+    oracle.write_ppm(str(tmp_path / "ref.ppm"), ref)
+    assert open(path, "rb").read() == open(str(tmp_path / "ref.ppm"), "rb").read()

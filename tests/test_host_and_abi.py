@@ -176,3 +176,50 @@ def test_generated_traversal_loops_are_up_to_date(tmp_path):
     gen.OUT = str(tmp_path / "rt_skip_rot.hpp")
     gen.main()
     assert open(gen.OUT).read() == committed
+
+
+def test_library_reads_no_environment_variable_and_keeps_diagnostics_out_of_the_abi():
+    # diagnostic switches live behind rt_debug_set (csrc/rt_debug.h, not in include/): the shipped library neither imports
+    # getenv nor carries RT_* switch names a stray environment variable could trigger
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--undefined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms
+    blob = open(capi.LIB_PATH, "rb").read()
+    assert re.findall(rb"RT_[A-Z_]{3,}", blob) == []
+    hdr = open(os.path.join(ROOT, "include", "rtrace_hip.h")).read()
+    assert "rt_debug" not in hdr
+    assert capi.lib.rt_debug_set(999, 1) == capi.RT_ERR_INVALID_ARGUMENT
+    for key in range(8):
+        assert capi.lib.rt_debug_set(key, -1) == capi.RT_OK
+
+
+def test_strict_64_and_writer_clock_on_the_host_mirror(tmp_path):
+    # f.2 progressive output (render.rs:422-433): with a file sink the whole image is rewritten when the first bucket arrives
+    # and then at most once per second -- observed here mid-render through the injectable clock: the file on disk is a
+    # syntactically valid P6 whose finished buckets hold their pixels and whose unfinished ones are still zero
+    now = [100.0]
+    path = str(tmp_path / "p.tga")
+    w = rta.PPMStdoutRGBABufferWriter(True, path, clock=lambda: now[0])
+    w.begin(128, 128)
+    tiles = [rta.ImageRegion(x, y + 64, x + 64, y) for y in (0, 64) for x in (0, 64)]
+    fill = [17, 34, 51, 68]
+
+    def on_disk():
+        data = open(path, "rb").read()
+        assert data.startswith(b"P6\n128 128\n255\n") and len(data) == 15 + 128 * 128 * 3
+        return np.frombuffer(data[15:], dtype=np.uint8).reshape(128, 128, 3)
+
+    w.write_rgba_buffer(rta.RGBABuffer(tiles[0], np.full((64, 64, 4), fill[0], dtype=np.uint8)))      # first bucket: written at once
+    img = on_disk()
+    assert (img[0:64, 0:64] == fill[0]).all() and (img[64:, :] == 0).all() and (img[0:64, 64:] == 0).all()
+    now[0] += 0.5
+    w.write_rgba_buffer(rta.RGBABuffer(tiles[1], np.full((64, 64, 4), fill[1], dtype=np.uint8)))      # within the second: not yet
+    assert (on_disk()[0:64, 64:] == 0).all()
+    now[0] += 0.6
+    w.write_rgba_buffer(rta.RGBABuffer(tiles[2], np.full((64, 64, 4), fill[2], dtype=np.uint8)))      # a second has passed: rewritten
+    img = on_disk()
+    assert (img[0:64, 64:] == fill[1]).all() and (img[64:, 0:64] == fill[2]).all() and (img[64:, 64:] == 0).all()
+    w.write_rgba_buffer(rta.RGBABuffer(tiles[3], np.full((64, 64, 4), fill[3], dtype=np.uint8)))
+    assert (on_disk()[64:, 64:] == 0).all()
+    w.close()                                                                                              # Drop writes the final image
+    assert (on_disk()[64:, 64:] == fill[3]).all()

@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
 """A/B timing of kernel tuning variants, interleaved in ONE process (cdna guide rule 24).  Checks every variant's frame
 and counters against the first variant.  usage: ab.py [rounds] [w h spp level]
-env: AB_TRAVERSAL=skip|flat  AB_ENV=RT_SKIP_VARIANT|RT_BLOCK_ORDER  AB_VARIANTS=1,3,7 (skip: 1 C++ loops, 3 generated assembly
+env: AB_TRAVERSAL=skip|flat  AB_KEY=skip_variant|block_order|narrow_max|packed_samples|host_copy (rt_debug.h)  AB_VARIANTS=1,3,7 (skip: 1 C++ loops, 3 generated assembly
 loops, 7 their fused flavour)  AB_LAUNCHES=5"""
-import ctypes
 import os
 import sys
 
@@ -13,17 +12,14 @@ import numpy as np
 import torch
 import rust_tracer_amd as rta
 
-libc = ctypes.CDLL(None)
-
 
 TRAV = rta.RT_TRAVERSAL_FLAT if os.environ.get("AB_TRAVERSAL", "skip") == "flat" else rta.RT_TRAVERSAL_SKIP
-ENV = os.environ.get("AB_ENV", "RT_SKIP_VARIANT")
+KEY = getattr(rta.capi, "DEBUG_" + os.environ.get("AB_KEY", "skip_variant").upper())
 LAUNCHES = int(os.environ.get("AB_LAUNCHES", "5"))
 
 
 def setvar(v):
-    os.environ[ENV] = str(v)
-    libc.setenv(ENV.encode(), str(v).encode(), 1)      # getenv() in the library reads the C environment
+    rta.capi.debug_set(KEY, v)
 
 
 def main():

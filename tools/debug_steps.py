@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: node-step statistics of one counted launch (RT_DEBUG_STEPS): wave-level node visits, how many of them at ITEM
+"""Diagnostic: node-step statistics of one counted launch (rt_debug.h, RT_DEBUG_PRINT_STEPS): wave-level node visits, how many of them at ITEM
 nodes, the busiest wave.   usage: debug_steps.py [w h spp level]"""
-import ctypes
 import os
 import sys
 
@@ -10,7 +9,7 @@ sys.path.insert(0, ROOT)
 import torch
 import rust_tracer_amd as rta
 
-ctypes.CDLL(None).setenv(b"RT_DEBUG_STEPS", b"1", 1)
+rta.capi.debug_set(rta.capi.DEBUG_PRINT_STEPS, 1)
 w, h, spp, level = (int(a) for a in sys.argv[1:5]) if len(sys.argv) > 4 else (1920, 1080, 1, 8)
 d = rta.Scene.default(level).device(0)
 regs = d._regions([tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))])

@@ -2,7 +2,6 @@
 """Soak / fuzz run for the generated assembly traversal loops (GPU box): bitwise stability over many launches, and random nested
 scenes where every loop flavour must agree with the counted C++ flavour (which the parity tests pin to the CPU path).
 usage: soak.py [seconds]"""
-import ctypes
 import os
 import sys
 import time
@@ -14,7 +13,6 @@ import torch
 import rust_tracer_amd as rta
 from tests import scenes as util        # numpy-only scene generators (the oracle is not loaded by this tool)
 
-libc = ctypes.CDLL(None)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 t_end = time.time() + budget
 stream = torch.cuda.current_stream().cuda_stream
@@ -50,13 +48,13 @@ while time.time() < t_end:
     dv = sc.device()
     w, h, spp = int(rng.integers(3, 9)) * 32, int(rng.integers(3, 9)) * 24, int(rng.integers(1, 3))
     regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
-    libc.setenv(b"RT_SKIP_VARIANT", b"1", 1)
+    rta.capi.debug_set(rta.capi.DEBUG_SKIP_VARIANT, 1)
     ref, st = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=True)
     for v in (0, 3, 7):
-        libc.setenv(b"RT_SKIP_VARIANT", str(v).encode(), 1)
+        rta.capi.debug_set(rta.capi.DEBUG_SKIP_VARIANT, v)
         got, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
         assert np.array_equal(got, ref), "seed %d: flavour %d differs" % (seed, v)
-    libc.unsetenv(b"RT_SKIP_VARIANT")
+    rta.capi.debug_set(rta.capi.DEBUG_SKIP_VARIANT, -1)
     dv.close()
     checked += 1
     seed += 1

@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-wave timeline of one k_render_skip launch (RT_WAVE_TRACE, rt_capi.hip).  Every wave records its start and
+"""Diagnostic: per-wave timeline of one k_render_skip launch (rt_debug_wave_trace, csrc/rt_debug.h).  Every wave records its start and
 end on the 100 MHz clock plus HW_ID / XCC_ID; this prints how the launch's time is made up: when the last wave was
 dispatched, how long the longest waves ran, how busy the SIMDs were over time.
-usage: wave_timeline.py [w h spp level]      env: RT_SKIP_VARIANT as usual"""
-import ctypes
+usage: wave_timeline.py [w h spp level]      """
 import os
 import sys
 
@@ -12,8 +11,6 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 import rust_tracer_amd as rta
-
-libc = ctypes.CDLL(None)
 
 
 def main():
@@ -29,10 +26,10 @@ def main():
     for _ in range(5):
         dev.render_frame_device(opts, regs_c, out.data_ptr(), stream)
     torch.cuda.synchronize()
-    libc.setenv(b"RT_WAVE_TRACE", path.encode(), 1)
+    rta.capi.wave_trace(path)
     dev.render_frame_device(opts, regs_c, out.data_ptr(), stream)
     torch.cuda.synchronize()
-    libc.unsetenv(b"RT_WAVE_TRACE")
+    rta.capi.wave_trace(None)
     rec = np.fromfile(path, dtype=np.uint32).reshape(-1, 4)
     ran = rec[:, 1] != 0
     r = rec[ran]
