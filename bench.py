@@ -1,80 +1,150 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s + ms/frame on the 1920x1080, 21,845-sphere default scene (BASELINE.json).
 
-A "step" is one frame PER GPU: every 64x64 bucket of the frame through the HIP hot path (primary + shadow rays), rendered
-straight into the row-major frame; for N > 1 the finished u8 frames are gathered to rank 0 over RCCL (the only collective;
-the gather of step k overlaps the render of step k+1).  Per-GPU work is fixed as N grows: weak scaling, `value` counts the
-rays of all N frames.  `--multi tiles` instead deals the buckets of ONE frame over the GPUs (BASELINE config 4, strong
-scaling; byte-identical output, but a 0.11 ms frame bounded by its heaviest wave cannot get faster that way).  The scene is already
-resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+A "step" is ONE frame: every 64x64 bucket of the 1080p frame through the HIP hot path (primary + shadow rays).
+  N = 1   the buckets are rendered straight into the row-major frame in HBM.
+  N > 1   BASELINE config 4: the buckets of that ONE frame are dealt round-robin (`tile_id % N`) over one process per GPU,
+          every rank renders its shard tile-major, ONE RCCL gather brings the u8 shards to rank 0 over xGMI and rank 0
+          blits them into the frame (strong scaling: total work fixed, `"scaling": "strong"`).  Consecutive frames are
+          software-pipelined (gather(k) overlaps render(k+1)).  Two more layouts ride along under their own keys:
+          `weak_frames` (every GPU renders whole frames) and `config5_tiles` (4096^2, 87,381 spheres, spp 4: the
+          workload where sharding pays).
+The scene is resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 
-The headline uses the product's default traversal, RT_TRAVERSAL_SKIP (the reference's own bounding-sphere
-hierarchy walked as a skip-pointer stream, bit-identical pixels and identical per-ray test counts).  The
-north-star "linear scan" kernel (RT_TRAVERSAL_FLAT) is timed beside it in the same run and reported under "flat".
+Timed region: `--repeats` (5) repetitions of: barrier + synchronize, EXACTLY `--steps` steps, barrier + synchronize; the max
+over ranks of each repetition; `ms_per_step` is the median repetition (min / max beside it).  The frame buffers are zeroed
+after the warm-up, so the frame left behind was produced by the timed launches: its CRC32 must equal the committed oracle
+vector (tests/golden/oracle_vectors.json) or the run fails.
+
+`roofline` (rank 0's render kernel): bound = VALU issue -- this path is un-fused f32 arithmetic on records that live in the
+scalar cache / L2, not an HBM stream.  achieved = SURVEY.md 8(d)'s 17 flops per ray x record test x the tests of one launch
+(counted by the kernel in this run, equal to the CPU path's) / the kernel's launch duration (HIP events on the launch
+stream, in this run); peak = 1,024 SIMDs x 64 lanes x 2.4 GHz / the measured cycles per wave64 VOP2 instruction at 8 waves
+per SIMD (profiles/r02_valu_issue_probe.json, tools/valu_issue_probe.hip).  Figures that need rocprofv3 counters (instruction
+issue, HBM traffic) are quoted from profiles/ under `from_profiles`, stamped with the kernel sources they were collected on,
+and dropped when that stamp is not the sources' of this run.
+
+`seam` (N = 1): the boundary the reference binds, timed from native threads by rust-tracer_amd/seam_bench (child process):
+host_tiles / host_region / end_to_end (render + D2H + PPM write).  `flat`: the north-star linear scan, same run.
+`cpu_baseline`: the oracle on this host's cores.
 
     python bench.py --gpus 1 --steps 100 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# name -> (width, height, samples_per_pixel, pyramid level).  The default is the configuration BASELINE.json's metric is
-# quoted on; the others are BASELINE's neighbouring configs, for scaling / sizing experiments (never the headline).
-WORKLOADS = {"1080p": (1920, 1080, 1, 8), "config2": (800, 600, 1, 8), "make_image": (1024, 768, 4, 8),
-             "config5": (4096, 4096, 4, 9)}
-WIDTH, HEIGHT, SPP, LEVEL = WORKLOADS["1080p"]
-N_ITEMS = 21845
+# name -> (width, height, samples_per_pixel, pyramid level, golden case in tests/golden/oracle_vectors.json).  The default is the
+# configuration BASELINE.json's metric is quoted on; the others are BASELINE's neighbouring configs (never the headline).
+WORKLOADS = {"1080p": (1920, 1080, 1, 8, "config3_1920x1080_f32"), "config2": (800, 600, 1, 8, "config2_800x600"),
+             "make_image": (1024, 768, 4, 8, "make_image_1024x768_spp4"), "config5": (4096, 4096, 4, 9, "config5_4096x4096_spp4_L9")}
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_OPS = 256 * 4 * 16 * 2 * 2.4e9  # un-fused f32 lane-ops/s with packed v_pk_mul/add: 256 CU x 4 SIMD x 16 lanes x 2 x
-                                          # 2.4 GHz = 78.6 T (the 157 TF headline needs FMA, which parity forbids)
-BYTES_PER_TEST = 16                      # one ray x one sphere = one {cx,cy,cz,r} f32 record
+N_SIMD, LANES, CLOCK_HZ = 1024, 64, 2.4e9
+BYTES_PER_TEST, FLOPS_PER_TEST = 16, 17  # one ray x one {cx,cy,cz,r} record; 3 sub + 8 mul + 6 add/sub to the reject test
+PROBE = os.path.join(ROOT, "profiles", "r02_valu_issue_probe.json")
 
 
-def cpu_baseline(budget_s=12.0):
+def kernel_src_sha():
+    """Stamp of the device code: sha1 over the kernel sources (profiles/ summaries carry the stamp they were collected on)."""
+    d = os.path.join(ROOT, "rust-tracer_amd", "csrc")
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def probe_cycles():
+    """-> {(kind prefix, waves per SIMD): cycles per instruction per SIMD} from the committed VALU-issue probe."""
+    out = {}
+    try:
+        for r in json.load(open(PROBE))["results"]:
+            out[(r["kind"], r["waves_per_simd"])] = r
+    except Exception:
+        pass
+    return out
+
+
+def golden_case(name):
+    try:
+        for c in json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_vectors.json")))["cases"]:
+            if c["name"] == name:
+                return c
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline(width, height, spp, level, budget_s=12.0):
     """The oracle (CPU restatement of the reference's hierarchical path) timed on this host, same workload."""
     import oracle
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    o = oracle.Scene.default(oracle.F32, LEVEL)
+    o = oracle.Scene.default(oracle.F32, level)
     t0 = time.perf_counter()
     # one single-threaded frame (the reference's default RTRACEMAXPROCS=1), unless the workload is far too big for that
-    _, st, _ = o.render(WIDTH, HEIGHT, SPP, nthreads=1 if WIDTH * HEIGHT * SPP * SPP <= 2.5e7 else cores)
+    _, st, _ = o.render(width, height, spp, nthreads=1 if width * height * spp * spp <= 2.5e7 else cores)
     t_single = time.perf_counter() - t0
     rays = st["primary"] + st["shadow"]
     best, frames, spent = None, 0, 0.0
     while frames < 3 or (spent < budget_s * 0.5 and frames < 20):
         t0 = time.perf_counter()
-        o.render(WIDTH, HEIGHT, SPP, nthreads=cores)
+        o.render(width, height, spp, nthreads=cores)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
         frames += 1
         spent += dt
-    return {"value": round(rays / best / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+    return {"value": round(rays / best / 1e6, 3), "unit": "Mrays/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
             "sample": "%d full frames of the same %dx%d spp %d L%d workload on %d threads (64x64 buckets), reference "
                       "hierarchical traversal, best frame; 1 thread: %.3f Mrays/s"
-                      % (frames, WIDTH, HEIGHT, SPP, LEVEL, cores, rays / t_single / 1e6),
+                      % (frames, width, height, spp, level, cores, rays / t_single / 1e6),
             "ms_per_frame": round(best * 1e3, 2), "single_core_value": round(rays / t_single / 1e6, 3)}
 
 
-def flat_valu(m):
-    """Useful un-fused f32 ops of the flat scan (8 per primary test with the pre-formed terms, 16 per shadow test,
-    primitive.rs:56-58) over the kernel time, against the packed un-fused VALU peak."""
-    st = m["my_stats"]
-    shadow_tests = st["tests_executed"] - st["primary"] * N_ITEMS       # what the any-hit passes really ran
-    ops = st["primary"] * N_ITEMS * 8 + shadow_tests * 16
-    t = m["kern_ms"] * 1e-3
-    return {"ops_per_test": "8 primary / 16 shadow", "tests_executed": st["tests_executed"],
-            "achieved_Tops": round(ops / t / 1e12, 2), "peak_Tops": round(VALU_PEAK_OPS / 1e12, 1),
-            "frac": round(ops / t / VALU_PEAK_OPS, 4),
-            "note": "un-fused f32 ops of the tests the pipeline executed (queue lengths x pass lengths) over the time of "
-                    "all its kernels, against the packed (v_pk_mul/add) un-fused VALU peak"}
+def run_seam(threads):
+    """rust-tracer_amd/seam_bench as a child process (started before this process touches the GPU)."""
+    exe = os.path.join(ROOT, "rust-tracer_amd", "seam_bench")
+    if not os.path.exists(exe):
+        return {"error": "rust-tracer_amd/seam_bench is not built"}
+    try:
+        r = subprocess.run([exe, "--frames", "20", "--threads", str(threads)], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": "seam_bench exit %d: %s" % (r.returncode, r.stderr[-300:])}
+        d = json.loads(r.stdout)
+        d["how"] = ("native threads through the C ABI (rust-tracer_amd/csrc/host/seam_bench.cpp), PCIe-inclusive, never `value`: host_tiles = "
+                    "rt_render_tiles, all buckets in one call; host_region = one rt_render_region call per bucket (render.rs:283-294) from 1 and "
+                    "from T pool threads, concurrent calls merged into shared passes; end_to_end = render + D2H + PPM encode + file write")
+        return d
+    except Exception as e:          # noqa: BLE001  (a failed side leg must not take the headline down)
+        return {"error": repr(e)}
 
 
 def main():
@@ -82,22 +152,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=5, help="repetitions of the timed --steps loop (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flat", action="store_true", help="skip the secondary flat-scan measurement")
+    ap.add_argument("--no-seam", action="store_true", help="skip the host-boundary legs (seam_bench child process)")
+    ap.add_argument("--no-extras", action="store_true", help="N > 1: skip the weak_frames and config5_tiles side measurements")
     ap.add_argument("--traversal", choices=("skip", "flat"), default="skip", help="traversal of the headline measurement")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: take the shard -> RCCL gather -> blit path even at N = 1 (needs torch.distributed.run)")
-    ap.add_argument("--multi", choices=("frames", "tiles"), default="frames",
-                    help="N > 1: 'frames' = every GPU renders whole frames, N per step, gathered to rank 0 (weak scaling); "
-                         "'tiles' = BASELINE config 4, the buckets of ONE frame dealt over the GPUs (strong scaling)")
+    ap.add_argument("--multi", choices=("tiles", "frames"), default="tiles",
+                    help="N > 1 headline layout: 'tiles' = BASELINE config 4, the buckets of ONE frame dealt over the GPUs (strong scaling); "
+                         "'frames' = every GPU renders whole frames, N per step (weak scaling)")
     ap.add_argument("--frames-per-gather", type=int, default=4,
-                    help="N > 1, 'frames' layout: frames a rank renders per RCCL gather (fewer, larger collectives)")
+                    help="'frames' layout: frames a rank renders per RCCL gather (fewer, larger collectives)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1080p",
                     help="1080p = the headline workload; the others are BASELINE's neighbouring configs")
     args = ap.parse_args()
-    global WIDTH, HEIGHT, SPP, LEVEL, N_ITEMS
-    WIDTH, HEIGHT, SPP, LEVEL = WORKLOADS[args.workload]
-    N_ITEMS = (4 ** LEVEL - 1) // 3
+    width, height, spp, level, golden_name = WORKLOADS[args.workload]
+    n_items = (4 ** level - 1) // 3
 
     # Exactly ONE line may reach stdout.  RCCL prints a version banner on stdout (NCCL_DEBUG=VERSION is set on the GPU
     # boxes) whenever a communicator exists, so fd 1 is pointed at stderr for the whole run and the JSON line is written
@@ -106,16 +178,22 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import torch
-    import rust_tracer_amd as rta
-    from rust_tracer_amd.dist import FrameSharder
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+
+    seam = None
+    if world == 1 and not args.no_seam and not args.force_collective and args.workload == "1080p":
+        seam = run_seam(min(64, os.cpu_count() or 1))       # a child process, before anything here initialises the GPU
+
+    import numpy as np
+    import torch
+    import rust_tracer_amd as rta
+    from rust_tracer_amd.dist import FrameSharder
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -126,17 +204,24 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    scene = rta.Scene.default(LEVEL, rta.RT_F32)
-    opts = rta.RenderOptions(WIDTH, HEIGHT, SPP)
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(traversal, steps, warmup):
-        """-> dict with whole-job ms/step (max over ranks), this rank's kernel ms (HIP events), ray/test counters."""
-        fs = FrameSharder(scene, opts, rank, world, local, traversal, force_collective=args.force_collective, mode=args.multi,
+    scenes = {}
+
+    def scene_of(lv):
+        if lv not in scenes:
+            scenes[lv] = rta.Scene.default(lv, rta.RT_F32)
+        return scenes[lv]
+
+    def measure(wl, traversal, steps, warmup, repeats, mode):
+        """-> dict: whole-job ms per step of each repetition (max over ranks), this rank's kernel ms (HIP events), counters,
+        and the CRC of the frame the timed launches left on rank 0."""
+        w, h, k, lv, gname = WORKLOADS[wl]
+        opts = rta.RenderOptions(w, h, k)
+        fs = FrameSharder(scene_of(lv), opts, rank, world, local, traversal, force_collective=args.force_collective, mode=mode,
                           frames_per_gather=args.frames_per_gather)
         st = fs.render_shard(want_stats=True)          # counters of this rank's shard (equal the oracle's; tests)
         cnt = torch.tensor([st["primary"], st["shadow"]], dtype=torch.int64, device="cuda")
@@ -145,118 +230,213 @@ def main():
         primary, shadow = (int(v) for v in cnt.tolist())
         fs.run(warmup)
         barrier()
-        # N = 1: the timed region is `steps` launches of the render kernel back to back on torch's current stream, which is the
-        # stream handed to the C ABI -- two HIP events on that stream bracket exactly those launches, inside the timed region
-        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        if not fs.collective:
-            k0.record()
-        fs.run(steps)                                  # N > 1: gather(k) on RCCL's stream overlaps render(k+1)
-        if not fs.collective:
-            k1.record()
+        # what the timed launches leave behind is checked afterwards: start from zeroed buffers
+        for b in fs.shards:
+            b.zero_()
+        if fs.frame is not None:
+            fs.frame.zero_()
+        if getattr(fs, "gathered_flat", None):
+            for g in fs.gathered_flat:
+                g.zero_()
         barrier()
-        elapsed = time.perf_counter() - t0
+        reps, kern = [], []
+        for _ in range(repeats):
+            # N = 1: the timed region is `steps` launches of the render kernel back to back on torch's current stream, which is the
+            # stream handed to the C ABI -- two HIP events on that stream bracket exactly those launches, inside the timed region
+            k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()
+            t0 = time.perf_counter()
+            if not fs.collective:
+                k0.record()
+            fs.run(steps)                              # N > 1: gather(k) on RCCL's stream overlaps render(k+1)
+            if not fs.collective:
+                k1.record()
+            barrier()
+            elapsed = time.perf_counter() - t0
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            if dist is not None:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            reps.append(float(tt.item()) / steps * 1e3)
+            if not fs.collective:
+                kern.append(k0.elapsed_time(k1) / steps)
+        crc, crc_ok = None, None
+        if rank == 0:
+            if mode == "frames" and fs.collective:
+                frame = fs.frame_host(slot=0, of_rank=world - 1, index=0)        # a frame that crossed the wire
+            else:
+                frame = fs.frame_host()
+            crc = zlib.crc32(np.ascontiguousarray(frame).tobytes()) & 0xFFFFFFFF
+            g = golden_case(gname)
+            crc_ok = (crc == g["frame_crc32"]) if g else None
         if fs.collective:
             # N > 1: the main stream also carries the waits on RCCL's stream, so the kernel alone is timed right after the
             # timed region: `steps` launches back to back between two HIP events (agrees with rocprofv3 --kernel-trace --stats)
+            k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             k0.record()
             for _ in range(steps):
                 fs.render_shard()
             k1.record()
             torch.cuda.synchronize()
-        kern_ms = k0.elapsed_time(k1) / steps
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        if dist is not None:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return {"elapsed": float(tt.item()), "kern_ms": kern_ms, "primary": primary, "shadow": shadow,
-                "my_tests": st["sphere_tests"] + st["bound_tests"], "my_stats": st}     # algorithmic tests
+            kern.append(k0.elapsed_time(k1) / steps)
+        srt = sorted(reps)
+        return {"ms_reps": reps, "ms_per_step": srt[len(srt) // 2], "kern_ms": sorted(kern)[len(kern) // 2], "primary": primary, "shadow": shadow,
+                "my_tests": st["sphere_tests"] + st["bound_tests"], "my_stats": st, "crc": crc, "crc_ok": crc_ok,
+                "timed_region_s": sum(r * steps for r in reps) / 1e3, "frames_per_step": world if (mode == "frames" and fs.collective) else 1}
 
-    def roofline(m, kernel, note):
-        alg = m["my_tests"] * BYTES_PER_TEST
-        ach = alg / (m["kern_ms"] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tpath):
+    probe = probe_cycles()
+    src_sha = kernel_src_sha()
+
+    def from_profiles(kernel, kern_ms):
+        """Counter figures of rank 0's kernel quoted from profiles/ (rocprofv3 --pmc, separate passes) -- only when they were
+        collected on exactly these kernel sources."""
+        out = {}
+        for name in ("roofline_sq.json", "roofline_traffic.json"):
+            p = os.path.join(ROOT, "profiles", name)
             try:
-                traffic = json.load(open(tpath)).get("%s_n%d" % (kernel, world))
+                d = json.load(open(p))
             except Exception:
-                traffic = None
-        out = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
-               "kernel_ms": round(m["kern_ms"], 4), "tests_per_launch": m["my_tests"], "note": note}
-        if traffic:
-            # the physical figure beside the logical one: measured HBM bytes per launch over the live kernel time
-            out["traffic_GBs"] = round(traffic / (m["kern_ms"] * 1e-3) / 1e9, 1)
-            out["traffic_frac_of_peak"] = round(traffic / (m["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        spath = os.path.join(ROOT, "profiles", "roofline_sq.json")
-        if os.path.exists(spath):
-            try:
-                sq = json.load(open(spath)).get("%s_n%d" % (kernel, world))
-            except Exception:
-                sq = None
-            if sq and sq.get("valu_insts"):
-                # what actually limits the kernel: VALU issue (one wave64 VALU instruction occupies a SIMD for 4 cycles)
-                cyc = m["kern_ms"] * 1e-3 * 2.4e9
-                out["valu_issue"] = {"valu_insts_per_launch": sq["valu_insts"], "salu_insts_per_launch": sq.get("salu_insts"),
-                                     "frac": round(sq["valu_insts"] * 4 / 1024 / cyc, 4),
-                                     "note": "SQ_INSTS_VALU per launch (profiles/, rocprofv3 --pmc) x 4 cycles / 1024 SIMDs "
-                                             "over the live kernel time at 2.4 GHz"}
+                continue
+            ok = d.get("kernel_src_sha") == src_sha
+            out[name] = {"tag": d.get("tag"), "git_head": d.get("git_head"), "kernel_src_sha": d.get("kernel_src_sha"), "matches_this_run": ok}
+            if not ok:
+                continue
+            v = d.get("%s_n%d" % (kernel, world)) or (d.get("%s_n1" % kernel) if world == 1 else None)
+            if v is None:
+                continue
+            t = kern_ms * 1e-3
+            if name == "roofline_traffic.json":
+                out["hbm_traffic"] = {"bytes_per_launch": v, "GBs": round(v / t / 1e9, 1), "frac_of_hbm_peak": round(v / t / 1e9 / HBM_PEAK_GBS, 4),
+                                      "note": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch (MI355X_MICROARCH.md gfx950 correction) over this run's kernel time"}
+            else:
+                insts = sum(v.get(k) or 0 for k in ("valu_insts", "salu_insts", "smem_insts", "branch_insts", "other_insts"))
+                mix = probe.get(("traversal-step mix: 10 VALU + 12 SALU per 22", 8))
+                if insts and mix:
+                    peak = N_SIMD * CLOCK_HZ / mix["cycles_per_instruction_per_simd"]
+                    out["instruction_issue"] = {
+                        "wave_instructions_per_launch": insts, "valu": v.get("valu_insts"), "salu": v.get("salu_insts"), "smem": v.get("smem_insts"),
+                        "achieved_Ginst_s": round(insts / t / 1e9, 1), "peak_Ginst_s": round(peak / 1e9, 1), "frac": round(insts / t / peak, 4),
+                        "note": "wave-instructions per launch (SQ_INSTS_*) over this run's kernel time, against 1,024 SIMDs x 2.4 GHz / the probe's "
+                                "cycles per instruction of the traversal-step mix (10 VALU + 12 SALU) at 8 waves per SIMD"}
+        return out
+
+    def roofline(m, kernel, flops_per_test, note):
+        t = m["kern_ms"] * 1e-3
+        vop2 = probe.get(("v_mul_f32 (SGPR x VGPR, independent)", 8))
+        cyc = vop2["cycles_per_instruction_per_simd"] if vop2 else 2.0
+        peak = N_SIMD * LANES * CLOCK_HZ / cyc / 1e12
+        ach = m["my_tests"] * flops_per_test / t / 1e12
+        logical = m["my_tests"] * BYTES_PER_TEST / t / 1e9
+        out = {"bound": "valu_issue", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s (un-fused f32 lane ops)",
+               "frac": round(ach / peak, 4), "traffic": None, "kernel": kernel, "kernel_ms": round(m["kern_ms"], 4),
+               "tests_per_launch": m["my_tests"], "flops_per_test": flops_per_test,
+               "peak_source": "profiles/r02_valu_issue_probe.json: %.3f cycles per wave64 VOP2 instruction per SIMD at 8 waves per SIMD "
+                              "(1,024 SIMDs x 64 lanes x 2.4 GHz / that)" % cyc,
+               "hbm_logical": {"GBs": round(logical, 1), "bytes_per_test": BYTES_PER_TEST,
+                               "note": "16 B x tests / kernel time: a LOGICAL record rate -- the records come from the scalar cache / L2 / LDS, "
+                                       "not from HBM, so it is not a fraction of the HBM peak (SURVEY.md H3)"},
+               "note": note}
+        fp = from_profiles(kernel, m["kern_ms"])
+        out["from_profiles"] = fp
+        if "hbm_traffic" in fp:
+            out["traffic"] = fp["hbm_traffic"]["bytes_per_launch"]
         return out
 
     head_trav = rta.RT_TRAVERSAL_SKIP if args.traversal == "skip" else rta.RT_TRAVERSAL_FLAT
-    m = measure(head_trav, args.steps, args.warmup)
+    multi = args.multi if (world > 1 or args.force_collective) else "tiles"
+    m = measure(args.workload, head_trav, args.steps, args.warmup, max(1, args.repeats), multi)
     flat = None
-    if args.traversal == "skip" and not args.no_flat:
-        flat = measure(rta.RT_TRAVERSAL_FLAT, max(2, min(5, args.steps)), 1)
+    if args.traversal == "skip" and not args.no_flat and world == 1:
+        flat = measure(args.workload, rta.RT_TRAVERSAL_FLAT, max(2, min(5, args.steps)), 1, 3, multi)
+    extras = {}
+    if world > 1 and not args.no_extras and args.workload == "1080p" and args.traversal == "skip":
+        other = "frames" if multi == "tiles" else "tiles"
+        e = measure("1080p", head_trav, args.steps, max(2, args.warmup // 2), 3, other)
+        extras["weak_frames" if other == "frames" else "strong_tiles"] = e
+        extras["config5_tiles"] = measure("config5", head_trav, 3, 1, 3, "tiles")
+
+    def summary(e, wl):
+        w, h, k, lv, _ = WORKLOADS[wl]
+        fr = e["frames_per_step"]
+        rays = (e["primary"] + e["shadow"])
+        srt = sorted(e["ms_reps"])
+        return {"workload": "%dx%d spp %d L%d" % (w, h, k, lv), "ms_per_step": round(e["ms_per_step"], 4), "ms_per_step_min_max": [round(srt[0], 4), round(srt[-1], 4)],
+                "frames_per_step": fr, "value": round(rays / (e["ms_per_step"] * 1e-3) / 1e6, 3), "unit": "Mrays/s",
+                "rank0_kernel_ms": round(e["kern_ms"], 4), "frame_crc32": e["crc"], "frame_crc_ok": e["crc_ok"]}
 
     if rank == 0:
-        ms_per_step = m["elapsed"] / args.steps * 1e3
+        ms_per_step = m["ms_per_step"]
         rays = m["primary"] + m["shadow"]
-        skip_note = ("algorithmic bytes = 16 B x (item + bound tests the reference's traversal makes for rank 0's rays, "
-                     "counted by the kernel and equal to the CPU path's) / hipEvent duration of k_render_skip; records "
-                     "arrive through the scalar cache / L2 (the whole scene is < 1 MB), so this is a logical rate, not "
-                     "HBM traffic (SURVEY.md H3)")
-        flat_note = ("algorithmic bytes = 16 B x (primary + shadow rays) x n_spheres items of rank 0's pass / hipEvent "
-                     "duration of its kernels (k_flat_primary + 2 x k_flat_shadow + k_resolve_samples); every record staged "
-                     "to LDS is re-used by all rays of a workgroup, so the logical rate exceeds the HBM peak; the binding "
-                     "limit is un-fused f32 VALU issue (see valu)")
+        skip_note = ("achieved = 17 flops x (item + bound tests the reference's traversal makes for rank 0's rays, counted by the kernel in "
+                     "this run and equal to the CPU path's) / HIP-event duration of k_render_skip in this run.  The records arrive "
+                     "through the scalar cache / L2 (the whole scene is < 1 MB): VALU issue binds, not HBM")
+        flat_note = ("achieved = un-fused flops of the tests the flat pipeline executed (8 per primary test with the pre-formed terms, 16 per "
+                     "shadow test; queue lengths x pass lengths) / HIP-event duration of its kernels (k_flat_primary + 2 x k_flat_shadow + "
+                     "k_resolve_samples); every record staged to LDS is re-used by all rays of a workgroup")
         if world == 1 and not args.force_collective:
             layout = "1 GPU, buckets rendered straight into the row-major frame"
-        elif args.multi == "frames":
+        elif multi == "frames":
             layout = ("%d GPUs, every GPU renders a whole frame per step (%d frames per step), u8 frames gathered to rank 0 "
                       "over RCCL %d frames per rank at a time, each gather overlapped with the render of the next frames"
                       % (world, world, args.frames_per_gather))
         else:
             layout = ("%d GPUs, the buckets of ONE frame dealt round-robin (tile_id %% N), u8 shards gathered to rank 0 over "
                       "RCCL and blitted into the frame there, pipelined across frames" % world)
+        srt = sorted(m["ms_reps"])
         out = {
             "metric": "Mrays/sec + ms/frame, 1920x1080 20k-sphere scene" if args.workload == "1080p" else
-                      "Mrays/sec + ms/frame, %dx%d spp %d L%d (non-headline workload %s)" % (WIDTH, HEIGHT, SPP, LEVEL, args.workload),
-            "value": round(rays / (ms_per_step * 1e-3) / 1e6, 3), "unit": "Mrays/s", "n_gpus": world,
+                      "Mrays/sec + ms/frame, %dx%d spp %d L%d (non-headline workload %s)" % (width, height, spp, level, args.workload),
+            "value": round(rays / (ms_per_step * 1e-3) / 1e6, 3),      # rays of every frame of a step (summed over ranks) / step time
+            "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak" if args.multi == "frames" else "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (the reference's deterministic default scene: pyramid level %d)" % LEVEL,
+            "higher_is_better": True, "scaling": "weak" if (multi == "frames" and world > 1) else "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (the reference's deterministic default scene: pyramid level %d)" % level,
             "config": {"workload": "%dx%d, %d spheres (pyramid L%d), spp %d, f32, %s traversal, %d 64x64 buckets per frame; %s"
-                                   % (WIDTH, HEIGHT, N_ITEMS, LEVEL, SPP, args.traversal, -(-WIDTH // 64) * -(-HEIGHT // 64), layout),
-                       "width": WIDTH, "height": HEIGHT, "samples_per_pixel": SPP, "n_spheres": N_ITEMS,
+                                   % (width, height, n_items, level, spp, args.traversal, -(-width // 64) * -(-height // 64), layout),
+                       "width": width, "height": height, "samples_per_pixel": spp, "n_spheres": n_items,
                        "primary_rays": m["primary"], "shadow_rays": m["shadow"], "traversal": args.traversal,
-                       "frames_per_step": world if (args.multi == "frames") else 1,
-                       "parallelism": ("frames x %d" if args.multi == "frames" else "tiles/%d") % world},
+                       "frames_per_step": m["frames_per_step"],
+                       "parallelism": ("frames x %d" if (multi == "frames" and world > 1) else "tiles/%d") % world,
+                       "rccl_world_size": (dist.get_world_size() if dist is not None else None)},
+            "repeats": {"n": len(m["ms_reps"]), "ms_per_step_each": [round(r, 4) for r in m["ms_reps"]], "median": round(ms_per_step, 4),
+                        "min": round(srt[0], 4), "max": round(srt[-1], 4), "timed_region_s": round(m["timed_region_s"], 4)},
+            "frame_crc32": m["crc"], "frame_crc_ok": m["crc_ok"],
+            "frame_crc_source": "tests/golden/oracle_vectors.json:%s.frame_crc32 (frame buffers zeroed after the warm-up; read back after the timed loop)" % golden_name,
             "mprimary_per_s": round(m["primary"] / (ms_per_step * 1e-3) / 1e6, 3),
-            "roofline": roofline(m, "k_render_skip" if args.traversal == "skip" else "k_flat_primary",
+            "git_head": git_head(), "kernel_src_sha": src_sha,
+            "roofline": roofline(m, "k_render_skip" if args.traversal == "skip" else "k_flat_primary", FLOPS_PER_TEST if args.traversal == "skip" else 8,
                                  skip_note if args.traversal == "skip" else flat_note),
         }
         if flat is not None:
-            fms = flat["elapsed"] / max(2, min(5, args.steps)) * 1e3
-            out["flat"] = {"ms_per_step": round(fms, 4), "value": round(rays / (fms * 1e-3) / 1e6, 3), "unit": "Mrays/s",
-                           "roofline": roofline(flat, "k_flat_primary", flat_note),
-                           "valu": flat_valu(flat)}
+            fst = flat["my_stats"]
+            shadow_tests = fst["tests_executed"] - fst["primary"] * n_items       # what the any-hit passes really ran
+            ops = fst["primary"] * n_items * 8 + shadow_tests * 16
+            vop3p = probe.get(("v_pk_mul_f32 (SGPR pair x VGPR pair, op_sel_hi:[0,1])", 8))
+            pk_peak = N_SIMD * LANES * 2 * CLOCK_HZ / (vop3p["cycles_per_instruction_per_simd"] if vop3p else 4.0)
+            t = flat["kern_ms"] * 1e-3
+            out["flat"] = {"ms_per_step": round(flat["ms_per_step"], 4), "value": round(rays / (flat["ms_per_step"] * 1e-3) / 1e6, 3), "unit": "Mrays/s",
+                           "frame_crc_ok": flat["crc_ok"],
+                           "roofline": {"bound": "valu_issue", "achieved": round(ops / t / 1e12, 2), "peak": round(pk_peak / 1e12, 1),
+                                        "unit": "TFLOP/s (un-fused f32 lane ops, packed v_pk_mul/add)", "frac": round(ops / t / pk_peak, 4),
+                                        "kernel": "k_flat_primary + k_flat_shadow", "kernel_ms": round(flat["kern_ms"], 4),
+                                        "tests_executed": fst["tests_executed"], "note": flat_note,
+                                        "peak_source": "probe: cycles per packed VOP3P instruction at 8 waves per SIMD, two lane ops each",
+                                        "from_profiles": from_profiles("k_flat_primary", flat["kern_ms"])}}
+        for k, e in extras.items():
+            out[k] = summary(e, "config5" if k == "config5_tiles" else "1080p")
+            out[k]["scaling"] = "weak" if k == "weak_frames" else "strong"
+        if seam is not None:
+            out["seam"] = seam
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(width, height, spp, level)
+        ok = m["crc_ok"] is not False and (flat is None or flat["crc_ok"] is not False) and all(e["crc_ok"] is not False for e in extras.values())
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+        if not ok:
+            sys.stderr.write("bench.py: the frame left by the timed launches does not match the committed oracle vector\n")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and not ok:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -45,6 +45,9 @@ def main():
     cases.append(dict(case("config3_1920x1080_f64", d64, 1920, 1080, 1), scene="default8", precision="f64"))
     cases.append(dict(case("make_image_1024x768_spp4", d32, 1024, 768, 4), scene="default8", precision="f32"))
     cases.append(dict(case("level9_320x256_spp2", oracle.Scene.default(oracle.F32, 9), 320, 256, 2), scene="default9", precision="f32"))
+    # BASELINE config 5 at full size (4096^2, pyramid level 9 = 87,381 spheres, spp 4): bench.py checks the frame its timed
+    # launches leave behind against this CRC; the -m gpu tests compare spot buckets bit for bit
+    cases.append(dict(case("config5_4096x4096_spp4_L9", oracle.Scene.default(oracle.F32, 9), 4096, 4096, 4), scene="default9", precision="f32"))
     tie = oracle.Scene.from_spheres(util.TIE_SPHERES, util.TIE_BOUND)
     cases.append(dict(case("tie_break_64x64", tie, 64, 64, 1), scene="tie", precision="f32"))
     inside = oracle.Scene.from_ranges(util.INSIDE_ITEMS, util.INSIDE_BOUNDS, util.INSIDE_RANGES)

@@ -18,6 +18,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_src_sha, git_head  # noqa: E402  (the stamp bench.py compares with the sources it runs on)
 SHORT = [("k_render_skip<float, false", "k_render_skip"), ("k_flat_primary<float", "k_flat_primary"), ("k_flat_shadow<float", "k_flat_shadow"),
          ("k_blit_tiles", "k_blit_tiles"), ("k_build_streams<float>", "k_build_streams"),
          ("k_resolve_samples<float>", "k_resolve_samples")]
@@ -52,9 +54,14 @@ def main():
         if "FETCH_SIZE_KiB_avg" in d and "WRITE_SIZE_KiB_avg" in d:
             d["hbm_bytes_per_launch_uncorrected"] = int((d["FETCH_SIZE_KiB_avg"] + d["WRITE_SIZE_KiB_avg"]) * 1024)
             d["hbm_bytes_per_launch"] = int((2 * d["FETCH_SIZE_KiB_avg"] + d["WRITE_SIZE_KiB_avg"]) * 1024)
+    stamp = {"tag": tag, "git_head": git_head(), "kernel_src_sha": kernel_src_sha()}
+    pmc["_stamp"] = stamp
     json.dump(pmc, open(os.path.join(prof, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     tpath = os.path.join(prof, "roofline_traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    if traffic.get("kernel_src_sha") != stamp["kernel_src_sha"]:
+        traffic = {}                                     # figures of other kernel sources do not mix with these
+    traffic.update(stamp)
     for k in ("k_render_skip", "k_flat_primary", "k_flat_shadow"):
         if k in pmc and "hbm_bytes_per_launch" in pmc[k]:
             traffic["%s_n%d" % (k, n)] = pmc[k]["hbm_bytes_per_launch"]

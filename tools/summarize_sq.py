@@ -9,13 +9,15 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_src_sha, git_head  # noqa: E402  (the stamp bench.py compares with the sources it runs on)
 KERNELS = [("k_render_skip<float, false", "k_render_skip"), ("k_flat_primary<float", "k_flat_primary"), ("k_flat_shadow<float", "k_flat_shadow")]
 
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     out = collections.defaultdict(dict)
-    for part in ("sq1", "sq2"):
+    for part in ("sq1", "sq2", "sq3"):
         for f in glob.glob(os.path.join(src, "%s_%s" % (part, tag), "*", "*_counter_collection.csv")):
             agg = collections.defaultdict(list)
             dur = collections.defaultdict(list)
@@ -31,16 +33,18 @@ def main():
     for k, d in out.items():
         if "SQ_INSTS_VALU" in d and "duration_ns_while_counting_sq1" in d:
             cyc = d["duration_ns_while_counting_sq1"] * 2.4          # shader cycles at 2.4 GHz
-            d["derived_valu_issue_fraction_at_4_cycles_per_inst"] = d["SQ_INSTS_VALU"] * 4 / 1024 / cyc
             d["derived_avg_waves_per_simd"] = d["SQ_WAVE_CYCLES"] * 4 / cyc / 1024
             d["derived_valu_insts_per_wave"] = d["SQ_INSTS_VALU"] / d["SQ_WAVES"]
-    json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_sq.json"), "w"), indent=1, sort_keys=True)
     # what bench.py quotes beside its live timing (instruction counts per launch do not depend on the clock)
-    quote = {"_source": "tools/summarize_sq.py from rocprofv3 --pmc SQ_* passes, tag " + tag}
+    stamp = {"tag": tag, "git_head": git_head(), "kernel_src_sha": kernel_src_sha()}
+    out["_stamp"] = stamp
+    json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_sq.json"), "w"), indent=1, sort_keys=True)
+    quote = dict(stamp, _source="tools/summarize_sq.py from rocprofv3 --pmc SQ_* passes (tools/profile_sq.sh), per-launch averages")
     for k, d in out.items():
-        if "SQ_INSTS_VALU" in d:
+        if k != "_stamp" and "SQ_INSTS_VALU" in d:
             quote[k + "_n1"] = {"valu_insts": d["SQ_INSTS_VALU"], "salu_insts": d.get("SQ_INSTS_SALU"), "smem_insts": d.get("SQ_INSTS_SMEM"),
-                                "waves": d.get("SQ_WAVES")}
+                                "branch_insts": d.get("SQ_INSTS_BRANCH"), "other_insts": (d.get("SQ_INSTS_SENDMSG") or 0) + (d.get("SQ_INSTS_VMEM") or 0) +
+                                (d.get("SQ_INSTS_LDS") or 0), "waves": d.get("SQ_WAVES")}
     json.dump(quote, open(os.path.join(ROOT, "profiles", "roofline_sq.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))
 
