@@ -101,7 +101,9 @@ rt_status rt_device_count(int *n);
  *   eye         REAL[3] Scene::eye.
  *   bounds/ranges/n_bounds  optional (NULL/NULL/0): group bounds REAL[4*n_bounds] with their item ranges in DFS
  *               pre-order (outer group before the groups nested in it); required for RT_TRAVERSAL_SKIP.
- * REAL is float for RT_F32 and double for RT_F64.  All values must be finite, |coordinate| <= 1e15, radius > 0.
+ * REAL is float for RT_F32 and double for RT_F64.  All values must be finite, |coordinate| <= 1e15 (items, bounds, eye),
+ * radius > 0, |light_unit component| <= 2: within these bounds no intermediate of the path overflows, so no NaN can arise
+ * and every comparison agrees with the reference's whichever way it is written.
  * The caller keeps ownership of every host buffer; nothing is retained but the returned handle. */
 rt_status rt_scene_create(int device, rt_precision precision,
                           const void *dfs_items, uint32_t n_items,
@@ -170,6 +172,26 @@ rt_status rt_render_region(rt_scene *scene, const rt_options *options, rt_traver
 rt_status rt_blit_tiles_device(rt_scene *scene, const rt_options *options, const rt_region *tiles, uint32_t n_tiles,
                                const uint32_t *src_px_offset, const void *src_tile_major_device,
                                void *frame_rgba_device, void *hip_stream);
+
+/* ---- several GPUs of one node, one process -------------------------------------------------------------
+ * The reference joins its pool threads' buckets through one channel (render.rs:271, 293, 301).  A gang does the same across
+ * GPUs: the Scene is replicated on every listed device, the buckets of a frame are dealt round-robin in list order
+ * (bucket i -> devices[i % n], the scheduler's row-major order render.rs:273-298), every device renders its shard
+ * tile-major, and ONE RCCL gather of the equal-length u8 shards (ncclGather over xGMI, root = devices[0]; communicators from
+ * ncclCommInitAll) brings them to the root GPU, which blits them into the row-major frame (set_pixels_from_buffer,
+ * render.rs:112-126) and hands that frame to the host.  The bytes are identical for every n.  librccl.so is loaded when the
+ * first gang is created (RT_ERR_UNSUPPORTED if it cannot be); single-GPU rendering never needs it. */
+typedef struct rt_gang rt_gang;
+rt_status rt_gang_create(const int *devices, int n_devices, rt_precision precision,
+                         const void *dfs_items, uint32_t n_items, const void *light_unit, const void *eye,
+                         const void *bounds, const rt_range *ranges, uint32_t n_bounds, rt_gang **out);
+rt_status rt_gang_destroy(rt_gang *gang);
+rt_status rt_gang_size(const rt_gang *gang, int *n_devices);
+/* frame_rgba_host: width * height * 4 bytes, row-major (what the writer's image holds after write_rgba_buffer() for every
+ * listed bucket; pixels outside the listed buckets are unspecified).  stats (may be NULL): counters summed over the devices,
+ * device_ms = the slowest device's render. */
+rt_status rt_gang_render_frame(rt_gang *gang, const rt_options *options, rt_traversal traversal,
+                               const rt_region *tiles, uint32_t n_tiles, uint8_t *frame_rgba_host, rt_stats *stats);
 
 /* Bytes rt_render_tiles writes for this tile list (4 * total area), or 0 on an invalid list. */
 uint64_t rt_tiles_rgba_bytes(const rt_region *tiles, uint32_t n_tiles);

@@ -5,10 +5,10 @@ include/rtrace_hip.h), scene.py / render.py (host-side mirror of the reference's
 dist.py (tile sharding across GPUs + RCCL gather).  Importing this package requires the built library."""
 from . import capi
 from .capi import RT_F32, RT_F64, RT_TRAVERSAL_FLAT, RT_TRAVERSAL_SKIP, RtError, device_count
-from .scene import Scene, DeviceScene, pyramid, normalized, build_hierarchy
+from .scene import Scene, DeviceScene, Gang, pyramid, normalized, build_hierarchy
 from .render import (RenderOptions, ImageRegion, RGBABuffer, RGBABufferWriter, PPMStdoutRGBABufferWriter,
                      Renderer, buckets, CHUNK_SIZE)
 
 __all__ = ["capi", "RT_F32", "RT_F64", "RT_TRAVERSAL_FLAT", "RT_TRAVERSAL_SKIP", "RtError", "device_count",
-           "Scene", "DeviceScene", "pyramid", "normalized", "build_hierarchy", "RenderOptions", "ImageRegion", "RGBABuffer",
+           "Scene", "DeviceScene", "Gang", "pyramid", "normalized", "build_hierarchy", "RenderOptions", "ImageRegion", "RGBABuffer",
            "RGBABufferWriter", "PPMStdoutRGBABufferWriter", "Renderer", "buckets", "CHUNK_SIZE"]

@@ -17,7 +17,8 @@ ABI_VERSION = 2
 # every symbol include/rtrace_hip.h declares
 SYMBOLS = ("rt_abi_version", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_scene_traits", "rt_render_tiles",
            "rt_render_tiles_device", "rt_render_frame_device", "rt_render_region", "rt_blit_tiles_device", "rt_selftest_sqrt", "rt_tiles_rgba_bytes", "rt_strerror", "rt_last_error_message",
-           "rt_host_alloc", "rt_host_free", "rt_host_register", "rt_host_unregister")
+           "rt_host_alloc", "rt_host_free", "rt_host_register", "rt_host_unregister",
+           "rt_gang_create", "rt_gang_destroy", "rt_gang_size", "rt_gang_render_frame")
 
 
 class Options(C.Structure):      # rt_options / RenderOptions render.rs:33-38
@@ -68,6 +69,11 @@ lib.rt_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
 lib.rt_host_free.argtypes = [C.c_void_p]
 lib.rt_host_register.argtypes = [C.c_void_p, C.c_size_t]
 lib.rt_host_unregister.argtypes = [C.c_void_p]
+lib.rt_gang_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_uint32, C.POINTER(C.c_void_p)]
+lib.rt_gang_destroy.argtypes = [C.c_void_p]
+lib.rt_gang_size.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+lib.rt_gang_render_frame.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
 lib.rt_selftest_sqrt.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
 lib.rt_scene_traits.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
 RT_SCENE_HAS_BOUNDS, RT_SCENE_CONCENTRIC = 1, 2

@@ -42,7 +42,8 @@ const char *USAGE =
     "    -V, --version                       Prints version information\n\n"
     "MI355X backend (not in the reference):\n"
     "        --device <N>                    first GPU to render on [default: 0]\n"
-    "        --devices <N>                   number of GPUs; buckets are dealt round-robin [default: 1]\n"
+    "        --devices <N>                   number of GPUs; buckets are dealt round-robin and gathered over RCCL [default: 1]\n"
+    "        --gather <rccl|host>            N > 1: one RCCL gather to the first GPU (default), or per-GPU host copies\n"
     "        --traversal <skip|flat>         hierarchy walk (default) or flat DFS scan; identical pixels\n"
     "        --level <N>                     pyramid level of the default scene [default: 8]\n"
     "        --stats                         print ray counters and device time on stderr\n"
@@ -99,7 +100,7 @@ int main(int argc, char **argv)
     }
 
     std::string width = "1024", height = "1024", ssp = "1", numcores = "1", output;
-    std::string device = "0", devices = "1", traversal = "skip", level = "8";
+    std::string device = "0", devices = "1", traversal = "skip", level = "8", gather = "";
     bool have_output = false, stats = false, strict64 = false;
     auto take = [&](int &i, const std::string &arg, const char *name, std::string &dst) -> bool {
         const std::string flag = std::string("--") + name;
@@ -119,7 +120,7 @@ int main(int argc, char **argv)
         if (a == "--strict-64") { strict64 = true; continue; }
         if (take(i, a, "width", width) || take(i, a, "height", height) || take(i, a, "samples-per-pixel", ssp) ||
             take(i, a, "num-cores", numcores) || take(i, a, "device", device) || take(i, a, "devices", devices) ||
-            take(i, a, "traversal", traversal) || take(i, a, "level", level))
+            take(i, a, "traversal", traversal) || take(i, a, "level", level) || take(i, a, "gather", gather))
             continue;
         if (a.size() > 1 && a[0] == '-' && a != "-") {
             fprintf(stderr, "error: Found argument '%s' which wasn't expected, or isn't valid in this context\n\nFor more information try --help\n", a.c_str());
@@ -170,7 +171,16 @@ int main(int argc, char **argv)
         else { fprintf(stderr, "error: --traversal must be skip or flat\n"); return 1; }
         const int dev0 = parse_or_panic<int>(device), ndev = parse_or_panic<int>(devices);
         if (ndev < 1) { fprintf(stderr, "error: --devices must be >= 1\n"); return 1; }
-        for (int d = 0; d < ndev; ++d) be.devices.push_back(std::make_shared<DeviceScene>(scene, dev0 + d));
+        if (!gather.empty() && gather != "rccl" && gather != "host") { fprintf(stderr, "error: --gather must be rccl or host\n"); return 1; }
+        // more than one GPU: the native gather (rt_gang: ncclCommInitAll + one ncclGather per frame); `--gather rccl` takes
+        // that path with a single GPU too (a one-rank communicator), `--gather host` keeps the per-device host copies
+        if (gather == "rccl" || (gather.empty() && ndev > 1)) {
+            std::vector<int> ids;
+            for (int d = 0; d < ndev; ++d) ids.push_back(dev0 + d);
+            be.gang = std::make_shared<DeviceGang>(scene, ids);
+        } else {
+            for (int d = 0; d < ndev; ++d) be.devices.push_back(std::make_shared<DeviceScene>(scene, dev0 + d));
+        }
 
         ThreadPool pool(pool_size);
         RenderStats st;

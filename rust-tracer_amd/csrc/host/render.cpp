@@ -2,6 +2,7 @@
 
 #include <unistd.h>
 
+#include <cstring>
 #include <exception>
 
 namespace rtrace {
@@ -25,6 +26,17 @@ DeviceScene::DeviceScene(const Scene &scene, int device)
     check(rt_scene_create(device, prec, f.items.data(), (uint32_t)(f.items.size() / 4), light, eye, f.bounds.data(),
                           reinterpret_cast<const rt_range *>(f.ranges.data()), (uint32_t)(f.ranges.size() / 2), &h_),
           "rt_scene_create");
+}
+
+DeviceGang::DeviceGang(const Scene &scene, const std::vector<int> &devices)
+{
+    const FlatScene f = scene.flatten();
+    const RFloat light[3] = { scene.directional_light.x, scene.directional_light.y, scene.directional_light.z };
+    const RFloat eye[3] = { scene.eye.x, scene.eye.y, scene.eye.z };
+    const rt_precision prec = sizeof(RFloat) == 4 ? RT_F32 : RT_F64;
+    check(rt_gang_create(devices.data(), (int)devices.size(), prec, f.items.data(), (uint32_t)(f.items.size() / 4), light, eye, f.bounds.data(),
+                         reinterpret_cast<const rt_range *>(f.ranges.data()), (uint32_t)(f.ranges.size() / 2), &h_),
+          "rt_gang_create");
 }
 
 void PPMStdoutRGBABufferWriter::write_buffer_with_header()
@@ -67,13 +79,37 @@ std::vector<ImageRegion> Renderer::buckets(const RenderOptions &o)
 
 RenderStats Renderer::render(const RenderOptions &o, const Backend &be, RGBABufferWriter &writer, ThreadPool &pool)
 {
-    if (be.devices.empty()) throw std::runtime_error("no device scene: the HIP backend has no CPU fallback");
+    if (be.devices.empty() && !be.gang) throw std::runtime_error("no device scene: the HIP backend has no CPU fallback");
     if (be.strict_64 && (o.width % CHUNK_SIZE != 0 || o.height % CHUNK_SIZE != 0))                 // render.rs:265-266
         throw std::runtime_error("TODO: handle chunk sizes");
     writer.begin(o.width, o.height);
 
     const std::vector<ImageRegion> all = buckets(o);
     size_t count = all.size();
+    if (be.gang) {
+        // Several GPUs: the whole bucket list in one gang call (bucket i -> GPU i % N, one RCCL gather of the u8 shards to the
+        // root GPU, blit there); the writer still receives the frame bucket by bucket, like the channel's consumer loop.
+        static_assert(sizeof(ImageRegion) == sizeof(rt_region), "ImageRegion is layout-compatible with rt_region");
+        const rt_options gopts{ o.width, o.height, o.samples_per_pixel };
+        std::vector<uint8_t> frame((size_t)o.width * o.height * 4);
+        rt_stats st{};
+        check(rt_gang_render_frame(be.gang->handle(), &gopts, be.traversal, reinterpret_cast<const rt_region *>(all.data()), (uint32_t)all.size(),
+                                   frame.data(), be.want_stats ? &st : nullptr),
+              "rt_gang_render_frame");
+        RenderStats total;
+        total.primary = st.primary; total.hits = st.hits; total.shadow = st.shadow; total.occluded = st.occluded;
+        total.sphere_tests = st.sphere_tests; total.bound_tests = st.bound_tests; total.device_ms = st.device_ms;
+        std::vector<uint8_t> tile;
+        for (const ImageRegion &r : all) {
+            tile.resize(r.area() * 4);
+            for (uint16_t y = r.b; y < r.t; ++y)
+                memcpy(tile.data() + (size_t)(y - r.b) * r.width() * 4, frame.data() + ((size_t)y * o.width + r.l) * 4, (size_t)r.width() * 4);
+            writer.write_rgba_buffer(RGBABuffer(r, tile.data()));
+            count -= 1;
+        }
+        if (count != 0) throw std::runtime_error("We really should have processed all chunks here");
+        return total;
+    }
     // Deal buckets round-robin over the devices, then cut each device's list into batches: one rt_render_tiles call
     // per batch (a launch per 64x64 bucket would leave 255 of 256 CUs idle).
     const size_t ndev = be.devices.size();

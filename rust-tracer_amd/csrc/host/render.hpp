@@ -117,13 +117,27 @@ private:
     rt_scene *h_ = nullptr;
 };
 
+// The Scene on several GPUs of this node (rt_gang: one process, buckets dealt round-robin, one RCCL gather to the root GPU).
+class DeviceGang {
+public:
+    DeviceGang(const Scene &scene, const std::vector<int> &devices);
+    ~DeviceGang() { rt_gang_destroy(h_); }
+    DeviceGang(const DeviceGang &) = delete;
+    DeviceGang &operator=(const DeviceGang &) = delete;
+    rt_gang *handle() const { return h_; }
+
+private:
+    rt_gang *h_ = nullptr;
+};
+
 struct RenderStats {
     uint64_t primary = 0, hits = 0, shadow = 0, occluded = 0, sphere_tests = 0, bound_tests = 0;
     double device_ms = 0;
 };
 
 struct Backend {                                                  // additions that do not exist in the reference
-    std::vector<std::shared_ptr<DeviceScene>> devices;            // buckets are dealt round-robin over these
+    std::vector<std::shared_ptr<DeviceScene>> devices;            // buckets are dealt round-robin over these (host buffers per device)
+    std::shared_ptr<DeviceGang> gang;                             // set: the frame goes through rt_gang_render_frame instead (RCCL gather)
     rt_traversal traversal = RT_TRAVERSAL_SKIP;
     size_t buckets_per_call = 0;                                  // 0 = split each device's buckets evenly over the pool (<= 64 per call)
     bool want_stats = false;                                      // collect RenderStats (ray / test counters, device time)

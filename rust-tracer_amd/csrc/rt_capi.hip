@@ -9,6 +9,8 @@
 #include "rt_flat_wf.hpp"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>       // types and prototypes only: librccl.so is loaded with dlopen when the first gang is created
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -949,8 +951,11 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
     for (int k = 0; k < 3; ++k) {
         s->light[k] = f32 ? (double)static_cast<const float *>(light_unit)[k] : static_cast<const double *>(light_unit)[k];
         s->eye[k] = f32 ? (double)static_cast<const float *>(eye)[k] : static_cast<const double *>(eye)[k];
-        if (!std::isfinite(s->light[k]) || !std::isfinite(s->eye[k])) {
-            snprintf(g_err, sizeof g_err, "rt_scene_create: light / eye must be finite");
+        // Bounds that keep every intermediate of primitive.rs:55-72 finite in f32 (squares of sums of coordinates stay below
+        // 2e33), so no inf - inf and no NaN can arise anywhere on the path: |eye| <= 1e15 like the items, and
+        // light_unit is a unit vector by contract (|component| <= 2 leaves room for rounding).
+        if (!std::isfinite(s->light[k]) || !std::isfinite(s->eye[k]) || std::fabs(s->eye[k]) > 1e15 || std::fabs(s->light[k]) > 2.0) {
+            snprintf(g_err, sizeof g_err, "rt_scene_create: eye must be finite with |coordinate| <= 1e15, light_unit a unit vector");
             return RT_ERR_INVALID_ARGUMENT;
         }
     }
@@ -1379,6 +1384,233 @@ rt_status rt_render_region(rt_scene *s, const rt_options *o, rt_traversal trav, 
     lk.unlock();
     if (me.st != RT_OK) snprintf(g_err, sizeof g_err, "%s", me.err);
     return me.st;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Gang: the buckets of one frame dealt over several GPUs of this node by ONE process, shards brought to the root GPU by one
+// RCCL gather over xGMI (replaces the channel of render.rs:271,293,301 for the multi-GPU case).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGather) Gather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    std::string error;
+};
+
+// librccl.so is ~0.5 GB: it is loaded on first use, never for single-GPU renders.
+Rccl *rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) { r.error = std::string("dlopen(librccl.so): ") + (dlerror() ? dlerror() : "not found"); return; }
+        auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); if (!p) r.error = std::string("librccl.so lacks ") + n; return p; };
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.Gather = reinterpret_cast<decltype(r.Gather)>(sym("ncclGather"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
+    });
+    return &r;
+}
+
+rt_status rccl_fail(ncclResult_t e, const char *what, int line)
+{
+    snprintf(g_err, sizeof g_err, "%s failed at rt_capi.hip:%d: %s", what, line, rccl()->GetErrorString ? rccl()->GetErrorString(e) : "RCCL error");
+    return RT_ERR_HIP;
+}
+
+#define RCCL_TRY(expr)                                                      \
+    do {                                                                    \
+        ncclResult_t e__ = (expr);                                          \
+        if (e__ != ncclSuccess) return rccl_fail(e__, #expr, __LINE__);     \
+    } while (0)
+
+}  // namespace
+
+struct rt_gang {
+    std::vector<int> devices;
+    std::vector<rt_scene *> scenes;
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> streams;
+    std::vector<uint8_t *> d_shard;           // per device: its tile-major shard
+    size_t shard_cap = 0;                     // bytes of each d_shard
+    uint8_t *d_gathered = nullptr;            // root: [n_devices][shard bytes]
+    size_t gathered_cap = 0;
+    uint8_t *d_frame = nullptr;               // root: row-major RGBA frame
+    size_t frame_cap = 0;
+    std::mutex mu;                            // one frame at a time per gang
+};
+
+rt_status rt_gang_create(const int *devices, int n_devices, rt_precision precision, const void *dfs_items, uint32_t n_items,
+                         const void *light_unit, const void *eye, const void *bounds, const rt_range *ranges, uint32_t n_bounds,
+                         rt_gang **out)
+{
+    if (out) *out = nullptr;
+    if (!out || !devices || n_devices < 1 || n_devices > 64) {
+        snprintf(g_err, sizeof g_err, "rt_gang_create: NULL argument or n_devices outside 1..64");
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    for (int a = 0; a < n_devices; ++a)
+        for (int b = a + 1; b < n_devices; ++b)
+            if (devices[a] == devices[b]) { snprintf(g_err, sizeof g_err, "rt_gang_create: device %d listed twice", devices[a]); return RT_ERR_INVALID_ARGUMENT; }
+    Rccl *r = rccl();
+    if (!r->error.empty() || !r->Gather) { snprintf(g_err, sizeof g_err, "rt_gang_create: %s", r->error.c_str()); return RT_ERR_UNSUPPORTED; }
+    std::unique_ptr<rt_gang> g(new (std::nothrow) rt_gang());
+    if (!g) return RT_ERR_OUT_OF_MEMORY;
+    auto fail = [&](rt_status st) { rt_gang_destroy(g.release()); return st; };
+    g->devices.assign(devices, devices + n_devices);
+    for (int d = 0; d < n_devices; ++d) {
+        rt_scene *s = nullptr;
+        rt_status st = rt_scene_create(devices[d], precision, dfs_items, n_items, light_unit, eye, bounds, ranges, n_bounds, &s);
+        if (st != RT_OK) return fail(st);
+        g->scenes.push_back(s);
+        hipStream_t stream = nullptr;
+        hipError_t e = hipSetDevice(devices[d]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return fail(hip_fail(e, "hipStreamCreate(gang)", __LINE__));
+        g->streams.push_back(stream);
+        g->d_shard.push_back(nullptr);
+    }
+    g->comms.assign((size_t)n_devices, nullptr);
+    ncclResult_t ne = r->CommInitAll(g->comms.data(), n_devices, g->devices.data());       // one communicator per device, this process
+    if (ne != ncclSuccess) { g->comms.clear(); return fail(rccl_fail(ne, "ncclCommInitAll", __LINE__)); }
+    *out = g.release();
+    return RT_OK;
+}
+
+rt_status rt_gang_destroy(rt_gang *g)
+{
+    if (!g) return RT_OK;
+    for (ncclComm_t c : g->comms)
+        if (c) (void)rccl()->CommDestroy(c);
+    for (size_t d = 0; d < g->devices.size(); ++d) {
+        (void)hipSetDevice(g->devices[d]);
+        if (d < g->d_shard.size() && g->d_shard[d]) (void)hipFree(g->d_shard[d]);
+        if (d < g->streams.size() && g->streams[d]) (void)hipStreamDestroy(g->streams[d]);
+        if (d == 0) {
+            if (g->d_gathered) (void)hipFree(g->d_gathered);
+            if (g->d_frame) (void)hipFree(g->d_frame);
+        }
+    }
+    for (rt_scene *s : g->scenes) rt_scene_destroy(s);
+    delete g;
+    return RT_OK;
+}
+
+rt_status rt_gang_size(const rt_gang *g, int *n_devices)
+{
+    if (!g || !n_devices) { snprintf(g_err, sizeof g_err, "NULL argument"); return RT_ERR_INVALID_ARGUMENT; }
+    *n_devices = (int)g->devices.size();
+    return RT_OK;
+}
+
+rt_status rt_gang_render_frame(rt_gang *g, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n,
+                               uint8_t *frame_rgba_host, rt_stats *stats)
+{
+    if (!g || !check_common(g->scenes.empty() ? nullptr : g->scenes[0], o, tiles, n, frame_rgba_host)) {
+        if (!g) snprintf(g_err, sizeof g_err, "NULL gang");
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    if (rt_tiles_rgba_bytes(tiles, n) == 0) { snprintf(g_err, sizeof g_err, "rt_gang_render_frame: empty region in the tile list"); return RT_ERR_INVALID_REGION; }
+    std::lock_guard<std::mutex> lk(g->mu);
+    Rccl *r = rccl();
+    const size_t nd = g->devices.size();
+    // bucket i -> device i % N in the caller's (the scheduler's row-major, render.rs:273-298) order; shards padded to equal length
+    std::vector<std::vector<rt_region>> shard(nd);
+    std::vector<rt_region> gathered_regs;
+    std::vector<uint32_t> gathered_off;
+    std::vector<uint64_t> shard_px(nd, 0);
+    for (uint32_t i = 0; i < n; ++i) shard[i % nd].push_back(tiles[i]);
+    uint64_t max_px = 0;
+    for (size_t d = 0; d < nd; ++d) {
+        for (const rt_region &t : shard[d]) shard_px[d] += (uint64_t)(t.r - t.l) * (t.t - t.b);
+        max_px = std::max(max_px, shard_px[d]);
+    }
+    if (max_px * nd > 0xFFFFFFFFull) { snprintf(g_err, sizeof g_err, "rt_gang_render_frame: tile list too large for one pass"); return RT_ERR_INVALID_ARGUMENT; }
+    for (size_t d = 0; d < nd; ++d) {
+        uint64_t px = 0;
+        for (const rt_region &t : shard[d]) {
+            gathered_regs.push_back(t);
+            gathered_off.push_back((uint32_t)(d * max_px + px));
+            px += (uint64_t)(t.r - t.l) * (t.t - t.b);
+        }
+    }
+    const size_t shard_bytes = (size_t)max_px * 4, frame_bytes = (size_t)o->width * o->height * 4;
+    // buffers
+    for (size_t d = 0; d < nd; ++d) {
+        HIP_TRY(hipSetDevice(g->devices[d]));
+        if (g->shard_cap < shard_bytes || !g->d_shard[d]) {
+            if (g->d_shard[d]) HIP_TRY(hipFree(g->d_shard[d]));
+            g->d_shard[d] = nullptr;
+            HIP_TRY(hipMalloc(&g->d_shard[d], shard_bytes));
+        }
+    }
+    g->shard_cap = std::max(g->shard_cap, shard_bytes);
+    HIP_TRY(hipSetDevice(g->devices[0]));
+    if (g->gathered_cap < shard_bytes * nd) {
+        if (g->d_gathered) HIP_TRY(hipFree(g->d_gathered));
+        g->d_gathered = nullptr; g->gathered_cap = 0;
+        HIP_TRY(hipMalloc(&g->d_gathered, shard_bytes * nd));
+        g->gathered_cap = shard_bytes * nd;
+    }
+    if (g->frame_cap < frame_bytes) {
+        if (g->d_frame) HIP_TRY(hipFree(g->d_frame));
+        g->d_frame = nullptr; g->frame_cap = 0;
+        HIP_TRY(hipMalloc(&g->d_frame, frame_bytes));
+        g->frame_cap = frame_bytes;
+    }
+    // 1. every device renders its shard (asynchronous unless counters are wanted)
+    rt_stats total{};
+    for (size_t d = 0; d < nd; ++d) {
+        if (shard[d].empty()) continue;
+        rt_stats st{};
+        rt_status rs = rt_render_tiles_device(g->scenes[d], o, trav, shard[d].data(), (uint32_t)shard[d].size(), g->d_shard[d], g->streams[d],
+                                              stats ? &st : nullptr);
+        if (rs != RT_OK) {
+            for (size_t k = 0; k <= d; ++k) { (void)hipSetDevice(g->devices[k]); (void)hipStreamSynchronize(g->streams[k]); }
+            return rs;
+        }
+        if (stats) {
+            total.primary += st.primary; total.hits += st.hits; total.shadow += st.shadow; total.occluded += st.occluded;
+            total.sphere_tests += st.sphere_tests; total.bound_tests += st.bound_tests; total.tests_executed += st.tests_executed;
+            total.device_ms = std::max(total.device_ms, st.device_ms);
+        }
+    }
+    // 2. the one collective on the data path: equal-length u8 shards to the root GPU
+    RCCL_TRY(r->GroupStart());
+    for (size_t d = 0; d < nd; ++d) {
+        ncclResult_t e = r->Gather(g->d_shard[d], d == 0 ? g->d_gathered : nullptr, shard_bytes, ncclUint8, 0, g->comms[d], g->streams[d]);
+        if (e != ncclSuccess) { (void)r->GroupEnd(); return rccl_fail(e, "ncclGather", __LINE__); }
+    }
+    RCCL_TRY(r->GroupEnd());
+    // 3. root: set_pixels_from_buffer for every bucket (render.rs:112-126, 422-424), then the frame goes to the host
+    HIP_TRY(hipSetDevice(g->devices[0]));
+    rt_status bs = rt_blit_tiles_device(g->scenes[0], o, gathered_regs.data(), (uint32_t)gathered_regs.size(), gathered_off.data(), g->d_gathered,
+                                        g->d_frame, g->streams[0]);
+    if (bs != RT_OK) { (void)hipStreamSynchronize(g->streams[0]); return bs; }
+    HIP_TRY(hipSetDevice(g->devices[0]));
+    HIP_TRY(hipMemcpyAsync(frame_rgba_host, g->d_frame, frame_bytes, hipMemcpyDeviceToHost, g->streams[0]));
+    for (size_t d = 0; d < nd; ++d) {
+        HIP_TRY(hipSetDevice(g->devices[d]));
+        HIP_TRY(hipStreamSynchronize(g->streams[d]));
+    }
+    if (stats) *stats = total;
+    return RT_OK;
 }
 
 }  // extern "C"

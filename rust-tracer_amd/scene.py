@@ -253,3 +253,46 @@ class DeviceScene:
         rc = capi.lib.rt_blit_tiles_device(self._h, C.byref(o), arr, len(arr), offs.ctypes.data if offs is not None else None,
                                            C.c_void_p(src_ptr), C.c_void_p(frame_ptr), C.c_void_p(stream))
         capi.check(rc, "rt_blit_tiles_device")
+
+
+class Gang:
+    """rt_gang: the Scene replicated on several GPUs of this node in ONE process; a frame's buckets are dealt round-robin over
+    them and the u8 shards come back through one RCCL gather (the native twin of dist.FrameSharder's one-process-per-GPU path)."""
+
+    def __init__(self, scene, devices):
+        self.scene = scene
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        nb = 0 if scene.bounds is None else scene.bounds.shape[0]
+        st = capi.lib.rt_gang_create(devs, len(devices), scene.precision, scene.items.ctypes.data, scene.items.shape[0],
+                                     scene.directional_light.ctypes.data, scene.eye.ctypes.data,
+                                     scene.bounds.ctypes.data if nb else None, scene.ranges.ctypes.data if nb else None, nb, C.byref(h))
+        capi.check(st, "rt_gang_create")
+        self._h = h
+
+    def size(self):
+        n = C.c_int(0)
+        capi.check(capi.lib.rt_gang_size(self._h, C.byref(n)), "rt_gang_size")
+        return n.value
+
+    def render_frame(self, options, regions, traversal=capi.RT_TRAVERSAL_SKIP, want_stats=False, out=None):
+        """rt_gang_render_frame -> (uint8[h, w, 4] row-major frame, stats dict | None)."""
+        arr = regions if isinstance(regions, C.Array) else DeviceScene._regions(regions)
+        o = capi.Options(*options)
+        if out is None:
+            out = np.zeros(o.width * o.height * 4, dtype=np.uint8)
+        st = capi.Stats()
+        rc = capi.lib.rt_gang_render_frame(self._h, C.byref(o), traversal, arr, len(arr), out.ctypes.data, C.byref(st) if want_stats else None)
+        capi.check(rc, "rt_gang_render_frame")
+        return out.reshape(o.height, o.width, 4), (st.as_dict() if want_stats else None)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            capi.lib.rt_gang_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

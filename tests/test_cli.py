@@ -122,3 +122,28 @@ def test_make_image_reproduces_the_reference_image(tmp_path, golden_dir):
     ref = np.load(os.path.join(golden_dir, "make_image_1024x768_spp4_rgb.npz"))["rgb"]
     assert int((rgb != ref).any(axis=2).sum()) == 0
     assert hashlib.md5(data).hexdigest() == "63e866ff6d39850bbcf0fcea87024d19"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndev", [1, 2])
+def test_cli_native_rccl_gather_writes_the_reference_bytes(tmp_path, ndev):
+    # rtrace --devices N: buckets dealt round-robin over N GPUs of this process, ONE ncclGather of the u8 shards to the first
+    # GPU, blit there (rt_gang, include/rtrace_hip.h).  --gather rccl takes that path with one GPU too (a one-rank communicator),
+    # so the collective code runs on a single-GPU box; N = 2 needs a second device.
+    import rust_tracer_amd as rta
+    if rta.device_count() < ndev:
+        pytest.skip("needs %d GPUs" % ndev)
+    out = str(tmp_path / "out.tga")
+    r = run(["--width=800", "--height=600", "--devices=%d" % ndev, "--gather=rccl", "--stats", out])
+    assert r.returncode == 0, r.stderr.decode()
+    ref, st = _oracle_ppm(tmp_path, 800, 600, 1)
+    assert open(out, "rb").read() == ref
+    assert ("primary %d hits %d shadow %d occluded %d" % (st["primary"], st["hits"], st["shadow"], st["occluded"])).encode() in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_strict_64_panics_like_the_reference(tmp_path):
+    r = run(["--width=800", "--height=600", "--strict-64", str(tmp_path / "o.tga")])       # render.rs:265-266
+    assert r.returncode == 101 and b"TODO: handle chunk sizes" in r.stderr
+    r = run(["--width=128", "--height=64", "--strict-64", str(tmp_path / "o.tga")])
+    assert r.returncode == 0

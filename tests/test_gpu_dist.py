@@ -96,3 +96,27 @@ def test_frames_mode_batched_gather_delivers_every_frame(one_rank_rccl):
     fs2.run(1)                                   # one partial batch: frames 1..3 of slot 0 were never gathered
     np.testing.assert_array_equal(fs2.frame_host(slot=0, index=0), ref)
     assert int(fs2.frame_host(slot=0, index=1).min()) == 0xCD and int(fs2.frame_host(slot=0, index=3).max()) == 0xCD
+
+
+@pytest.mark.parametrize("ndev", [1, 2])
+@pytest.mark.parametrize("size", [(1920, 1080, 1), (200, 130, 2)])
+def test_native_gang_rccl_gather_is_byte_identical(ndev, size):
+    # rt_gang_*: one process, N GPUs, bucket i -> GPU i % N, one ncclGather to the root, blit, frame to the host.  Byte-identical
+    # to the oracle for N in {1, 2} (N = 2 skips below two devices), counters summed over the devices equal the CPU path's.
+    import oracle
+    if rta.device_count() < ndev:
+        pytest.skip("needs %d GPUs" % ndev)
+    w, h, spp = size
+    s = rta.Scene.default(8 if w > 1000 else 6)
+    o = oracle.Scene.default(level=8 if w > 1000 else 6)
+    g = rta.Gang(s, list(range(ndev)))
+    assert g.size() == ndev
+    regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
+    ref, rst, _ = o.render(w, h, spp, os.cpu_count() or 1, oracle.MODE_HIERARCHY | oracle.MODE_ANYHIT_EXIT)
+    frame, st = g.render_frame((w, h, spp), regs, want_stats=True)
+    np.testing.assert_array_equal(frame, ref)
+    for k in ("primary", "hits", "shadow", "occluded", "sphere_tests", "bound_tests"):
+        assert st[k] == rst[k], k
+    frame2, _ = g.render_frame((w, h, spp), regs[::-1])          # the deal follows the list order; the frame does not care
+    np.testing.assert_array_equal(frame2, ref)
+    g.close()

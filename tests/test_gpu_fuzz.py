@@ -34,3 +34,42 @@ def test_random_scene(seed):
     fref, frst, _ = o.render(w, h, spp, os.cpu_count() or 1, oracle.MODE_FLAT)
     np.testing.assert_array_equal(util.stitch((w, h), regs, flat), fref)
     assert util.ray_stats(fst) == util.ray_stats(frst)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 3, 7])
+@pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64], ids=["f32", "f64"])
+@pytest.mark.parametrize("scale", [1e-20, 1e-10, 1e6, 1e12, 5e13])
+def test_scaled_scenes_every_loop_flavour(scale, precision, variant):
+    # The whole scene (items, bounds, eye) scaled by 1e-20 ... 5e13: at 1e-20 the f32 squares (rr, vv, b*b ~ 1e-40) are
+    # denormals, so every root goes through the traversal loops' scaled `tiny` branches (and the C++ lean sqrt's general path);
+    # at 5e13 coordinates sit just under the 1e15 validation bound and squares reach 1e29.  Denormals are kept on both sides.
+    # All four loop flavours (0/1 C++, 3 generated assembly, 7 fused; the library drops the fused bit for the nested scene)
+    # against the oracle: pixels, alpha and every counter.
+    for seed, concentric in ((31, False), (32, True)):
+        items, bounds, ranges = util.random_nested_scene(seed, depth=3, fan=3, leaf_items=2, concentric=concentric)
+        R = np.float32 if precision == rta.RT_F32 else np.float64
+        sc = lambda a: (np.asarray(a, dtype=np.float64) * scale).astype(R).astype(np.float64)
+        eye = tuple(float(v) for v in sc((0.07, -0.12, -3.1)))
+        s, o = util.scene_pair_ranges(sc(items), sc(bounds), ranges, precision, eye=eye)
+        w, h, spp = 96, 72, 2
+        regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
+        ref, rst, _ = o.render(w, h, spp, os.cpu_count() or 1, HIER_EXIT)
+        assert rst["hits"] > 500 and rst["shadow"] > 100           # the scaled scene is still in view
+        with rta.capi.debug(rta.capi.DEBUG_SKIP_VARIANT, variant):
+            plain, _ = s.device().render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
+            counted, st = s.device().render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=True)
+        np.testing.assert_array_equal(util.stitch((w, h), regs, plain), ref)
+        np.testing.assert_array_equal(counted, plain)
+        assert util.all_stats(st) == util.all_stats(rst)
+
+
+def test_inputs_that_could_overflow_are_rejected():
+    # the no-NaN argument rests on these bounds: coordinates and eye within 1e15, light a unit vector
+    items = np.array([[0, 0, 0, 1.0]])
+    for kw in (dict(eye=(0, 0, -2e15)), dict(light=(0.0, -3.0, 0.0)), dict(items=np.array([[2e15, 0, 0, 1.0]]))):
+        it = kw.pop("items", items)
+        light = np.asarray(kw.pop("light", rta.normalized((-1, -3, 2), rta.RT_F32)), dtype=np.float64)
+        s = rta.Scene(it, light, kw.pop("eye", (0, 0, -4)), np.array([[0, 0, 0, 3.0]]), np.array([[0, 1]], dtype=np.int32))
+        with pytest.raises(rta.RtError) as e:
+            s.device()
+        assert e.value.status == rta.capi.RT_ERR_INVALID_ARGUMENT
