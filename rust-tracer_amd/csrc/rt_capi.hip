@@ -101,8 +101,9 @@ struct rt_scene {
     rt_precision precision = RT_F32;
     uint32_t n_items = 0, n_bounds = 0;
     void *d_items = nullptr;       // Item<REAL>[n_items], DFS order
-    void *d_prim = nullptr, *d_shad = nullptr;   // Node<REAL>[n_nodes]: skip-pointer streams (RT_TRAVERSAL_SKIP)
-    uint32_t n_nodes = 0;
+    void *d_prim = nullptr, *d_shad = nullptr;   // Node<REAL>[n_nodes + kNodePad]: skip-pointer streams (RT_TRAVERSAL_SKIP)
+    void *d_cprim = nullptr, *d_cshad = nullptr;   // fused scenes: the compacted streams of the fused assembly loops
+    uint32_t n_nodes = 0, n_fnodes = 0;
     bool fused = false;            // every BOUND is followed by an ITEM with the same centre (rt_skip.hpp, Node)
     void *d_fprim = nullptr, *d_fprim_rr = nullptr, *d_fshad = nullptr;   // pre-formed per-item terms (RT_TRAVERSAL_FLAT)
     uint32_t n_padded = 0;
@@ -263,8 +264,11 @@ rt::SkipView<T> skip_view_of(const rt_scene *s)
     rt::SkipView<T> v;
     v.prim = static_cast<const rt::Node<T> *>(s->d_prim);
     v.shad = static_cast<const rt::Node<T> *>(s->d_shad);
+    v.fprim = static_cast<const rt::Node<T> *>(s->d_cprim);
+    v.fshad = static_cast<const rt::Node<T> *>(s->d_cshad);
     v.items = static_cast<const rt::Item<T> *>(s->d_items);
     v.n_nodes = s->n_nodes;
+    v.n_fnodes = s->n_fnodes;
     v.light = { (T)s->light[0], (T)s->light[1], (T)s->light[2] };
     v.eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
     return v;
@@ -296,7 +300,7 @@ rt_status build_raw_stream(const T *items, uint32_t n_items, const T *bounds, co
             }
             if (ranges[b].count > 0) {
                 stack.push_back({ (uint32_t)out.size(), end });
-                out.push_back({ bounds[4 * b], bounds[4 * b + 1], bounds[4 * b + 2], bounds[4 * b + 3], 0u, 0u });
+                out.push_back({ bounds[4 * b], bounds[4 * b + 1], bounds[4 * b + 2], bounds[4 * b + 3], 0u, 0u, T(0), 0u, 0u });
             }
             ++b;
         }
@@ -304,7 +308,7 @@ rt_status build_raw_stream(const T *items, uint32_t n_items, const T *bounds, co
             snprintf(g_err, sizeof g_err, "rt_scene_create: ranges are not in DFS pre-order at %u", b);
             return RT_ERR_INVALID_ARGUMENT;
         }
-        out.push_back({ items[4 * pos], items[4 * pos + 1], items[4 * pos + 2], items[4 * pos + 3], 0u, pos });
+        out.push_back({ items[4 * pos], items[4 * pos + 1], items[4 * pos + 2], items[4 * pos + 3], 0u, pos, T(0), 0u, 0u });
     }
     if (b != n_bounds || !stack.empty()) {
         snprintf(g_err, sizeof g_err, "rt_scene_create: ranges are not a DFS pre-order nesting of the item array");
@@ -314,15 +318,37 @@ rt_status build_raw_stream(const T *items, uint32_t n_items, const T *bounds, co
     return RT_OK;
 }
 
+// Device streams (primary + shadow) of one raw stream: nodes [0, n) and kNodePad END nodes behind them.
+template <typename T>
+rt_status derive_streams(const rt_scene *s, const std::vector<rt::RawNode<T>> &raw, bool compacted, void **d_prim, void **d_shad)
+{
+    const size_t n = raw.size(), total = n + rt::kNodePad;
+    rt::RawNode<T> *d_raw = nullptr;
+    HIP_TRY(hipMalloc(&d_raw, sizeof(rt::RawNode<T>) * n));
+    hipError_t e = hipMemcpy(d_raw, raw.data(), sizeof(rt::RawNode<T>) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(d_prim, sizeof(rt::Node<T>) * total);
+    if (e == hipSuccess) e = hipMalloc(d_shad, sizeof(rt::Node<T>) * total);
+    if (e == hipSuccess) {
+        const rt::V3<T> eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
+        hipLaunchKernelGGL((rt::k_build_streams<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, d_raw, (unsigned)n, eye, compacted,
+                           static_cast<rt::Node<T> *>(*d_prim), static_cast<rt::Node<T> *>(*d_shad));
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    (void)hipFree(d_raw);
+    if (e != hipSuccess) return hip_fail(e, "derive_streams", __LINE__);
+    return RT_OK;
+}
+
 template <typename T>
 rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, const rt_range *ranges)
 {
     std::vector<rt::RawNode<T>> raw;
     rt_status st = build_raw_stream<T>(static_cast<const T *>(items), s->n_items, static_cast<const T *>(bounds), ranges, s->n_bounds, raw);
     if (st != RT_OK) return st;
-    // the traversal loops address the streams with 32-bit byte offsets (two pad nodes included)
-    if (((uint64_t)raw.size() + 2) * sizeof(rt::Node<T>) > 0xFFFFFFFFull) {
-        snprintf(g_err, sizeof g_err, "rt_scene_create: %zu stream nodes exceed the 4 GiB the traversal streams can address", raw.size());
+    // the traversal loops address the streams with 32-bit byte offsets (END nodes included) and keep two flag bits in the item word
+    if (((uint64_t)raw.size() + rt::kNodePad) * sizeof(rt::Node<T>) > 0xFFFFFFFFull || s->n_items > rt::kNodeIndexMask) {
+        snprintf(g_err, sizeof g_err, "rt_scene_create: %zu stream nodes exceed what the traversal streams can address", raw.size());
         return RT_ERR_UNSUPPORTED;
     }
     s->n_nodes = (uint32_t)raw.size();
@@ -333,23 +359,32 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
         if (raw[i].skip != 0u)
             fused = i + 1 < raw.size() && raw[i + 1].skip == 0u && memcmp(&raw[i].cx, &raw[i + 1].cx, 3 * sizeof(T)) == 0;
     s->fused = fused;
-    rt::RawNode<T> *d_raw = nullptr;
-    HIP_TRY(hipMalloc(&d_raw, sizeof(rt::RawNode<T>) * raw.size()));
-    hipError_t e = hipMemcpy(d_raw, raw.data(), sizeof(rt::RawNode<T>) * raw.size(), hipMemcpyHostToDevice);
-    // two zeroed pad nodes at [n], [n + 1]: the traversal prefetches the next node (one or two on) without a bounds check
-    if (e == hipSuccess) e = hipMalloc(&s->d_prim, sizeof(rt::Node<T>) * (raw.size() + 2));
-    if (e == hipSuccess) e = hipMalloc(&s->d_shad, sizeof(rt::Node<T>) * (raw.size() + 2));
-    if (e == hipSuccess) e = hipMemset(s->d_prim, 0, sizeof(rt::Node<T>) * (raw.size() + 2));
-    if (e == hipSuccess) e = hipMemset(s->d_shad, 0, sizeof(rt::Node<T>) * (raw.size() + 2));
-    if (e == hipSuccess) {
-        const rt::V3<T> eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
-        hipLaunchKernelGGL((rt::k_build_streams<T>), dim3((s->n_nodes + 255) / 256), dim3(256), 0, nullptr, d_raw, s->n_nodes, eye, s->fused,
-                           static_cast<rt::Node<T> *>(s->d_prim), static_cast<rt::Node<T> *>(s->d_shad));
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
+    if ((st = derive_streams<T>(s, raw, false, &s->d_prim, &s->d_shad)) != RT_OK) return st;
+    if (fused) {
+        // compacted streams: the ITEM behind every BOUND moves into the BOUND node (it is never a jump target: `skip` points
+        // behind a whole subtree, and a subtree never starts with its group's own sphere)
+        std::vector<uint32_t> new_index(raw.size() + 1);
+        uint32_t k = 0;
+        for (size_t i = 0; i < raw.size(); ++i) {
+            new_index[i] = k;
+            if (!(i > 0 && raw[i - 1].skip != 0u)) ++k;              // dropped: the node directly behind a BOUND
+        }
+        new_index[raw.size()] = k;
+        std::vector<rt::RawNode<T>> compact;
+        compact.reserve(k);
+        for (size_t i = 0; i < raw.size(); ++i) {
+            if (i > 0 && raw[i - 1].skip != 0u) continue;
+            rt::RawNode<T> r = raw[i];
+            if (r.skip != 0u) {
+                r.own_r = raw[i + 1].r; r.own_item = raw[i + 1].item;
+                r.skip = new_index[r.skip];
+                if (r.skip == 0u) { snprintf(g_err, sizeof g_err, "rt_scene_create: internal: skip target 0"); return RT_ERR_INVALID_ARGUMENT; }
+            }
+            compact.push_back(r);
+        }
+        s->n_fnodes = (uint32_t)compact.size();
+        if ((st = derive_streams<T>(s, compact, true, &s->d_cprim, &s->d_cshad)) != RT_OK) return st;
     }
-    (void)hipFree(d_raw);
-    if (e != hipSuccess) return hip_fail(e, "upload_streams", __LINE__);
     return RT_OK;
 }
 
@@ -985,6 +1020,8 @@ rt_status rt_scene_destroy(rt_scene *s)
     if (s->d_items) (void)hipFree(s->d_items);
     if (s->d_prim) (void)hipFree(s->d_prim);
     if (s->d_shad) (void)hipFree(s->d_shad);
+    if (s->d_cprim) (void)hipFree(s->d_cprim);
+    if (s->d_cshad) (void)hipFree(s->d_cshad);
     if (s->d_fprim) (void)hipFree(s->d_fprim);
     if (s->d_fprim_rr) (void)hipFree(s->d_fprim_rr);
     if (s->d_fshad) (void)hipFree(s->d_fshad);

@@ -22,51 +22,80 @@ namespace rt {
 // v = centre - eye, vv = dot(v, v), rr = radius * radius -- the ray-independent sub-expressions of
 // primitive.rs:56-58, computed on the device with the same individually rounded operations.
 // SHADOW stream (per-lane origin): a = {cx, cy, cz, rr, -}.
-// skip_off != 0: BOUND node; skip_off = byte offset of the first node after the group's subtree.  skip_off == 0: ITEM node.
+// item word: ITEM nodes carry their index into the DFS items | kNodeItem; the END node behind the last node carries kNodeEnd
+// (disc = +inf for every ray: the assembly loops leave when they hit it); BOUND nodes carry no flag.
+// skip_off: byte offset of the node the walk continues at when nobody enters -- the first node after a BOUND's subtree, the
+// node behind an ITEM.
 // A scene is FUSED when every BOUND is directly followed by an ITEM with the same centre, bit for bit (the reference's
-// pyramid: a group's first child is the sphere its bound is built around, group.rs:37-41).  Its BOUND nodes also carry that
-// sphere's rr and item index, so the assembly loops can test it inside the BOUND step (rt_skip_rot.hpp).
+// pyramid: a group's first child is the sphere its bound is built around, group.rs:37-41).  Such a scene also gets a COMPACTED
+// pair of streams for the fused assembly loops: those ITEM nodes are dropped and each BOUND node carries its sphere's rr and
+// item index, so the BOUND step tests it for the lanes that enter (rt_skip_rot.hpp).
+constexpr uint32_t kNodeItem = 0x80000000u, kNodeEnd = 0x40000000u, kNodeIndexMask = 0x3FFFFFFFu;
+constexpr unsigned kNodePad = 3;            // END + two more END copies: the loops prefetch up to two nodes past END
 template <typename T> struct alignas(sizeof(T) * 8) Node {
     T a0, a1, a2, a3, a4;
-    uint32_t item;          // ITEM: index into the DFS items.  Fused BOUND: the index of the group's own sphere.
+    uint32_t item;          // see above.  Compacted BOUND: the index of the group's own sphere.
     uint32_t skip_off;
-    T own_rr;               // rr of the group's own sphere (fused scenes, BOUND nodes)
-    __device__ __forceinline__ bool is_bound() const { return skip_off != 0u; }
+    T own_rr;               // rr of the group's own sphere (compacted streams, BOUND nodes)
+    __device__ __forceinline__ bool is_bound() const { return (item & (kNodeItem | kNodeEnd)) == 0u; }
     __device__ __forceinline__ unsigned skip() const { return skip_off / (unsigned)sizeof(Node); }   // as a node index
+    __device__ __forceinline__ unsigned index() const { return item & kNodeIndexMask; }
 };
 static_assert(sizeof(Node<float>) == 32 && sizeof(Node<double>) == 64, "node records are one aligned scalar-load unit");
 
-// Host-built raw stream entry (before the device derives the two streams above).
+// Host-built raw stream entry (before the device derives the two streams above).  skip: node index, 0 for an ITEM.
 template <typename T> struct RawNode {
     T cx, cy, cz, r;
     uint32_t skip, item;
+    T own_r;                // compacted stream, BOUND: radius / index of the sphere the bound is built around
+    uint32_t own_item, pad;
 };
 
 template <typename T> struct SkipView {
     const Node<T> *prim;    // primary-ray stream
     const Node<T> *shad;    // shadow-ray stream
+    const Node<T> *fprim;   // compacted streams of a fused scene (else NULL)
+    const Node<T> *fshad;
     const Item<T> *items;   // DFS items (centre of the winning item for the normal)
-    uint32_t n_nodes;
+    uint32_t n_nodes, n_fnodes;
     V3<T> light, eye;
 };
 
-// Derives both streams from the raw one: exact IEEE ops, no contraction (same products the CPU path forms).
+// Derives both streams from the raw one: exact IEEE ops, no contraction (same products the CPU path forms).  Threads
+// n .. n + kNodePad - 1 write the END nodes.
 template <typename T>
-__global__ void k_build_streams(const RawNode<T> *__restrict__ raw, unsigned n, V3<T> eye, bool fused, Node<T> *__restrict__ prim,
+__global__ void k_build_streams(const RawNode<T> *__restrict__ raw, unsigned n, V3<T> eye, bool compacted, Node<T> *__restrict__ prim,
                                 Node<T> *__restrict__ shad)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const RawNode<T> r = raw[i];
-    const V3<T> v = { r.cx - eye.x, r.cy - eye.y, r.cz - eye.z };      // primitive.rs:56
-    const T rr = r.r * r.r;                                           // primitive.rs:58
-    Node<T> p; p.a0 = v.x; p.a1 = v.y; p.a2 = v.z; p.a3 = dot(v, v); p.a4 = rr; p.own_rr = T(0); p.item = r.item;
-    Node<T> s; s.a0 = r.cx; s.a1 = r.cy; s.a2 = r.cz; s.a3 = rr; s.a4 = T(0); s.own_rr = T(0); s.item = r.item;
-    p.skip_off = s.skip_off = r.skip * (unsigned)sizeof(Node<T>);
-    if (fused && r.skip != 0u) {                                      // the ITEM behind this BOUND has the same centre
-        const RawNode<T> own = raw[i + 1];
-        p.own_rr = s.own_rr = own.r * own.r;                          // primitive.rs:58
-        p.item = s.item = own.item;
+    if (i >= n + kNodePad) return;
+    constexpr unsigned kStride = (unsigned)sizeof(Node<T>);
+    Node<T> p, s;
+    if (i >= n) {
+        // END: v = 0 and rr = +inf make disc = (b*b - vv) + rr = +inf for every ray of either kind
+        p.a0 = p.a1 = p.a2 = p.a3 = T(0); p.a4 = inf<T>();
+        s.a0 = s.a1 = s.a2 = T(0); s.a3 = inf<T>(); s.a4 = T(0);
+        p.own_rr = s.own_rr = T(0);
+        p.item = s.item = kNodeEnd;
+        p.skip_off = s.skip_off = n * kStride;
+    } else {
+        const RawNode<T> r = raw[i];
+        const V3<T> v = { r.cx - eye.x, r.cy - eye.y, r.cz - eye.z };      // primitive.rs:56
+        const T rr = r.r * r.r;                                           // primitive.rs:58
+        p.a0 = v.x; p.a1 = v.y; p.a2 = v.z; p.a3 = dot(v, v); p.a4 = rr;
+        s.a0 = r.cx; s.a1 = r.cy; s.a2 = r.cz; s.a3 = rr; s.a4 = T(0);
+        p.own_rr = s.own_rr = T(0);
+        if (r.skip == 0u) {                                               // ITEM
+            p.item = s.item = r.item | kNodeItem;
+            p.skip_off = s.skip_off = (i + 1u) * kStride;
+        } else {                                                          // BOUND
+            p.item = s.item = 0u;
+            p.skip_off = s.skip_off = r.skip * kStride;
+            if (compacted) {
+                p.own_rr = s.own_rr = r.own_r * r.own_r;                  // primitive.rs:58
+                p.item = s.item = r.own_item;
+            }
+        }
     }
     prim[i] = p;
     shad[i] = s;
@@ -204,10 +233,14 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             unsigned best_item = 0;
             unsigned resume = inside ? 0u : kNever;
             unsigned i = 0;
+            // the assembly loops count in bytes; a lane without a ray sleeps until the END node (offset nb), where every lane
+            // is awake and the walk ends
+            constexpr unsigned kStride = (unsigned)sizeof(Node<T>);
+            const unsigned nb = ((VAR & 4) ? sc.n_fnodes : sc.n_nodes) * kStride;
             if constexpr ((VAR & 2) && !COUNT) {
-                constexpr unsigned kStride = (unsigned)sizeof(Node<T>);    // the assembly loops count in bytes
-                if constexpr ((VAR & 4) != 0) skip_primary_rot_fused(sc.prim, n * kStride, dir.x, dir.y, dir.z, resume, best, best_item);
-                else skip_primary_rot(sc.prim, n * kStride, dir.x, dir.y, dir.z, resume, best, best_item);
+                if constexpr ((VAR & 4) != 0) skip_primary_rot_fused(sc.fprim, nb, dir.x, dir.y, dir.z, inside ? 0u : nb, best, best_item);
+                else skip_primary_rot(sc.prim, nb, dir.x, dir.y, dir.z, inside ? 0u : nb, best, best_item);
+                best_item &= kNodeIndexMask;
             } else {
             Node<T> nd = sc.prim[0];                                    // wave-uniform record -> SGPRs
             for (;;) {
@@ -233,7 +266,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                         if (COUNT) c_bounds += active ? 1u : 0u;
                         ni = (__ballot(active && !cull) == 0) ? nd.skip() : i + 1;
                     } else {                                            // ITEM   primitive.rs:78-83
-                        if (active && !(d >= best)) { best = d; best_item = nd.item; }
+                        if (active && !(d >= best)) { best = d; best_item = nd.index(); }
                         if (COUNT) { c_items += active ? 1u : 0u; ++c_isteps; }
                         ni = i + 1;
                     }
@@ -279,17 +312,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             i = 0;
             if constexpr ((VAR & 2) && !COUNT) {
                 if (__ballot(need_shadow) != 0) {
-                    constexpr unsigned kStride = (unsigned)sizeof(Node<T>);
-                    const unsigned nb = n * kStride;                // the assembly loops count in bytes
+                    resume = need_shadow ? 0u : nb;                 // lanes without a shadow ray sleep until END
                     while (i < nb) {
                         unsigned fin;
-                        if constexpr ((VAR & 4) != 0) i = skip_shadow_rot_fused(sc.shad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
+                        if constexpr ((VAR & 4) != 0) i = skip_shadow_rot_fused(sc.fshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
                         else i = skip_shadow_rot(sc.shad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
                         if (i >= nb) break;
-                        if (fin) { occluded = true; resume = kNever; }
-                        // some lane retired at the ITEM at i: go straight to the next node any lane still wants
+                        if (fin) { occluded = true; resume = nb; }
+                        // some lane retired at the node at i: go straight to the next node any lane still wants (nb: nobody is left)
                         i = (unsigned)__builtin_amdgcn_readfirstlane(
-                            (int)wave_min_u32(resume == kNever ? kNever : (resume > i ? resume : i + kStride)));
+                            (int)wave_min_u32(resume >= nb ? nb : (resume > i ? resume : i + kStride)));
                     }
                 }
             } else if (__ballot(need_shadow) != 0) {

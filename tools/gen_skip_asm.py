@@ -2,26 +2,33 @@
 """Generates rust-tracer_amd/csrc/rt_skip_rot.hpp: the traversal loops of k_render_skip in gfx950 assembly (f32 and f64,
 plain and fused flavours).
 
-Same arithmetic, operation for operation, as the C++ loops of rt_skip.hpp (and as the first, hand-written assembly loops,
-which this file's f32 output was validated against frame for frame before they were retired); what is generated is the
-bookkeeping around it.  A lone wave retires about one instruction per 6 cycles whatever its type, and a 1080p frame is as
-long as its longest wave, so every scalar instruction of a step counts:
+Same arithmetic, operation for operation, as the C++ loops of rt_skip.hpp; what is generated is the bookkeeping around it.
+The probe (tools/valu_issue_probe.hip, profiles/r02_valu_issue_probe.json) shows that scalar instructions compete with the
+vector ones for a SIMD's issue slots (a step of 10 VALU + 12 SALU costs 35 cycles per SIMD at 8 waves, the 10 VALU alone
+about 16), and a frame is as long as its longest wave, so every instruction of a step counts:
 
-  * node positions are BYTE offsets into the stream (i, resume, skip): no shifts before the scalar loads;
-  * both successors of a node (the next one and skip) are fetched at the top of its step into two of THREE register banks,
-    and the step ends by branching into the copy of the loop body whose "current node" bank is the one that holds the
-    successor it chose -- no select instructions.  With banks (0, 1, 2) three copies suffice:
+  * a position is a BYTE offset into the stream and every node is one stride long (fused scenes walk a COMPACTED stream:
+    the sphere a group's bound is built around lives inside the BOUND node), so the only position the loop keeps is NX, the
+    offset of the node after the current one; `active = i >= resume` is formed as NX > resume;
+  * both successors of a node (the next one and `skip`) are fetched at the top of its step into two of THREE register banks,
+    and the step ends in the copy of the loop body whose "current node" bank is the one that holds the successor it chose
+    -- no select instructions.  With banks (0, 1, 2) three copies suffice:
         copy A: current 0, next -> 1, skip -> 2      next: B   skip: C
         copy B: current 1, next -> 0, skip -> 2      next: A   skip: C
         copy C: current 2, next -> 0, skip -> 1      next: A   skip: B
-  * the commonest step (a BOUND no live lane can hit) falls straight through to its jump: 22 instructions, one taken
-    branch (the hand-written loop: 32 and three);
-  * a step knows its node's type from the first instruction on (BOUND and ITEM steps are separate bodies), so an ITEM step
-    fetches one successor only;
+    The main paths are laid out A, C, B so that A's and C's `skip` transitions fall through;
+  * the commonest step (a node no live lane can hit) does not ask what kind of node it is: an ITEM's `skip` is simply the node
+    behind it, so "nobody hits -> go to skip" is right for both.  The kind (flag bits in the item word) is only looked at
+    when somebody hits;
+  * the stream ends in an END node that every lane hits (disc = +inf) and every lane is awake at (a lane without a ray sleeps
+    until END, not for ever), so the walk needs no end-of-stream test: the commonest step is 16 or 17 instructions (10 VALU, two
+    scalar loads, s_and, branch, s_add, s_waitcnt[, s_branch]); round 1's was 22;
   * FUSED flavour, for scenes in which every group's first child is a sphere concentric with the group's bound (the
     reference's pyramid, group.rs:37-41): a BOUND step goes on to test that sphere for the lanes that enter -- v, b and
-    b*b - vv are the same bits, only rr differs -- and the walk continues two nodes on.  One step and eight VALU
-    operations fewer per entered group, same tests, same order, same values.
+    b*b - vv are the same bits, only rr differs.  One step and eight VALU operations fewer per entered group, same tests,
+    same order, same values;
+  * the f32 loops keep to s[36:73]: with the six registers the hardware adds the kernel stays at 80 SGPRs, the most a wave may
+    have at 8 waves per SIMD (86 meant 7).
 
 f32 forms the correctly rounded root as v_sqrt_f32 + two exact FMA residuals (== sqrt_rn_lean, checked against the IEEE sqrt on
 all 2^32 inputs).  f64 replays, instruction for instruction, the expansion hipcc emits for the IEEE-correct __builtin_sqrt
@@ -36,6 +43,8 @@ OUT = os.path.join(ROOT, "rust-tracer_amd", "csrc", "rt_skip_rot.hpp")
 COPIES = {"A": (0, 1, 2), "B": (1, 0, 2), "C": (2, 0, 1)}          # current, next, skip
 NEXT_COPY = {"A": "B", "B": "A", "C": "A"}
 SKIP_COPY = {"A": "C", "B": "C", "C": "B"}
+LAYOUT = "ACB"                                                     # main paths in this order: A.skip and C.skip fall through
+FLAG_LIMIT = "0x3fffffff"                                          # item word above this: ITEM (bit 31) or END (bit 30)
 
 
 class Asm:
@@ -47,6 +56,9 @@ class Asm:
 
     def label(self, name):
         self.lines.append(("", name + ":", None))
+
+    def extend(self, other):
+        self.lines.extend(other.lines)
 
     def render(self, indent="        "):
         out = []
@@ -74,10 +86,10 @@ class Prec:
 
 class F32(Prec):
     name, ctype, stride = "f32", "float", 32
-    bank_first, bank_dwords, load_op = (40, 64, 72), 8, "s_load_dwordx8"
-    I, NX = "s48", "s51"
-    ACT, M54, M56, M58, TINY, EX = sp(52), sp(54), sp(56), sp(58), sp(60), sp(62)
-    clobber_lo, clobber_hi = 40, 79
+    bank_first, bank_dwords, load_op = (36, 44, 52), 8, "s_load_dwordx8"
+    NX = "s60"
+    ACT, M54, M56, M58, TINY, EX = sp(62), sp(64), sp(66), sp(68), sp(70), sp(72)
+    clobber_lo, clobber_hi = 36, 73
 
     def fld(self, b, k):                             # geometry term k = 0..4
         return "s%d" % (self.bank(b) + k)
@@ -125,50 +137,47 @@ class F32(Prec):
     def fused_disc(self, a, c):
         a.op("v_add_f32_e32 %%[disc], %s, %%[q]" % self.own(c), "disc = (b*b - vv) + rr of the group's own sphere")
 
-    CORRECT = [
-        "v_add_u32_e32 %[t0], -1, %[root]",
-        "v_add_u32_e32 %[t1], 1, %[root]",
-        "v_fma_f32 %[t3], -%[t0], %[root], {x}",
-        "v_fma_f32 %[t4], -%[t1], %[root], {x}",
-        "v_cmp_ge_f32_e64 s[56:57], 0, %[t3]",
-        "v_cmp_lt_f32_e64 s[58:59], 0, %[t4]",
-        "s_nop {nop}",
-        "v_cndmask_b32_e64 %[root], %[root], %[t0], s[56:57]",
-        "v_cndmask_b32_e64 %[root], %[root], %[t1], s[58:59]",
-    ]
+    def correct(self, a, x, nop):
+        a.op("v_add_u32_e32 %[t0], -1, %[root]")
+        a.op("v_add_u32_e32 %[t1], 1, %[root]")
+        a.op("v_fma_f32 %%[t3], -%%[t0], %%[root], %s" % x)
+        a.op("v_fma_f32 %%[t4], -%%[t1], %%[root], %s" % x)
+        a.op("v_cmp_ge_f32_e64 %s, 0, %%[t3]" % self.M56)
+        a.op("v_cmp_lt_f32_e64 %s, 0, %%[t4]" % self.M58)
+        a.op("s_nop %d" % nop)
+        a.op("v_cndmask_b32_e64 %%[root], %%[root], %%[t0], %s" % self.M56)
+        a.op("v_cndmask_b32_e64 %%[root], %%[root], %%[t1], %s" % self.M58)
 
     def root(self, a, need_mask, done_label, tiny_label):
         """Correctly rounded sqrt(disc) into %[root] (== sqrt_rn_lean).  need_mask: the lanes whose root is used."""
         a.op("v_sqrt_f32_e32 %[root], %[disc]")
-        a.op("v_cmp_lt_f32_e64 s[60:61], |%[disc]|, %[tiny]")
-        a.op("s_and_b64 s[56:57], s[60:61], %s" % need_mask)
+        a.op("v_cmp_lt_f32_e64 %s, |%%[disc]|, %%[tiny]" % self.TINY)
+        a.op("s_and_b64 %s, %s, %s" % (self.M56, self.TINY, need_mask))
         a.op("s_cbranch_scc1 %s" % tiny_label, "some needed lane below 2^-96: scaled path")
-        for t in self.CORRECT:
-            a.op(t.format(x="%[disc]", nop=0))
+        self.correct(a, "%[disc]", 0)
         a.label(done_label)
 
     def tiny(self, a, tiny_label, done_label):
         a.label(tiny_label)
         a.op("v_mul_f32_e32 %[t0], 0x4f800000, %[disc]", "root with the 2^32 / 2^-16 scaling for tiny lanes")
-        a.op("v_cndmask_b32_e64 %[t5], %[disc], %[t0], s[60:61]")
+        a.op("v_cndmask_b32_e64 %%[t5], %%[disc], %%[t0], %s" % self.TINY)
         a.op("v_sqrt_f32_e32 %[root], %[t5]")
         a.op("s_nop 0")
-        for t in self.CORRECT:
-            a.op(t.format(x="%[t5]", nop=1))
+        self.correct(a, "%[t5]", 1)
         a.op("v_mul_f32_e32 %[t0], 0x37800000, %[root]")
-        a.op("v_cndmask_b32_e64 %[root], %[root], %[t0], s[60:61]")
+        a.op("v_cndmask_b32_e64 %%[root], %%[root], %%[t0], %s" % self.TINY)
         a.op("s_branch %s" % done_label)
 
     def primary_distance(self, a):
         """vcc (live lanes with disc >= 0) -> vcc = go: t2 >= 0 and d < hit.distance; d left in t4."""
         a.op("v_add_f32_e32 %[t3], %[b], %[root]", "t2")
         a.op("v_sub_f32_e32 %[t4], %[b], %[root]", "t1")
-        a.op("v_cmp_lt_f32_e64 s[56:57], 0, %[t4]", "t1 > 0")
-        a.op("v_cmp_le_f32_e64 s[58:59], 0, %[t3]", "t2 >= 0")
-        a.op("s_and_b64 vcc, vcc, s[58:59]")
-        a.op("v_cndmask_b32_e64 %[t4], %[t3], %[t4], s[56:57]", "d = t1 > 0 ? t1 : t2")
-        a.op("v_cmp_lt_f32_e64 s[56:57], %[t4], %[best]", "d < hit.distance")
-        a.op("s_and_b64 vcc, vcc, s[56:57]", "go")
+        a.op("v_cmp_lt_f32_e64 %s, 0, %%[t4]" % self.M56, "t1 > 0")
+        a.op("v_cmp_le_f32_e64 %s, 0, %%[t3]" % self.M58, "t2 >= 0")
+        a.op("s_and_b64 vcc, vcc, %s" % self.M58)
+        a.op("v_cndmask_b32_e64 %%[t4], %%[t3], %%[t4], %s" % self.M56, "d = t1 > 0 ? t1 : t2")
+        a.op("v_cmp_lt_f32_e64 %s, %%[t4], %%[best]" % self.M56, "d < hit.distance")
+        a.op("s_and_b64 vcc, vcc, %s" % self.M56, "go")
 
     def item_update(self, a, c):
         a.op("s_mov_b64 exec, vcc", "primitive.rs:80-83")
@@ -196,7 +205,7 @@ class F32(Prec):
 class F64(Prec):
     name, ctype, stride = "f64", "double", 64
     bank_first, bank_dwords, load_op = (36, 52, 68), 16, "s_load_dwordx16"
-    I, NX = "s84", "s85"
+    NX = "s85"
     ACT, M54, M56, M58, TINY, EX = sp(86), sp(88), sp(90), sp(92), sp(94), sp(96)
     clobber_lo, clobber_hi = 36, 97
 
@@ -312,42 +321,34 @@ class F64(Prec):
     inf = "__builtin_huge_val()"
 
 
-def emit_next(a, P, name):
-    a.op("s_cmp_ge_u32 %s, %%[n]" % P.NX)
-    a.op("s_cbranch_scc1 .Lrt_exit_%=")
-    a.op("s_mov_b32 %s, %s" % (P.I, P.NX))
-    a.op("s_waitcnt lgkmcnt(0)")
-    a.op("s_branch .Lrt_%s_top_%%=" % NEXT_COPY[name])
+def top_of(name):
+    return ".Lrt_%s_top_%%=" % name
 
 
-def emit_transitions(a, P, name, c, lab):
-    """skip / next (with end check); `next` uses the position computed at the top of the step."""
+def emit_skip(a, P, name, c, lab):
+    """`skip` transition: the successor is the node behind the subtree (an ITEM's own successor)."""
     a.label(lab("skip"))
-    a.op("s_mov_b32 %s, %s" % (P.I, P.skip(c)), "jump over the subtree")
-    a.op("s_cmp_ge_u32 %s, %%[n]" % P.I)
-    a.op("s_cbranch_scc1 .Lrt_exit_%=")
+    a.op("s_add_u32 %s, %s, %d" % (P.NX, P.skip(c), P.stride), "jump over the subtree")
     a.op("s_waitcnt lgkmcnt(0)")
-    a.op("s_branch .Lrt_%s_top_%%=" % SKIP_COPY[name])
-    a.label(lab("next"))
-    emit_next(a, P, name)
+    nxt = SKIP_COPY[name]
+    if LAYOUT.index(nxt) != LAYOUT.index(name) + 1:                # A -> C and C -> B fall through
+        a.op("s_branch %s" % top_of(nxt))
 
 
-def live_mask(a, P):
-    """Issued before the terms: it depends on nothing they compute, and the chain disc -> compare -> branch stays short."""
-    a.op("v_cmp_ge_u32_e64 %s, %s, %%[resume]" % (P.ACT, P.I), "active = i >= resume")
+def emit_next(a, P, name):
+    a.op("s_add_u32 %s, %s, %d" % (P.NX, P.NX, P.stride))
+    a.op("s_waitcnt lgkmcnt(0)")
+    a.op("s_branch %s" % top_of(NEXT_COPY[name]))
 
 
-def candidates(a, P, hit_label):
-    P.cand_cmp(a)
-    a.op("s_and_b64 vcc, vcc, %s" % P.ACT, "live lanes whose line meets the sphere")
-    a.op("s_cbranch_vccnz %s" % hit_label)
-
-
-def bound_top(a, P, c, n, s, fused):
-    a.op("s_add_u32 %s, %s, %d" % (P.NX, P.I, 2 * P.stride if fused else P.stride),
-         "the walk goes on behind the group's own sphere" if fused else None)
+def step_top(a, P, c, n, s, terms):
+    """The part of a step every node shares: fetch both successors, form the live mask and the discriminant."""
     P.load(a, n, P.NX, "both successors, while this node is processed")
     P.load(a, s, P.skip(c))
+    a.op("v_cmp_gt_u32_e64 %s, %s, %%[resume]" % (P.ACT, P.NX), "active = i >= resume  (NX = i + stride)")
+    terms(a, c)
+    P.cand_cmp(a)
+    a.op("s_and_b64 vcc, vcc, %s" % P.ACT, "live lanes whose line meets the sphere")
 
 
 def sleep_culled(a, P, c):
@@ -356,52 +357,53 @@ def sleep_culled(a, P, c):
     a.op("s_mov_b64 exec, %s" % P.EX)
 
 
-def primary_copy(a, P, name, fused):
+def kind_test(a, P, c, lab):
+    a.op("s_cmp_gt_u32 %s, %s" % (P.item(c), FLAG_LIMIT), "an ITEM or the END node?  (flag bits of the item word)")
+    a.op("s_cbranch_scc1 %s" % lab("flagged"))
+
+
+def primary_copy(P, name, fused):
     c, n, s = COPIES[name]
     lab = lambda x: ".Lrt_%s_%s_%%=" % (name, x)
-    a.label(lab("top"))
-    a.op("s_cmp_eq_u32 %s, 0" % P.skip(c))
-    a.op("s_cbranch_scc1 %s" % lab("item"))
-    # ---------------- BOUND step (group.rs:73) ----------------
-    bound_top(a, P, c, n, s, fused)
-    live_mask(a, P)
-    P.primary_terms(a, c)
-    candidates(a, P, lab("bhit"))
-    emit_transitions(a, P, name, c, lab)   # nobody can hit the bound: jump (the lanes that culled it are awake again at `skip`)
-    a.label(lab("bhit"))
-    P.root(a, "vcc", lab("brooted"), lab("btiny"))
-    P.primary_distance(a)
-    a.op("s_cmp_eq_u64 vcc, 0")
-    a.op("s_cbranch_scc1 %s" % lab("skip"), "nobody enters")
-    sleep_culled(a, P, c)
+    m, k = Asm(), Asm()
+    m.label(lab("top"))
+    step_top(m, P, c, n, s, P.primary_terms)
+    m.op("s_cbranch_vccnz %s" % lab("hit"))
+    emit_skip(m, P, name, c, lab)          # nobody can hit the node: a BOUND is jumped over, an ITEM changes nothing
+    # ---------------- somebody's line meets the sphere ----------------
+    k.label(lab("hit"))
+    kind_test(k, P, c, lab)
+    # BOUND (group.rs:73)
+    P.root(k, "vcc", lab("brooted"), lab("btiny"))
+    P.primary_distance(k)
+    k.op("s_cmp_eq_u64 vcc, 0")
+    k.op("s_cbranch_scc1 %s" % lab("skip"), "nobody enters (the lanes that culled it are awake again at `skip`)")
+    sleep_culled(k, P, c)
     if fused:
         # the group's own sphere, for the lanes that entered: same centre, so v, b and b*b - vv are the values just formed
-        a.op("s_mov_b64 %s, vcc" % P.ACT, "the lanes that are live at the next node")
-        P.fused_disc(a, c)
-        P.cand_cmp(a)
-        a.op("s_and_b64 vcc, vcc, %s" % P.ACT)
-        a.op("s_cbranch_vccz %s" % lab("next"))
-        P.root(a, "vcc", lab("frooted"), lab("ftiny"))
-        P.primary_distance(a)
-        P.item_update(a, c)
-    a.op("s_branch %s" % lab("next"))
-    P.tiny(a, lab("btiny"), lab("brooted"))
+        k.op("s_mov_b64 %s, vcc" % P.ACT, "the lanes that are live at the next node")
+        P.fused_disc(k, c)
+        P.cand_cmp(k)
+        k.op("s_and_b64 vcc, vcc, %s" % P.ACT)
+        k.op("s_cbranch_vccz %s" % lab("next"))
+        P.root(k, "vcc", lab("frooted"), lab("ftiny"))
+        P.primary_distance(k)
+        P.item_update(k, c)
+    k.label(lab("next"))
+    emit_next(k, P, name)
+    P.tiny(k, lab("btiny"), lab("brooted"))
     if fused:
-        P.tiny(a, lab("ftiny"), lab("frooted"))
-    # ---------------- ITEM step (primitive.rs:77-84) ----------------
-    a.label(lab("item"))
-    a.op("s_add_u32 %s, %s, %d" % (P.NX, P.I, P.stride))
-    P.load(a, n, P.NX)
-    live_mask(a, P)
-    P.primary_terms(a, c)
-    candidates(a, P, lab("ihit"))
-    emit_next(a, P, name)                  # nobody can hit: an ITEM changes nothing
-    a.label(lab("ihit"))
-    P.root(a, "vcc", lab("irooted"), lab("itiny"))
-    P.primary_distance(a)
-    P.item_update(a, c)
-    a.op("s_branch %s" % lab("next"))
-    P.tiny(a, lab("itiny"), lab("irooted"))
+        P.tiny(k, lab("ftiny"), lab("frooted"))
+    # ITEM (primitive.rs:77-84) or END
+    k.label(lab("flagged"))
+    k.op("s_bitcmp1_b32 %s, 30" % P.item(c))
+    k.op("s_cbranch_scc1 .Lrt_exit_%=", "END: every lane is awake here and hits it")
+    P.root(k, "vcc", lab("irooted"), lab("itiny"))
+    P.primary_distance(k)
+    P.item_update(k, c)
+    k.op("s_branch %s" % lab("next"))
+    P.tiny(k, lab("itiny"), lab("irooted"))
+    return m, k
 
 
 def shadow_decide(a, P, lab, tag):
@@ -416,56 +418,45 @@ def shadow_decide(a, P, lab, tag):
     a.label(lab(tag + "decided"))
 
 
-def shadow_copy(a, P, name, fused):
+def shadow_copy(P, name, fused):
     c, n, s = COPIES[name]
     lab = lambda x: ".Lrt_%s_%s_%%=" % (name, x)
-    a.label(lab("top"))
-    a.op("s_cmp_eq_u32 %s, 0" % P.skip(c))
-    a.op("s_cbranch_scc1 %s" % lab("item"))
-    # ---------------- BOUND step: hit.distance is INF, so a bound culls iff the ray misses it ----------------
-    bound_top(a, P, c, n, s, fused)
-    live_mask(a, P)
-    P.shadow_terms(a, c)
-    candidates(a, P, lab("bhit"))
-    emit_transitions(a, P, name, c, lab)
-    a.label(lab("bhit"))
-    shadow_decide(a, P, lab, "b")
-    a.op("s_cmp_eq_u64 vcc, 0")
-    a.op("s_cbranch_scc1 %s" % lab("skip"))
-    sleep_culled(a, P, c)
+    m, k = Asm(), Asm()
+    m.label(lab("top"))
+    step_top(m, P, c, n, s, P.shadow_terms)
+    m.op("s_cbranch_vccnz %s" % lab("hit"))
+    emit_skip(m, P, name, c, lab)
+    k.label(lab("hit"))
+    kind_test(k, P, c, lab)
+    # BOUND: hit.distance is INF, so a bound culls iff the ray misses it
+    shadow_decide(k, P, lab, "b")
+    k.op("s_cmp_eq_u64 vcc, 0")
+    k.op("s_cbranch_scc1 %s" % lab("skip"))
+    sleep_culled(k, P, c)
     if fused:
-        a.op("s_mov_b64 %s, vcc" % P.ACT, "the lanes that are live at the next node")
-        P.fused_disc(a, c)
-        P.cand_cmp(a)
-        a.op("s_and_b64 vcc, vcc, %s" % P.ACT)
-        a.op("s_cbranch_vccz %s" % lab("next"))
-        shadow_decide(a, P, lab, "f")
-        a.op("s_cmp_eq_u64 vcc, 0")
-        a.op("s_cbranch_scc1 %s" % lab("next"))
-        a.op("v_cndmask_b32_e64 %[fin], 0, 1, vcc", "any hit ends those rays; hand them to the caller")
-        a.op("s_add_u32 %%[stop], %s, %d" % (P.I, P.stride), "they hit the ITEM behind this BOUND")
-        a.op("s_branch .Lrt_out_%=")
-    else:
-        a.op("s_branch %s" % lab("next"))
-    P.tiny(a, lab("btiny"), lab("brooted"))
+        k.op("s_mov_b64 %s, vcc" % P.ACT, "the lanes that are live at the next node")
+        P.fused_disc(k, c)
+        P.cand_cmp(k)
+        k.op("s_and_b64 vcc, vcc, %s" % P.ACT)
+        k.op("s_cbranch_vccz %s" % lab("next"))
+        shadow_decide(k, P, lab, "f")
+        k.op("s_cmp_eq_u64 vcc, 0")
+        k.op("s_cbranch_scc1 %s" % lab("next"))
+        k.op("s_branch .Lrt_fin_%=", "any hit ends those rays; hand them to the caller")
+    k.label(lab("next"))
+    emit_next(k, P, name)
+    P.tiny(k, lab("btiny"), lab("brooted"))
     if fused:
-        P.tiny(a, lab("ftiny"), lab("frooted"))
-    # ---------------- ITEM step ----------------
-    a.label(lab("item"))
-    a.op("s_add_u32 %s, %s, %d" % (P.NX, P.I, P.stride))
-    P.load(a, n, P.NX)
-    live_mask(a, P)
-    P.shadow_terms(a, c)
-    candidates(a, P, lab("ihit"))
-    emit_next(a, P, name)
-    a.label(lab("ihit"))
-    shadow_decide(a, P, lab, "i")
-    a.op("s_cmp_eq_u64 vcc, 0")
-    a.op("s_cbranch_scc1 %s" % lab("next"))
-    a.op("v_cndmask_b32_e64 %[fin], 0, 1, vcc", "any hit ends those rays; hand them to the caller")
-    a.op("s_mov_b32 %%[stop], %s" % P.I)
-    a.op("s_branch .Lrt_out_%=")
-    P.tiny(a, lab("itiny"), lab("irooted"))
+        P.tiny(k, lab("ftiny"), lab("frooted"))
+    k.label(lab("flagged"))
+    k.op("s_bitcmp1_b32 %s, 30" % P.item(c))
+    k.op("s_cbranch_scc1 .Lrt_exit_%=", "END: every lane is awake here and hits it")
+    shadow_decide(k, P, lab, "i")
+    k.op("s_cmp_eq_u64 vcc, 0")
+    k.op("s_cbranch_scc1 %s" % lab("next"))
+    k.op("s_branch .Lrt_fin_%=")
+    P.tiny(k, lab("itiny"), lab("irooted"))
+    return m, k
 
 
 HEADER = """// rt_skip_rot.hpp -- GENERATED by tools/gen_skip_asm.py; edit the generator, not this file.
@@ -479,27 +470,31 @@ HEADER = """// rt_skip_rot.hpp -- GENERATED by tools/gen_skip_asm.py; edit the g
 //                                                  expansion of __builtin_sqrt, instruction for instruction
 //      t2 = b + root, t1 = b - root, d = t1 > 0 ? t1 : t2            primitive.rs:65-71
 //      go = live && disc >= 0 && t2 >= 0 && d < hit.distance         (the negation of `d >= hit.distance`, group.rs:73 /
-//                                                                      primitive.rs:79, for the NaN-free values a
-//                                                                      validated scene produces)
+//                                                                      primitive.rs:79: a scene that passed rt_scene_create
+//                                                                      cannot produce a NaN anywhere on the path, DESIGN.md 2)
 // The root is only formed when some live lane has disc >= 0 (shadow rays: and b < 0, since t2 >= 0 is certain otherwise).
 //
-// Bookkeeping (why the loops are generated): a lone wave retires about one instruction per 6 cycles whatever its type and
-// a 1080p frame is as long as its longest wave, so every scalar instruction of a step counts.  Node positions are byte
-// offsets; both successors of a node (the next one and `skip`) are fetched at the top of its step into two of three
-// scalar register banks, and the step ends by branching into the copy of the loop body (A, B, C) whose current-node bank
-// already holds the chosen successor -- no selects, no shifts, one taken branch for the commonest step.  BOUND and ITEM steps
-// are separate bodies.  The *_fused flavour serves scenes in which every BOUND is followed by an ITEM with the same centre
-// (the reference's pyramid): the BOUND step goes on to test that sphere for the lanes that enter (v, b, b*b - vv are the
-// same bits; only rr differs) and continues two nodes on.
+// Bookkeeping (why the loops are generated): scalar instructions compete with the vector ones for a SIMD's issue slots
+// (profiles/r02_valu_issue_probe.json) and a 1080p frame is as long as its longest wave, so every instruction of a step counts.
+// A position is a byte offset and every node is one stride long; the loop keeps NX, the offset behind the current node
+// (`active = i >= resume` is NX > resume).  Both successors of a node (the next one and `skip`) are fetched at the top of its
+// step into two of three scalar register banks, and the step ends in the copy of the loop body (A, B, C; laid out A, C, B so
+// that two of the three `skip` transitions fall through) whose current-node bank already holds the chosen successor -- no
+// selects, no shifts.  The commonest step (nobody can hit the node) does not look at the node's kind: an ITEM's `skip` is the
+// node behind it.  The stream ends in an END node (flag in the item word) that every lane is awake at and hits, so there is no
+// end-of-stream test.  The *_fused flavour serves scenes in which every BOUND is followed by an ITEM with the same centre (the
+// reference's pyramid), walking a compacted stream whose BOUND nodes carry that sphere: the BOUND step goes on to test it for
+// the lanes that enter (v, b, b*b - vv are the same bits; only rr differs).
 //
 // Hazards follow what hipcc itself emits for gfx950: a VALU-written SGPR pair is not read as a v_cndmask mask within the
 // next two instructions, a transcendental result (v_sqrt_f32, v_rsq_f64) is not consumed by the next instruction,
 // s_waitcnt lgkmcnt(0) before loaded registers are read and at every exit (the speculative loads must have landed before
 // their registers are free again).  64-bit selects narrow EXEC and use v_mov_b64.
 //
-// Node<T> (rt_skip.hpp): five geometry terms, item, skip as a byte offset (0: ITEM), rr of the group's own sphere (fused
-// scenes, BOUND nodes).  Fixed SGPRs, f32: s[40:47] / s[64:71] / s[72:79] node banks, s48 position, s51 next, s[52:61]
-// masks, s[62:63] EXEC at entry; f64: s[36:51] / s[52:67] / s[68:83], s84, s85, s[86:95], s[96:97].
+// Node<T> (rt_skip.hpp): five geometry terms, item word (index | kNodeItem | kNodeEnd), skip as a byte offset, rr of the group's
+// own sphere (fused streams, BOUND nodes).  Fixed SGPRs, f32: s[36:43] / s[44:51] / s[52:59] node banks, s60 NX, s[62:71] masks,
+// s[72:73] EXEC at entry (80 SGPRs with the hardware's six: 8 waves per SIMD); f64: s[36:51] / s[52:67] / s[68:83], s85,
+// s[86:95], s[96:97].
 #pragma once
 #include "rt_kernels.hpp"
 
@@ -507,18 +502,20 @@ namespace rt {
 
 """
 
-PRIMARY_FN = """// Primary-ray traversal: s.group.intersect(&mut h, r) for all 64 rays of the wave.  nodes: Node<%(ctype)s>[n + 2];
-// n_bytes = n * %(stride)d.  resume: 0 for lanes with a ray, 0xFFFFFFFF for lanes without.  Returns hit.distance / item per lane.
+PRIMARY_FN = """// Primary-ray traversal: s.group.intersect(&mut h, r) for all 64 rays of the wave.  nodes: Node<%(ctype)s>[n + 3], END at [n];
+// n_bytes = n * %(stride)d.  resume: 0 for lanes with a ray, n_bytes for lanes without (they sleep until END).  Returns
+// hit.distance / item word per lane (mask the item with kNodeIndexMask).
 __device__ __forceinline__ void %(name)s(const void *nodes, unsigned n_bytes, %(ctype)s dx, %(ctype)s dy, %(ctype)s dz, unsigned resume,
                                                  %(ctype)s &best_out, unsigned &item_out)
 {
     %(ctype)s best = %(inf)s;
     unsigned bitem = 0;
+    (void)n_bytes;
     %(decl)s
     asm volatile(
 %(body)s
         : [best] "+v"(best), [bitem] "+v"(bitem), [resume] "+v"(resume), %(out)s
-        : [base] "s"(nodes), [n] "s"(n_bytes), [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz)%(extra_in)s
+        : [base] "s"(nodes), [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz)%(extra_in)s
         : %(clobbers)s);
     best_out = best;
     item_out = bitem;
@@ -527,8 +524,8 @@ __device__ __forceinline__ void %(name)s(const void *nodes, unsigned n_bytes, %(
 """
 
 SHADOW_FN = """// Shadow-ray traversal (any hit, render.rs:202-208) from byte offset `start` until the stream ends or some lane's ray hits
-// an ITEM: the caller retires those lanes, finds the next node any lane still wants and calls again.  Returns the byte
-// offset it stopped at (>= n_bytes: stream finished); fin = 1 in the lanes that hit the ITEM there.  resume in bytes.
+// an ITEM: the caller retires those lanes (resume = n_bytes), finds the next node any lane still wants and calls again.  Returns
+// the byte offset it stopped at (n_bytes: stream finished); fin = 1 in the lanes that hit the ITEM there.  resume in bytes.
 // hit.distance is INF throughout, so a node is "hit" iff disc >= 0 and t2 = b + root >= 0.
 __device__ __forceinline__ unsigned %(name)s(const void *nodes, unsigned n_bytes, unsigned start, %(ctype)s ox, %(ctype)s oy, %(ctype)s oz,
                                                    %(ctype)s lx, %(ctype)s ly, %(ctype)s lz, unsigned &resume_io, unsigned &fin_out)
@@ -562,14 +559,23 @@ def clobbers(P):
     return "\n".join(lines)
 
 
+def assemble(a, P, copy_fn, fused):
+    mains, colds = {}, {}
+    for name in "ABC":
+        mains[name], colds[name] = copy_fn(P, name, fused)
+    for name in LAYOUT:
+        a.extend(mains[name])
+    for name in "ABC":
+        a.extend(colds[name])
+
+
 def primary(P, fused):
     a = Asm()
-    a.op("s_mov_b32 %s, 0" % P.I)
+    a.op("s_mov_b32 %s, %d" % (P.NX, P.stride))
     a.op("s_mov_b64 %s, exec" % P.EX)
     P.load(a, 0, "0x0")
     a.op("s_waitcnt lgkmcnt(0)")
-    for name in "ABC":
-        primary_copy(a, P, name, fused)
+    assemble(a, P, primary_copy, fused)
     a.label(".Lrt_exit_%=")
     a.op("s_waitcnt lgkmcnt(0)")
     return a.render()
@@ -577,12 +583,15 @@ def primary(P, fused):
 
 def shadow(P, fused):
     a = Asm()
-    a.op("s_mov_b32 %s, %%[start]" % P.I)
+    a.op("s_add_u32 %s, %%[start], %d" % (P.NX, P.stride))
     a.op("s_mov_b64 %s, exec" % P.EX)
-    P.load(a, 0, P.I)
+    P.load(a, 0, "%[start]")
     a.op("s_waitcnt lgkmcnt(0)")
-    for name in "ABC":
-        shadow_copy(a, P, name, fused)
+    assemble(a, P, shadow_copy, fused)
+    a.label(".Lrt_fin_%=")
+    a.op("v_cndmask_b32_e64 %[fin], 0, 1, vcc", "the lanes whose ray hit the ITEM (or the group's own sphere) of the current node")
+    a.op("s_sub_u32 %%[stop], %s, %d" % (P.NX, P.stride), "its position")
+    a.op("s_branch .Lrt_out_%=")
     a.label(".Lrt_exit_%=")
     a.op("s_mov_b32 %[stop], %[n]", "stream finished")
     a.label(".Lrt_out_%=")
