@@ -30,7 +30,7 @@ namespace {
 thread_local char g_err[512] = "";
 
 // Diagnostic controls (rt_debug.h): process-wide, -1 = default.  The library reads no environment variable.
-std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
+std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
 std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = { {0}, {0} };
 std::atomic<bool> g_trace_on{ false };
 std::mutex g_trace_mu;
@@ -666,6 +666,7 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
                           rt::BlockList order)
 {
     const dim3 b(rt::kBlockThreads);
+    const unsigned lds = (unsigned)std::max(0ll, knob(RT_DEBUG_LDS_BYTES));
     uint32_t *no_cost = nullptr;
     // rt_debug_wave_trace(<file>) (diagnostic, tools/wave_timeline.py): the launch records every wave's start / end /
     // placement and the records are written to <file> -- synchronous, one file per launch (overwritten).
@@ -693,10 +694,10 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     rt::SampleBuf<T> sb{ nullptr, nullptr, (unsigned)total_px };
     if (!use_split(spp)) {
         if (spp == 1)
-            hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipOne>), rgrid, b, 0, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
+            hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipOne>), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
                                frame_w, order.d, no_cost);
         else
-            hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipLoop>), rgrid, b, 0, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
+            hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipLoop>), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
                                frame_w, order.d, no_cost);
         return RT_OK;
     }
@@ -709,10 +710,10 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     sb.state = c->d_sample_state;
     const bool packed = packed_samples(spp);
     if (packed)
-        hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipPacked>), dim3(rgrid.x, (unsigned)ns), b, 0, stream, skip_view_of<T>(s), w, h, spp,
+        hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipPacked>), dim3(rgrid.x, (unsigned)ns), b, lds, stream, skip_view_of<T>(s), w, h, spp,
                            d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost);
     else
-        hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipSplit>), dim3(rgrid.x, (unsigned)ns), b, 0, stream, skip_view_of<T>(s), w, h, spp,
+        hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipSplit>), dim3(rgrid.x, (unsigned)ns), b, lds, stream, skip_view_of<T>(s), w, h, spp,
                            d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL((rt::k_resolve_samples<T>), grid, b, 0, stream, sb, spp, d_tab, nt, d_out, frame_w, packed);

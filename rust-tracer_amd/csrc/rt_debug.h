@@ -25,7 +25,9 @@ typedef enum rt_debug_key {
     RT_DEBUG_HOST_COPY = 6,      /* how rt_render_tiles returns bytes to host memory: 0 the library's choice, 1 one copy to the
                                     caller's pointer, 2 pinned staging + CPU copy, 3 the kernel stores into pinned host memory */
     RT_DEBUG_COALESCE = 7,       /* 0: concurrent rt_render_region calls are not merged into shared passes; n > 0: at most n merged passes in flight.  Default 2 */
-    RT_DEBUG_KEYS = 8
+    RT_DEBUG_LDS_BYTES = 8,      /* dynamic LDS reserved per render workgroup: caps the waves per SIMD (160 KiB / n workgroups per CU) for
+                                    occupancy experiments; the kernels do not touch it */
+    RT_DEBUG_KEYS = 9
 } rt_debug_key;
 
 /* value < 0 restores the default. */

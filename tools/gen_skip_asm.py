@@ -5,14 +5,16 @@ plain and fused flavours).
 Same arithmetic, operation for operation, as the C++ loops of rt_skip.hpp; what is generated is the bookkeeping around it.
 The probe (tools/valu_issue_probe.hip, profiles/r02_valu_issue_probe.json) shows that scalar instructions compete with the
 vector ones for a SIMD's issue slots (a step of 10 VALU + 12 SALU costs 35 cycles per SIMD at 8 waves, the 10 VALU alone
-about 16), and a frame is as long as its longest wave, so every instruction of a step counts:
+about 16), and a frame is as long as its longest wave, so every instruction of a step counts -- and so does every scalar-
+cache line: the 16 KB scalar cache serves 64 waves, and a speculative fetch that is not walked evicts a line that is:
 
   * a position is a BYTE offset into the stream and every node is one stride long (fused scenes walk a COMPACTED stream:
     the sphere a group's bound is built around lives inside the BOUND node), so the only position the loop keeps is NX, the
     offset of the node after the current one; `active = i >= resume` is formed as NX > resume;
-  * both successors of a node (the next one and `skip`) are fetched at the top of its step into two of THREE register banks,
-    and the step ends in the copy of the loop body whose "current node" bank is the one that holds the successor it chose
-    -- no select instructions.  With banks (0, 1, 2) three copies suffice:
+  * the likely successor of a node (`skip`: three of four BOUND tests end there, and an ITEM's `skip` is the node behind
+    it) is fetched at the top of its step, the first child of a group when somebody enters it, into two of THREE register
+    banks, and the step ends in the copy of the loop body whose "current node" bank is the one that holds the successor it
+    chose -- no select instructions.  With banks (0, 1, 2) three copies suffice:
         copy A: current 0, next -> 1, skip -> 2      next: B   skip: C
         copy B: current 1, next -> 0, skip -> 2      next: A   skip: C
         copy C: current 2, next -> 0, skip -> 1      next: A   skip: B
@@ -21,8 +23,8 @@ about 16), and a frame is as long as its longest wave, so every instruction of a
     behind it, so "nobody hits -> go to skip" is right for both.  The kind (flag bits in the item word) is only looked at
     when somebody hits;
   * the stream ends in an END node that every lane hits (disc = +inf) and every lane is awake at (a lane without a ray sleeps
-    until END, not for ever), so the walk needs no end-of-stream test: the commonest step is 16 or 17 instructions (10 VALU, two
-    scalar loads, s_and, branch, s_add, s_waitcnt[, s_branch]); round 1's was 22;
+    until END, not for ever), so the walk needs no end-of-stream test: the commonest step is 15 or 16 instructions (10 VALU, one
+    scalar load, s_and, branch, s_add, s_waitcnt[, s_branch]); round 1's was 22;
   * FUSED flavour, for scenes in which every group's first child is a sphere concentric with the group's bound (the
     reference's pyramid, group.rs:37-41): a BOUND step goes on to test that sphere for the lanes that enter -- v, b and
     b*b - vv are the same bits, only rr differs.  One step and eight VALU operations fewer per entered group, same tests,
@@ -342,13 +344,19 @@ def emit_next(a, P, name):
 
 
 def step_top(a, P, c, n, s, terms):
-    """The part of a step every node shares: fetch both successors, form the live mask and the discriminant."""
-    P.load(a, n, P.NX, "both successors, while this node is processed")
-    P.load(a, s, P.skip(c))
+    """The part of a step every node shares: fetch the likely successor, form the live mask and the discriminant."""
+    # Only `skip` is fetched ahead: three of four BOUND tests end there, and an ITEM's `skip` IS its successor.  The first
+    # child of a group is fetched when somebody enters (enter_group): fetched at the top of every BOUND step it doubled the
+    # scalar-cache misses (most of those lines are never walked), which cost more than the late fetch on the entered quarter.
+    P.load(a, s, P.skip(c), "the likely successor, while this node is processed")
     a.op("v_cmp_gt_u32_e64 %s, %s, %%[resume]" % (P.ACT, P.NX), "active = i >= resume  (NX = i + stride)")
     terms(a, c)
     P.cand_cmp(a)
     a.op("s_and_b64 vcc, vcc, %s" % P.ACT, "live lanes whose line meets the sphere")
+
+
+def enter_group(a, P, c, n):
+    P.load(a, n, P.NX, "somebody enters: fetch the group's first child")
 
 
 def sleep_culled(a, P, c):
@@ -378,6 +386,7 @@ def primary_copy(P, name, fused):
     P.primary_distance(k)
     k.op("s_cmp_eq_u64 vcc, 0")
     k.op("s_cbranch_scc1 %s" % lab("skip"), "nobody enters (the lanes that culled it are awake again at `skip`)")
+    enter_group(k, P, c, n)
     sleep_culled(k, P, c)
     if fused:
         # the group's own sphere, for the lanes that entered: same centre, so v, b and b*b - vv are the values just formed
@@ -401,7 +410,7 @@ def primary_copy(P, name, fused):
     P.root(k, "vcc", lab("irooted"), lab("itiny"))
     P.primary_distance(k)
     P.item_update(k, c)
-    k.op("s_branch %s" % lab("next"))
+    k.op("s_branch %s" % lab("skip"), "an ITEM's `skip` is the node behind it")
     P.tiny(k, lab("itiny"), lab("irooted"))
     return m, k
 
@@ -432,6 +441,7 @@ def shadow_copy(P, name, fused):
     shadow_decide(k, P, lab, "b")
     k.op("s_cmp_eq_u64 vcc, 0")
     k.op("s_cbranch_scc1 %s" % lab("skip"))
+    enter_group(k, P, c, n)
     sleep_culled(k, P, c)
     if fused:
         k.op("s_mov_b64 %s, vcc" % P.ACT, "the lanes that are live at the next node")
@@ -453,7 +463,7 @@ def shadow_copy(P, name, fused):
     k.op("s_cbranch_scc1 .Lrt_exit_%=", "END: every lane is awake here and hits it")
     shadow_decide(k, P, lab, "i")
     k.op("s_cmp_eq_u64 vcc, 0")
-    k.op("s_cbranch_scc1 %s" % lab("next"))
+    k.op("s_cbranch_scc1 %s" % lab("skip"), "an ITEM's `skip` is the node behind it")
     k.op("s_branch .Lrt_fin_%=")
     P.tiny(k, lab("itiny"), lab("irooted"))
     return m, k
@@ -477,8 +487,8 @@ HEADER = """// rt_skip_rot.hpp -- GENERATED by tools/gen_skip_asm.py; edit the g
 // Bookkeeping (why the loops are generated): scalar instructions compete with the vector ones for a SIMD's issue slots
 // (profiles/r02_valu_issue_probe.json) and a 1080p frame is as long as its longest wave, so every instruction of a step counts.
 // A position is a byte offset and every node is one stride long; the loop keeps NX, the offset behind the current node
-// (`active = i >= resume` is NX > resume).  Both successors of a node (the next one and `skip`) are fetched at the top of its
-// step into two of three scalar register banks, and the step ends in the copy of the loop body (A, B, C; laid out A, C, B so
+// (`active = i >= resume` is NX > resume).  A node's likely successor (`skip`) is fetched at the top of its step and a group's
+// first child when somebody enters, into two of three scalar register banks, and the step ends in the copy of the loop body (A, B, C; laid out A, C, B so
 // that two of the three `skip` transitions fall through) whose current-node bank already holds the chosen successor -- no
 // selects, no shifts.  The commonest step (nobody can hit the node) does not look at the node's kind: an ITEM's `skip` is the
 // node behind it.  The stream ends in an END node (flag in the item word) that every lane is awake at and hits, so there is no
