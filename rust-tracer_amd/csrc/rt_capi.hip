@@ -30,7 +30,7 @@ namespace {
 thread_local char g_err[512] = "";
 
 // Diagnostic controls (rt_debug.h): process-wide, -1 = default.  The library reads no environment variable.
-std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
+std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
 std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = { {0}, {0} };
 std::atomic<bool> g_trace_on{ false };
 std::mutex g_trace_mu;
@@ -113,7 +113,8 @@ struct rt_scene {
     // Immutable device copies of recently used tile tables (a scheduler re-submits the same bucket list every
     // frame): a hit means a pass enqueues nothing but its kernel.
     // dev_order: one descriptor per 16x16 block of the pass, most expensive first (block_order below), or NULL.
-    struct CachedTable { std::vector<rt::TileDev> host; unsigned w = 0, h = 0, passes = 0; rt::TileDev *dev = nullptr; rt::BlockDesc *dev_order = nullptr; uint32_t n_order = 0; };
+    struct CachedTable { std::vector<rt::TileDev> host; unsigned w = 0, h = 0, passes = 0; rt::TileDev *dev = nullptr; rt::BlockDesc *dev_order = nullptr; uint32_t n_order = 0;
+                         uint32_t *dev_wg = nullptr; uint32_t n_wg = 0; };
     std::vector<CachedTable> tables;
     // Tests per primary ray (its shadow ray included) on a kCostRes x kCostRes grid over the camera's field of view,
     // rendered once per scene with the counting kernel.  It only ever decides the ORDER in which blocks are dispatched.
@@ -450,7 +451,7 @@ rt_status render_cost_map(rt_scene *s, std::vector<uint32_t> &map)
     if (e == hipSuccess) {
         rt::SampleBuf<T> sb{ nullptr, nullptr, R * R };
         hipLaunchKernelGGL((rt::k_render_skip<T, true, 1, rt::kSkipLoop>), dim3((R / rt::kBlockW) * (R / rt::kBlockH)), dim3(rt::kBlockThreads), 0, stream,
-                           skip_view_of<T>(s), R, R, 1u, d_tile, 1u, d_out, d_cnt, sb, 0u, (const rt::BlockDesc *)nullptr, d_cost);
+                           skip_view_of<T>(s), R, R, 1u, d_tile, 1u, d_out, d_cnt, sb, 0u, (const rt::BlockDesc *)nullptr, d_cost, (const uint32_t *)nullptr);
         e = hipGetLastError();
     }
     map.assign((size_t)R * R, 0u);
@@ -480,15 +481,20 @@ const std::vector<uint32_t> *cost_map_of(rt_scene *s)
 // ties in grid order.  The frame is as long as its last wave's chain of dependent node steps and the chains differ by
 // more than 10x across the image, so the long ones have to start first (measured at 1080p: 141 -> 115 us for the
 // same one-block tiles in raster vs. descending order).
+constexpr uint64_t kFixedBlockCost = 8;      // what a block costs besides its tests (ray set-up, store), in units of the cost map
 constexpr size_t kNarrowMax = 64;
 constexpr uint64_t kNarrowPercent = 60;
 constexpr size_t kNarrowPassBlocks = 16384;
 constexpr size_t kNarrowLevel2Blocks = 4096;
 
 // `passes`: how many times the render kernel walks the list in one launch (one per sample in the sample-parallel path).
+// Workgroups a launch keeps resident at once: 8 waves per SIMD, 4 waves per workgroup, 256 CUs.
+constexpr size_t kResidentWorkgroups = 2048;
+
 void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev> &tab, unsigned w, unsigned h, unsigned passes,
-                 std::vector<rt::BlockDesc> &descs)
+                 std::vector<rt::BlockDesc> &descs, std::vector<uint32_t> &wg_first)
 {
+    wg_first.clear();
     constexpr int R = (int)kCostRes;
     std::vector<uint32_t> cost;
     std::vector<rt::BlockDesc> raster;
@@ -533,9 +539,11 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
     }
     descs.clear();
     descs.reserve(order.size() + 15 * n_narrow);
+    std::vector<uint32_t> dcost;                          // cost estimate of every descriptor, descending
+    dcost.reserve(order.size() + 15 * n_narrow);
     for (size_t i = 0; i < order.size(); ++i) {
         const rt::BlockDesc &d = raster[order[i]];
-        if (i >= n_narrow) { descs.push_back(d); continue; }
+        if (i >= n_narrow) { descs.push_back(d); dcost.push_back(cost[order[i]]); continue; }
         // 4x4 pixels per wave; 2x2 in a pass so small that its waves all start at once anyway (800x600: 63 -> 52 us; at 1080p the
         // sixteen-fold wave count of 2x2 costs more throughput than the shorter chains buy)
         const unsigned level = order.size() <= kNarrowLevel2Blocks ? 2u : 1u, step = 16u >> level, cnt = 1u << level;
@@ -544,8 +552,44 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
                 rt::BlockDesc n = d;
                 n.x0 = (uint16_t)(d.x0 + qx * step); n.y0 = (uint16_t)(d.y0 + qy * step);
                 n.pitch |= level << rt::kBlockNarrowShift;
-                if (n.x0 < d.r && n.y0 < d.t) descs.push_back(n);      // parts outside a clipped edge tile have no pixels
+                if (n.x0 < d.r && n.y0 < d.t) { descs.push_back(n); dcost.push_back(cost[order[i]]); }      // parts outside a clipped edge tile have no pixels
             }
+    }
+    // A sample-parallel pass has one workgroup per block AND sample: 49,152 for `make image`, 1,048,576 for BASELINE config 5,
+    // each living a few microseconds.  Past 32,768 workgroups the blocks are dealt out here instead, about eight to a
+    // workgroup (8,192 .. 65,536 workgroups per launch): descriptors in descending cost, each to the workgroup with the least
+    // estimated work so far (longest-processing-time-first); a workgroup renders its descriptors in that order, so the long
+    // chains still start first.  Measured (tools/knob_sweep.py wg_policy): make image 303 -> 278 us, config 5 4.67 -> 4.26 ms;
+    // passes the dispatcher can deal one block at a time (1080p, 4K at spp 1) lose by it -- its dynamic balancing beats
+    // a static deal by estimated cost -- and are left alone.
+    const long long policy = knob(RT_DEBUG_WG_POLICY);
+    const size_t total_wg = (size_t)descs.size() * std::max(1u, passes);
+    size_t n_wg = 0;
+    if (policy > 0) n_wg = kResidentWorkgroups * (size_t)policy / std::max(1u, passes);
+    else if (policy < 0 && total_wg > 32768) n_wg = std::clamp<size_t>(total_wg / 8, 8192, 65536) / std::max(1u, passes);
+    if (map && n_wg >= 64 && descs.size() > n_wg) {
+        std::vector<std::vector<uint32_t>> lists(n_wg);
+        std::vector<std::pair<uint64_t, uint32_t>> heap;                      // (load, workgroup), min-heap
+        heap.reserve(n_wg);
+        for (uint32_t g = 0; g < n_wg; ++g) heap.emplace_back(0ull, g);
+        auto cmp = [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) { return a > b; };
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        for (uint32_t i = 0; i < descs.size(); ++i) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            auto &top = heap.back();
+            lists[top.second].push_back(i);
+            top.first += (uint64_t)dcost[i] + kFixedBlockCost;
+            std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+        std::vector<rt::BlockDesc> dealt;
+        dealt.reserve(descs.size());
+        wg_first.reserve(n_wg + 1);
+        for (const auto &l : lists) {
+            wg_first.push_back((uint32_t)dealt.size());
+            for (uint32_t i : l) dealt.push_back(descs[i]);
+        }
+        wg_first.push_back((uint32_t)dealt.size());
+        descs.swap(dealt);
     }
 }
 
@@ -564,7 +608,7 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
         for (auto &t : s->tables)
             if ((!o || (t.w == w && t.h == h && t.passes == passes)) && t.host.size() == tab.size() && memcmp(t.host.data(), tab.data(), bytes) == 0) {
                 *out = t.dev;
-                if (order_out && block_order_enabled()) *order_out = rt::BlockList{ t.dev_order, t.n_order };
+                if (order_out && block_order_enabled()) *order_out = rt::BlockList{ t.dev_order, t.n_order, t.dev_wg, t.n_wg };
                 return RT_OK;
             }
         if (s->tables.size() < kMaxCachedTables) {
@@ -574,15 +618,24 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
             if (e != hipSuccess) { (void)hipFree(t.dev); return hip_fail(e, "hipMemcpy(tile table)", __LINE__); }
             if (o && order_out) {
                 std::vector<rt::BlockDesc> order;
-                block_order(map, tab, w, h, passes, order);
+                std::vector<uint32_t> wg_first;
+                block_order(map, tab, w, h, passes, order, wg_first);
                 e = hipMalloc(&t.dev_order, order.size() * sizeof(rt::BlockDesc));
                 if (e == hipSuccess) e = hipMemcpy(t.dev_order, order.data(), order.size() * sizeof(rt::BlockDesc), hipMemcpyHostToDevice);
-                if (e != hipSuccess) { (void)hipFree(t.dev); if (t.dev_order) (void)hipFree(t.dev_order); return hip_fail(e, "block order", __LINE__); }
+                if (e == hipSuccess && !wg_first.empty()) {
+                    e = hipMalloc(&t.dev_wg, wg_first.size() * sizeof(uint32_t));
+                    if (e == hipSuccess) e = hipMemcpy(t.dev_wg, wg_first.data(), wg_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+                    t.n_wg = (uint32_t)wg_first.size() - 1;
+                }
+                if (e != hipSuccess) {
+                    (void)hipFree(t.dev); if (t.dev_order) (void)hipFree(t.dev_order); if (t.dev_wg) (void)hipFree(t.dev_wg);
+                    return hip_fail(e, "block order", __LINE__);
+                }
                 t.n_order = (uint32_t)order.size();
             }
             t.host = tab; t.w = w; t.h = h; t.passes = passes;
             *out = t.dev;
-            if (order_out && block_order_enabled()) *order_out = rt::BlockList{ t.dev_order, t.n_order };
+            if (order_out && block_order_enabled()) *order_out = rt::BlockList{ t.dev_order, t.n_order, t.dev_wg, t.n_wg };
             s->tables.push_back(std::move(t));
             return RT_OK;
         }
@@ -673,8 +726,8 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     std::string trace_file;
     if (VAR & 8) { std::lock_guard<std::mutex> lk(g_trace_mu); trace_file = g_trace_path; }
     const char *trace_path = trace_file.empty() ? nullptr : trace_file.c_str();
-    const dim3 rgrid(order.d ? order.n : grid.x);      // render workgroups: one per descriptor
-    const size_t trace_words = (size_t)rgrid.x * 4 * 4 * (use_split(spp) ? (size_t)spp * spp : 1);
+    const dim3 rgrid(order.d ? (order.wg_first ? order.n_wg : order.n) : grid.x);      // render workgroups: one per descriptor, or dealt
+    const size_t trace_words = (size_t)(order.d ? order.n : grid.x) * 4 * 4 * (use_split(spp) ? (size_t)spp * spp : 1);
     struct Trace {
         uint32_t *d = nullptr; const char *path; size_t words; hipStream_t stream;
         ~Trace()
@@ -695,10 +748,10 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     if (!use_split(spp)) {
         if (spp == 1)
             hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipOne>), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
-                               frame_w, order.d, no_cost);
+                               frame_w, order.d, no_cost, order.wg_first);
         else
             hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipLoop>), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
-                               frame_w, order.d, no_cost);
+                               frame_w, order.d, no_cost, order.wg_first);
         return RT_OK;
     }
     const size_t ns = (size_t)spp * spp;
@@ -711,10 +764,10 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     const bool packed = packed_samples(spp);
     if (packed)
         hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipPacked>), dim3(rgrid.x, (unsigned)ns), b, lds, stream, skip_view_of<T>(s), w, h, spp,
-                           d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost);
+                           d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost, order.wg_first);
     else
         hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipSplit>), dim3(rgrid.x, (unsigned)ns), b, lds, stream, skip_view_of<T>(s), w, h, spp,
-                           d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost);
+                           d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost, order.wg_first);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL((rt::k_resolve_samples<T>), grid, b, 0, stream, sb, spp, d_tab, nt, d_out, frame_w, packed);
     return RT_OK;
@@ -1017,7 +1070,7 @@ rt_status rt_scene_destroy(rt_scene *s)
     if (!s) return RT_OK;
     (void)hipSetDevice(s->device);
     s->pool.clear();
-    for (auto &t : s->tables) { (void)hipFree(t.dev); if (t.dev_order) (void)hipFree(t.dev_order); }
+    for (auto &t : s->tables) { (void)hipFree(t.dev); if (t.dev_order) (void)hipFree(t.dev_order); if (t.dev_wg) (void)hipFree(t.dev_wg); }
     if (s->d_items) (void)hipFree(s->d_items);
     if (s->d_prim) (void)hipFree(s->d_prim);
     if (s->d_shad) (void)hipFree(s->d_shad);

@@ -27,7 +27,9 @@ typedef enum rt_debug_key {
     RT_DEBUG_COALESCE = 7,       /* 0: concurrent rt_render_region calls are not merged into shared passes; n > 0: at most n merged passes in flight.  Default 2 */
     RT_DEBUG_LDS_BYTES = 8,      /* dynamic LDS reserved per render workgroup: caps the waves per SIMD (160 KiB / n workgroups per CU) for
                                     occupancy experiments; the kernels do not touch it */
-    RT_DEBUG_KEYS = 9
+    RT_DEBUG_WG_POLICY = 9,      /* 0: one workgroup per block and sample (the dispatcher deals); n > 0: n x 2,048 workgroups per launch, blocks
+                                    dealt on the host; default: dealt only past 32,768 workgroups (read when a tile list is first seen) */
+    RT_DEBUG_KEYS = 10
 } rt_debug_key;
 
 /* value < 0 restores the default. */

@@ -34,7 +34,8 @@ static_assert(sizeof(BlockDesc) == 16, "one s_load_dwordx4");
 // each: their chains get ~17 % shorter (1080p: 74 -> 66 us with the ~30 heaviest blocks narrowed; narrowing hundreds costs
 // throughput).  Level 2 (2x2 patches, sixteen workgroups per block) is used in passes too small to fill the chip.
 constexpr uint32_t kBlockNarrowShift = 16;       // pitch >> 16: 0 full, 1: 4x4 pixels per wave, 2: 2x2
-struct BlockList { const BlockDesc *d = nullptr; uint32_t n = 0; };
+// wg_first (optional): n_wg + 1 offsets into d -- workgroup w renders the descriptors [wg_first[w], wg_first[w + 1]).
+struct BlockList { const BlockDesc *d = nullptr; uint32_t n = 0; const uint32_t *wg_first = nullptr; uint32_t n_wg = 0; };
 
 // Outcome of one sample, stored by the sample-parallel paths and consumed by k_resolve_samples in the reference's
 // accumulation order: the four exits of Renderer::raytrace (render.rs:190-213) and n.light where it is needed.

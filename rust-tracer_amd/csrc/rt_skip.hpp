@@ -146,17 +146,24 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                                                               const TileDev *__restrict__ tiles, unsigned n_tiles,
                                                               uint8_t *__restrict__ out, Counters *__restrict__ counters,
                                                               SampleBuf<T> sb, unsigned frame_w,
-                                                              const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost)
+                                                              const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost,
+                                                              const uint32_t *__restrict__ wg_first)
 {
     constexpr bool PACKED = MODE == kSkipPacked, SPLIT = MODE == kSkipSplit || PACKED, ONE = MODE == kSkipOne;
     const unsigned spp = ONE ? 1u : spp_arg;
-    // `order` (optional): one descriptor per workgroup in dispatch order, most expensive block first -- a pass is as long
-    // as its last wave, so the long chains must not be the ones dispatched last (rt_capi.hip, block_order).  Without it
-    // the workgroup finds its block in the tile table.
+    // `order` (optional): block descriptors in dispatch order, most expensive block first -- a pass is as long as its last
+    // wave, so the long chains must not be the ones dispatched last (rt_capi.hip, block_order).  Without it the workgroup
+    // finds its block in the tile table.  `wg_first` (optional, with `order`): workgroup w renders the descriptors
+    // [wg_first[w], wg_first[w + 1]) one after the other -- a pass of more blocks than the chip holds workgroups is dealt out
+    // on the host (longest first, to the least loaded workgroup), every workgroup is resident from the start and nothing
+    // waits for the dispatcher (sustained, it starts ~190 workgroups per microsecond: 43 us for the 8,181 of a 1080p frame).
+    unsigned d_first = blockIdx.x, d_last = blockIdx.x + 1;
+    if (order && wg_first) { d_first = wg_first[blockIdx.x]; d_last = wg_first[blockIdx.x + 1]; }
+    for (unsigned di = d_first; di < d_last; ++di) {
     unsigned bx0, by0, tile_r, tile_t, pitch, base;
     unsigned level = 0;             // 0: 8x8 pixels per wave; 1: 4x4 (16 live lanes); 2: 2x2 (4 live lanes)
     if (order) {
-        const BlockDesc bd = order[blockIdx.x];
+        const BlockDesc bd = order[di];
         bx0 = bd.x0; by0 = bd.y0; tile_r = bd.r; tile_t = bd.t; pitch = bd.pitch & 0xFFFFu; base = bd.base;
         level = bd.pitch >> kBlockNarrowShift;
     } else {
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
         pitch = (unsigned)tile.r - tile.l;
         base = tile.out_px - tile.b * pitch - tile.l;
     }
-    const unsigned gblock = blockIdx.x;
+    const unsigned gblock = di;
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned x, y, sample = 0;
     bool inside;
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
         inside = x < tile_r && y < tile_t && lane < pw * pw;
         sample = blockIdx.y;
     }
-    if (__ballot(inside) == 0) return;          // waves are independent here: no LDS, no barrier
+    if (__ballot(inside) == 0) continue;        // waves are independent here: no LDS, no barrier
 
     unsigned long long t_start = 0, r_start = 0;
     if (COUNT) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
@@ -395,31 +402,33 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     }
 
     if (trace && lane_cost && lane == 0) {
-        uint32_t *rec = lane_cost + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 4;     // in dispatch order
+        const unsigned n_desc = (order && wg_first) ? wg_first[gridDim.x] : gridDim.x;
+        uint32_t *rec = lane_cost + (((size_t)blockIdx.y * n_desc + di) * 4 + wave) * 4;     // in descriptor order
         rec[0] = (uint32_t)r_start;
         rec[1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
         rec[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16);  // HW_ID | XCC_ID << 16
         rec[3] = gblock;
     }
     if (COUNT) {
-        counters += (gblock + blockIdx.y) % kCounterStripes;
+        Counters *const stripe = counters + (gblock + blockIdx.y) % kCounterStripes;
         const unsigned long long prim = wave_sum(inside ? (SPLIT ? 1u : spp * spp) : 0u);
         const unsigned long long hits = wave_sum(c_hits), sh = wave_sum(c_shadow), oc = wave_sum(c_occ);
         const unsigned long long its = wave_sum(c_items), bds = wave_sum(c_bounds);
         if (lane == 0) {
-            atomicAdd(&counters->primary, prim);
-            atomicAdd(&counters->hits, hits);
-            atomicAdd(&counters->shadow, sh);
-            atomicAdd(&counters->occluded, oc);
-            atomicAdd(&counters->sphere_tests, its);
-            atomicAdd(&counters->bound_tests, bds);
-            atomicAdd(&counters->wave_steps, (unsigned long long)c_steps);
-            atomicAdd(&counters->wave_item_steps, (unsigned long long)c_isteps);
-            atomicMax(&counters->max_wave_steps, (unsigned long long)c_steps);
-            atomicMax(&counters->max_wave_cycles, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start));
-            atomicMax(&counters->max_wave_ref100mhz, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r_start));
+            atomicAdd(&stripe->primary, prim);
+            atomicAdd(&stripe->hits, hits);
+            atomicAdd(&stripe->shadow, sh);
+            atomicAdd(&stripe->occluded, oc);
+            atomicAdd(&stripe->sphere_tests, its);
+            atomicAdd(&stripe->bound_tests, bds);
+            atomicAdd(&stripe->wave_steps, (unsigned long long)c_steps);
+            atomicAdd(&stripe->wave_item_steps, (unsigned long long)c_isteps);
+            atomicMax(&stripe->max_wave_steps, (unsigned long long)c_steps);
+            atomicMax(&stripe->max_wave_cycles, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start));
+            atomicMax(&stripe->max_wave_ref100mhz, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r_start));
         }
     }
+    }       // descriptors of this workgroup
 }
 
 // Second pass of the SPLIT path: render.rs:233-252 for one pixel -- its samples' contributions accumulated strictly

@@ -818,3 +818,21 @@ def test_progressive_output_partial_ppm_on_disk_mid_render(tmp_path):
     w.close()
     oracle.write_ppm(str(tmp_path / "ref.ppm"), ref)
     assert open(path, "rb").read() == open(str(tmp_path / "ref.ppm"), "rb").read()
+
+
+@pytest.mark.parametrize("policy", [0, 1, 4])
+@pytest.mark.parametrize("size", [(1920, 1080, 1), (333, 277, 4), (640, 480, 2)])
+def test_dealing_blocks_to_workgroups_never_changes_a_pixel(size, policy):
+    # Past 32,768 workgroups a pass's blocks are dealt to fewer workgroups on the host (several descriptors per workgroup,
+    # longest first); csrc/rt_debug.h RT_DEBUG_WG_POLICY forces it for any pass.  Same bytes and counters as one block per workgroup.
+    w, h, spp = size
+    s, o = rta.Scene.default(7), oracle.Scene.default(level=7)
+    regs = bucket_list(w, h, spp)
+    ref, rst, _ = o.render(w, h, spp, os.cpu_count() or 1, HIER_EXIT)
+    with rta.capi.debug(rta.capi.DEBUG_WG_POLICY, policy):
+        d = s.device()
+        plain, _ = d.render_tiles((w, h, spp), regs, SKIP, want_stats=False)
+        counted, st = d.render_tiles((w, h, spp), regs, SKIP, want_stats=True)
+    np.testing.assert_array_equal(util.stitch((w, h), regs, plain), ref)
+    np.testing.assert_array_equal(counted, plain)
+    assert util.all_stats(st) == util.all_stats(rst)
