@@ -30,7 +30,7 @@ namespace {
 thread_local char g_err[512] = "";
 
 // Diagnostic controls (rt_debug.h): process-wide, -1 = default.  The library reads no environment variable.
-std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
+std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
 std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = { {0}, {0} };
 std::atomic<bool> g_trace_on{ false };
 std::mutex g_trace_mu;
@@ -546,7 +546,8 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
         if (i >= n_narrow) { descs.push_back(d); dcost.push_back(cost[order[i]]); continue; }
         // 4x4 pixels per wave; 2x2 in a pass so small that its waves all start at once anyway (800x600: 63 -> 52 us; at 1080p the
         // sixteen-fold wave count of 2x2 costs more throughput than the shorter chains buy)
-        const unsigned level = order.size() <= kNarrowLevel2Blocks ? 2u : 1u, step = 16u >> level, cnt = 1u << level;
+        const long long l2 = knob(RT_DEBUG_NARROW_L2);
+        const unsigned level = (l2 >= 0 ? (long long)i < l2 : order.size() <= kNarrowLevel2Blocks) ? 2u : 1u, step = 16u >> level, cnt = 1u << level;
         for (unsigned qy = 0; qy < cnt; ++qy)
             for (unsigned qx = 0; qx < cnt; ++qx) {
                 rt::BlockDesc n = d;

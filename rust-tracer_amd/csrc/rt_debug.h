@@ -29,7 +29,9 @@ typedef enum rt_debug_key {
                                     occupancy experiments; the kernels do not touch it */
     RT_DEBUG_WG_POLICY = 9,      /* 0: one workgroup per block and sample (the dispatcher deals); n > 0: n x 2,048 workgroups per launch, blocks
                                     dealt on the host; default: dealt only past 32,768 workgroups (read when a tile list is first seen) */
-    RT_DEBUG_KEYS = 10
+    RT_DEBUG_NARROW_L2 = 10,     /* of the narrow blocks, how many of the most expensive go out as sixteen 2x2-pixel-per-wave workgroups
+                                    (the rest as four 4x4 ones); default: all in a pass of <= 4,096 blocks, none otherwise */
+    RT_DEBUG_KEYS = 11
 } rt_debug_key;
 
 /* value < 0 restores the default. */

@@ -18,23 +18,19 @@ template <typename T> __host__ __device__ __forceinline__ constexpr T eps() { re
 __device__ __forceinline__ float rsqrt_exact(float x) { return __builtin_sqrtf(x); }    // IEEE correctly rounded
 __device__ __forceinline__ double rsqrt_exact(double x) { return __builtin_sqrt(x); }
 
-// Correctly rounded f32 sqrt for the traversal loops, x >= 0 (or NaN, or negative -> NaN).  Same result as
-// rsqrt_exact() for every input (checked exhaustively on the device by rt_selftest_sqrt), ~half the instructions
-// of the compiler's expansion in the common case: v_sqrt_f32 is within 1 ulp, so the correctly rounded root is
-// s-1ulp, s or s+1ulp, decided by the sign of the exactly computed residuals fma(-s', s, x).  Inputs below 2^-96
-// (denormal residuals would lose bits) take the general path; that branch is almost never taken.
+// Correctly rounded f32 sqrt for the traversal loops.  Same result as rsqrt_exact() for every input (checked exhaustively on
+// the device by rt_selftest_sqrt), a third of the instructions of the compiler's expansion: y = v_rsq_f32(x) is within 1 ulp
+// of 1/sqrt(x); g = x*y is then within a few ulp of the root, r = x - g*g is exact in one FMA, and g + r*(y/2) in one more FMA
+// rounds to the IEEE root (Markstein's final step: the last FMA sees the exact residual).  Zeros, denormals and tiny values
+// of either sign (denormal residuals would lose bits), +inf (0 * inf) and NaN take the general path; that branch is almost
+// never taken.
 __device__ __forceinline__ float sqrt_rn_lean(float x)
 {
-    // |x| < 2^-96 (zeros, denormals, tiny values of either sign): general path.  +inf needs none: its residuals are NaN.
-    if (__builtin_expect(__builtin_fabsf(x) < 0x1p-96f, 0)) return __builtin_sqrtf(x);
-    float s = __builtin_amdgcn_sqrtf(x);
-    const float sd = __uint_as_float(__float_as_uint(s) - 1u);
-    const float su = __uint_as_float(__float_as_uint(s) + 1u);
-    const float rd = __builtin_fmaf(-sd, s, x);
-    const float ru = __builtin_fmaf(-su, s, x);
-    s = (rd <= 0.0f) ? sd : s;
-    s = (ru > 0.0f) ? su : s;
-    return s;
+    if (__builtin_expect(!(__builtin_fabsf(x) >= 0x1p-96f && x < __builtin_huge_valf()), 0)) return __builtin_sqrtf(x);
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y, h = 0.5f * y;
+    const float r = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(r, h, g);
 }
 __device__ __forceinline__ double sqrt_rn_lean(double x) { return __builtin_sqrt(x); }
 

@@ -32,8 +32,8 @@ cache line: the 16 KB scalar cache serves 64 waves, and a speculative fetch that
   * the f32 loops keep to s[36:73]: with the six registers the hardware adds the kernel stays at 80 SGPRs, the most a wave may
     have at 8 waves per SIMD (86 meant 7).
 
-f32 forms the correctly rounded root as v_sqrt_f32 + two exact FMA residuals (== sqrt_rn_lean, checked against the IEEE sqrt on
-all 2^32 inputs).  f64 replays, instruction for instruction, the expansion hipcc emits for the IEEE-correct __builtin_sqrt
+f32 forms the correctly rounded root as v_rsq_f32 + one exact FMA residual + one FMA correction (== sqrt_rn_lean, checked
+against the IEEE sqrt on all 2^32 inputs): 5 instructions; round 1's v_sqrt_f32 + two residuals + two selects took 10.  f64 replays, instruction for instruction, the expansion hipcc emits for the IEEE-correct __builtin_sqrt
 (scale by 2^256 below 2^-767, v_rsq_f64, two Goldschmidt/Newton steps in FMA, scale back, pass +-0 and +inf through).
 
 Run:  python3 tools/gen_skip_asm.py   (writes the header; the build does not need this script)."""
@@ -139,33 +139,32 @@ class F32(Prec):
     def fused_disc(self, a, c):
         a.op("v_add_f32_e32 %%[disc], %s, %%[q]" % self.own(c), "disc = (b*b - vv) + rr of the group's own sphere")
 
-    def correct(self, a, x, nop):
-        a.op("v_add_u32_e32 %[t0], -1, %[root]")
-        a.op("v_add_u32_e32 %[t1], 1, %[root]")
-        a.op("v_fma_f32 %%[t3], -%%[t0], %%[root], %s" % x)
-        a.op("v_fma_f32 %%[t4], -%%[t1], %%[root], %s" % x)
-        a.op("v_cmp_ge_f32_e64 %s, 0, %%[t3]" % self.M56)
-        a.op("v_cmp_lt_f32_e64 %s, 0, %%[t4]" % self.M58)
-        a.op("s_nop %d" % nop)
-        a.op("v_cndmask_b32_e64 %%[root], %%[root], %%[t0], %s" % self.M56)
-        a.op("v_cndmask_b32_e64 %%[root], %%[root], %%[t1], %s" % self.M58)
+    def refine(self, a, x):
+        """t0 = y ~ 1/sqrt(x) (v_rsq_f32, 1 ulp)  ->  %[root] = the correctly rounded sqrt(x): g = x*y, h = y/2, r = x - g*g (exact,
+        one FMA), root = g + r*h (one FMA).  Equal to the IEEE root for every finite x >= 2^-96 (checked on the device against
+        all of them: rt_selftest_sqrt runs the same sequence, sqrt_rn_lean in rt_math.hpp)."""
+        a.op("v_mul_f32_e32 %%[root], %s, %%[t0]" % x, "g = x*y")
+        a.op("v_mul_f32_e32 %[t0], 0.5, %[t0]", "h = y/2")
+        a.op("v_fma_f32 %%[t1], -%%[root], %%[root], %s" % x, "r = x - g*g")
+        a.op("v_fma_f32 %[root], %[t1], %[t0], %[root]", "g + r*h")
 
     def root(self, a, need_mask, done_label, tiny_label):
         """Correctly rounded sqrt(disc) into %[root] (== sqrt_rn_lean).  need_mask: the lanes whose root is used."""
-        a.op("v_sqrt_f32_e32 %[root], %[disc]")
+        a.op("v_rsq_f32_e32 %[t0], %[disc]")
         a.op("v_cmp_lt_f32_e64 %s, |%%[disc]|, %%[tiny]" % self.TINY)
         a.op("s_and_b64 %s, %s, %s" % (self.M56, self.TINY, need_mask))
-        a.op("s_cbranch_scc1 %s" % tiny_label, "some needed lane below 2^-96: scaled path")
-        self.correct(a, "%[disc]", 0)
+        a.op("s_cbranch_scc1 %s" % tiny_label, "some needed lane below 2^-96 (zero included): scaled path")
+        self.refine(a, "%[disc]")
         a.label(done_label)
 
     def tiny(self, a, tiny_label, done_label):
         a.label(tiny_label)
         a.op("v_mul_f32_e32 %[t0], 0x4f800000, %[disc]", "root with the 2^32 / 2^-16 scaling for tiny lanes")
         a.op("v_cndmask_b32_e64 %%[t5], %%[disc], %%[t0], %s" % self.TINY)
-        a.op("v_sqrt_f32_e32 %[root], %[t5]")
-        a.op("s_nop 0")
-        self.correct(a, "%[t5]", 1)
+        a.op("v_rsq_f32_e32 %[t0], %[t5]")
+        a.op("v_cmp_eq_f32_e64 %s, 0, %%[t5]" % self.M58, "sqrt(+-0) = +-0 (rsq would make it 0 * inf)")
+        self.refine(a, "%[t5]")
+        a.op("v_cndmask_b32_e64 %%[root], %%[root], %%[t5], %s" % self.M58)
         a.op("v_mul_f32_e32 %[t0], 0x37800000, %[root]")
         a.op("v_cndmask_b32_e64 %%[root], %%[root], %%[t0], %s" % self.TINY)
         a.op("s_branch %s" % done_label)
@@ -475,8 +474,8 @@ HEADER = """// rt_skip_rot.hpp -- GENERATED by tools/gen_skip_asm.py; edit the g
 // loop beside it in rt_skip.hpp (the reference implementation: every launch that counts tests), operation for operation:
 //      b    = (vx*dx + vy*dy) + vz*dz              primitive.rs:57   (node terms as SGPR operands)
 //      disc = (b*b - vv) + rr                      primitive.rs:58
-//      root = correctly rounded sqrt(disc)         f32: v_sqrt_f32 + two exact FMA residuals (== sqrt_rn_lean, which is checked
-//                                                  against the IEEE sqrt on all 2^32 inputs); f64: hipcc's own IEEE-correct
+//      root = correctly rounded sqrt(disc)         f32: y = v_rsq_f32, g = x*y, g + (x - g*g)*(y/2) in two FMAs (== sqrt_rn_lean, which is
+//                                                  checked against the IEEE sqrt on all 2^32 inputs); f64: hipcc's own IEEE-correct
 //                                                  expansion of __builtin_sqrt, instruction for instruction
 //      t2 = b + root, t1 = b - root, d = t1 > 0 ? t1 : t2            primitive.rs:65-71
 //      go = live && disc >= 0 && t2 >= 0 && d < hit.distance         (the negation of `d >= hit.distance`, group.rs:73 /
