@@ -7,6 +7,7 @@
 #include "rt_skip.hpp"
 #include "rt_flat.hpp"
 #include "rt_flat_wf.hpp"
+#include "rt_flat_sc.hpp"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>       // types and prototypes only: librccl.so is loaded with dlopen when the first gang is created
@@ -30,7 +31,7 @@ namespace {
 thread_local char g_err[512] = "";
 
 // Diagnostic controls (rt_debug.h): process-wide, -1 = default.  The library reads no environment variable.
-std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
+std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
 std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = { {0}, {0} };
 std::atomic<bool> g_trace_on{ false };
 std::mutex g_trace_mu;
@@ -70,6 +71,7 @@ struct Context {
     void *d_queue1 = nullptr, *d_queue2 = nullptr;   // flat wavefront pipeline: shadow-ray queues, Quad<REAL> per sample
     size_t queue_cap = 0;             // bytes of each queue
     rt::FlatQueues *d_queues = nullptr;
+    unsigned flat_first_pass_items = 0;   // items the first shadow pass of the last flat launch covered (rt_stats.tests_executed)
     bool busy = false;       // leased to a caller right now
     bool inflight = false;   // released by an asynchronous caller; reusable once ev1 has completed
 
@@ -107,6 +109,8 @@ struct rt_scene {
     bool fused = false;            // every BOUND is followed by an ITEM with the same centre (rt_skip.hpp, Node)
     void *d_fprim = nullptr, *d_fprim_rr = nullptr, *d_fshad = nullptr;   // pre-formed per-item terms (RT_TRAVERSAL_FLAT)
     uint32_t n_padded = 0;
+    void *d_pg = nullptr, *d_sg = nullptr;      // the same terms in groups of four for the scalar-fed scan (rt_flat_sc.hpp)
+    uint32_t n_groups = 0;
     double light[3] = { 0, 0, 0 }, eye[3] = { 0, 0, 0 };   // exact copies of the REAL values
     std::mutex mu;
     std::vector<std::unique_ptr<Context>> pool;
@@ -255,8 +259,29 @@ rt_status upload_flat(rt_scene *s, const void *host_items)
                        static_cast<const rt::Item<T> *>(s->d_items), d_order, s->n_items, s->n_padded, eye, static_cast<rt::Quad<T> *>(s->d_fprim),
                        static_cast<T *>(s->d_fprim_rr), static_cast<rt::Quad<T> *>(s->d_fshad));
     HIP_TRY(hipGetLastError());
+    s->n_groups = (s->n_items + 3u) / 4u;
+    HIP_TRY(hipMalloc(&s->d_pg, sizeof(rt::PGroup<T>) * s->n_groups));
+    HIP_TRY(hipMalloc(&s->d_sg, sizeof(rt::SGroup<T>) * s->n_groups));
+    hipLaunchKernelGGL((rt::k_build_flat_groups<T>), dim3((s->n_groups * 4 + 255) / 256), dim3(256), 0, nullptr,
+                       static_cast<const rt::Item<T> *>(s->d_items), d_order, s->n_items, s->n_groups, eye, static_cast<rt::PGroup<T> *>(s->d_pg),
+                       static_cast<rt::SGroup<T> *>(s->d_sg));
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     return RT_OK;
+}
+
+template <typename T>
+rt::FlatScView<T> flat_sc_view_of(const rt_scene *s)
+{
+    rt::FlatScView<T> v;
+    v.pg = static_cast<const rt::PGroup<T> *>(s->d_pg);
+    v.sg = static_cast<const rt::SGroup<T> *>(s->d_sg);
+    v.items = static_cast<const rt::Item<T> *>(s->d_items);
+    v.n_items = s->n_items;
+    v.n_groups = s->n_groups;
+    v.light = { (T)s->light[0], (T)s->light[1], (T)s->light[2] };
+    v.eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
+    return v;
 }
 
 template <typename T>
@@ -634,6 +659,13 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
                 }
                 t.n_order = (uint32_t)order.size();
             }
+            // The copies above are blocking for the host, but the render kernel runs on another (non-blocking) stream: make sure
+            // the tables have landed in device memory before anything can be launched against them (once per tile list).
+            e = hipDeviceSynchronize();
+            if (e != hipSuccess) {
+                (void)hipFree(t.dev); if (t.dev_order) (void)hipFree(t.dev_order); if (t.dev_wg) (void)hipFree(t.dev_wg);
+                return hip_fail(e, "hipDeviceSynchronize(tile tables)", __LINE__);
+            }
             t.host = tab; t.w = w; t.h = h; t.passes = passes;
             *out = t.dev;
             if (order_out && block_order_enabled()) *order_out = rt::BlockList{ t.dev_order, t.n_order, t.dev_wg, t.n_wg };
@@ -700,6 +732,23 @@ rt_status launch_flat_wavefront(const rt_scene *s, Context *c, hipStream_t strea
     rt::SampleBuf<T> sb{ static_cast<T *>(c->d_sample_gdot), c->d_sample_state, (unsigned)total_px };
     rt::Quad<T> *q1 = static_cast<rt::Quad<T> *>(c->d_queue1), *q2 = static_cast<rt::Quad<T> *>(c->d_queue2);
     const dim3 b(rt::kBlockThreads);
+    if (knob(RT_DEBUG_FLAT_KERNELS) > 0) {
+        // the scalar-fed scan (rt_flat_sc.hpp): one ray per lane, 16x16-pixel workgroups (the resolve table serves both)
+        constexpr unsigned kFirstPassGroups = 256;                  // the 1,024 largest spheres
+        const rt::FlatScView<T> sv = flat_sc_view_of<T>(s);
+        c->flat_first_pass_items = kFirstPassGroups * 4;
+        hipLaunchKernelGGL((rt::k_flat_primary_sc<T>), dim3(blocks16, (unsigned)ns), b, 0, stream, sv, w, h, spp, d_tab16, nt, sb, q1, c->d_queues, cnt);
+        HIP_TRY(hipGetLastError());
+        const dim3 gsh((unsigned)((samples + rt::kBlockThreads - 1) / rt::kBlockThreads));      // worst case; surplus waves leave at once
+        hipLaunchKernelGGL((rt::k_flat_shadow_sc<T>), gsh, b, 0, stream, sv, 0u, kFirstPassGroups, q1, &c->d_queues->n1, q2, &c->d_queues->n2, sb, cnt);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL((rt::k_flat_shadow_sc<T>), gsh, b, 0, stream, sv, kFirstPassGroups, 0xFFFFFFFFu, q2, &c->d_queues->n2,
+                           (rt::Quad<T> *)nullptr, (unsigned *)nullptr, sb, cnt);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL((rt::k_resolve_samples<T>), dim3(blocks16), b, 0, stream, sb, spp, d_tab16, nt, d_out, frame_w, false);
+        return RT_OK;
+    }
+    c->flat_first_pass_items = (unsigned)CHUNK;
     const rt::FlatView<T> view = flat_view_of<T>(s);
     hipLaunchKernelGGL((rt::k_flat_primary<T, CHUNK>), dim3(blocks32, (unsigned)ns), b, 0, stream, view, w, h, spp, d_tab32, nt, sb, q1, c->d_queues, cnt);
     HIP_TRY(hipGetLastError());
@@ -895,7 +944,7 @@ rt_status read_stats(rt_scene *s, Context *c, hipStream_t stream, rt_traversal t
         if (c->d_queues) {                                          // the shadow queues' lengths say what actually ran
             rt::FlatQueues q{};
             HIP_TRY(hipMemcpy(&q, c->d_queues, sizeof q, hipMemcpyDeviceToHost));
-            const uint64_t chunk = s->precision == RT_F32 ? 1024 : 512, n = s->n_items;
+            const uint64_t chunk = c->flat_first_pass_items, n = s->n_items;
             st->tests_executed = h.primary * n + (uint64_t)q.n1 * std::min<uint64_t>(chunk, n) + (uint64_t)q.n2 * (n > chunk ? n - chunk : 0);
         }
     } else {
@@ -1080,6 +1129,8 @@ rt_status rt_scene_destroy(rt_scene *s)
     if (s->d_fprim) (void)hipFree(s->d_fprim);
     if (s->d_fprim_rr) (void)hipFree(s->d_fprim_rr);
     if (s->d_fshad) (void)hipFree(s->d_fshad);
+    if (s->d_pg) (void)hipFree(s->d_pg);
+    if (s->d_sg) (void)hipFree(s->d_sg);
     delete s;
     return RT_OK;
 }

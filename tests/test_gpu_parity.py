@@ -836,3 +836,24 @@ def test_dealing_blocks_to_workgroups_never_changes_a_pixel(size, policy):
     np.testing.assert_array_equal(util.stitch((w, h), regs, plain), ref)
     np.testing.assert_array_equal(counted, plain)
     assert util.all_stats(st) == util.all_stats(rst)
+
+
+@pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64], ids=["f32", "f64"])
+@pytest.mark.parametrize("size", [(320, 200, 1), (150, 70, 3)])
+def test_scalar_fed_flat_scan_kernels(size, precision):
+    # RT_TRAVERSAL_FLAT has two kernel sets (csrc/rt_debug.h RT_DEBUG_FLAT_KERNELS): the LDS-staged packed-math pipeline (default)
+    # and the scalar-fed scan of rt_flat_sc.hpp.  Same bytes, same ray counters, on the default scene and on a scene whose item
+    # count is not a multiple of the group size.
+    w, h, spp = size
+    for s, o in (util.scene_pair_default(precision, level=6),
+                 util.scene_pair_spheres(np.random.default_rng(3).uniform([-1.5, -1.5, -1.5, 0.03], [1.5, 1.5, 1.5, 0.2], (1027, 4)).astype(np.float32).astype(np.float64),
+                                         (0, 0, 0, 3.0), precision)):
+        regs = bucket_list(w, h, spp)
+        ref, rst, _ = o.render(w, h, spp, os.cpu_count() or 1, oracle.MODE_FLAT)
+        with rta.capi.debug(rta.capi.DEBUG_FLAT_KERNELS, 1):
+            data, st = s.device().render_tiles((w, h, spp), regs, FLAT)
+        np.testing.assert_array_equal(util.stitch((w, h), regs, data), ref)
+        assert util.ray_stats(st) == util.ray_stats(rst)
+        base, bst = s.device().render_tiles((w, h, spp), regs, FLAT)
+        np.testing.assert_array_equal(base, data)
+        assert util.ray_stats(bst) == util.ray_stats(st)

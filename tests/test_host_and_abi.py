@@ -189,7 +189,7 @@ def test_library_reads_no_environment_variable_and_keeps_diagnostics_out_of_the_
     hdr = open(os.path.join(ROOT, "include", "rtrace_hip.h")).read()
     assert "rt_debug" not in hdr
     assert capi.lib.rt_debug_set(999, 1) == capi.RT_ERR_INVALID_ARGUMENT
-    for key in range(11):
+    for key in range(12):
         assert capi.lib.rt_debug_set(key, -1) == capi.RT_OK
 
 
