@@ -120,3 +120,30 @@ def test_native_gang_rccl_gather_is_byte_identical(ndev, size):
     frame2, _ = g.render_frame((w, h, spp), regs[::-1])          # the deal follows the list order; the frame does not care
     np.testing.assert_array_equal(frame2, ref)
     g.close()
+
+
+@pytest.mark.parametrize("multi", ["tiles", "frames"])
+def test_bench_collective_path_checks_its_own_frame(multi):
+    # bench.py is what the driver runs at N = 1, 2, 4, 8: here the N > 1 code (shards, RCCL gather, blit, software pipeline) runs as
+    # a one-rank job in a child process, and the line it prints must carry a frame CRC equal to the committed oracle vector -- the
+    # same self-check every N > 1 run performs on rank 0.
+    import json
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-collective", "--multi", multi, "--steps", "4",
+                        "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--no-flat", "--no-seam"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "bench.py must print exactly one line"
+    d = json.loads(lines[0])
+    assert d["frame_crc_ok"] is True and d["frame_crc32"] == 4168428064
+    assert d["config"]["rccl_world_size"] == 1 and d["n_gpus"] == 1
+    assert d["scaling"] == "strong" and d["roofline"]["bound"] == "valu_issue" and 0 < d["roofline"]["frac"] <= 1
+    assert d["repeats"]["n"] == 2 and d["value"] > 1000
