@@ -109,8 +109,8 @@ struct rt_scene {
     bool fused = false;            // every BOUND is followed by an ITEM with the same centre (rt_skip.hpp, Node)
     void *d_fprim = nullptr, *d_fprim_rr = nullptr, *d_fshad = nullptr;   // pre-formed per-item terms (RT_TRAVERSAL_FLAT)
     uint32_t n_padded = 0;
-    void *d_pg = nullptr, *d_sg = nullptr;      // the same terms in groups of four for the scalar-fed scan (rt_flat_sc.hpp)
-    uint32_t n_groups = 0;
+    void *d_pg = nullptr, *d_sg = nullptr;      // f32: the same terms in 64-byte groups of three for the scalar-fed scan (rt_flat_sc.hpp)
+    uint32_t flat_sc_bytes = 0;                 // 128 x number of group pairs
     double light[3] = { 0, 0, 0 }, eye[3] = { 0, 0, 0 };   // exact copies of the REAL values
     std::mutex mu;
     std::vector<std::unique_ptr<Context>> pool;
@@ -259,28 +259,31 @@ rt_status upload_flat(rt_scene *s, const void *host_items)
                        static_cast<const rt::Item<T> *>(s->d_items), d_order, s->n_items, s->n_padded, eye, static_cast<rt::Quad<T> *>(s->d_fprim),
                        static_cast<T *>(s->d_fprim_rr), static_cast<rt::Quad<T> *>(s->d_fshad));
     HIP_TRY(hipGetLastError());
-    s->n_groups = (s->n_items + 3u) / 4u;
-    HIP_TRY(hipMalloc(&s->d_pg, sizeof(rt::PGroup<T>) * s->n_groups));
-    HIP_TRY(hipMalloc(&s->d_sg, sizeof(rt::SGroup<T>) * s->n_groups));
-    hipLaunchKernelGGL((rt::k_build_flat_groups<T>), dim3((s->n_groups * 4 + 255) / 256), dim3(256), 0, nullptr,
-                       static_cast<const rt::Item<T> *>(s->d_items), d_order, s->n_items, s->n_groups, eye, static_cast<rt::PGroup<T> *>(s->d_pg),
-                       static_cast<rt::SGroup<T> *>(s->d_sg));
-    HIP_TRY(hipGetLastError());
+    if constexpr (sizeof(T) == 4) {
+        const uint32_t n3 = (s->n_items + rt::kFlatGroupItems - 1) / rt::kFlatGroupItems, pairs = (n3 + 1) / 2;
+        const uint32_t n_groups = 2 * pairs + rt::kFlatPadGroups;            // pad groups: never hit; the scan loads one pair ahead
+        s->flat_sc_bytes = pairs * 128u;
+        HIP_TRY(hipMalloc(&s->d_pg, sizeof(rt::FGroup) * n_groups));
+        HIP_TRY(hipMalloc(&s->d_sg, sizeof(rt::FGroup) * n_groups));
+        hipLaunchKernelGGL(rt::k_build_flat_groups, dim3((n_groups * rt::kFlatGroupItems + 255) / 256), dim3(256), 0, nullptr,
+                           static_cast<const rt::Item<float> *>(s->d_items), d_order, s->n_items, n_groups, rt::V3<float>{ (float)s->eye[0], (float)s->eye[1], (float)s->eye[2] },
+                           static_cast<rt::FGroup *>(s->d_pg), static_cast<rt::FGroup *>(s->d_sg));
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipDeviceSynchronize());
     return RT_OK;
 }
 
-template <typename T>
-rt::FlatScView<T> flat_sc_view_of(const rt_scene *s)
+rt::FlatScView flat_sc_view_of(const rt_scene *s)
 {
-    rt::FlatScView<T> v;
-    v.pg = static_cast<const rt::PGroup<T> *>(s->d_pg);
-    v.sg = static_cast<const rt::SGroup<T> *>(s->d_sg);
-    v.items = static_cast<const rt::Item<T> *>(s->d_items);
+    rt::FlatScView v;
+    v.pg = static_cast<const rt::FGroup *>(s->d_pg);
+    v.sg = static_cast<const rt::FGroup *>(s->d_sg);
+    v.items = static_cast<const rt::Item<float> *>(s->d_items);
     v.n_items = s->n_items;
-    v.n_groups = s->n_groups;
-    v.light = { (T)s->light[0], (T)s->light[1], (T)s->light[2] };
-    v.eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
+    v.n_bytes = s->flat_sc_bytes;
+    v.light = { (float)s->light[0], (float)s->light[1], (float)s->light[2] };
+    v.eye = { (float)s->eye[0], (float)s->eye[1], (float)s->eye[2] };
     return v;
 }
 
@@ -732,21 +735,24 @@ rt_status launch_flat_wavefront(const rt_scene *s, Context *c, hipStream_t strea
     rt::SampleBuf<T> sb{ static_cast<T *>(c->d_sample_gdot), c->d_sample_state, (unsigned)total_px };
     rt::Quad<T> *q1 = static_cast<rt::Quad<T> *>(c->d_queue1), *q2 = static_cast<rt::Quad<T> *>(c->d_queue2);
     const dim3 b(rt::kBlockThreads);
-    if (knob(RT_DEBUG_FLAT_KERNELS) > 0) {
-        // the scalar-fed scan (rt_flat_sc.hpp): one ray per lane, 16x16-pixel workgroups (the resolve table serves both)
-        constexpr unsigned kFirstPassGroups = 256;                  // the 1,024 largest spheres
-        const rt::FlatScView<T> sv = flat_sc_view_of<T>(s);
-        c->flat_first_pass_items = kFirstPassGroups * 4;
-        hipLaunchKernelGGL((rt::k_flat_primary_sc<T>), dim3(blocks16, (unsigned)ns), b, 0, stream, sv, w, h, spp, d_tab16, nt, sb, q1, c->d_queues, cnt);
-        HIP_TRY(hipGetLastError());
-        const dim3 gsh((unsigned)((samples + rt::kBlockThreads - 1) / rt::kBlockThreads));      // worst case; surplus waves leave at once
-        hipLaunchKernelGGL((rt::k_flat_shadow_sc<T>), gsh, b, 0, stream, sv, 0u, kFirstPassGroups, q1, &c->d_queues->n1, q2, &c->d_queues->n2, sb, cnt);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL((rt::k_flat_shadow_sc<T>), gsh, b, 0, stream, sv, kFirstPassGroups, 0xFFFFFFFFu, q2, &c->d_queues->n2,
-                           (rt::Quad<T> *)nullptr, (unsigned *)nullptr, sb, cnt);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL((rt::k_resolve_samples<T>), dim3(blocks16), b, 0, stream, sb, spp, d_tab16, nt, d_out, frame_w, false);
-        return RT_OK;
+    if constexpr (sizeof(T) == 4) {
+        if (knob(RT_DEBUG_FLAT_KERNELS) != 0) {
+            // f32: the scalar-fed scan (rt_flat_sc.hpp): one ray per lane, 16x16-pixel workgroups (the resolve table serves both)
+            constexpr unsigned kFirstPassGroups = 342;                  // the 1,026 largest spheres (an even number of groups)
+            const rt::FlatScView sv = flat_sc_view_of(s);
+            const unsigned first_bytes = std::min(kFirstPassGroups * 64u, sv.n_bytes);
+            c->flat_first_pass_items = first_bytes / 64u * rt::kFlatGroupItems;
+            hipLaunchKernelGGL(rt::k_flat_primary_sc, dim3(blocks16, (unsigned)ns), b, 0, stream, sv, w, h, spp, d_tab16, nt, sb, q1, c->d_queues, cnt);
+            HIP_TRY(hipGetLastError());
+            const dim3 gsh((unsigned)((samples + rt::kBlockThreads - 1) / rt::kBlockThreads));      // worst case; surplus waves leave at once
+            hipLaunchKernelGGL(rt::k_flat_shadow_sc, gsh, b, 0, stream, sv, 0u, first_bytes, q1, &c->d_queues->n1, q2, &c->d_queues->n2, sb, cnt);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(rt::k_flat_shadow_sc, gsh, b, 0, stream, sv, first_bytes, 0xFFFFFF80u, q2, &c->d_queues->n2,
+                               (rt::Quad<T> *)nullptr, (unsigned *)nullptr, sb, cnt);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL((rt::k_resolve_samples<T>), dim3(blocks16), b, 0, stream, sb, spp, d_tab16, nt, d_out, frame_w, false);
+            return RT_OK;
+        }
     }
     c->flat_first_pass_items = (unsigned)CHUNK;
     const rt::FlatView<T> view = flat_view_of<T>(s);

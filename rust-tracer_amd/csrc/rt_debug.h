@@ -31,8 +31,8 @@ typedef enum rt_debug_key {
                                     dealt on the host; default: dealt only past 32,768 workgroups (read when a tile list is first seen) */
     RT_DEBUG_NARROW_L2 = 10,     /* of the narrow blocks, how many of the most expensive go out as sixteen 2x2-pixel-per-wave workgroups
                                     (the rest as four 4x4 ones); default: all in a pass of <= 4,096 blocks, none otherwise */
-    RT_DEBUG_FLAT_KERNELS = 11,  /* 1: the flat traversal runs the scalar-fed scan kernels (rt_flat_sc.hpp) instead of the LDS-staged packed-math
-                                    ones (rt_flat_wf.hpp, the default: 11.7 against 13.4 ms at 1080p) */
+    RT_DEBUG_FLAT_KERNELS = 11,  /* 0: the f32 flat traversal runs round 1's LDS-staged packed-math kernels (rt_flat_wf.hpp, what f64 always
+                                    runs) instead of the scalar-fed scan (rt_flat_sc.hpp) */
     RT_DEBUG_KEYS = 12
 } rt_debug_key;
 

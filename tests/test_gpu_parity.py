@@ -838,22 +838,41 @@ def test_dealing_blocks_to_workgroups_never_changes_a_pixel(size, policy):
     assert util.all_stats(st) == util.all_stats(rst)
 
 
-@pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64], ids=["f32", "f64"])
-@pytest.mark.parametrize("size", [(320, 200, 1), (150, 70, 3)])
-def test_scalar_fed_flat_scan_kernels(size, precision):
-    # RT_TRAVERSAL_FLAT has two kernel sets (csrc/rt_debug.h RT_DEBUG_FLAT_KERNELS): the LDS-staged packed-math pipeline (default)
-    # and the scalar-fed scan of rt_flat_sc.hpp.  Same bytes, same ray counters, on the default scene and on a scene whose item
-    # count is not a multiple of the group size.
-    w, h, spp = size
-    for s, o in (util.scene_pair_default(precision, level=6),
-                 util.scene_pair_spheres(np.random.default_rng(3).uniform([-1.5, -1.5, -1.5, 0.03], [1.5, 1.5, 1.5, 0.2], (1027, 4)).astype(np.float32).astype(np.float64),
-                                         (0, 0, 0, 3.0), precision)):
-        regs = bucket_list(w, h, spp)
-        ref, rst, _ = o.render(w, h, spp, os.cpu_count() or 1, oracle.MODE_FLAT)
-        with rta.capi.debug(rta.capi.DEBUG_FLAT_KERNELS, 1):
-            data, st = s.device().render_tiles((w, h, spp), regs, FLAT)
-        np.testing.assert_array_equal(util.stitch((w, h), regs, data), ref)
-        assert util.ray_stats(st) == util.ray_stats(rst)
-        base, bst = s.device().render_tiles((w, h, spp), regs, FLAT)
-        np.testing.assert_array_equal(base, data)
-        assert util.ray_stats(bst) == util.ray_stats(st)
+@pytest.mark.parametrize("n_items", [1, 2, 3, 5, 6, 7, 1025, 1026, 1027, 2053])
+def test_scalar_fed_flat_scan_item_counts_around_the_group_and_pass_sizes(n_items):
+    # f32 RT_TRAVERSAL_FLAT runs the scalar-fed scan (rt_flat_sc.hpp + generated rt_flat_rot.hpp): groups of three items, two groups
+    # per loop iteration, the first shadow pass covers 342 groups = 1,026 items.  Item counts around every one of those boundaries,
+    # against the oracle's flat semantics, and against round 1's LDS kernels (csrc/rt_debug.h RT_DEBUG_FLAT_KERNELS = 0).
+    rng = np.random.default_rng(n_items)
+    sp = np.concatenate([rng.uniform(-1.5, 1.5, (n_items, 3)), rng.uniform(0.02, 0.12, (n_items, 1))], axis=1)
+    sp = sp.astype(np.float32).astype(np.float64)
+    s, o = util.scene_pair_spheres(sp, (0, 0, 0, 3.0))
+    regs = bucket_list(150, 70, 2)
+    ref, rst, _ = o.render(150, 70, 2, os.cpu_count() or 1, oracle.MODE_FLAT)
+    data, st = s.device().render_tiles((150, 70, 2), regs, FLAT)
+    np.testing.assert_array_equal(util.stitch((150, 70), regs, data), ref)
+    assert util.ray_stats(st) == util.ray_stats(rst)
+    with rta.capi.debug(rta.capi.DEBUG_FLAT_KERNELS, 0):
+        lds, lst = s.device().render_tiles((150, 70, 2), regs, FLAT)
+    np.testing.assert_array_equal(lds, data)
+    assert util.ray_stats(lst) == util.ray_stats(st)
+
+
+def test_scalar_fed_flat_scan_on_tiny_discriminants():
+    # the exact path of the flat scan's assembly (root of a denormal / zero discriminant: the scaled `tiny` branch) on a scene
+    # scaled by 1e-20, and the default scene at 1080p against the golden frame CRC
+    items, bounds, ranges = util.random_nested_scene(41, depth=2, fan=3, leaf_items=3)
+    sc = lambda a: (np.asarray(a, dtype=np.float64) * 1e-20).astype(np.float32).astype(np.float64)
+    eye = tuple(float(v) for v in sc((0.07, -0.12, -3.1)))
+    s, o = util.scene_pair_ranges(sc(items), sc(bounds), ranges, rta.RT_F32, eye=eye)
+    regs = bucket_list(96, 72, 2)
+    ref, rst, _ = o.render(96, 72, 2, os.cpu_count() or 1, oracle.MODE_FLAT)
+    assert rst["hits"] > 500
+    data, st = s.device().render_tiles((96, 72, 2), regs, FLAT)
+    np.testing.assert_array_equal(util.stitch((96, 72), regs, data), ref)
+    assert util.ray_stats(st) == util.ray_stats(rst)
+    s, _ = util.scene_pair_default()
+    regs = bucket_list(1920, 1080)
+    data, st = s.device().render_tiles((1920, 1080, 1), regs, FLAT, want_stats=False)
+    case = next(c for c in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))["cases"] if c["name"] == "config3_1920x1080_f32")
+    assert zlib.crc32(util.stitch((1920, 1080), regs, data).tobytes()) & 0xFFFFFFFF == case["frame_crc32"]

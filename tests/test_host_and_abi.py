@@ -166,14 +166,16 @@ def test_header_is_plain_c_and_the_library_links_from_c(tmp_path):
     assert ctypes.sizeof(capi.Options) == 6 and ctypes.sizeof(capi.Region) == 8 and ctypes.sizeof(capi.Range) == 8
 
 
-def test_generated_traversal_loops_are_up_to_date(tmp_path):
-    # csrc/rt_skip_rot.hpp is the output of tools/gen_skip_asm.py: the committed header must be what the generator writes
+@pytest.mark.parametrize("name,header", [("gen_skip_asm", "rt_skip_rot.hpp"), ("gen_flat_asm", "rt_flat_rot.hpp")])
+def test_generated_traversal_loops_are_up_to_date(tmp_path, name, header):
+    # csrc/rt_skip_rot.hpp / rt_flat_rot.hpp are the output of tools/gen_*_asm.py: the committed header must be what the generator writes
     import importlib.util
-    spec = importlib.util.spec_from_file_location("gen_skip_asm", os.path.join(ROOT, "tools", "gen_skip_asm.py"))
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
     committed = open(gen.OUT).read()
-    gen.OUT = str(tmp_path / "rt_skip_rot.hpp")
+    assert gen.OUT.endswith(header)
+    gen.OUT = str(tmp_path / header)
     gen.main()
     assert open(gen.OUT).read() == committed
 
