@@ -370,8 +370,9 @@ def main():
                      "this run and equal to the CPU path's) / HIP-event duration of k_render_skip in this run.  The records arrive "
                      "through the scalar cache / L2 (the whole scene is < 1 MB): VALU issue binds, not HBM")
         flat_note = ("achieved = un-fused flops of the tests the flat pipeline executed (8 per primary test with the pre-formed terms, 16 per "
-                     "shadow test; queue lengths x pass lengths) / HIP-event duration of its kernels (k_flat_primary + 2 x k_flat_shadow + "
-                     "k_resolve_samples); every record staged to LDS is re-used by all rays of a workgroup")
+                     "shadow test; queue lengths x pass lengths) / HIP-event duration of its kernels (k_flat_primary_sc + 2 x k_flat_shadow_sc + "
+                     "k_resolve_samples); the items are wave-uniform scalars (s_load -> SGPR operands of VOP2 instructions), served by the "
+                     "scalar cache / L2")
         if world == 1 and not args.force_collective:
             layout = "1 GPU, buckets rendered straight into the row-major frame"
         elif multi == "frames":
@@ -410,17 +411,18 @@ def main():
             fst = flat["my_stats"]
             shadow_tests = fst["tests_executed"] - fst["primary"] * n_items       # what the any-hit passes really ran
             ops = fst["primary"] * n_items * 8 + shadow_tests * 16
-            vop3p = probe.get(("v_pk_mul_f32 (SGPR pair x VGPR pair, op_sel_hi:[0,1])", 8))
-            pk_peak = N_SIMD * LANES * 2 * CLOCK_HZ / (vop3p["cycles_per_instruction_per_simd"] if vop3p else 4.0)
+            vop2 = probe.get(("v_mul_f32 (SGPR x VGPR, independent)", 8))
+            pk_peak = N_SIMD * LANES * CLOCK_HZ / (vop2["cycles_per_instruction_per_simd"] if vop2 else 2.0)      # the same VOP2 roof as the headline
             t = flat["kern_ms"] * 1e-3
             out["flat"] = {"ms_per_step": round(flat["ms_per_step"], 4), "value": round(rays / (flat["ms_per_step"] * 1e-3) / 1e6, 3), "unit": "Mrays/s",
                            "frame_crc_ok": flat["crc_ok"],
                            "roofline": {"bound": "valu_issue", "achieved": round(ops / t / 1e12, 2), "peak": round(pk_peak / 1e12, 1),
-                                        "unit": "TFLOP/s (un-fused f32 lane ops, packed v_pk_mul/add)", "frac": round(ops / t / pk_peak, 4),
-                                        "kernel": "k_flat_primary + k_flat_shadow", "kernel_ms": round(flat["kern_ms"], 4),
+                                        "unit": "TFLOP/s (un-fused f32 lane ops)", "frac": round(ops / t / pk_peak, 4),
+                                        "kernel": "k_flat_primary_sc + k_flat_shadow_sc", "kernel_ms": round(flat["kern_ms"], 4),
                                         "tests_executed": fst["tests_executed"], "note": flat_note,
-                                        "peak_source": "probe: cycles per packed VOP3P instruction at 8 waves per SIMD, two lane ops each",
-                                        "from_profiles": from_profiles("k_flat_primary", flat["kern_ms"])}}
+                                        "peak_source": "probe: cycles per wave64 VOP2 instruction per SIMD at 8 waves per SIMD (a VOP2 whose SGPR operand changes "
+                                                       "from one instruction to the next issues at the VOP3 rate, 2.55: profiles/r02_valu_issue_probe.json)",
+                                        "from_profiles": from_profiles("k_flat_primary_sc", flat["kern_ms"])}}
         for k, e in extras.items():
             out[k] = summary(e, "config5" if k == "config5_tiles" else "1080p")
             out[k]["scaling"] = "weak" if k == "weak_frames" else "strong"

@@ -20,7 +20,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import kernel_src_sha, git_head  # noqa: E402  (the stamp bench.py compares with the sources it runs on)
-SHORT = [("k_render_skip<float, false", "k_render_skip"), ("k_flat_primary<float", "k_flat_primary"), ("k_flat_shadow<float", "k_flat_shadow"),
+SHORT = [("k_render_skip<float, false", "k_render_skip"), ("k_flat_primary<float", "k_flat_primary"), ("k_flat_shadow<float", "k_flat_shadow"), ("k_flat_primary_sc", "k_flat_primary_sc"), ("k_flat_shadow_sc", "k_flat_shadow_sc"),
          ("k_blit_tiles", "k_blit_tiles"), ("k_build_streams<float>", "k_build_streams"),
          ("k_resolve_samples<float>", "k_resolve_samples")]
 
@@ -62,7 +62,7 @@ def main():
     if traffic.get("kernel_src_sha") != stamp["kernel_src_sha"]:
         traffic = {}                                     # figures of other kernel sources do not mix with these
     traffic.update(stamp)
-    for k in ("k_render_skip", "k_flat_primary", "k_flat_shadow"):
+    for k in ("k_render_skip", "k_flat_primary", "k_flat_shadow", "k_flat_primary_sc", "k_flat_shadow_sc"):
         if k in pmc and "hbm_bytes_per_launch" in pmc[k]:
             traffic["%s_n%d" % (k, n)] = pmc[k]["hbm_bytes_per_launch"]
     traffic["_source"] = "tools/summarize_profile.py from rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, tag " + tag
