@@ -122,7 +122,8 @@ enum { RT_SCENE_HAS_BOUNDS = 1u, RT_SCENE_CONCENTRIC = 2u };
 rt_status rt_scene_traits(const rt_scene *scene, uint32_t *traits);
 
 /* Host memory for RGBABuffer storage (render.rs:74-90 allocates it with vec![0; area * 4]) that the device can reach
- * directly.  rt_render_tiles / rt_render_region recognise such memory by address (any pointer inside the range) and then
+ * directly.  rt_render_tiles / rt_render_region recognise such memory by address (any pointer inside a range this library
+ * pinned -- memory pinned by other means counts as pageable) and then
  * the render kernel stores its pixels straight into it over PCIe: no device-side copy of the frame, no staging, no CPU copy.
  * Pageable memory (a plain Vec<u8>) works everywhere too, but every byte then takes a bounce through pinned staging and a CPU
  * copy (about 3x slower for a 1080p frame).

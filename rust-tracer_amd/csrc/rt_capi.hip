@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -1219,21 +1220,36 @@ rt_status rt_render_frame_device(rt_scene *s, const rt_options *o, rt_traversal 
 //            pinned staging and the CPU hands each caller its 16 KB.
 enum HostCopy { kCopyAuto = 0, kCopyDirect = 1, kCopyStaged = 2, kCopyZero = 3, kCopyZeroStaged = 4 };
 
-struct HostDest { bool pinned = false; uint8_t *dev_alias = nullptr; bool bad = false; };
+struct HostDest { bool pinned = false; uint8_t *dev_alias = nullptr; bool bad = false; size_t room = 0; };
+
+// Host ranges this library pinned itself (rt_host_alloc / rt_host_register), base -> {bytes, device alias}.  Only these are
+// written by the render kernel directly.  Asking the runtime instead (hipPointerGetAttributes) is not safe: it also reports
+// ranges it locked on its own for an earlier pageable copy, and such a record can outlive the caller's buffer -- a kernel
+// store to it is a GPU memory fault (seen as an intermittent fault on freshly allocated numpy buffers).
+struct PinnedRange { size_t bytes; uint8_t *alias; };
+static std::mutex g_pinned_mu;
+static std::map<uintptr_t, PinnedRange> g_pinned;
 
 static HostDest classify_host_pointer(const void *p)
 {
     HostDest d;
-    hipPointerAttribute_t a{};
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return d; }      // plain pageable memory
-    if (a.type == hipMemoryTypeHost) {
-        d.pinned = true;
-        void *alias = nullptr;
-        if (hipHostGetDevicePointer(&alias, const_cast<void *>(p), 0) == hipSuccess) d.dev_alias = static_cast<uint8_t *>(alias);
-        else (void)hipGetLastError();
-    } else if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeArray) {
-        d.bad = true;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        auto it = g_pinned.upper_bound(a);
+        if (it != g_pinned.begin()) {
+            --it;
+            if (a - it->first < it->second.bytes) {
+                d.pinned = true;
+                d.dev_alias = it->second.alias ? it->second.alias + (a - it->first) : nullptr;
+                d.room = it->second.bytes - (a - it->first);
+                return d;
+            }
+        }
     }
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return d; }      // plain pageable memory
+    if (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeArray) d.bad = true;            // a device pointer is a caller error here
     return d;
 }
 
@@ -1264,7 +1280,7 @@ static rt_status render_tiles_host(rt_scene *s, const rt_options *o, rt_traversa
     long long mode = knob(RT_DEBUG_HOST_COPY);
     if (mode <= 0) mode = dest.pinned ? (dest.dev_alias ? kCopyZero : kCopyDirect) : kCopyDirect;
     if (scatter) mode = kCopyZeroStaged;
-    if (mode == kCopyZero && !dest.dev_alias) mode = kCopyDirect;
+    if (mode == kCopyZero && (!dest.dev_alias || dest.room < (size_t)total_px * 4)) mode = kCopyDirect;
     if (mode == kCopyStaged && dest.pinned) mode = kCopyDirect;          // staging a pinned destination is pointless
 
     Context *c = nullptr;
@@ -1364,12 +1380,23 @@ rt_status rt_host_alloc(size_t bytes, void **out)
     rt_status st = rt_device_count(&ndev);
     if (st != RT_OK) return st;
     HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocPortable | hipHostMallocMapped));
+    void *alias = nullptr;
+    if (hipHostGetDevicePointer(&alias, *out, 0) != hipSuccess) { (void)hipGetLastError(); alias = nullptr; }
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    g_pinned[reinterpret_cast<uintptr_t>(*out)] = PinnedRange{ bytes, static_cast<uint8_t *>(alias) };
     return RT_OK;
 }
 
 rt_status rt_host_free(void *p)
 {
     if (!p) return RT_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        if (g_pinned.erase(reinterpret_cast<uintptr_t>(p)) == 0) {
+            snprintf(g_err, sizeof g_err, "rt_host_free: not a pointer rt_host_alloc returned");
+            return RT_ERR_INVALID_ARGUMENT;
+        }
+    }
     HIP_TRY(hipHostFree(p));
     return RT_OK;
 }
@@ -1381,12 +1408,23 @@ rt_status rt_host_register(void *p, size_t bytes)
     rt_status st = rt_device_count(&ndev);
     if (st != RT_OK) return st;
     HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+    void *alias = nullptr;
+    if (hipHostGetDevicePointer(&alias, p, 0) != hipSuccess) { (void)hipGetLastError(); alias = nullptr; }
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    g_pinned[reinterpret_cast<uintptr_t>(p)] = PinnedRange{ bytes, static_cast<uint8_t *>(alias) };
     return RT_OK;
 }
 
 rt_status rt_host_unregister(void *p)
 {
     if (!p) return RT_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        if (g_pinned.erase(reinterpret_cast<uintptr_t>(p)) == 0) {
+            snprintf(g_err, sizeof g_err, "rt_host_unregister: not a pointer rt_host_register was given");
+            return RT_ERR_INVALID_ARGUMENT;
+        }
+    }
     HIP_TRY(hipHostUnregister(p));
     return RT_OK;
 }
@@ -1555,7 +1593,7 @@ struct Rccl {
 };
 
 // librccl.so is ~0.5 GB: it is loaded on first use, never for single-GPU renders.
-Rccl *rccl()
+static Rccl *rccl()
 {
     static Rccl r;
     static std::once_flag once;
@@ -1577,7 +1615,7 @@ Rccl *rccl()
     return &r;
 }
 
-rt_status rccl_fail(ncclResult_t e, const char *what, int line)
+static rt_status rccl_fail(ncclResult_t e, const char *what, int line)
 {
     snprintf(g_err, sizeof g_err, "%s failed at rt_capi.hip:%d: %s", what, line, rccl()->GetErrorString ? rccl()->GetErrorString(e) : "RCCL error");
     return RT_ERR_HIP;

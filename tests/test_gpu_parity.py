@@ -876,3 +876,33 @@ def test_scalar_fed_flat_scan_on_tiny_discriminants():
     data, st = s.device().render_tiles((1920, 1080, 1), regs, FLAT, want_stats=False)
     case = next(c for c in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))["cases"] if c["name"] == "config3_1920x1080_f32")
     assert zlib.crc32(util.stitch((1920, 1080), regs, data).tobytes()) & 0xFFFFFFFF == case["frame_crc32"]
+
+
+def test_only_memory_this_library_pinned_is_written_by_the_kernel():
+    # rt_render_tiles lets the kernel store into host memory only inside ranges rt_host_alloc / rt_host_register recorded.  The
+    # runtime's own view (hipPointerGetAttributes) also lists ranges it locked for an earlier pageable copy, and such a record can
+    # outlive the buffer -- trusting it faulted intermittently on freshly allocated numpy buffers.  Fresh 8 MB buffers in a row,
+    # memory pinned by somebody else (torch), and the error paths of free / unregister.
+    import torch
+    s, _ = util.scene_pair_default()
+    d = s.device()
+    regs = bucket_list(1920, 1080)
+    ref, _ = d.render_tiles((1920, 1080, 1), regs, SKIP, want_stats=False)
+    ref = ref.copy()
+    for _ in range(12):
+        buf = np.empty(ref.size, dtype=np.uint8)                 # a new mapping each time: large allocations are mmap'ed and unmapped
+        data, _ = d.render_tiles((1920, 1080, 1), regs, SKIP, want_stats=False, out=buf)
+        assert np.array_equal(data, ref)
+        del buf, data
+    t = torch.empty(ref.size, dtype=torch.uint8).pin_memory()    # pinned, but not by this library: treated as pageable
+    data, _ = d.render_tiles((1920, 1080, 1), regs, SKIP, want_stats=False, out=t.numpy())
+    assert np.array_equal(data, ref)
+    assert rta.capi.lib.rt_host_free(t.data_ptr()) == rta.capi.RT_ERR_INVALID_ARGUMENT
+    assert rta.capi.lib.rt_host_unregister(t.data_ptr()) == rta.capi.RT_ERR_INVALID_ARGUMENT
+    hb = rta.capi.HostBuffer(ref.size + 4096)
+    data, _ = d.render_tiles((1920, 1080, 1), regs, SKIP, want_stats=False, out=hb.array[4096:])      # interior pointer, exact room
+    assert np.array_equal(data, ref)
+    small = rta.capi.HostBuffer(65536)                            # too small for the pass from this offset: copied, not overrun
+    with pytest.raises(ValueError):
+        d.render_tiles((1920, 1080, 1), regs, SKIP, want_stats=False, out=small.array)
+    hb.close(); small.close()
