@@ -31,17 +31,18 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 enum Kind { K_MUL, K_ADD, K_MUL_SGPR, K_FMA, K_PK_MUL, K_PK_ADD, K_PK_MUL_SGPR, K_CMP_E64, K_CNDMASK, K_SQRT, K_DEP_ADD, K_VALU_SALU,
-            K_STEP_MIX, K_PK_FMA, K_MUL_SGPR_ROT, K_ITEM_SGPR, K_COUNT };
+            K_STEP_MIX, K_PK_FMA, K_MUL_SGPR_ROT, K_ITEM_SGPR, K_ITEM_SGPR_R2, K_COUNT };
 
 static const char *kNames[K_COUNT] = {
     "v_mul_f32 (VGPR x VGPR, independent)", "v_add_f32 (independent)", "v_mul_f32 (SGPR x VGPR, independent)", "v_fma_f32 (independent)",
     "v_pk_mul_f32 (VGPR pairs, independent)", "v_pk_add_f32 (VGPR pairs, independent)", "v_pk_mul_f32 (SGPR pair x VGPR pair, op_sel_hi:[0,1])",
     "v_cmp_lt_f32_e64 -> SGPR pair", "v_cndmask_b32 (vcc)", "v_sqrt_f32 (independent)", "v_add_f32 (dependent chain)",
     "alternating v_mul_f32 / s_add_u32", "traversal-step mix: 10 VALU + 12 SALU per 22", "v_pk_fma_f32 (VGPR pairs, independent)",
-    "v_mul_f32 (a DIFFERENT SGPR x VGPR each instruction, independent)", "flat-scan item: 8 dependent VOP2, 5 distinct SGPR operands" };
+    "v_mul_f32 (a DIFFERENT SGPR x VGPR each instruction, independent)", "flat-scan item: 8 dependent VOP2, 5 distinct SGPR operands",
+    "flat-scan item for TWO rays per lane: 16 VOP2, each SGPR operand used by two consecutive instructions" };
 // vector instructions per 64-instruction block (the rest are scalar)
-static const int kValuPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 32, 30, 64, 64, 64 };
-static const int kInstPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 66, 64, 64, 64 };
+static const int kValuPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 32, 30, 64, 64, 64, 64 };
+static const int kInstPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 66, 64, 64, 64, 64 };
 
 #define R8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
 #define R64(M) R8(M) R8(M) R8(M) R8(M) R8(M) R8(M) R8(M) R8(M)
@@ -76,6 +77,13 @@ static const int kInstPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 
 // one item of the scalar-fed flat scan (rt_flat_rot.hpp): b = (vx*dx + vy*dy) + vz*dz ; disc = (b*b - vv) + rr
 #define I_ITEM(k) "v_mul_f32_e32 %0, s20, %5\n" "v_mul_f32_e32 %1, s21, %6\n" "v_mul_f32_e32 %2, s22, %7\n" "v_add_f32_e32 %0, %0, %1\n" \
                   "v_add_f32_e32 %3, %0, %2\n" "v_mul_f32_e32 %0, %3, %3\n" "v_subrev_f32_e32 %0, s23, %0\n" "v_add_f32_e32 %4, s24, %0\n"
+
+// the same item for two rays per lane (ray A in %0..%3, ray B in %4..%7 as temporaries; directions shared for the probe)
+#define I_ITEM2(k) "v_mul_f32_e32 %0, s20, %8\n" "v_mul_f32_e32 %4, s20, %8\n" "v_mul_f32_e32 %1, s21, %8\n" "v_mul_f32_e32 %5, s21, %8\n" \
+                   "v_mul_f32_e32 %2, s22, %8\n" "v_mul_f32_e32 %6, s22, %8\n" "v_add_f32_e32 %0, %0, %1\n" "v_add_f32_e32 %4, %4, %5\n"   \
+                   "v_add_f32_e32 %3, %0, %2\n" "v_add_f32_e32 %7, %4, %6\n" "v_mul_f32_e32 %0, %3, %3\n" "v_mul_f32_e32 %4, %7, %7\n"     \
+                   "v_subrev_f32_e32 %0, s23, %0\n" "v_subrev_f32_e32 %4, s23, %4\n" "v_add_f32_e32 %1, s24, %0\n" "v_add_f32_e32 %5, s24, %4\n"
+#define R4(M) M(0) M(1) M(2) M(3)
 
 struct Rec { unsigned long long cycles, ref100; unsigned hw_id, xcc; };
 
@@ -123,6 +131,9 @@ __global__ __launch_bounds__(1024) void k_probe(int iters, Rec *rec, float *sink
                          : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
         else if constexpr (KIND == K_ITEM_SGPR)
             asm volatile(R8(I_ITEM) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone)
+                         : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+        else if constexpr (KIND == K_ITEM_SGPR_R2)
+            asm volatile(R4(I_ITEM2) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone)
                          : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
         else if constexpr (KIND == K_STEP_MIX)
             asm volatile(R3(I_STEP)
@@ -212,6 +223,7 @@ int main()
     run_kind<K_STEP_MIX>(n_cu, d_rec, d_sink, false);
     run_kind<K_MUL_SGPR_ROT>(n_cu, d_rec, d_sink, false);
     run_kind<K_ITEM_SGPR>(n_cu, d_rec, d_sink, false);
+    run_kind<K_ITEM_SGPR_R2>(n_cu, d_rec, d_sink, false);
     printf("\n ]}\n");
     CHECK(hipFree(d_rec)); CHECK(hipFree(d_sink));
     return 0;
