@@ -85,7 +85,9 @@ typedef struct rt_stats {
     uint64_t tests_executed;/* ray x record tests the kernels actually ran: SKIP = sphere_tests + bound_tests;
                                FLAT = primary * n_items + (shadow rays) * first chunk + (survivors) * rest --
                                the any-hit passes stop early, so FLAT's figure is below sphere_tests         */
-    double device_ms;       /* hipEvent time of all kernels of this call on its stream       */
+    double device_ms;       /* hipEvent time of all kernels of this call on its stream.  A call that asks for
+                               stats runs the counting flavour of the kernels (same bytes, about 2.5x slower):
+                               it is not the product's speed -- time calls without stats with your own events */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;   /* opaque: device copies of a Scene (render.rs:138-142) */
