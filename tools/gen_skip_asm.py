@@ -181,10 +181,9 @@ class F32(Prec):
         a.op("s_and_b64 vcc, vcc, %s" % self.M56, "go")
 
     def item_update(self, a, c):
-        a.op("s_mov_b64 exec, vcc", "primitive.rs:80-83")
-        a.op("v_mov_b32_e32 %[best], %[t4]")
-        a.op("v_mov_b32_e32 %%[bitem], %s" % self.item(c))
-        a.op("s_mov_b64 exec, %s" % self.EX)
+        a.op("v_mov_b32_e32 %%[t0], %s" % self.item(c), "(a VOP3 may read one scalar source: vcc is it)")
+        a.op("v_cndmask_b32_e32 %[best], %[best], %[t4], vcc", "primitive.rs:80-83")
+        a.op("v_cndmask_b32_e32 %[bitem], %[bitem], %[t0], vcc")
 
     def shadow_t2_negative(self, a):
         a.op("v_cmp_gt_f32_e64 %s, 0, %%[b]" % self.M54, "b < 0: t2 may still be negative")
@@ -383,8 +382,7 @@ def primary_copy(P, name, fused):
     # BOUND (group.rs:73)
     P.root(k, "vcc", lab("brooted"), lab("btiny"))
     P.primary_distance(k)
-    k.op("s_cmp_eq_u64 vcc, 0")
-    k.op("s_cbranch_scc1 %s" % lab("skip"), "nobody enters (the lanes that culled it are awake again at `skip`)")
+    k.op("s_cbranch_vccz %s" % lab("skip"), "nobody enters (the lanes that culled it are awake again at `skip`)")
     enter_group(k, P, c, n)
     sleep_culled(k, P, c)
     if fused:
@@ -438,8 +436,7 @@ def shadow_copy(P, name, fused):
     kind_test(k, P, c, lab)
     # BOUND: hit.distance is INF, so a bound culls iff the ray misses it
     shadow_decide(k, P, lab, "b")
-    k.op("s_cmp_eq_u64 vcc, 0")
-    k.op("s_cbranch_scc1 %s" % lab("skip"))
+    k.op("s_cbranch_vccz %s" % lab("skip"))
     enter_group(k, P, c, n)
     sleep_culled(k, P, c)
     if fused:
@@ -449,8 +446,7 @@ def shadow_copy(P, name, fused):
         k.op("s_and_b64 vcc, vcc, %s" % P.ACT)
         k.op("s_cbranch_vccz %s" % lab("next"))
         shadow_decide(k, P, lab, "f")
-        k.op("s_cmp_eq_u64 vcc, 0")
-        k.op("s_cbranch_scc1 %s" % lab("next"))
+        k.op("s_cbranch_vccz %s" % lab("next"))
         k.op("s_branch .Lrt_fin_%=", "any hit ends those rays; hand them to the caller")
     k.label(lab("next"))
     emit_next(k, P, name)
@@ -461,8 +457,7 @@ def shadow_copy(P, name, fused):
     k.op("s_bitcmp1_b32 %s, 30" % P.item(c))
     k.op("s_cbranch_scc1 .Lrt_exit_%=", "END: every lane is awake here and hits it")
     shadow_decide(k, P, lab, "i")
-    k.op("s_cmp_eq_u64 vcc, 0")
-    k.op("s_cbranch_scc1 %s" % lab("skip"), "an ITEM's `skip` is the node behind it")
+    k.op("s_cbranch_vccz %s" % lab("skip"), "an ITEM's `skip` is the node behind it")
     k.op("s_branch .Lrt_fin_%=")
     P.tiny(k, lab("itiny"), lab("irooted"))
     return m, k
