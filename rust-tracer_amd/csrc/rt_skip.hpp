@@ -154,9 +154,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     // `order` (optional): block descriptors in dispatch order, most expensive block first -- a pass is as long as its last
     // wave, so the long chains must not be the ones dispatched last (rt_capi.hip, block_order).  Without it the workgroup
     // finds its block in the tile table.  `wg_first` (optional, with `order`): workgroup w renders the descriptors
-    // [wg_first[w], wg_first[w + 1]) one after the other -- a pass of more blocks than the chip holds workgroups is dealt out
-    // on the host (longest first, to the least loaded workgroup), every workgroup is resident from the start and nothing
-    // waits for the dispatcher (sustained, it starts ~190 workgroups per microsecond: 43 us for the 8,181 of a 1080p frame).
+    // [wg_first[w], wg_first[w + 1]) one after the other: sample-parallel passes of more than 32,768 workgroups are dealt out
+    // on the host, about eight descriptors to a workgroup, longest first to the least loaded one (rt_capi.hip, block_order).
     unsigned d_first = blockIdx.x, d_last = blockIdx.x + 1;
     if (order && wg_first) { d_first = wg_first[blockIdx.x]; d_last = wg_first[blockIdx.x + 1]; }
     for (unsigned di = d_first; di < d_last; ++di) {
