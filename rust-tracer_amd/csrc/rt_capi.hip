@@ -5,6 +5,7 @@
 #include "rt_debug.h"
 #include "rt_kernels.hpp"
 #include "rt_skip.hpp"
+#include "rt_skip2.hpp"
 #include "rt_flat.hpp"
 #include "rt_flat_wf.hpp"
 #include "rt_flat_sc.hpp"
@@ -32,7 +33,7 @@ namespace {
 thread_local char g_err[512] = "";
 
 // Diagnostic controls (rt_debug.h): process-wide, -1 = default.  The library reads no environment variable.
-std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
+std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
 std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = { {0}, {0} };
 std::atomic<bool> g_trace_on{ false };
 std::mutex g_trace_mu;
@@ -426,6 +427,12 @@ bool packed_samples(unsigned spp)
     return (spp == 2 || spp == 4 || spp == 8) && knob(RT_DEBUG_PACKED_SAMPLES) != 0;
 }
 
+// Two rays per lane (rt_skip2.hpp) unless csrc/rt_debug.h RT_DEBUG_SKIP_RAYS says otherwise: for passes over at least 4 M pixels.
+// Measured: 3840x2160 spp 1 0.184 -> 0.173 ms, 4096x4096 spp 4 level 9 4.10 -> 3.84 ms; but a 1080p frame is as
+// long as its heaviest waves, and a wave of 128 rays walks the union of more paths: 54.8 -> 64.4 us (`make image`, 0.79 M
+// pixels: 0.289 -> 0.296 ms).
+bool skip2_by_default(uint64_t total_px) { return total_px >= (4ull << 20); }
+
 constexpr size_t kMaxCachedTables = 32;
 
 // Device copy of `tab`: from the scene's cache when seen before (or cacheable now), else through the context.
@@ -738,14 +745,16 @@ rt_status launch_flat_wavefront(const rt_scene *s, Context *c, hipStream_t strea
     const dim3 b(rt::kBlockThreads);
     if constexpr (sizeof(T) == 4) {
         if (knob(RT_DEBUG_FLAT_KERNELS) != 0) {
-            // f32: the scalar-fed scan (rt_flat_sc.hpp): one ray per lane, 16x16-pixel workgroups (the resolve table serves both)
+            // f32: the scalar-fed scan (rt_flat_sc.hpp): two rays per lane, a workgroup = two 16x16-pixel blocks of two waves each (the resolve table serves both)
             constexpr unsigned kFirstPassGroups = 342;                  // the 1,026 largest spheres (an even number of groups)
             const rt::FlatScView sv = flat_sc_view_of(s);
             const unsigned first_bytes = std::min(kFirstPassGroups * 64u, sv.n_bytes);
             c->flat_first_pass_items = first_bytes / 64u * rt::kFlatGroupItems;
-            hipLaunchKernelGGL(rt::k_flat_primary_sc, dim3(blocks16, (unsigned)ns), b, 0, stream, sv, w, h, spp, d_tab16, nt, sb, q1, c->d_queues, cnt);
+            hipLaunchKernelGGL(rt::k_flat_primary_sc, dim3((blocks16 + 1) / 2, (unsigned)ns), dim3(rt::kFlatScPrimaryThreads), 0, stream, sv, w, h, spp,
+                               d_tab16, nt, blocks16, sb, q1, c->d_queues, cnt);
             HIP_TRY(hipGetLastError());
-            const dim3 gsh((unsigned)((samples + rt::kBlockThreads - 1) / rt::kBlockThreads));      // worst case; surplus waves leave at once
+            const size_t rays_per_wg = (size_t)rt::kBlockThreads * rt::kFlatScRays;
+            const dim3 gsh((unsigned)((samples + rays_per_wg - 1) / rays_per_wg));      // worst case; surplus waves leave at once
             hipLaunchKernelGGL(rt::k_flat_shadow_sc, gsh, b, 0, stream, sv, 0u, first_bytes, q1, &c->d_queues->n1, q2, &c->d_queues->n2, sb, cnt);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(rt::k_flat_shadow_sc, gsh, b, 0, stream, sv, first_bytes, 0xFFFFFF80u, q2, &c->d_queues->n2,
@@ -802,7 +811,22 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
         no_cost = tr.d;
     }
     rt::SampleBuf<T> sb{ nullptr, nullptr, (unsigned)total_px };
+    // two rays per lane (rt_skip2.hpp): f32, fused assembly loops, launches that neither count nor trace
+    bool two_rays = false;
+    if constexpr (!COUNT && VAR == 7 && sizeof(T) == 4) {
+        const long long k = knob(RT_DEBUG_SKIP_RAYS);
+        two_rays = k < 0 ? skip2_by_default(total_px) : k == 2;
+        two_rays = two_rays && (spp == 1 || (use_split(spp) && packed_samples(spp)));
+    }
+    const dim3 b2(rt::kSkip2Threads);
     if (!use_split(spp)) {
+        if constexpr (!COUNT && VAR == 7 && sizeof(T) == 4) {
+            if (two_rays) {
+                hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipOne>), rgrid, b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt, d_out, sb, frame_w,
+                                   order.d, order.wg_first);
+                return RT_OK;
+            }
+        }
         if (spp == 1)
             hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipOne>), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
                                frame_w, order.d, no_cost, order.wg_first);
@@ -819,7 +843,16 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     sb.gdot = static_cast<T *>(c->d_sample_gdot);
     sb.state = c->d_sample_state;
     const bool packed = packed_samples(spp);
-    if (packed)
+    bool done2 = false;
+    if constexpr (!COUNT && VAR == 7 && sizeof(T) == 4) {
+        if (two_rays) {
+            hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipPacked>), dim3(rgrid.x, (unsigned)ns), b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt,
+                               d_out, sb, frame_w, order.d, order.wg_first);
+            done2 = true;
+        }
+    }
+    if (done2) {
+    } else if (packed)
         hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipPacked>), dim3(rgrid.x, (unsigned)ns), b, lds, stream, skip_view_of<T>(s), w, h, spp,
                            d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost, order.wg_first);
     else

@@ -66,68 +66,83 @@ __global__ void k_build_flat_groups(const Item<float> *__restrict__ items, const
     if (k == 0) { p[15] = 0.f; s[12] = s[13] = s[14] = s[15] = 0.f; }
 }
 
-__global__ __launch_bounds__(kBlockThreads) void k_flat_primary_sc(FlatScView sc, unsigned width, unsigned height, unsigned spp,
-                                                                  const TileDev *__restrict__ tiles, unsigned n_tiles, SampleBuf<float> sb,
-                                                                  Quad<float> *__restrict__ queue1, FlatQueues *__restrict__ queues,
-                                                                  Counters *__restrict__ counters)
+constexpr unsigned kFlatScRays = 2;                       // rays per lane (one VGPR pair per quantity)
+constexpr unsigned kFlatScPrimaryThreads = kBlockThreads;     // 4 waves = two 16x16 pixel blocks, one 16x8 patch per wave
+
+__global__ __launch_bounds__(kFlatScPrimaryThreads) void k_flat_primary_sc(FlatScView sc, unsigned width, unsigned height, unsigned spp,
+                                                                          const TileDev *__restrict__ tiles, unsigned n_tiles, unsigned n_blocks,
+                                                                          SampleBuf<float> sb, Quad<float> *__restrict__ queue1, FlatQueues *__restrict__ queues,
+                                                                          Counters *__restrict__ counters)
 {
     typedef float T;
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned blk = blockIdx.x * 2 + (threadIdx.x >> 7), wave = (threadIdx.x >> 6) & 1;      // waves are independent: no LDS, no barrier
+    if (blk >= n_blocks) return;
     unsigned lo = 0, hi = n_tiles - 1;
     while (lo < hi) {
         unsigned mid = (lo + hi + 1) >> 1;
-        if (tiles[mid].blk_first <= blockIdx.x) lo = mid; else hi = mid - 1;
+        if (tiles[mid].blk_first <= blk) lo = mid; else hi = mid - 1;
     }
     const TileDev tile = tiles[lo];
-    const unsigned lb = blockIdx.x - tile.blk_first;
-    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned x = tile.l + (lb % tile.blks_x) * kBlockW + (wave & 1) * 8 + (lane & 7);       // a wave = an 8x8 pixel patch
-    const unsigned y = tile.b + (lb / tile.blks_x) * kBlockH + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = x < tile.r && y < tile.t;
-    if (__ballot(inside) == 0) return;                                         // waves are independent: no LDS, no barrier
+    const unsigned lb = blk - tile.blk_first;
+    // a wave = a 16x8 pixel patch: ray h of a lane is the pixel 8h to the right of the lane's own
+    const unsigned x0 = tile.l + (lb % tile.blks_x) * kBlockW + (lane & 7);
+    const unsigned y = tile.b + (lb / tile.blks_x) * kBlockH + wave * 8 + (lane >> 3);
+    bool inside[kFlatScRays];
+    for (unsigned h = 0; h < kFlatScRays; ++h) inside[h] = x0 + 8 * h < tile.r && y < tile.t;
+    if (__ballot(inside[0]) == 0) return;
 
-    const unsigned ssx = blockIdx.y / spp, ssy = blockIdx.y % spp;            // one sample per thread (grid.y = spp*spp)
+    const unsigned ssx = blockIdx.y / spp, ssy = blockIdx.y % spp;            // one sample per ray (grid.y = spp*spp)
     const T ssf = T(spp);
     const T fw = T(width), fh = T(height);
     const T half_w = fw / T(2.0), half_h = fh / T(2.0);
     const V3<T> eye = sc.eye, light = sc.light;
-    const T xres = T(x) + T(ssx) / ssf;                                        // render.rs:238-243
-    const T yres = T(y) + T(ssy) / ssf;
-    const V3<T> dir = normalized(V3<T>{ xres - half_w, (fh - yres) - half_h, fw });
-
-    // ---------------- primary ray: nearest hit, strict `<`, first item in DFS order wins ties ----------------
-    T best;
-    unsigned best_i;
-    flat_primary_scan(sc.pg, sc.n_bytes, dir.x, dir.y, dir.z, best, best_i);
-
-    // ---------------- shade (render.rs:190-199), store the sample, queue the shadow ray ----------------
-    bool need_shadow = false;
-    T gdot = T(0.0);
-    V3<T> sp = { T(0.0), T(0.0), T(0.0) };
-    uint8_t state = kMiss;
-    unsigned c_hits = 0, c_shadow = 0;
-    if (inside && !(best == inf<T>())) {
-        ++c_hits;
-        const Item<T> it = sc.items[best_i];
-        const V3<T> c = { it.cx, it.cy, it.cz };
-        const V3<T> nrm = normalized(add(eye, sub(mulf(dir, best), c)));       // primitive.rs:83
-        gdot = dot(nrm, light);
-        if (gdot >= T(0.0)) {
-            state = kAmbient;
-        } else {
-            need_shadow = true;
-            ++c_shadow;
-            state = kLit;                                                       // until a shadow pass finds an occluder
-            const V3<T> ns = mulf(nrm, best * rsqrt_exact(eps<T>()));
-            sp = add(add(eye, mulf(dir, best)), ns);                            // render.rs:199
-        }
+    const T yres = T(y) + T(ssy) / ssf;                                        // render.rs:238-243
+    V3<T> dir[kFlatScRays];
+    T dx[kFlatScRays], dy[kFlatScRays], dz[kFlatScRays];
+    for (unsigned h = 0; h < kFlatScRays; ++h) {
+        const T xres = T(x0 + 8 * h) + T(ssx) / ssf;
+        dir[h] = normalized(V3<T>{ xres - half_w, (fh - yres) - half_h, fw });
+        dx[h] = dir[h].x; dy[h] = dir[h].y; dz[h] = dir[h].z;
     }
-    const unsigned q = blockIdx.y * sb.n_px + (unsigned)out_index(tile, x, y, 0);      // sample slot (tile-major pixel)
-    if (inside) { sb.state[q] = state; sb.gdot[q] = gdot; }
-    wave_append(need_shadow, Quad<T>{ sp.x, sp.y, sp.z, owner_to_real<T>(q) }, queue1, &queues->n1);
+
+    // ---------------- primary rays: nearest hit, strict `<`, first item in DFS order wins ties ----------------
+    T best[kFlatScRays];
+    unsigned best_i[kFlatScRays];
+    flat_primary_scan(sc.pg, sc.n_bytes, dx, dy, dz, best, best_i);
+
+    // ---------------- shade (render.rs:190-199), store the samples, queue the shadow rays ----------------
+    unsigned c_prim = 0, c_hits = 0, c_shadow = 0;
+    for (unsigned h = 0; h < kFlatScRays; ++h) {
+        const unsigned x = x0 + 8 * h;
+        bool need_shadow = false;
+        T gdot = T(0.0);
+        V3<T> sp = { T(0.0), T(0.0), T(0.0) };
+        uint8_t state = kMiss;
+        if (inside[h] && !(best[h] == inf<T>())) {
+            ++c_hits;
+            const Item<T> it = sc.items[best_i[h]];
+            const V3<T> c = { it.cx, it.cy, it.cz };
+            const V3<T> nrm = normalized(add(eye, sub(mulf(dir[h], best[h]), c)));     // primitive.rs:83
+            gdot = dot(nrm, light);
+            if (gdot >= T(0.0)) {
+                state = kAmbient;
+            } else {
+                need_shadow = true;
+                ++c_shadow;
+                state = kLit;                                                   // until a shadow pass finds an occluder
+                const V3<T> ns = mulf(nrm, best[h] * rsqrt_exact(eps<T>()));
+                sp = add(add(eye, mulf(dir[h], best[h])), ns);                  // render.rs:199
+            }
+        }
+        const unsigned q = blockIdx.y * sb.n_px + (unsigned)out_index(tile, x, y, 0);  // sample slot (tile-major pixel)
+        if (inside[h]) { sb.state[q] = state; sb.gdot[q] = gdot; ++c_prim; }
+        wave_append(need_shadow, Quad<T>{ sp.x, sp.y, sp.z, owner_to_real<T>(q) }, queue1, &queues->n1);
+    }
 
     if (counters) {
-        Counters *const stripe = counters + (blockIdx.x + blockIdx.y) % kCounterStripes;
-        const unsigned long long prim = wave_sum(inside ? 1u : 0u), hits = wave_sum(c_hits), sh = wave_sum(c_shadow);
+        Counters *const stripe = counters + (blk + blockIdx.y) % kCounterStripes;
+        const unsigned long long prim = wave_sum(c_prim), hits = wave_sum(c_hits), sh = wave_sum(c_shadow);
         if (lane == 0) {
             atomicAdd(&stripe->primary, prim);
             atomicAdd(&stripe->hits, hits);
@@ -136,8 +151,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_flat_primary_sc(FlatScView sc
     }
 }
 
-// One shadow pass: the rays of `queue_in` against the shadow groups [begin_bytes / 64, end_bytes / 64), any hit.  Occluded rays mark
-// their sample kShadowed; the others go to queue_out (or, in the last pass, stay kLit).
+// One shadow pass: the rays of `queue_in` against the shadow groups [begin_bytes / 64, end_bytes / 64), any hit; a wave takes
+// 128 consecutive queue entries (ray h of a lane is entry 64h + lane of them).  Occluded rays mark their sample kShadowed; the
+// others go to queue_out (or, in the last pass, stay kLit).
 __global__ __launch_bounds__(kBlockThreads) void k_flat_shadow_sc(FlatScView sc, unsigned begin_bytes, unsigned end_bytes,
                                                                  const Quad<float> *__restrict__ queue_in, const unsigned *__restrict__ n_in,
                                                                  Quad<float> *__restrict__ queue_out, unsigned *__restrict__ n_out, SampleBuf<float> sb,
@@ -145,25 +161,33 @@ __global__ __launch_bounds__(kBlockThreads) void k_flat_shadow_sc(FlatScView sc,
 {
     typedef float T;
     const unsigned n_rays = *n_in;
-    const unsigned idx = blockIdx.x * kBlockThreads + threadIdx.x;
-    const unsigned lane = threadIdx.x & 63;
-    const bool have = idx < n_rays;
-    if (__ballot(have) == 0) return;
-    V3<T> sp = { T(0.0), T(0.0), T(0.0) };
-    unsigned owner = 0;
-    if (have) {
-        const Quad<T> e = queue_in[idx];
-        sp = { e.x, e.y, e.z };
-        owner = real_to_owner(e.w);
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned first = (blockIdx.x * (kBlockThreads / 64) + wave) * (64 * kFlatScRays) + lane;
+    if (first - lane >= n_rays) return;                                        // wave-uniform: surplus waves leave at once
+    T ox[kFlatScRays], oy[kFlatScRays], oz[kFlatScRays];
+    unsigned owner[kFlatScRays], have[kFlatScRays], occluded[kFlatScRays];
+    for (unsigned h = 0; h < kFlatScRays; ++h) {
+        const unsigned idx = first + 64 * h;
+        have[h] = idx < n_rays ? 1u : 0u;
+        ox[h] = oy[h] = oz[h] = T(0.0);
+        owner[h] = 0;
+        occluded[h] = 0;
+        if (have[h]) {
+            const Quad<T> e = queue_in[idx];
+            ox[h] = e.x; oy[h] = e.y; oz[h] = e.z;
+            owner[h] = real_to_owner(e.w);
+        }
     }
     const V3<T> sdir = mulf(sc.light, T(-1.0));                                // render.rs:206
     const unsigned end = min(end_bytes, sc.n_bytes);
-    bool occluded = false;
     if (begin_bytes < end)
-        occluded = flat_shadow_scan(sc.sg, begin_bytes, end, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, have ? 1u : 0u) != 0u;
+        flat_shadow_scan(sc.sg, begin_bytes, end, ox, oy, oz, sdir.x, sdir.y, sdir.z, have, occluded);
     unsigned c_occ = 0;
-    if (have && occluded) { sb.state[owner] = kShadowed; ++c_occ; }            // render.rs:211-213
-    if (queue_out) wave_append(have && !occluded, Quad<T>{ sp.x, sp.y, sp.z, owner_to_real<T>(owner) }, queue_out, n_out);
+    for (unsigned h = 0; h < kFlatScRays; ++h) {
+        const bool occ = have[h] && occluded[h];
+        if (occ) { sb.state[owner[h]] = kShadowed; ++c_occ; }                  // render.rs:211-213
+        if (queue_out) wave_append(have[h] && !occ, Quad<T>{ ox[h], oy[h], oz[h], owner_to_real<T>(owner[h]) }, queue_out, n_out);
+    }
     if (counters) {
         Counters *const stripe = counters + blockIdx.x % kCounterStripes;
         const unsigned long long oc = wave_sum(c_occ);

@@ -63,6 +63,46 @@ def test_scaled_scenes_every_loop_flavour(scale, precision, variant):
         assert util.all_stats(st) == util.all_stats(rst)
 
 
+@pytest.mark.parametrize("seed", [2101, 2104, 2107, 2110, 2113, 2116, 2119, 2122])
+def test_two_rays_per_lane_walk_on_random_concentric_scenes(seed):
+    # k_render_skip2 (rt_skip2.hpp: two rays per lane on packed math, generated rt_skip2_rot.hpp) serves fused f32 scenes at spp 1 and
+    # the sample-packed spp 2 / 4 / 8; by default only large frames use it, csrc/rt_debug.h RT_DEBUG_SKIP_RAYS = 2 forces it.  Random
+    # concentric scenes, random eye (often inside bounds), ragged image sizes: pixels and alpha against the oracle, bytes against
+    # the one-ray kernel.
+    rng = np.random.default_rng(seed)
+    depth, fan, leaf = int(rng.integers(2, 6)), int(rng.integers(2, 5)), int(rng.integers(1, 4))
+    items, bounds, ranges = util.random_nested_scene(seed, depth=depth, fan=fan, leaf_items=leaf, concentric=True)
+    eye = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-4.5, -1.0)))
+    light = (float(rng.uniform(-2, 2)), float(rng.uniform(-3, -0.5)), float(rng.uniform(-2, 2)))
+    s, o = util.scene_pair_ranges(items, bounds, ranges, rta.RT_F32, light=light, eye=eye)
+    for spp in (1, 2, 4, 8):
+        w, h = int(rng.integers(2, 7)) * 32 + int(rng.integers(0, 17)), int(rng.integers(2, 5)) * 24 + int(rng.integers(0, 13))
+        regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
+        ref, rst, _ = o.render(w, h, spp, os.cpu_count() or 1, HIER_EXIT)
+        with rta.capi.debug(rta.capi.DEBUG_SKIP_RAYS, 2):
+            two, _ = s.device().render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
+        with rta.capi.debug(rta.capi.DEBUG_SKIP_RAYS, 1):
+            one, _ = s.device().render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
+        np.testing.assert_array_equal(util.stitch((w, h), regs, two), ref)
+        np.testing.assert_array_equal(two, one)
+
+
+@pytest.mark.parametrize("scale", [1e-20, 1e-10, 1e6, 5e13])
+def test_two_rays_per_lane_walk_on_scaled_scenes(scale):
+    # the exact path of the two-ray loops per half, including the scaled `tiny` branches (1e-20: every square is a denormal)
+    items, bounds, ranges = util.random_nested_scene(32, depth=3, fan=3, leaf_items=2, concentric=True)
+    sc = lambda a: (np.asarray(a, dtype=np.float64) * scale).astype(np.float32).astype(np.float64)
+    eye = tuple(float(v) for v in sc((0.07, -0.12, -3.1)))
+    s, o = util.scene_pair_ranges(sc(items), sc(bounds), ranges, rta.RT_F32, eye=eye)
+    for (w, h, spp) in ((96, 72, 2), (75, 50, 1), (40, 33, 4)):
+        regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
+        ref, rst, _ = o.render(w, h, spp, os.cpu_count() or 1, HIER_EXIT)
+        assert rst["hits"] > 200 and rst["shadow"] > 50
+        with rta.capi.debug(rta.capi.DEBUG_SKIP_RAYS, 2):
+            two, _ = s.device().render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
+        np.testing.assert_array_equal(util.stitch((w, h), regs, two), ref)
+
+
 def test_inputs_that_could_overflow_are_rejected():
     # the no-NaN argument rests on these bounds: coordinates and eye within 1e15, light a unit vector
     items = np.array([[0, 0, 0, 1.0]])

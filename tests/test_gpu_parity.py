@@ -878,6 +878,28 @@ def test_scalar_fed_flat_scan_on_tiny_discriminants():
     assert zlib.crc32(util.stitch((1920, 1080), regs, data).tobytes()) & 0xFFFFFFFF == case["frame_crc32"]
 
 
+@pytest.mark.parametrize("w,h,spp,level", [(1920, 1080, 1, 8), (1024, 768, 4, 8), (800, 600, 2, 8), (97, 64, 8, 4), (333, 217, 1, 6),
+                                           (2048, 2048, 4, 7), (2560, 1664, 1, 8)])
+def test_two_rays_per_lane_walk_on_the_default_scene(w, h, spp, level):
+    # k_render_skip2 against k_render_skip, byte for byte, on the reference's pyramid: cost-ordered and narrowed descriptors
+    # (1080p), the sample-packed modes, a ragged frame, a pass dealt out over workgroups (2048 x 2048 spp 4: 262,144 descriptors)
+    # and the library's own choice -- frames of 4 M pixels and more take the two-ray kernel without being asked
+    s = rta.Scene.default(level)
+    regs = bucket_list(w, h, spp)
+    d = s.device()
+    with rta.capi.debug(rta.capi.DEBUG_SKIP_RAYS, 1):
+        one, _ = d.render_tiles((w, h, spp), regs, SKIP, want_stats=False)
+        one = one.copy()
+    with rta.capi.debug(rta.capi.DEBUG_SKIP_RAYS, 2):
+        two, _ = d.render_tiles((w, h, spp), regs, SKIP, want_stats=False)
+        two = two.copy()
+    auto, _ = d.render_tiles((w, h, spp), regs, SKIP, want_stats=False)
+    assert np.array_equal(two, one) and np.array_equal(auto, one)
+    if (w, h, spp, level) == (1920, 1080, 1, 8):
+        case = next(c for c in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))["cases"] if c["name"] == "config3_1920x1080_f32")
+        assert zlib.crc32(util.stitch((w, h), regs, two).tobytes()) & 0xFFFFFFFF == case["frame_crc32"]
+
+
 def test_only_memory_this_library_pinned_is_written_by_the_kernel():
     # rt_render_tiles lets the kernel store into host memory only inside ranges rt_host_alloc / rt_host_register recorded.  The
     # runtime's own view (hipPointerGetAttributes) also lists ranges it locked for an earlier pageable copy, and such a record can

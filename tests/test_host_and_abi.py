@@ -166,7 +166,7 @@ def test_header_is_plain_c_and_the_library_links_from_c(tmp_path):
     assert ctypes.sizeof(capi.Options) == 6 and ctypes.sizeof(capi.Region) == 8 and ctypes.sizeof(capi.Range) == 8
 
 
-@pytest.mark.parametrize("name,header", [("gen_skip_asm", "rt_skip_rot.hpp"), ("gen_flat_asm", "rt_flat_rot.hpp")])
+@pytest.mark.parametrize("name,header", [("gen_skip_asm", "rt_skip_rot.hpp"), ("gen_skip2_asm", "rt_skip2_rot.hpp"), ("gen_flat_asm", "rt_flat_rot.hpp")])
 def test_generated_traversal_loops_are_up_to_date(tmp_path, name, header):
     # csrc/rt_skip_rot.hpp / rt_flat_rot.hpp are the output of tools/gen_*_asm.py: the committed header must be what the generator writes
     import importlib.util
@@ -191,7 +191,7 @@ def test_library_reads_no_environment_variable_and_keeps_diagnostics_out_of_the_
     hdr = open(os.path.join(ROOT, "include", "rtrace_hip.h")).read()
     assert "rt_debug" not in hdr
     assert capi.lib.rt_debug_set(999, 1) == capi.RT_ERR_INVALID_ARGUMENT
-    for key in range(12):
+    for key in range(13):
         assert capi.lib.rt_debug_set(key, -1) == capi.RT_OK
 
 

@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """Generates rust-tracer_amd/csrc/rt_flat_rot.hpp: the inner loops of the scalar-fed flat scan (rt_flat_sc.hpp) in gfx950
-assembly, f32.
+assembly, f32, TWO rays per lane on packed math.
 
-A linear scan is wave-uniform: all 64 rays of a wave test the same item at the same moment, so the items are scalars.  A group
+A linear scan is wave-uniform: all rays of a wave test the same item at the same moment, so the items are scalars.  A group
 of THREE items is one 64-byte record = one s_load_dwordx16 into one of two SGPR banks; the next group's load is issued before
-the current group's arithmetic, whose operands are the bank's SGPRs in plain 4-byte VOP2 instructions (1.46 cycles per wave at 8
-waves per SIMD, profiles/r02_valu_issue_probe.json; a packed v_pk_* is 2.55 for twice the lanes, LDS reads not counted).  The
-three discriminants are reduced with ONE v_max3_f32 and one branch rejects the group; the exact path (root, t2, t1, d, strict
-`<` against hit.distance, in item order) runs only when some lane's line meets one of the three spheres.
+the current group's arithmetic.  Every arithmetic instruction of a test reads a scalar operand it shares with no neighbour, and
+tools/valu_issue_probe.hip measured what that costs on gfx950 at 8 waves per SIMD: a VOP2 whose SGPR operand differs from the
+previous instruction's issues in 2.55 cycles, not 1.46 -- exactly what a packed v_pk_mul/add_f32 costs, whose SGPR operand
+(either half of an aligned pair, broadcast to both results with op_sel) is free on top.  So each lane carries two rays in
+VGPR pairs and one packed instruction does one operation of the test for both: 8 x 2.55 = 20.4 cycles per item and 128 rays
+against 14.4 per item and 64 rays for the VOP2 form (profiles/r02_valu_issue_probe.json, the last rows), and the scalar load,
+the wait and the branch of a group are shared by twice the rays.
 
-Per six items the loop issues 2 scalar loads + 48 (primary) / 96 (shadow) VOP2 + 2 v_max3 + 2 compares + 2 branches + 2 waits
-+ 3 loop instructions: 10.2 / 18.2 instructions per item and wave of rays.  hipcc's rendering of the same scan (groups of four,
-C++) spent 12.5 per item on the primary pass, 4.8 of them scalar.
+The three discriminants of both rays are reduced with two v_max3_f32 + one v_max_f32 and one branch rejects the group; the
+exact path (root, t2, t1, d, strict `<` against hit.distance, in item order) runs per ray on the 32-bit halves, only when some
+lane's line meets one of the three spheres.  The halves of a register pair have to be named, which inline-asm operands cannot
+do, so the loops own FIXED registers (v[32:63], s[36:77]; listed as clobbers -- the kernels around them need 20 VGPRs) and move
+their operands in and out.
 
-Arithmetic, operation for operation (primitive.rs:55-72; each + - * rounded once, no FMA outside the exact root):
+Arithmetic, operation for operation (primitive.rs:55-72; each + - * rounded once, no FMA outside the exact root; a packed
+subtraction is an addition with the IEEE sign flip of the neg modifier):
     primary   b = (vx*dx + vy*dy) + vz*dz ; disc = (b*b - vv) + rr            (v = c - eye, vv, rr pre-formed per item)
     shadow    v = c - o ; b = (v.x*l.x + v.y*l.y) + v.z*l.z ; vv = (v.x*v.x + v.y*v.y) + v.z*v.z ; disc = (b*b - vv) + rr
     exact     disc >= 0 ; root = correctly rounded sqrt(disc) (== sqrt_rn_lean) ; t2 = b + root >= 0 ; t1 = b - root ;
               d = t1 > 0 ? t1 : t2 ; primary: d < hit.distance -> hit.distance = d, item = index ; shadow: any hit retires the ray
+A shadow ray that is settled (or a lane half without a ray) gets a NaN origin: every discriminant it forms from then on is NaN,
+which is never `>= 0`, so it needs no mask of its own.
 
 Run:  python3 tools/gen_flat_asm.py   (writes the header; the build does not need this script)."""
 import os
@@ -27,7 +35,18 @@ OUT = os.path.join(ROOT, "rust-tracer_amd", "csrc", "rt_flat_rot.hpp")
 
 BANK = {"A": 36, "B": 52}            # s[36:51], s[52:67]
 OFF, IDX, EXS, TINY = "s68", "s69", "s[70:71]", "s[72:73]"
+LIGHT = 74                           # s74..s76: light direction of the shadow scan (s77 pads the pair)
 STRIDE = 64
+SGPR_LAST = 77
+VGPR_FIRST, VGPR_LAST = 32, 63
+
+
+class Pair:
+    """A VGPR pair: .p the pair, .h[0] / .h[1] its halves (ray 0 / ray 1)."""
+
+    def __init__(self, lo):
+        self.p = "v[%d:%d]" % (lo, lo + 1)
+        self.h = ("v%d" % lo, "v%d" % (lo + 1))
 
 
 class Asm:
@@ -51,165 +70,229 @@ class Asm:
 
 
 def sreg(bank, field, k):
-    """SGPR of item k's field (0..4) in a bank: fields are stored [field][item]."""
-    return "s%d" % (BANK[bank] + 3 * field + k)
+    """SGPR number of item k's field in a bank: fields are stored [field][item]."""
+    return BANK[bank] + 3 * field + k
+
+
+def pk(a, op, dst, x, y, sx=None, sy=None, neg_y=False, comment=None):
+    """dst = x op y on both rays.  sx / sy: SGPR NUMBER whose value is broadcast to both rays in place of a VGPR pair."""
+    sel, sel_hi = [0, 0], [1, 1]
+    if sx is not None:
+        x = "s[%d:%d]" % (sx & ~1, (sx & ~1) + 1)
+        sel[0] = sel_hi[0] = sx & 1
+    if sy is not None:
+        y = "s[%d:%d]" % (sy & ~1, (sy & ~1) + 1)
+        sel[1] = sel_hi[1] = sy & 1
+    mods = ""
+    if sel != [0, 0]:
+        mods += " op_sel:[%d,%d]" % tuple(sel)
+    if sel_hi != [1, 1]:
+        mods += " op_sel_hi:[%d,%d]" % tuple(sel_hi)
+    if neg_y:
+        mods += " neg_lo:[0,1] neg_hi:[0,1]"
+    a.op("v_pk_%s_f32 %s, %s, %s%s" % (op, dst, x, y, mods), comment)
 
 
 def load(a, bank, off, comment=None):
     a.op("s_load_dwordx16 s[%d:%d], %%[base], %s" % (BANK[bank], BANK[bank] + 15, off), comment)
 
 
-def refine(a, x):
-    a.op("v_mul_f32_e32 %%[root], %s, %%[t0]" % x, "g = x*y")
-    a.op("v_mul_f32_e32 %[t0], 0.5, %[t0]", "h = y/2")
-    a.op("v_fma_f32 %%[t1], -%%[root], %%[root], %s" % x, "r = x - g*g")
-    a.op("v_fma_f32 %[root], %[t1], %[t0], %[root]", "g + r*h")
+def refine(a, x, t0, t1, root):
+    a.op("v_mul_f32_e32 %s, %s, %s" % (root, x, t0), "g = x*y")
+    a.op("v_mul_f32_e32 %s, 0.5, %s" % (t0, t0), "h = y/2")
+    a.op("v_fma_f32 %s, -%s, %s, %s" % (t1, root, root, x), "r = x - g*g")
+    a.op("v_fma_f32 %s, %s, %s, %s" % (root, t1, t0, root), "g + r*h")
 
 
-def exact_root(a, disc, tag):
-    """Correctly rounded sqrt(disc) into %[root] for the lanes in EXEC (== sqrt_rn_lean)."""
-    a.op("v_rsq_f32_e32 %%[t0], %s" % disc)
+def exact_root(a, disc, tag, r):
+    """Correctly rounded sqrt(disc) into r.root for the lanes in EXEC (== sqrt_rn_lean)."""
+    a.op("v_rsq_f32_e32 %s, %s" % (r.t0, disc))
     a.op("v_cmp_lt_f32_e64 %s, |%s|, %%[tiny]" % (TINY, disc))
     a.op("s_cmp_lg_u64 %s, 0" % TINY)
     a.op("s_cbranch_scc1 .Lfl_tiny_%s_%%=" % tag, "a lane below 2^-96 (zero included): scaled path")
-    refine(a, disc)
+    refine(a, disc, r.t0, r.t1, r.root)
     a.label(".Lfl_rooted_%s_%%=" % tag)
 
 
-def exact_tiny(a, disc, tag):
+def exact_tiny(a, disc, tag, r):
     a.label(".Lfl_tiny_%s_%%=" % tag)
-    a.op("v_mul_f32_e32 %%[t0], 0x4f800000, %s" % disc, "root with the 2^32 / 2^-16 scaling for tiny lanes")
-    a.op("v_cndmask_b32_e64 %%[t2], %s, %%[t0], %s" % (disc, TINY))
-    a.op("v_rsq_f32_e32 %[t0], %[t2]")
-    a.op("v_cmp_eq_f32_e32 vcc, 0, %[t2]", "sqrt(+-0) = +-0 (rsq would make it 0 * inf)")
-    refine(a, "%[t2]")
-    a.op("v_cndmask_b32_e32 %[root], %[root], %[t2], vcc")
-    a.op("v_mul_f32_e32 %[t0], 0x37800000, %[root]")
-    a.op("v_cndmask_b32_e64 %%[root], %%[root], %%[t0], %s" % TINY)
+    a.op("v_mul_f32_e32 %s, 0x4f800000, %s" % (r.t0, disc), "root with the 2^32 / 2^-16 scaling for tiny lanes")
+    a.op("v_cndmask_b32_e64 %s, %s, %s, %s" % (r.t2, disc, r.t0, TINY))
+    a.op("v_rsq_f32_e32 %s, %s" % (r.t0, r.t2))
+    a.op("v_cmp_eq_f32_e32 vcc, 0, %s" % r.t2, "sqrt(+-0) = +-0 (rsq would make it 0 * inf)")
+    refine(a, r.t2, r.t0, r.t1, r.root)
+    a.op("v_cndmask_b32_e32 %s, %s, %s, vcc" % (r.root, r.root, r.t2))
+    a.op("v_mul_f32_e32 %s, 0x37800000, %s" % (r.t0, r.root))
+    a.op("v_cndmask_b32_e64 %s, %s, %s, %s" % (r.root, r.root, r.t0, TINY))
     a.op("s_branch .Lfl_rooted_%s_%%=" % tag)
 
 
-def primary_group(a, bank):
-    for k in range(3):
-        b, d = "%%[b%d]" % k, "%%[d%d]" % k
-        a.op("v_mul_f32_e32 %%[t0], %s, %%[dx]" % sreg(bank, 0, k), "item %d: b = (vx*dx + vy*dy) + vz*dz" % k if k == 0 else None)
-        a.op("v_mul_f32_e32 %%[t1], %s, %%[dy]" % sreg(bank, 1, k))
-        a.op("v_mul_f32_e32 %%[t2], %s, %%[dz]" % sreg(bank, 2, k))
-        a.op("v_add_f32_e32 %[t0], %[t0], %[t1]")
-        a.op("v_add_f32_e32 %s, %%[t0], %%[t2]" % b)
-        a.op("v_mul_f32_e32 %%[t0], %s, %s" % (b, b), "disc = (b*b - vv) + rr" if k == 0 else None)
-        a.op("v_subrev_f32_e32 %%[t0], %s, %%[t0]" % sreg(bank, 3, k))
-        a.op("v_add_f32_e32 %s, %s, %%[t0]" % (d, sreg(bank, 4, k)))
-    a.op("v_max3_f32 %[t0], %[d0], %[d1], %[d2]")
-    a.op("v_cmp_le_f32_e32 vcc, 0, %[t0]")
-    a.op("s_cbranch_vccnz .Lfl_slow_%s_%%=" % bank, "some lane's line meets one of the three spheres")
+def any_candidate(a, r, bank):
+    """One branch for the group: does any ray of the wave have disc >= 0 for any of the three items?"""
+    m = r.T0.h[0]
+    a.op("v_max3_f32 %s, %s, %s, %s" % (m, r.D[0].h[0], r.D[1].h[0], r.D[2].h[0]))
+    a.op("v_max3_f32 %s, %s, %s, %s" % (m, m, r.D[0].h[1], r.D[1].h[1]))
+    a.op("v_max_f32_e32 %s, %s, %s" % (m, m, r.D[2].h[1]))
+    a.op("v_cmp_le_f32_e32 vcc, 0, %s" % m)
+    a.op("s_cbranch_vccnz .Lfl_slow_%s_%%=" % bank, "some ray's line meets one of the three spheres")
     a.label(".Lfl_cont_%s_%%=" % bank)
 
 
-def primary_slow(a, bank):
+# ------------------------------------------------------------------------------------------------------------------ primary
+
+class PrimaryRegs:
+    def __init__(self):
+        v = VGPR_FIRST
+        self.DX, self.DY, self.DZ = Pair(v), Pair(v + 2), Pair(v + 4)
+        self.BEST, self.BITEM = Pair(v + 6), Pair(v + 8)
+        self.T0, self.T1, self.T2 = Pair(v + 10), Pair(v + 12), Pair(v + 14)
+        self.B = [Pair(v + 16), Pair(v + 18), Pair(v + 20)]
+        self.D = [Pair(v + 22), Pair(v + 24), Pair(v + 26)]
+        self.root = "v%d" % (v + 28)
+        # 32-bit temporaries of the exact path: the halves of T0 / T1 are free once the group's arithmetic is done
+        self.t0, self.t1, self.t2 = self.T0.h[0], self.T0.h[1], self.T1.h[0]
+
+
+def primary_group(a, bank, r):
+    for k in range(3):
+        pk(a, "mul", r.T0.p, None, r.DX.p, sx=sreg(bank, 0, k), comment="item %d: b = (vx*dx + vy*dy) + vz*dz, both rays" % k if k == 0 else None)
+        pk(a, "mul", r.T1.p, None, r.DY.p, sx=sreg(bank, 1, k))
+        pk(a, "mul", r.T2.p, None, r.DZ.p, sx=sreg(bank, 2, k))
+        pk(a, "add", r.T0.p, r.T0.p, r.T1.p)
+        pk(a, "add", r.B[k].p, r.T0.p, r.T2.p)
+        pk(a, "mul", r.T0.p, r.B[k].p, r.B[k].p, comment="disc = (b*b - vv) + rr" if k == 0 else None)
+        pk(a, "add", r.T0.p, r.T0.p, None, sy=sreg(bank, 3, k), neg_y=True)
+        pk(a, "add", r.D[k].p, None, r.T0.p, sx=sreg(bank, 4, k))
+    any_candidate(a, r, bank)
+
+
+def primary_slow(a, bank, r):
     a.label(".Lfl_slow_%s_%%=" % bank)
     a.op("s_lshr_b32 %s, %s, 6" % (IDX, OFF), "index of the group's first item: 3 * (offset / 64)%s" % (" + 3" if bank == "B" else ""))
     a.op("s_mul_i32 %s, %s, 3" % (IDX, IDX))
     if bank == "B":
         a.op("s_add_u32 %s, %s, 3" % (IDX, IDX))
     for k in range(3):
-        tag = "%s%d" % (bank, k)
-        b, d = "%%[b%d]" % k, "%%[d%d]" % k
-        a.op("v_cmp_le_f32_e32 vcc, 0, %s" % d, "item %d, in item order (primitive.rs:79: the first one keeps a tie)" % k)
-        a.op("s_and_saveexec_b64 %s, vcc" % EXS)
-        a.op("s_cbranch_execz .Lfl_next_%s_%%=" % tag)
-        exact_root(a, d, tag)
-        a.op("v_add_f32_e32 %%[t0], %s, %%[root]" % b, "t2")
-        a.op("v_sub_f32_e32 %%[t1], %s, %%[root]" % b, "t1")
-        a.op("v_cmp_lt_f32_e32 vcc, 0, %[t1]")
-        a.op("v_cndmask_b32_e32 %[t1], %[t0], %[t1], vcc", "d = t1 > 0 ? t1 : t2")
-        a.op("v_cmpx_le_f32_e32 0, %[t0]", "t2 >= 0")
-        a.op("v_cmpx_lt_f32_e32 %[t1], %[best]", "d < hit.distance")
-        a.op("v_mov_b32_e32 %[best], %[t1]", "primitive.rs:80-83")
-        a.op("v_mov_b32_e32 %%[bitem], %s" % IDX)
-        a.label(".Lfl_next_%s_%%=" % tag)
-        a.op("s_mov_b64 exec, %s" % EXS)
+        for h in range(2):
+            tag = "%s%d%d" % (bank, k, h)
+            b, d, best, bitem = r.B[k].h[h], r.D[k].h[h], r.BEST.h[h], r.BITEM.h[h]
+            a.op("v_cmp_le_f32_e32 vcc, 0, %s" % d, "item %d, ray %d, in item order (primitive.rs:79: the first one keeps a tie)" % (k, h))
+            a.op("s_and_saveexec_b64 %s, vcc" % EXS)
+            a.op("s_cbranch_execz .Lfl_next_%s_%%=" % tag)
+            exact_root(a, d, tag, r)
+            a.op("v_add_f32_e32 %s, %s, %s" % (r.t0, b, r.root), "t2")
+            a.op("v_sub_f32_e32 %s, %s, %s" % (r.t1, b, r.root), "t1")
+            a.op("v_cmp_lt_f32_e32 vcc, 0, %s" % r.t1)
+            a.op("v_cndmask_b32_e32 %s, %s, %s, vcc" % (r.t1, r.t0, r.t1), "d = t1 > 0 ? t1 : t2")
+            a.op("v_cmpx_le_f32_e32 0, %s" % r.t0, "t2 >= 0")
+            a.op("v_cmpx_lt_f32_e32 %s, %s" % (r.t1, best), "d < hit.distance")
+            a.op("v_mov_b32_e32 %s, %s" % (best, r.t1), "primitive.rs:80-83")
+            a.op("v_mov_b32_e32 %s, %s" % (bitem, IDX))
+            a.label(".Lfl_next_%s_%%=" % tag)
+            a.op("s_mov_b64 exec, %s" % EXS)
         if k < 2:
             a.op("s_add_u32 %s, %s, 1" % (IDX, IDX))
     a.op("s_branch .Lfl_cont_%s_%%=" % bank)
     for k in range(3):
-        exact_tiny(a, "%%[d%d]" % k, "%s%d" % (bank, k))
+        for h in range(2):
+            exact_tiny(a, r.D[k].h[h], "%s%d%d" % (bank, k, h), r)
 
 
-def shadow_group(a, bank):
+# ------------------------------------------------------------------------------------------------------------------- shadow
+
+class ShadowRegs:
+    def __init__(self):
+        v = VGPR_FIRST
+        self.OX, self.OY, self.OZ = Pair(v), Pair(v + 2), Pair(v + 4)
+        self.VX, self.VY, self.VZ = Pair(v + 6), Pair(v + 8), Pair(v + 10)
+        self.T0, self.T1 = Pair(v + 12), Pair(v + 14)
+        self.B = [Pair(v + 16), Pair(v + 18), Pair(v + 20)]
+        self.D = [Pair(v + 22), Pair(v + 24), Pair(v + 26)]
+        self.OCC = Pair(v + 28)
+        self.root = "v%d" % (v + 30)
+        self.t0, self.t1, self.t2 = self.T0.h[0], self.T0.h[1], self.T1.h[0]
+
+
+def shadow_group(a, bank, r):
     for k in range(3):
-        b, d = "%%[b%d]" % k, "%%[d%d]" % k
-        a.op("v_sub_f32_e32 %%[vx], %s, %%[ox]" % sreg(bank, 0, k), "item %d: v = centre - origin" % k if k == 0 else None)
-        a.op("v_sub_f32_e32 %%[vy], %s, %%[oy]" % sreg(bank, 1, k))
-        a.op("v_sub_f32_e32 %%[vz], %s, %%[oz]" % sreg(bank, 2, k))
-        a.op("v_mul_f32_e32 %[t0], %[lx], %[vx]")
-        a.op("v_mul_f32_e32 %[t1], %[ly], %[vy]")
-        a.op("v_mul_f32_e32 %[t2], %[lz], %[vz]")
-        a.op("v_add_f32_e32 %[t0], %[t0], %[t1]")
-        a.op("v_add_f32_e32 %s, %%[t0], %%[t2]" % b, "b = dot(v, dir)" if k == 0 else None)
-        a.op("v_mul_f32_e32 %[t0], %[vx], %[vx]")
-        a.op("v_mul_f32_e32 %[t1], %[vy], %[vy]")
-        a.op("v_mul_f32_e32 %[t2], %[vz], %[vz]")
-        a.op("v_add_f32_e32 %[t0], %[t0], %[t1]")
-        a.op("v_add_f32_e32 %[t0], %[t0], %[t2]", "dot(v, v)" if k == 0 else None)
-        a.op("v_mul_f32_e32 %%[t1], %s, %s" % (b, b))
-        a.op("v_sub_f32_e32 %[t0], %[t1], %[t0]")
-        a.op("v_add_f32_e32 %s, %s, %%[t0]" % (d, sreg(bank, 3, k)), "disc = (b*b - vv) + rr" if k == 0 else None)
-    a.op("v_max3_f32 %[t0], %[d0], %[d1], %[d2]")
-    a.op("v_cmp_le_f32_e32 vcc, 0, %[t0]")
-    a.op("s_cbranch_vccnz .Lfl_slow_%s_%%=" % bank)
-    a.label(".Lfl_cont_%s_%%=" % bank)
+        pk(a, "add", r.VX.p, None, r.OX.p, sx=sreg(bank, 0, k), neg_y=True, comment="item %d: v = centre - origin, both rays" % k if k == 0 else None)
+        pk(a, "add", r.VY.p, None, r.OY.p, sx=sreg(bank, 1, k), neg_y=True)
+        pk(a, "add", r.VZ.p, None, r.OZ.p, sx=sreg(bank, 2, k), neg_y=True)
+        pk(a, "mul", r.T0.p, None, r.VX.p, sx=LIGHT + 0)
+        pk(a, "mul", r.T1.p, None, r.VY.p, sx=LIGHT + 1)
+        pk(a, "add", r.T0.p, r.T0.p, r.T1.p)
+        pk(a, "mul", r.T1.p, None, r.VZ.p, sx=LIGHT + 2)
+        pk(a, "add", r.B[k].p, r.T0.p, r.T1.p, comment="b = dot(v, dir)" if k == 0 else None)
+        pk(a, "mul", r.VX.p, r.VX.p, r.VX.p)
+        pk(a, "mul", r.VY.p, r.VY.p, r.VY.p)
+        pk(a, "add", r.VX.p, r.VX.p, r.VY.p)
+        pk(a, "mul", r.VZ.p, r.VZ.p, r.VZ.p)
+        pk(a, "add", r.VX.p, r.VX.p, r.VZ.p, comment="dot(v, v)" if k == 0 else None)
+        pk(a, "mul", r.T0.p, r.B[k].p, r.B[k].p)
+        pk(a, "add", r.T0.p, r.T0.p, r.VX.p, neg_y=True)
+        pk(a, "add", r.D[k].p, None, r.T0.p, sx=sreg(bank, 3, k), comment="disc = (b*b - vv) + rr" if k == 0 else None)
+    any_candidate(a, r, bank)
 
 
-def shadow_slow(a, bank):
-    """EXEC = the rays still pending.  A ray that hits any of the three items retires: flagged and taken out of EXEC."""
+def shadow_slow(a, bank, r):
+    """A ray that hits any of the three items is settled: flagged, and its origin becomes NaN.  A lane whose two rays are both
+    settled leaves EXEC; the wave leaves the scan when EXEC is empty."""
     a.label(".Lfl_slow_%s_%%=" % bank)
     for k in range(3):
-        tag = "%s%d" % (bank, k)
-        b, d = "%%[b%d]" % k, "%%[d%d]" % k
-        a.op("v_cmp_le_f32_e32 vcc, 0, %s" % d, "item %d: disc >= 0 among the pending rays" % k)
-        a.op("s_and_saveexec_b64 %s, vcc" % EXS)
-        a.op("s_cbranch_execz .Lfl_next_%s_%%=" % tag)
-        exact_root(a, d, tag)
-        a.op("v_add_f32_e32 %%[t0], %s, %%[root]" % b, "t2")
-        a.op("v_cmp_le_f32_e32 vcc, 0, %[t0]", "t2 >= 0: the ray is occluded (render.rs:208 only asks has_missed())")
-        a.op("v_cndmask_b32_e64 %[occ], %[occ], 1, vcc")
-        a.op("s_andn2_b64 %s, %s, vcc" % (EXS, EXS), "retired")
-        a.label(".Lfl_next_%s_%%=" % tag)
-        a.op("s_mov_b64 exec, %s" % EXS)
-        a.op("s_cbranch_execz .Lfl_exit_%=", "every ray of the wave is settled")
+        for h in range(2):
+            tag = "%s%d%d" % (bank, k, h)
+            b, d = r.B[k].h[h], r.D[k].h[h]
+            a.op("v_cmp_le_f32_e32 vcc, 0, %s" % d, "item %d, ray %d: disc >= 0 (NaN for a settled ray)" % (k, h))
+            a.op("s_and_saveexec_b64 %s, vcc" % EXS)
+            a.op("s_cbranch_execz .Lfl_next_%s_%%=" % tag)
+            exact_root(a, d, tag, r)
+            a.op("v_add_f32_e32 %s, %s, %s" % (r.t0, b, r.root), "t2")
+            a.op("v_cmpx_le_f32_e32 0, %s" % r.t0, "t2 >= 0: the ray is occluded (render.rs:208 only asks has_missed())")
+            a.op("v_mov_b32_e32 %s, 1" % r.OCC.h[h])
+            a.op("v_mov_b32_e32 %s, 0x7fc00000" % r.OX.h[h], "settled")
+            a.label(".Lfl_next_%s_%%=" % tag)
+            a.op("s_mov_b64 exec, %s" % EXS)
+    a.op("v_cmp_o_f32_e32 vcc, %s, %s" % (r.OX.h[0], r.OX.h[0]), "lanes that still carry an unsettled ray")
+    a.op("v_cmp_o_f32_e64 %s, %s, %s" % (TINY, r.OX.h[1], r.OX.h[1]))
+    a.op("s_or_b64 vcc, vcc, %s" % TINY)
+    a.op("s_and_b64 exec, exec, vcc")
+    a.op("s_cbranch_execz .Lfl_exit_%=", "every ray of the wave is settled")
     a.op("s_branch .Lfl_cont_%s_%%=" % bank)
     for k in range(3):
-        exact_tiny(a, "%%[d%d]" % k, "%s%d" % (bank, k))
+        for h in range(2):
+            exact_tiny(a, r.D[k].h[h], "%s%d%d" % (bank, k, h), r)
 
 
-def loop(a, group, slow):
+def loop(a, group, slow, r):
     """Two groups per iteration, double-buffered: bank A holds the current group on entry."""
     a.label(".Lfl_loop_%=")
     a.op("s_add_u32 %s, %s, %d" % (IDX, OFF, STRIDE))
     load(a, "B", IDX, "the next group, while this one is tested")
-    group(a, "A")
+    group(a, "A", r)
     a.op("s_waitcnt lgkmcnt(0)")
     a.op("s_add_u32 %s, %s, %d" % (IDX, OFF, 2 * STRIDE))
     load(a, "A", IDX)
-    group(a, "B")
+    group(a, "B", r)
     a.op("s_add_u32 %s, %s, %d" % (OFF, OFF, 2 * STRIDE))
     a.op("s_cmp_lt_u32 %s, %%[end]" % OFF)
     a.op("s_waitcnt lgkmcnt(0)")
     a.op("s_cbranch_scc1 .Lfl_loop_%=")
     a.op("s_branch .Lfl_exit_%=")
-    slow(a, "A")
-    slow(a, "B")
+    slow(a, "A", r)
+    slow(a, "B", r)
 
 
 HEADER = """// rt_flat_rot.hpp -- GENERATED by tools/gen_flat_asm.py; edit the generator, not this file.
 //
-// The inner loops of the scalar-fed flat scan (rt_flat_sc.hpp) in gfx950 assembly, f32.  A group of three items is one 64-byte
-// record = one s_load_dwordx16 into one of two SGPR banks (s[36:51], s[52:67]); the next group's load is issued before the
-// current group's arithmetic, whose operands are the bank's SGPRs in plain VOP2 instructions.  One v_max3_f32 and one branch
-// reject a group; the exact path (root == sqrt_rn_lean, t2, t1, d, strict `<`, item order) runs only when some lane's line meets
-// one of the three spheres.  s68 byte offset of the current group pair, s69 scratch / item index, s[70:71] saved EXEC,
-// s[72:73] tiny mask: the kernels stay at 80 SGPRs (8 waves per SIMD).
+// The inner loops of the scalar-fed flat scan (rt_flat_sc.hpp) in gfx950 assembly, f32, two rays per lane on packed math.  A
+// group of three items is one 64-byte record = one s_load_dwordx16 into one of two SGPR banks (s[36:51], s[52:67]); the next
+// group's load is issued before the current group's arithmetic.  Each operation of a test is ONE v_pk_mul/add_f32 for the lane's
+// two rays, its item term the low or high half of an aligned SGPR pair broadcast with op_sel (a VOP2 that reads a new SGPR
+// costs the same 2.55 issue cycles as the packed instruction: tools/valu_issue_probe.hip).  Two v_max3_f32 + one v_max_f32 and
+// one branch reject a group; the exact path (root == sqrt_rn_lean, t2, t1, d, strict `<`, item order) runs per ray on the 32-bit
+// halves, only when some ray's line meets one of the three spheres.  The loops own v[32:63] and s[36:77] (clobbers): s68 byte
+// offset of the current group pair, s69 scratch / item index, s[70:71] saved EXEC, s[72:73] mask scratch, s[74:76] the shadow
+// rays' direction.  64 VGPRs and 84 SGPRs keep 8 waves per SIMD.
 //
 // Group record (rt_flat_sc.hpp, FGroup): primary {vx[3], vy[3], vz[3], vv[3], rr[3], pad}; shadow {cx[3], cy[3], cz[3], rr[3], pad[4]}.
 // The arrays end in pad groups (rr = -inf: never a candidate) so that the load issued one pair ahead stays inside them.
@@ -220,50 +303,46 @@ namespace rt {
 
 """
 
-PRIMARY = """// Nearest hit of all groups [0, n_bytes / 64) for the wave's 64 primary rays (n_bytes: a multiple of 128).  Lanes without a ray
-// scan along (their result is ignored).  Returns hit.distance and the index of the winning item per lane.
-__device__ __forceinline__ void flat_primary_scan(const void *groups, unsigned n_bytes, float dx, float dy, float dz, float &best_out,
-                                                  unsigned &item_out)
+PRIMARY = """// Nearest hit of all groups [0, n_bytes / 64) for the wave's 128 primary rays (n_bytes: a multiple of 128); ray h of a lane has
+// the direction (dx[h], dy[h], dz[h]).  Lane halves without a ray scan along (their result is ignored).  Returns hit.distance and
+// the index of the winning item per ray.
+__device__ __forceinline__ void flat_primary_scan(const void *groups, unsigned n_bytes, const float (&dx)[2], const float (&dy)[2],
+                                                  const float (&dz)[2], float (&best_out)[2], unsigned (&item_out)[2])
 {
-    float best = __builtin_huge_valf();
-    unsigned bitem = 0;
-    float t0, t1, t2, root, b0, b1, b2, d0, d1, d2;
     const float tiny = 0x1p-96f;
     asm volatile(
 %(body)s
-        : [best] "+v"(best), [bitem] "+v"(bitem), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [root] "=&v"(root),
-          [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2)
-        : [base] "s"(groups), [end] "s"(n_bytes), [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz), [tiny] "s"(tiny)
+        : [best0] "=v"(best_out[0]), [best1] "=v"(best_out[1]), [item0] "=v"(item_out[0]), [item1] "=v"(item_out[1])
+        : [base] "s"(groups), [end] "s"(n_bytes), [dx0] "v"(dx[0]), [dx1] "v"(dx[1]), [dy0] "v"(dy[0]), [dy1] "v"(dy[1]), [dz0] "v"(dz[0]),
+          [dz1] "v"(dz[1]), [tiny] "s"(tiny)
         : %(clobbers)s);
-    best_out = best;
-    item_out = bitem;
 }
 
 """
 
-SHADOW = """// Any hit over the groups [begin_bytes / 64, end_bytes / 64) (multiples of 128) for the lanes with pending != 0; returns 1 in the
-// lanes whose ray is occluded.  The wave leaves as soon as every pending ray is settled.
-__device__ __forceinline__ unsigned flat_shadow_scan(const void *groups, unsigned begin_bytes, unsigned end_bytes, float ox, float oy, float oz,
-                                                     float lx, float ly, float lz, unsigned pending)
+SHADOW = """// Any hit over the groups [begin_bytes / 64, end_bytes / 64) (multiples of 128) for the wave's 128 shadow rays; ray h of a lane
+// starts at (ox[h], oy[h], oz[h]) and counts only if pending[h] != 0.  Returns 1 in occluded[h] for an occluded ray.  The wave
+// leaves as soon as every pending ray is settled.
+__device__ __forceinline__ void flat_shadow_scan(const void *groups, unsigned begin_bytes, unsigned end_bytes, const float (&ox)[2],
+                                                 const float (&oy)[2], const float (&oz)[2], float lx, float ly, float lz,
+                                                 const unsigned (&pending)[2], unsigned (&occluded)[2])
 {
-    unsigned occ = 0;
-    float t0, t1, t2, root, vx, vy, vz, b0, b1, b2, d0, d1, d2;
     const float tiny = 0x1p-96f;
+    unsigned long long saved;
     asm volatile(
 %(body)s
-        : [occ] "+v"(occ), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [root] "=&v"(root), [vx] "=&v"(vx), [vy] "=&v"(vy), [vz] "=&v"(vz),
-          [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2)
-        : [base] "s"(groups), [begin] "s"(begin_bytes), [end] "s"(end_bytes), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [lx] "s"(lx),
-          [ly] "s"(ly), [lz] "s"(lz), [pend] "v"(pending), [tiny] "s"(tiny)
+        : [occ0] "=v"(occluded[0]), [occ1] "=v"(occluded[1]), [saved] "=&s"(saved)
+        : [base] "s"(groups), [begin] "s"(begin_bytes), [end] "s"(end_bytes), [ox0] "v"(ox[0]), [ox1] "v"(ox[1]), [oy0] "v"(oy[0]),
+          [oy1] "v"(oy[1]), [oz0] "v"(oz[0]), [oz1] "v"(oz[1]), [lx] "s"(lx), [ly] "s"(ly), [lz] "s"(lz), [pend0] "v"(pending[0]),
+          [pend1] "v"(pending[1]), [tiny] "s"(tiny)
         : %(clobbers)s);
-    return occ;
 }
 
 """
 
 
 def clobbers():
-    regs = ['"s%d"' % r for r in range(36, 74)]
+    regs = ['"s%d"' % r for r in range(36, SGPR_LAST + 1)] + ['"v%d"' % r for r in range(VGPR_FIRST, VGPR_LAST + 1)]
     lines, cur = [], '"memory", "vcc", "scc"'
     for r in regs:
         if len(cur) + len(r) + 2 > 118:
@@ -276,39 +355,60 @@ def clobbers():
 
 
 def primary():
-    a = Asm()
+    a, r = Asm(), PrimaryRegs()
+    for h in range(2):
+        a.op("v_mov_b32_e32 %s, %%[dx%d]" % (r.DX.h[h], h), "operands into the loop's own registers" if h == 0 else None)
+        a.op("v_mov_b32_e32 %s, %%[dy%d]" % (r.DY.h[h], h))
+        a.op("v_mov_b32_e32 %s, %%[dz%d]" % (r.DZ.h[h], h))
+        a.op("v_mov_b32_e32 %s, 0x7f800000" % r.BEST.h[h], "hit.distance = INF (primitive.rs:96)" if h == 0 else None)
+        a.op("v_mov_b32_e32 %s, 0" % r.BITEM.h[h])
     a.op("s_mov_b32 %s, 0" % OFF)
     load(a, "A", "0x0")
     a.op("s_waitcnt lgkmcnt(0)")
-    loop(a, primary_group, primary_slow)
+    loop(a, primary_group, primary_slow, r)
     a.label(".Lfl_exit_%=")
     a.op("s_waitcnt lgkmcnt(0)", "the load issued one pair ahead must have landed before its registers are free again")
+    for h in range(2):
+        a.op("v_mov_b32_e32 %%[best%d], %s" % (h, r.BEST.h[h]))
+        a.op("v_mov_b32_e32 %%[item%d], %s" % (h, r.BITEM.h[h]))
     return a.render()
 
 
 def shadow_body():
-    a = Asm()
+    a, r = Asm(), ShadowRegs()
     a.op("s_mov_b64 %[saved], exec")
-    a.op("v_cmp_ne_u32_e32 vcc, 0, %[pend]")
-    a.op("s_and_b64 exec, exec, vcc", "EXEC = the rays still pending, for the whole scan")
+    for h in range(2):
+        a.op("v_cmp_ne_u32_e32 vcc, 0, %%[pend%d]" % h, "a lane half without a pending ray: NaN origin, never a candidate" if h == 0 else None)
+        a.op("v_mov_b32_e32 %s, 0x7fc00000" % r.t0)
+        a.op("v_cndmask_b32_e32 %s, %s, %%[ox%d], vcc" % (r.OX.h[h], r.t0, h))
+        a.op("v_mov_b32_e32 %s, %%[oy%d]" % (r.OY.h[h], h))
+        a.op("v_mov_b32_e32 %s, %%[oz%d]" % (r.OZ.h[h], h))
+        a.op("v_mov_b32_e32 %s, 0" % r.OCC.h[h])
+    a.op("s_mov_b32 s%d, %%[lx]" % (LIGHT + 0))
+    a.op("s_mov_b32 s%d, %%[ly]" % (LIGHT + 1))
+    a.op("s_mov_b32 s%d, %%[lz]" % (LIGHT + 2))
+    a.op("v_cmp_o_f32_e32 vcc, %s, %s" % (r.OX.h[0], r.OX.h[0]))
+    a.op("v_cmp_o_f32_e64 %s, %s, %s" % (TINY, r.OX.h[1], r.OX.h[1]))
+    a.op("s_or_b64 vcc, vcc, %s" % TINY)
+    a.op("s_and_b64 exec, exec, vcc", "EXEC = the lanes that carry a pending ray")
     a.op("s_cbranch_execz .Lfl_done_%=")
     a.op("s_mov_b32 %s, %%[begin]" % OFF)
     load(a, "A", OFF)
     a.op("s_waitcnt lgkmcnt(0)")
-    loop(a, shadow_group, shadow_slow)
+    loop(a, shadow_group, shadow_slow, r)
     a.label(".Lfl_exit_%=")
     a.op("s_waitcnt lgkmcnt(0)")
     a.label(".Lfl_done_%=")
     a.op("s_mov_b64 exec, %[saved]")
+    for h in range(2):
+        a.op("v_mov_b32_e32 %%[occ%d], %s" % (h, r.OCC.h[h]))
     return a.render()
 
 
 def main():
     text = HEADER
     text += PRIMARY % {"body": primary(), "clobbers": clobbers()}
-    sh = SHADOW.replace("unsigned occ = 0;", "unsigned occ = 0;\n    unsigned long long saved;")
-    sh = sh.replace(': [occ] "+v"(occ),', ': [occ] "+v"(occ), [saved] "=&s"(saved),')
-    text += sh % {"body": shadow_body(), "clobbers": clobbers()}
+    text += SHADOW % {"body": shadow_body(), "clobbers": clobbers()}
     text += "}  // namespace rt\n"
     with open(OUT, "w") as f:
         f.write(text)

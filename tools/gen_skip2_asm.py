@@ -1,0 +1,531 @@
+#!/usr/bin/env python3
+"""Generates rust-tracer_amd/csrc/rt_skip2_rot.hpp: the traversal loops of k_render_skip2 -- the f32 fused hierarchy walk with
+TWO rays per lane on packed math -- in gfx950 assembly.
+
+Why (tools/valu_issue_probe.hip, profiles/r02_valu_issue_probe.json, counting the LONGEST wave): on gfx950 a wave64 VOP2 issues
+in 2.2 cycles, but a VOP2 whose SGPR operand differs from the previous instruction's takes 4.1 -- what every VOP3 / VOP3P
+instruction takes.  Five of the eight operations of a sphere test read a node term from an SGPR, each a different one, so a test
+costs 5 x 4.1 + 3 x 2.2 = 27 cycles per 64 rays.  A packed v_pk_mul/add_f32 takes the same 4.1 cycles with or without a
+scalar operand (either half of an aligned SGPR pair, broadcast to both results with op_sel) and does the operation for TWO
+rays: 8 x 4.1 = 33 cycles per 128 rays.  The scalar bookkeeping of a step (successor fetch, wait, position, branches) is
+shared by twice the rays as well.  What does not pack is done per half on the 32-bit registers of the pair: the two `active`
+compares, the two candidate compares and the exact path (root, t1, t2, d, `<` against hit.distance).
+
+Everything else is rt_skip_rot.hpp's fused f32 loop (tools/gen_skip_asm.py, which documents the walk): byte offsets, one
+stride per node, NX = offset behind the current node, `skip` fetched at the top of the step and the first child on entering,
+three scalar register banks and three copies of the body laid out A, C, B, kind flags only looked at on a hit, END node.
+A lane's two rays have their own `resume`, hit.distance and item; a wave walks the union of its 128 rays' nodes, so the kernel
+pairs rays that share most of their walk (two samples' worth of neighbouring pixels).
+
+The halves of a register pair have to be named, which inline-asm operands cannot do: the loops own FIXED registers (v[32:63],
+s[36:81]; listed as clobbers) and move their operands in and out.
+
+Run:  python3 tools/gen_skip2_asm.py   (writes the header; the build does not need this script)."""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "rust-tracer_amd", "csrc", "rt_skip2_rot.hpp")
+
+COPIES = {"A": (0, 1, 2), "B": (1, 0, 2), "C": (2, 0, 1)}          # current, next, skip
+NEXT_COPY = {"A": "B", "B": "A", "C": "A"}
+SKIP_COPY = {"A": "C", "B": "C", "C": "B"}
+LAYOUT = "ACB"
+FLAG_LIMIT = "0x3fffffff"
+STRIDE = 32
+BANK = (36, 44, 52)
+NX = "s60"
+LIGHT = 78                                                           # s78..s80: the shadow rays' direction (s81 pads the pair)
+SGPR_LAST, VGPR_FIRST, VGPR_LAST = 81, 32, 63
+
+
+def sp(first):
+    return "s[%d:%d]" % (first, first + 1)
+
+
+ACT = (sp(62), sp(64))          # per half: the rays awake at the current node
+C = (sp(66), sp(68))            # per half: candidates -> the rays that go on (enter / hit)
+M, M2, TINY, EX = sp(70), sp(76), sp(72), sp(74)
+
+
+class Pair:
+    def __init__(self, lo):
+        self.p = "v[%d:%d]" % (lo, lo + 1)
+        self.h = ("v%d" % lo, "v%d" % (lo + 1))
+
+
+class Asm:
+    def __init__(self):
+        self.lines = []
+
+    def op(self, text, comment=None):
+        self.lines.append(("\t", text, comment))
+
+    def label(self, name):
+        self.lines.append(("", name + ":", None))
+
+    def extend(self, other):
+        self.lines.extend(other.lines)
+
+    def render(self, indent="        "):
+        out = []
+        for tab, text, comment in self.lines:
+            s = '%s"%s%s\\n"' % (indent, "" if tab == "" else "\\t", text)
+            if comment:
+                s += "  /* %s */" % comment
+            out.append(s)
+        return "\n".join(out)
+
+
+def fld(b, k):
+    return BANK[b] + k
+
+
+def item(b):
+    return "s%d" % (BANK[b] + 5)
+
+
+def skip(b):
+    return "s%d" % (BANK[b] + 6)
+
+
+def own(b):
+    return BANK[b] + 7
+
+
+def load(a, b, off, comment=None):
+    a.op("s_load_dwordx8 s[%d:%d], %%[base], %s" % (BANK[b], BANK[b] + 7, off), comment)
+
+
+def pk(a, op, dst, x, y, sx=None, sy=None, neg_y=False, comment=None):
+    """dst = x op y on both rays.  sx / sy: SGPR NUMBER whose value is broadcast to both rays in place of a VGPR pair."""
+    sel, sel_hi = [0, 0], [1, 1]
+    if sx is not None:
+        x = "s[%d:%d]" % (sx & ~1, (sx & ~1) + 1)
+        sel[0] = sel_hi[0] = sx & 1
+    if sy is not None:
+        y = "s[%d:%d]" % (sy & ~1, (sy & ~1) + 1)
+        sel[1] = sel_hi[1] = sy & 1
+    mods = ""
+    if sel != [0, 0]:
+        mods += " op_sel:[%d,%d]" % tuple(sel)
+    if sel_hi != [1, 1]:
+        mods += " op_sel_hi:[%d,%d]" % tuple(sel_hi)
+    if neg_y:
+        mods += " neg_lo:[0,1] neg_hi:[0,1]"
+    a.op("v_pk_%s_f32 %s, %s, %s%s" % (op, dst, x, y, mods), comment)
+
+
+class Regs:
+    """v[32:63].  Primary: D = ray directions, BEST / BITEM the hit; shadow: D = ray origins, V the centre - origin vector."""
+
+    def __init__(self, shadow):
+        v = VGPR_FIRST
+        self.DX, self.DY, self.DZ = Pair(v), Pair(v + 2), Pair(v + 4)
+        self.RES = Pair(v + 6)
+        self.T0, self.T1, self.T2 = Pair(v + 8), Pair(v + 10), Pair(v + 12)
+        self.B, self.Q, self.DISC = Pair(v + 14), Pair(v + 16), Pair(v + 18)
+        if shadow:
+            self.VX, self.VY, self.VZ = Pair(v + 20), Pair(v + 22), Pair(v + 24)
+            self.FIN = Pair(v + 26)
+        else:
+            self.BEST, self.BITEM = Pair(v + 20), Pair(v + 22)
+        self.root = "v%d" % (v + 28)
+        # 32-bit temporaries of the exact path: the T pairs are free once the step's arithmetic is done
+        self.t0, self.t1, self.t3, self.t4, self.t5 = self.T0.h[0], self.T0.h[1], self.T1.h[0], self.T1.h[1], self.T2.h[0]
+
+
+def refine(a, r, x):
+    a.op("v_mul_f32_e32 %s, %s, %s" % (r.root, x, r.t0), "g = x*y")
+    a.op("v_mul_f32_e32 %s, 0.5, %s" % (r.t0, r.t0), "h = y/2")
+    a.op("v_fma_f32 %s, -%s, %s, %s" % (r.t1, r.root, r.root, x), "r = x - g*g")
+    a.op("v_fma_f32 %s, %s, %s, %s" % (r.root, r.t1, r.t0, r.root), "g + r*h")
+
+
+def root(a, r, disc, need_mask, done_label, tiny_label):
+    """Correctly rounded sqrt(disc) into r.root (== sqrt_rn_lean).  need_mask: the lanes whose root is used."""
+    a.op("v_rsq_f32_e32 %s, %s" % (r.t0, disc))
+    a.op("v_cmp_lt_f32_e64 %s, |%s|, %%[tiny]" % (TINY, disc))
+    a.op("s_and_b64 %s, %s, %s" % (M2, TINY, need_mask))
+    a.op("s_cbranch_scc1 %s" % tiny_label, "some needed lane below 2^-96 (zero included): scaled path")
+    refine(a, r, disc)
+    a.label(done_label)
+
+
+def tiny(a, r, disc, tiny_label, done_label):
+    a.label(tiny_label)
+    a.op("v_mul_f32_e32 %s, 0x4f800000, %s" % (r.t0, disc), "root with the 2^32 / 2^-16 scaling for tiny lanes")
+    a.op("v_cndmask_b32_e64 %s, %s, %s, %s" % (r.t5, disc, r.t0, TINY))
+    a.op("v_rsq_f32_e32 %s, %s" % (r.t0, r.t5))
+    a.op("v_cmp_eq_f32_e64 %s, 0, %s" % (M2, r.t5), "sqrt(+-0) = +-0 (rsq would make it 0 * inf)")
+    refine(a, r, r.t5)
+    a.op("v_cndmask_b32_e64 %s, %s, %s, %s" % (r.root, r.root, r.t5, M2))
+    a.op("v_mul_f32_e32 %s, 0x37800000, %s" % (r.t0, r.root))
+    a.op("v_cndmask_b32_e64 %s, %s, %s, %s" % (r.root, r.root, r.t0, TINY))
+    a.op("s_branch %s" % done_label)
+
+
+def top_of(name):
+    return ".Lr2_%s_top_%%=" % name
+
+
+def emit_skip(a, name, c, lab):
+    a.label(lab("skip"))
+    a.op("s_add_u32 %s, %s, %d" % (NX, skip(c), STRIDE), "jump over the subtree")
+    a.op("s_waitcnt lgkmcnt(0)")
+    nxt = SKIP_COPY[name]
+    if LAYOUT.index(nxt) != LAYOUT.index(name) + 1:
+        a.op("s_branch %s" % top_of(nxt))
+
+
+def emit_next(a, name):
+    a.op("s_add_u32 %s, %s, %d" % (NX, NX, STRIDE))
+    a.op("s_waitcnt lgkmcnt(0)")
+    a.op("s_branch %s" % top_of(NEXT_COPY[name]))
+
+
+def step_top(a, r, c, s, terms):
+    """The part of a step every node shares: fetch the likely successor, form both discriminants; vcc = the lanes in which some
+    ray's line meets the sphere, awake or not.  Who is awake is only asked when there is such a lane (wake_check): the two
+    compares are VOP3s of 4 issue cycles each, and three steps of four end at `skip` without needing them."""
+    load(a, s, skip(c), "the likely successor, while this node is processed")
+    terms(a, r, c)
+    a.op("v_max_f32_e32 %s, %s, %s" % (r.t0, r.DISC.h[0], r.DISC.h[1]))
+    a.op("v_cmp_le_f32_e32 vcc, 0, %s" % r.t0)
+
+
+def wake_check(a, r, lab):
+    """C[h] = the awake rays of half h whose line meets the sphere; nobody: on to `skip`."""
+    for h in range(2):
+        a.op("v_cmp_gt_u32_e64 %s, %s, %s" % (ACT[h], NX, r.RES.h[h]), "active = i >= resume  (NX = i + stride)" if h == 0 else None)
+    a.op("v_cmp_le_f32_e64 %s, 0, %s" % (C[0], r.DISC.h[0]))
+    a.op("v_cmp_le_f32_e32 vcc, 0, %s" % r.DISC.h[1])
+    a.op("s_and_b64 %s, %s, %s" % (C[0], C[0], ACT[0]))
+    a.op("s_and_b64 %s, vcc, %s" % (C[1], ACT[1]))
+    a.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+    a.op("s_cbranch_scc0 %s" % lab("skip"), "only sleeping rays: a BOUND is jumped over, an ITEM changes nothing")
+
+
+def sleep_culled(a, r, c):
+    """The awake rays that do not go on sleep until `skip`."""
+    for h in range(2):
+        a.op("s_andn2_b64 exec, %s, %s" % (ACT[h], C[h]))
+        a.op("v_mov_b32_e32 %s, %s" % (r.RES.h[h], skip(c)))
+    a.op("s_mov_b64 exec, %s" % EX)
+
+
+def kind_test(a, c, lab):
+    a.op("s_cmp_gt_u32 %s, %s" % (item(c), FLAG_LIMIT), "an ITEM or the END node?  (flag bits of the item word)")
+    a.op("s_cbranch_scc1 %s" % lab("flagged"))
+
+
+# ------------------------------------------------------------------------------------------------------------------ primary
+
+def primary_terms(a, r, c):
+    pk(a, "mul", r.T0.p, None, r.DX.p, sx=fld(c, 0), comment="b = (vx*dx + vy*dy) + vz*dz, both rays   primitive.rs:57")
+    pk(a, "mul", r.T1.p, None, r.DY.p, sx=fld(c, 1))
+    pk(a, "mul", r.T2.p, None, r.DZ.p, sx=fld(c, 2))
+    pk(a, "add", r.T0.p, r.T0.p, r.T1.p)
+    pk(a, "add", r.B.p, r.T0.p, r.T2.p)
+    pk(a, "mul", r.T0.p, r.B.p, r.B.p, comment="disc = (b*b - vv) + rr   primitive.rs:58")
+    pk(a, "add", r.Q.p, r.T0.p, None, sy=fld(c, 3), neg_y=True)
+    pk(a, "add", r.DISC.p, None, r.Q.p, sx=fld(c, 4))
+
+
+def primary_go(a, r, h, tag, lab, tinies):
+    """C[h] (awake rays of half h with disc >= 0) -> C[h] = go: t2 >= 0 and d < hit.distance; d left in t4.  Skipped when the
+    half has no candidate."""
+    done = lab("pg%s%d" % (tag, h))
+    a.op("s_cmp_eq_u64 %s, 0" % C[h])
+    a.op("s_cbranch_scc1 %s" % done)
+    root(a, r, r.DISC.h[h], C[h], lab("rooted%s%d" % (tag, h)), lab("tiny%s%d" % (tag, h)))
+    tinies.append((r.DISC.h[h], lab("tiny%s%d" % (tag, h)), lab("rooted%s%d" % (tag, h))))
+    a.op("v_add_f32_e32 %s, %s, %s" % (r.t3, r.B.h[h], r.root), "t2")
+    a.op("v_sub_f32_e32 %s, %s, %s" % (r.t4, r.B.h[h], r.root), "t1")
+    a.op("v_cmp_lt_f32_e64 %s, 0, %s" % (M, r.t4), "t1 > 0")
+    a.op("v_cmp_le_f32_e64 %s, 0, %s" % (M2, r.t3), "t2 >= 0")
+    a.op("s_and_b64 %s, %s, %s" % (C[h], C[h], M2))
+    a.op("v_cndmask_b32_e64 %s, %s, %s, %s" % (r.t4, r.t3, r.t4, M), "d = t1 > 0 ? t1 : t2")
+    a.op("v_cmp_lt_f32_e64 %s, %s, %s" % (M, r.t4, r.BEST.h[h]), "d < hit.distance")
+    a.op("s_and_b64 %s, %s, %s" % (C[h], C[h], M), "go")
+    return done
+
+
+def primary_update(a, r, h, c, done):
+    a.op("s_mov_b64 exec, %s" % C[h], "primitive.rs:80-83")
+    a.op("v_mov_b32_e32 %s, %s" % (r.BEST.h[h], r.t4))
+    a.op("v_mov_b32_e32 %s, %s" % (r.BITEM.h[h], item(c)))
+    a.op("s_mov_b64 exec, %s" % EX)
+    a.label(done)
+
+
+def primary_copy(r, name):
+    c, n, s = COPIES[name]
+    lab = lambda x: ".Lr2_%s_%s_%%=" % (name, x)
+    m, k, tinies = Asm(), Asm(), []
+    m.label(lab("top"))
+    step_top(m, r, c, s, primary_terms)
+    m.op("s_cbranch_vccnz %s" % lab("hit"))
+    emit_skip(m, name, c, lab)
+    # ---------------- some ray's line meets the sphere ----------------
+    k.label(lab("hit"))
+    wake_check(k, r, lab)
+    kind_test(k, c, lab)
+    # BOUND (group.rs:73)
+    for h in range(2):
+        k.label(primary_go(k, r, h, "b", lab, tinies))
+    k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+    k.op("s_cbranch_scc0 %s" % lab("skip"), "nobody enters (the rays that culled it are awake again at `skip`)")
+    load(k, n, NX, "somebody enters: fetch the group's first child")
+    sleep_culled(k, r, c)
+    # the group's own sphere, for the rays that entered: same centre, so v, b and b*b - vv are the values just formed
+    pk(k, "add", r.DISC.p, None, r.Q.p, sx=own(c), comment="disc = (b*b - vv) + rr of the group's own sphere")
+    k.op("v_cmp_le_f32_e64 %s, 0, %s" % (M, r.DISC.h[0]))
+    k.op("v_cmp_le_f32_e32 vcc, 0, %s" % r.DISC.h[1])
+    k.op("s_and_b64 %s, %s, %s" % (C[0], C[0], M))
+    k.op("s_and_b64 %s, %s, vcc" % (C[1], C[1]))
+    k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+    k.op("s_cbranch_scc0 %s" % lab("next"))
+    for h in range(2):
+        primary_update(k, r, h, c, primary_go(k, r, h, "f", lab, tinies))
+    k.label(lab("next"))
+    emit_next(k, name)
+    # ITEM (primitive.rs:77-84) or END
+    k.label(lab("flagged"))
+    k.op("s_bitcmp1_b32 %s, 30" % item(c))
+    k.op("s_cbranch_scc1 .Lr2_exit_%=", "END: every ray is awake here and hits it")
+    for h in range(2):
+        primary_update(k, r, h, c, primary_go(k, r, h, "i", lab, tinies))
+    k.op("s_branch %s" % lab("skip"), "an ITEM's `skip` is the node behind it")
+    for disc, tl, dl in tinies:
+        tiny(k, r, disc, tl, dl)
+    return m, k
+
+
+# ------------------------------------------------------------------------------------------------------------------- shadow
+
+def shadow_terms(a, r, c):
+    pk(a, "add", r.VX.p, None, r.DX.p, sx=fld(c, 0), neg_y=True, comment="v = centre - origin, both rays   primitive.rs:56")
+    pk(a, "add", r.VY.p, None, r.DY.p, sx=fld(c, 1), neg_y=True)
+    pk(a, "add", r.VZ.p, None, r.DZ.p, sx=fld(c, 2), neg_y=True)
+    pk(a, "mul", r.T0.p, None, r.VX.p, sx=LIGHT + 0)
+    pk(a, "mul", r.T1.p, None, r.VY.p, sx=LIGHT + 1)
+    pk(a, "mul", r.T2.p, None, r.VZ.p, sx=LIGHT + 2)
+    pk(a, "add", r.T0.p, r.T0.p, r.T1.p)
+    pk(a, "add", r.B.p, r.T0.p, r.T2.p, comment="b = dot(v, dir)   primitive.rs:57")
+    pk(a, "mul", r.VX.p, r.VX.p, r.VX.p)
+    pk(a, "mul", r.VY.p, r.VY.p, r.VY.p)
+    pk(a, "mul", r.VZ.p, r.VZ.p, r.VZ.p)
+    pk(a, "add", r.VX.p, r.VX.p, r.VY.p)
+    pk(a, "add", r.VX.p, r.VX.p, r.VZ.p, comment="dot(v, v)")
+    pk(a, "mul", r.T0.p, r.B.p, r.B.p)
+    pk(a, "add", r.Q.p, r.T0.p, r.VX.p, neg_y=True)
+    pk(a, "add", r.DISC.p, None, r.Q.p, sx=fld(c, 3), comment="disc = (b*b - vv) + rr   primitive.rs:58")
+
+
+def shadow_decide(a, r, h, tag, lab, tinies):
+    """C[h] (awake rays of half h with disc >= 0) -> C[h] = the rays that hit the sphere (t2 >= 0; certain when b >= 0)."""
+    done = lab("sd%s%d" % (tag, h))
+    a.op("v_cmp_gt_f32_e64 %s, 0, %s" % (M, r.B.h[h]), "b < 0: t2 may still be negative")
+    a.op("s_and_b64 %s, %s, %s" % (M, M, C[h]))
+    a.op("s_cbranch_scc0 %s" % done, "nobody needs the root: hit = candidates")
+    root(a, r, r.DISC.h[h], M, lab("rooted%s%d" % (tag, h)), lab("tiny%s%d" % (tag, h)))
+    tinies.append((r.DISC.h[h], lab("tiny%s%d" % (tag, h)), lab("rooted%s%d" % (tag, h))))
+    a.op("v_add_f32_e32 %s, %s, %s" % (r.t3, r.B.h[h], r.root), "t2")
+    a.op("v_cmp_gt_f32_e64 %s, 0, %s" % (M2, r.t3), "t2 < 0")
+    a.op("s_and_b64 %s, %s, %s" % (M2, M2, M), "root lanes that miss after all")
+    a.op("s_andn2_b64 %s, %s, %s" % (C[h], C[h], M2))
+    a.label(done)
+
+
+def shadow_copy(r, name):
+    c, n, s = COPIES[name]
+    lab = lambda x: ".Lr2_%s_%s_%%=" % (name, x)
+    m, k, tinies = Asm(), Asm(), []
+    m.label(lab("top"))
+    step_top(m, r, c, s, shadow_terms)
+    m.op("s_cbranch_vccnz %s" % lab("hit"))
+    emit_skip(m, name, c, lab)
+    k.label(lab("hit"))
+    wake_check(k, r, lab)
+    kind_test(k, c, lab)
+    # BOUND: hit.distance is INF, so a bound culls iff the ray misses it
+    for h in range(2):
+        shadow_decide(k, r, h, "b", lab, tinies)
+    k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+    k.op("s_cbranch_scc0 %s" % lab("skip"))
+    load(k, n, NX, "somebody enters: fetch the group's first child")
+    sleep_culled(k, r, c)
+    pk(k, "add", r.DISC.p, None, r.Q.p, sx=own(c), comment="disc = (b*b - vv) + rr of the group's own sphere")
+    k.op("v_cmp_le_f32_e64 %s, 0, %s" % (M, r.DISC.h[0]))
+    k.op("v_cmp_le_f32_e32 vcc, 0, %s" % r.DISC.h[1])
+    k.op("s_and_b64 %s, %s, %s" % (C[0], C[0], M))
+    k.op("s_and_b64 %s, %s, vcc" % (C[1], C[1]))
+    k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+    k.op("s_cbranch_scc0 %s" % lab("next"))
+    for h in range(2):
+        shadow_decide(k, r, h, "f", lab, tinies)
+    k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+    k.op("s_cbranch_scc1 .Lr2_fin_%=", "any hit ends those rays; hand them to the caller")
+    k.label(lab("next"))
+    emit_next(k, name)
+    k.label(lab("flagged"))
+    k.op("s_bitcmp1_b32 %s, 30" % item(c))
+    k.op("s_cbranch_scc1 .Lr2_exit_%=", "END: every ray is awake here and hits it")
+    for h in range(2):
+        shadow_decide(k, r, h, "i", lab, tinies)
+    k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+    k.op("s_cbranch_scc0 %s" % lab("skip"), "an ITEM's `skip` is the node behind it")
+    k.op("s_branch .Lr2_fin_%=")
+    for disc, tl, dl in tinies:
+        tiny(k, r, disc, tl, dl)
+    return m, k
+
+
+def assemble(a, r, copy_fn):
+    mains, colds = {}, {}
+    for name in "ABC":
+        mains[name], colds[name] = copy_fn(r, name)
+    for name in LAYOUT:
+        a.extend(mains[name])
+    for name in "ABC":
+        a.extend(colds[name])
+
+
+def primary():
+    a, r = Asm(), Regs(False)
+    for h in range(2):
+        a.op("v_mov_b32_e32 %s, %%[dx%d]" % (r.DX.h[h], h), "operands into the loop's own registers" if h == 0 else None)
+        a.op("v_mov_b32_e32 %s, %%[dy%d]" % (r.DY.h[h], h))
+        a.op("v_mov_b32_e32 %s, %%[dz%d]" % (r.DZ.h[h], h))
+        a.op("v_mov_b32_e32 %s, %%[res%d]" % (r.RES.h[h], h))
+        a.op("v_mov_b32_e32 %s, 0x7f800000" % r.BEST.h[h], "hit.distance = INF (primitive.rs:96)" if h == 0 else None)
+        a.op("v_mov_b32_e32 %s, 0" % r.BITEM.h[h])
+    a.op("s_mov_b32 %s, %d" % (NX, STRIDE))
+    a.op("s_mov_b64 %s, exec" % EX)
+    load(a, 0, "0x0")
+    a.op("s_waitcnt lgkmcnt(0)")
+    assemble(a, r, primary_copy)
+    a.label(".Lr2_exit_%=")
+    a.op("s_waitcnt lgkmcnt(0)")
+    for h in range(2):
+        a.op("v_mov_b32_e32 %%[best%d], %s" % (h, r.BEST.h[h]))
+        a.op("v_mov_b32_e32 %%[item%d], %s" % (h, r.BITEM.h[h]))
+    return a.render()
+
+
+def shadow():
+    a, r = Asm(), Regs(True)
+    for h in range(2):
+        a.op("v_mov_b32_e32 %s, %%[ox%d]" % (r.DX.h[h], h), "operands into the loop's own registers" if h == 0 else None)
+        a.op("v_mov_b32_e32 %s, %%[oy%d]" % (r.DY.h[h], h))
+        a.op("v_mov_b32_e32 %s, %%[oz%d]" % (r.DZ.h[h], h))
+        a.op("v_mov_b32_e32 %s, %%[res%d]" % (r.RES.h[h], h))
+        a.op("v_mov_b32_e32 %s, 0" % r.FIN.h[h])
+    a.op("s_mov_b32 s%d, %%[lx]" % (LIGHT + 0))
+    a.op("s_mov_b32 s%d, %%[ly]" % (LIGHT + 1))
+    a.op("s_mov_b32 s%d, %%[lz]" % (LIGHT + 2))
+    a.op("s_add_u32 %s, %%[start], %d" % (NX, STRIDE))
+    a.op("s_mov_b64 %s, exec" % EX)
+    load(a, 0, "%[start]")
+    a.op("s_waitcnt lgkmcnt(0)")
+    assemble(a, r, shadow_copy)
+    a.label(".Lr2_fin_%=")
+    for h in range(2):
+        a.op("v_cndmask_b32_e64 %s, 0, 1, %s" % (r.FIN.h[h], C[h]), "the rays that hit the ITEM (or the group's own sphere) of the current node" if h == 0 else None)
+    a.op("s_sub_u32 %%[stop], %s, %d" % (NX, STRIDE), "its position")
+    a.op("s_branch .Lr2_out_%=")
+    a.label(".Lr2_exit_%=")
+    a.op("s_mov_b32 %[stop], %[n]", "stream finished")
+    a.label(".Lr2_out_%=")
+    a.op("s_waitcnt lgkmcnt(0)")
+    for h in range(2):
+        a.op("v_mov_b32_e32 %%[fin%d], %s" % (h, r.FIN.h[h]))
+        a.op("v_mov_b32_e32 %%[rout%d], %s" % (h, r.RES.h[h]))
+    return a.render()
+
+
+HEADER = """// rt_skip2_rot.hpp -- GENERATED by tools/gen_skip2_asm.py; edit the generator, not this file.
+//
+// The traversal loops of k_render_skip2 in gfx950 assembly: rt_skip_rot.hpp's fused f32 walk with TWO rays per lane.  The
+// eight operations of a sphere test are one v_pk_mul/add_f32 each for the lane's two rays, the node term the low or high half
+// of an aligned SGPR pair broadcast with op_sel -- a packed instruction issues in the same 4.1 cycles as the VOP2 that reads a
+// new SGPR does for one ray (tools/valu_issue_probe.hip) -- and the successor fetch, the wait, the position and the branches of
+// a step serve 128 rays.  `active`, the candidate test and the exact path (root == sqrt_rn_lean, t2, t1, d, strict `<`) run per
+// half on the 32-bit registers of the pairs; each ray has its own resume, hit.distance and item.  Same arithmetic, operation
+// for operation, and the same walk as the one-ray loops (tools/gen_skip_asm.py documents it).
+//
+// The loops own v[32:63] and s[36:81] (clobbers): s[36:59] three node banks, s60 NX, s[62:65] awake masks, s[66:69] candidate /
+// go masks, s[70:77] scratch masks and EXEC at entry, s[78:80] the shadow rays' direction.
+#pragma once
+#include "rt_kernels.hpp"
+
+namespace rt {
+
+"""
+
+PRIMARY_FN = """// Primary-ray traversal: s.group.intersect(&mut h, r) for the wave's 128 rays.  nodes: compacted Node<float>[n + 3], END at [n].
+// resume[h]: 0 for a ray, n * 32 for a lane half without one (it sleeps until END).  Returns hit.distance / item word per ray (mask
+// the item with kNodeIndexMask).
+__device__ __forceinline__ void skip2_primary_rot_fused(const void *nodes, const float (&dx)[2], const float (&dy)[2], const float (&dz)[2],
+                                                        const unsigned (&resume)[2], float (&best_out)[2], unsigned (&item_out)[2])
+{
+    const float tiny = 0x1p-96f;
+    asm volatile(
+%(body)s
+        : [best0] "=v"(best_out[0]), [best1] "=v"(best_out[1]), [item0] "=v"(item_out[0]), [item1] "=v"(item_out[1])
+        : [base] "s"(nodes), [dx0] "v"(dx[0]), [dx1] "v"(dx[1]), [dy0] "v"(dy[0]), [dy1] "v"(dy[1]), [dz0] "v"(dz[0]), [dz1] "v"(dz[1]),
+          [res0] "v"(resume[0]), [res1] "v"(resume[1]), [tiny] "s"(tiny)
+        : %(clobbers)s);
+}
+
+"""
+
+SHADOW_FN = """// Shadow-ray traversal (any hit, render.rs:202-208) from byte offset `start` until the stream ends or some ray hits an ITEM: the
+// caller retires those rays (resume = n_bytes), finds the next node any ray still wants and calls again.  Returns the byte offset
+// it stopped at (n_bytes: stream finished); fin[h] = 1 for the rays that hit the ITEM there.  hit.distance is INF throughout, so
+// a node is "hit" iff disc >= 0 and t2 = b + root >= 0.
+__device__ __forceinline__ unsigned skip2_shadow_rot_fused(const void *nodes, unsigned n_bytes, unsigned start, const float (&ox)[2],
+                                                           const float (&oy)[2], const float (&oz)[2], float lx, float ly, float lz,
+                                                           unsigned (&resume)[2], unsigned (&fin)[2])
+{
+    const float tiny = 0x1p-96f;
+    unsigned stop;
+    start = (unsigned)__builtin_amdgcn_readfirstlane((int)start);       // wave-uniform by construction; the operand must be an SGPR
+    asm volatile(
+%(body)s
+        : [fin0] "=v"(fin[0]), [fin1] "=v"(fin[1]), [rout0] "=v"(resume[0]), [rout1] "=v"(resume[1]), [stop] "=&s"(stop)
+        : [base] "s"(nodes), [n] "s"(n_bytes), [start] "s"(start), [ox0] "v"(ox[0]), [ox1] "v"(ox[1]), [oy0] "v"(oy[0]), [oy1] "v"(oy[1]),
+          [oz0] "v"(oz[0]), [oz1] "v"(oz[1]), [res0] "v"(resume[0]), [res1] "v"(resume[1]), [lx] "s"(lx), [ly] "s"(ly), [lz] "s"(lz),
+          [tiny] "s"(tiny)
+        : %(clobbers)s);
+    return stop;
+}
+
+"""
+
+
+def clobbers():
+    regs = ['"s%d"' % r for r in range(36, SGPR_LAST + 1)] + ['"v%d"' % r for r in range(VGPR_FIRST, VGPR_LAST + 1)]
+    lines, cur = [], '"memory", "vcc", "scc"'
+    for r in regs:
+        if len(cur) + len(r) + 2 > 118:
+            lines.append(cur + ",")
+            cur = "          " + r
+        else:
+            cur += ", " + r
+    lines.append(cur)
+    return "\n".join(lines)
+
+
+def main():
+    text = HEADER
+    text += PRIMARY_FN % {"body": primary(), "clobbers": clobbers()}
+    text += SHADOW_FN % {"body": shadow(), "clobbers": clobbers()}
+    text += "}  // namespace rt\n"
+    with open(OUT, "w") as f:
+        f.write(text)
+    print("wrote", OUT, "(%d lines)" % text.count("\n"))
+
+
+if __name__ == "__main__":
+    main()

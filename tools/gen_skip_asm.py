@@ -181,9 +181,12 @@ class F32(Prec):
         a.op("s_and_b64 vcc, vcc, %s" % self.M56, "go")
 
     def item_update(self, a, c):
-        a.op("v_mov_b32_e32 %%[t0], %s" % self.item(c), "(a VOP3 may read one scalar source: vcc is it)")
-        a.op("v_cndmask_b32_e32 %[best], %[best], %[t4], vcc", "primitive.rs:80-83")
-        a.op("v_cndmask_b32_e32 %[bitem], %[bitem], %[t0], vcc")
+        # by EXEC, not by v_cndmask: a v_cndmask_b32_e32 that reads VCC occupies the SIMD for 23 cycles (an e64 one with its mask
+        # in another SGPR pair for 4.2; tools/valu_issue_probe.hip), a v_mov for 2.2
+        a.op("s_mov_b64 exec, vcc", "primitive.rs:80-83")
+        a.op("v_mov_b32_e32 %[best], %[t4]")
+        a.op("v_mov_b32_e32 %%[bitem], %s" % self.item(c))
+        a.op("s_mov_b64 exec, %s" % self.EX)
 
     def shadow_t2_negative(self, a):
         a.op("v_cmp_gt_f32_e64 %s, 0, %%[b]" % self.M54, "b < 0: t2 may still be negative")

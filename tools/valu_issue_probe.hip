@@ -9,9 +9,12 @@
 //      op_sel_hi), v_cmp_*_e64 writing an SGPR pair, v_cndmask, v_sqrt_f32, a dependent v_add_f32 chain, a 50/50 VALU/SALU mix and
 //      the 10 VALU + 12 SALU mix of the commonest traversal step.
 // Every wave runs ITERS x 64 instructions of one kind between two s_memtime stamps (shader-clock cycles) and two
-// s_memrealtime stamps (100 MHz); with W co-resident waves per SIMD that all overlap, cycles per instruction per SIMD =
-// median wave cycles / (W x instructions per wave).  The HW_ID of every wave is recorded to check that the waves really sat
-// W to a SIMD.
+// s_memrealtime stamps (100 MHz); with W co-resident waves per SIMD that all start together, cycles per instruction per SIMD =
+// the LONGEST wave's cycles / (W x instructions per wave): the SIMD arbitrates oldest-first, so its waves finish one after the
+// other (the first at the lone-wave rate) and only the last one spans the whole run -- the median wave understates the cost
+// (round 2's first table did exactly that and read 1.46 cycles for a VOP2 that takes 2.2).  The event time of the launch times
+// the measured shader clock is printed beside it as a cross-check.  The HW_ID of every wave is recorded to check that the waves
+// really sat W to a SIMD.
 //
 //   hipcc -O2 --offload-arch=gfx950 -o valu_issue_probe tools/valu_issue_probe.hip && ./valu_issue_probe > profiles/r02_valu_issue_probe.json
 #include <hip/hip_runtime.h>
@@ -31,7 +34,7 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 enum Kind { K_MUL, K_ADD, K_MUL_SGPR, K_FMA, K_PK_MUL, K_PK_ADD, K_PK_MUL_SGPR, K_CMP_E64, K_CNDMASK, K_SQRT, K_DEP_ADD, K_VALU_SALU,
-            K_STEP_MIX, K_PK_FMA, K_MUL_SGPR_ROT, K_ITEM_SGPR, K_ITEM_SGPR_R2, K_COUNT };
+            K_STEP_MIX, K_PK_FMA, K_MUL_SGPR_ROT, K_ITEM_SGPR, K_ITEM_SGPR_R2, K_PK_MUL_SGPR_ROT, K_ITEM_PK, K_CND_E64, K_MOV, K_EXEC_MOV, K_CND_ZERO, K_COUNT };
 
 static const char *kNames[K_COUNT] = {
     "v_mul_f32 (VGPR x VGPR, independent)", "v_add_f32 (independent)", "v_mul_f32 (SGPR x VGPR, independent)", "v_fma_f32 (independent)",
@@ -39,10 +42,14 @@ static const char *kNames[K_COUNT] = {
     "v_cmp_lt_f32_e64 -> SGPR pair", "v_cndmask_b32 (vcc)", "v_sqrt_f32 (independent)", "v_add_f32 (dependent chain)",
     "alternating v_mul_f32 / s_add_u32", "traversal-step mix: 10 VALU + 12 SALU per 22", "v_pk_fma_f32 (VGPR pairs, independent)",
     "v_mul_f32 (a DIFFERENT SGPR x VGPR each instruction, independent)", "flat-scan item: 8 dependent VOP2, 5 distinct SGPR operands",
-    "flat-scan item for TWO rays per lane: 16 VOP2, each SGPR operand used by two consecutive instructions" };
+    "flat-scan item for TWO rays per lane: 16 VOP2, each SGPR operand used by two consecutive instructions",
+    "v_pk_mul_f32 (a DIFFERENT SGPR broadcast x VGPR pair each instruction, independent)",
+    "flat-scan item for TWO rays per lane, packed: 8 dependent v_pk_*_f32, 5 distinct SGPR broadcast operands",
+    "v_cndmask_b32_e64 (mask in an SGPR pair)", "v_mov_b32 (independent)", "select by EXEC: s_and_saveexec_b64 / v_mov_b32 / s_mov_b64 exec (per 3)",
+    "v_cndmask_b32_e64 (mask in an SGPR pair that is all zeros)" };
 // vector instructions per 64-instruction block (the rest are scalar)
-static const int kValuPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 32, 30, 64, 64, 64, 64 };
-static const int kInstPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 66, 64, 64, 64, 64 };
+static const int kValuPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 32, 30, 64, 64, 64, 64, 64, 64, 64, 64, 21, 64 };
+static const int kInstPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 66, 64, 64, 64, 64, 64, 64, 64, 64, 63, 64 };
 
 #define R8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
 #define R64(M) R8(M) R8(M) R8(M) R8(M) R8(M) R8(M) R8(M) R8(M)
@@ -71,6 +78,10 @@ static const int kInstPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 
     "s_and_b64 vcc, vcc, s[24:25]\n" "s_mov_b32 s26, s21\n" "s_cmp_ge_u32 s26, s27\n" "s_mov_b32 s28, s26\n"           \
     "s_add_u32 s29, s29, 1\n" "s_add_u32 s30, s30, 1\n" "s_add_u32 s31, s31, 1\n" "s_nop 0\n"
 #define R3(M) M(0) M(1) M(2)
+#define I_CND64(k) "v_cndmask_b32_e64 %" #k ", %8, %" #k ", s[20:21]\n"
+#define I_MOV(k) "v_mov_b32_e32 %" #k ", %8\n"
+#define I_XMOV(k) "s_and_saveexec_b64 s[22:23], s[20:21]\n" "v_mov_b32_e32 %" #k ", %8\n" "s_mov_b64 exec, s[22:23]\n"
+#define R21(M) R8(M) R8(M) M(0) M(1) M(2) M(3) M(4)
 // eight multiplies, each with its own SGPR operand (s20..s27 are never written: only which register is read matters)
 #define I_ROT(k) "v_mul_f32_e32 %0, s20, %0\n" "v_mul_f32_e32 %1, s21, %1\n" "v_mul_f32_e32 %2, s22, %2\n" "v_mul_f32_e32 %3, s23, %3\n" \
                  "v_mul_f32_e32 %4, s24, %4\n" "v_mul_f32_e32 %5, s25, %5\n" "v_mul_f32_e32 %6, s26, %6\n" "v_mul_f32_e32 %7, s27, %7\n"
@@ -84,6 +95,16 @@ static const int kInstPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 
                    "v_add_f32_e32 %3, %0, %2\n" "v_add_f32_e32 %7, %4, %6\n" "v_mul_f32_e32 %0, %3, %3\n" "v_mul_f32_e32 %4, %7, %7\n"     \
                    "v_subrev_f32_e32 %0, s23, %0\n" "v_subrev_f32_e32 %4, s23, %4\n" "v_add_f32_e32 %1, s24, %0\n" "v_add_f32_e32 %5, s24, %4\n"
 #define R4(M) M(0) M(1) M(2) M(3)
+// packed: the low or the high half of an SGPR pair broadcast to both rays of a lane (op_sel picks the half, s20..s27 never written)
+#define I_PKROT(k) "v_pk_mul_f32 %0, s[20:21], %0 op_sel_hi:[0,1]\n" "v_pk_mul_f32 %1, s[20:21], %1 op_sel:[1,0] op_sel_hi:[1,1]\n"         \
+                   "v_pk_mul_f32 %2, s[22:23], %2 op_sel_hi:[0,1]\n" "v_pk_mul_f32 %3, s[22:23], %3 op_sel:[1,0] op_sel_hi:[1,1]\n"         \
+                   "v_pk_mul_f32 %4, s[24:25], %4 op_sel_hi:[0,1]\n" "v_pk_mul_f32 %5, s[24:25], %5 op_sel:[1,0] op_sel_hi:[1,1]\n"         \
+                   "v_pk_mul_f32 %6, s[26:27], %6 op_sel_hi:[0,1]\n" "v_pk_mul_f32 %7, s[26:27], %7 op_sel:[1,0] op_sel_hi:[1,1]\n"
+// the flat-scan item for two rays per lane in packed form (directions in %5..%7, v2f each)
+#define I_ITEMPK(k) "v_pk_mul_f32 %0, s[20:21], %5 op_sel_hi:[0,1]\n" "v_pk_mul_f32 %1, s[20:21], %6 op_sel:[1,0] op_sel_hi:[1,1]\n"       \
+                    "v_pk_mul_f32 %2, s[22:23], %7 op_sel_hi:[0,1]\n" "v_pk_add_f32 %0, %0, %1\n" "v_pk_add_f32 %3, %0, %2\n"              \
+                    "v_pk_mul_f32 %0, %3, %3\n" "v_pk_add_f32 %0, %0, s[22:23] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n"  \
+                    "v_pk_add_f32 %4, s[24:25], %0 op_sel_hi:[0,1]\n"
 
 struct Rec { unsigned long long cycles, ref100; unsigned hw_id, xcc; };
 
@@ -97,6 +118,8 @@ __global__ __launch_bounds__(1024) void k_probe(int iters, Rec *rec, float *sink
     const float sone = __builtin_amdgcn_readfirstlane(one);
     unsigned long long sone2;
     { unsigned u = __float_as_uint(sone); sone2 = ((unsigned long long)u << 32) | u; }
+    if constexpr (KIND == K_CND_E64 || KIND == K_EXEC_MOV || KIND == K_CNDMASK) asm volatile("s_mov_b64 s[20:21], 0x5555\n s_mov_b64 vcc, 0x5555" ::: "s20", "s21", "vcc");
+    if constexpr (KIND == K_CND_ZERO) asm volatile("s_mov_b64 s[20:21], 0" ::: "s20", "s21");
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
         if constexpr (KIND == K_MUL)
@@ -135,6 +158,18 @@ __global__ __launch_bounds__(1024) void k_probe(int iters, Rec *rec, float *sink
         else if constexpr (KIND == K_ITEM_SGPR_R2)
             asm volatile(R4(I_ITEM2) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone)
                          : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+        else if constexpr (KIND == K_PK_MUL_SGPR_ROT)
+            asm volatile(R8(I_PKROT) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(one2), "s"(sone2)
+                         : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+        else if constexpr (KIND == K_ITEM_PK)
+            asm volatile(R8(I_ITEMPK) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(one2), "s"(sone2)
+                         : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+        else if constexpr (KIND == K_CND_E64 || KIND == K_CND_ZERO)
+            asm volatile(R64(I_CND64) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone));
+        else if constexpr (KIND == K_MOV)
+            asm volatile(R64(I_MOV) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone));
+        else if constexpr (KIND == K_EXEC_MOV)
+            asm volatile(R21(I_XMOV) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone) : "s22", "s23", "scc");
         else if constexpr (KIND == K_STEP_MIX)
             asm volatile(R3(I_STEP)
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone)
@@ -152,10 +187,12 @@ __global__ __launch_bounds__(1024) void k_probe(int iters, Rec *rec, float *sink
     if (s == 12345.678f) sink[0] = s;          // keeps every accumulator alive without a store in practice
 }
 
+static int g_iters = 2000;      // argv[1]: longer runs show what the clock does under sustained load
+
 template <int KIND>
 void run_kind(int n_cu, Rec *d_rec, float *d_sink, bool first)
 {
-    const int iters = 2000;
+    const int iters = g_iters;
     for (int W : { 1, 2, 4, 8 }) {
         // W waves per SIMD: one workgroup of 256*W threads per CU (its waves go round-robin over the 4 SIMDs); W = 8 takes two
         // 1,024-thread workgroups per CU
@@ -184,19 +221,24 @@ void run_kind(int n_cu, Rec *d_rec, float *d_sink, bool first)
         std::sort(cyc.begin(), cyc.end()); std::sort(ref.begin(), ref.end());
         int occ_min = 1 << 30, occ_max = 0;
         for (auto &kv : per_simd) { occ_min = std::min(occ_min, kv.second); occ_max = std::max(occ_max, kv.second); }
-        const double med = (double)cyc[waves / 2], med_ref = (double)ref[waves / 2];
+        // The SIMD arbitrates oldest-first: co-resident waves do NOT progress evenly (the oldest runs at the lone-wave rate, the
+        // youngest finishes last), so the time the SIMD needs for W x inst instructions is the LONGEST wave's, not the median's.
+        const double med = (double)cyc[waves / 2], longest = (double)cyc.back(), med_ref = (double)ref[waves / 2];
         const double inst = (double)iters * kInstPerBlock[KIND], valu = (double)iters * kValuPerBlock[KIND];
+        const double mhz = med_ref > 0 ? med / med_ref * 100.0 : 0.0;
         printf("%s    {\"kind\": \"%s\", \"waves_per_simd\": %d, \"simds_seen\": %zu, \"waves_on_a_simd_min_max\": [%d, %d], "
                "\"wave_cycles_median\": %.0f, \"wave_cycles_min_max\": [%llu, %llu], \"cycles_per_instruction_per_simd\": %.3f, "
-               "\"cycles_per_valu_instruction_per_simd\": %.3f, \"shader_clock_MHz\": %.0f, \"kernel_ms\": %.4f}",
+               "\"cycles_per_valu_instruction_per_simd\": %.3f, \"cycles_per_instruction_per_simd_by_kernel_time\": %.3f, "
+               "\"cycles_per_instruction_of_the_first_wave_to_finish\": %.3f, \"shader_clock_MHz\": %.0f, \"kernel_ms\": %.4f}",
                first && W == 1 ? "" : ",\n", kNames[KIND], W, per_simd.size(), occ_min, occ_max, med, cyc.front(), cyc.back(),
-               med / (W * inst), med / (W * valu), med_ref > 0 ? med / med_ref * 100.0 : 0.0, ms);
+               longest / (W * inst), longest / (W * valu), ms * 1e-3 * mhz * 1e6 / (W * inst), (double)cyc.front() / inst, mhz, ms);
         CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
     }
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1) g_iters = atoi(argv[1]);
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int n_cu = prop.multiProcessorCount;
@@ -204,9 +246,9 @@ int main()
     CHECK(hipMalloc(&d_rec, sizeof(Rec) * n_cu * 2 * 16));
     CHECK(hipMalloc(&d_sink, 64));
     printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"compute_units\": %d, \"clock_rate_kHz\": %d,\n"
-           " \"method\": \"every wave runs 2000 x 64 instructions of one kind between s_memtime stamps; W waves per SIMD on every SIMD at once; "
-           "cycles per instruction per SIMD = median wave cycles / (W x instructions per wave)\",\n \"results\": [\n",
-           prop.name, prop.gcnArchName, n_cu, prop.clockRate);
+           " \"method\": \"every wave runs %d x 64 instructions of one kind between s_memtime stamps; W waves per SIMD on every SIMD at once; "
+           "cycles per instruction per SIMD = LONGEST wave's cycles / (W x instructions per wave) -- the SIMD arbitrates oldest-first, so its waves finish one after the other and the last one spans the whole run; the event time of the launch x the shader clock gives the same figure (..._by_kernel_time)\",\n \"results\": [\n",
+           prop.name, prop.gcnArchName, n_cu, prop.clockRate, g_iters);
     run_kind<K_MUL>(n_cu, d_rec, d_sink, true);
     run_kind<K_ADD>(n_cu, d_rec, d_sink, false);
     run_kind<K_MUL_SGPR>(n_cu, d_rec, d_sink, false);
@@ -224,6 +266,12 @@ int main()
     run_kind<K_MUL_SGPR_ROT>(n_cu, d_rec, d_sink, false);
     run_kind<K_ITEM_SGPR>(n_cu, d_rec, d_sink, false);
     run_kind<K_ITEM_SGPR_R2>(n_cu, d_rec, d_sink, false);
+    run_kind<K_PK_MUL_SGPR_ROT>(n_cu, d_rec, d_sink, false);
+    run_kind<K_ITEM_PK>(n_cu, d_rec, d_sink, false);
+    run_kind<K_CND_E64>(n_cu, d_rec, d_sink, false);
+    run_kind<K_CND_ZERO>(n_cu, d_rec, d_sink, false);
+    run_kind<K_MOV>(n_cu, d_rec, d_sink, false);
+    run_kind<K_EXEC_MOV>(n_cu, d_rec, d_sink, false);
     printf("\n ]}\n");
     CHECK(hipFree(d_rec)); CHECK(hipFree(d_sink));
     return 0;
