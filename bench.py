@@ -19,8 +19,9 @@ vector (tests/golden/oracle_vectors.json) or the run fails.
 `roofline` (rank 0's render kernel): bound = VALU issue -- this path is un-fused f32 arithmetic on records that live in the
 scalar cache / L2, not an HBM stream.  achieved = SURVEY.md 8(d)'s 17 flops per ray x record test x the tests of one launch
 (counted by the kernel in this run, equal to the CPU path's) / the kernel's launch duration (HIP events on the launch
-stream, in this run); peak = 1,024 SIMDs x 64 lanes x 2.4 GHz / the measured cycles per wave64 VOP2 instruction at 8 waves
-per SIMD (profiles/r02_valu_issue_probe.json, tools/valu_issue_probe.hip).  Figures that need rocprofv3 counters (instruction
+stream, in this run); peak = 1,024 SIMDs x 64 lanes x 2.4 GHz / the measured cycles a SIMD needs per wave64 VOP2 instruction at
+8 waves per SIMD (profiles/r02_valu_issue_probe.json, tools/valu_issue_probe.hip: 2.22 -- the longest wave of the probe, not
+the median one; the first table of round 2 read 1.46 from the median and was wrong).  Figures that need rocprofv3 counters (instruction
 issue, HBM traffic) are quoted from profiles/ under `from_profiles`, stamped with the kernel sources they were collected on,
 and dropped when that stamp is not the sources' of this run.
 
@@ -369,10 +370,12 @@ def main():
         skip_note = ("achieved = 17 flops x (item + bound tests the reference's traversal makes for rank 0's rays, counted by the kernel in "
                      "this run and equal to the CPU path's) / HIP-event duration of k_render_skip in this run.  The records arrive "
                      "through the scalar cache / L2 (the whole scene is < 1 MB): VALU issue binds, not HBM")
-        flat_note = ("achieved = un-fused flops of the tests the flat pipeline executed (8 per primary test with the pre-formed terms, 16 per "
-                     "shadow test; queue lengths x pass lengths) / HIP-event duration of its kernels (k_flat_primary_sc + 2 x k_flat_shadow_sc + "
-                     "k_resolve_samples); the items are wave-uniform scalars (s_load -> SGPR operands of VOP2 instructions), served by the "
-                     "scalar cache / L2")
+        flat_note = ("achieved = the reference's un-fused flops for the tests the flat pipeline covered (8 per primary test with the pre-formed "
+                     "terms, 16 per shadow test; queue lengths x pass lengths) / HIP-event duration of its kernels (k_flat_primary_sc + 2 x "
+                     "k_flat_shadow_sc + k_resolve_samples).  The items are wave-uniform scalars (s_load -> SGPR-pair operands of packed "
+                     "instructions, two rays per lane); a conservative bound of the discriminant (4 / 11 packed FMAs per item and ray pair, "
+                     "margin proven and checked exhaustively: rt_debug_flat_filter_check) rejects items, and the reference's individually "
+                     "rounded operations run only for the survivors -- so the peak it is priced against is the packed-FMA issue rate")
         if world == 1 and not args.force_collective:
             layout = "1 GPU, buckets rendered straight into the row-major frame"
         elif multi == "frames":
@@ -411,17 +414,19 @@ def main():
             fst = flat["my_stats"]
             shadow_tests = fst["tests_executed"] - fst["primary"] * n_items       # what the any-hit passes really ran
             ops = fst["primary"] * n_items * 8 + shadow_tests * 16
-            vop2 = probe.get(("v_mul_f32 (SGPR x VGPR, independent)", 8))
-            pk_peak = N_SIMD * LANES * CLOCK_HZ / (vop2["cycles_per_instruction_per_simd"] if vop2 else 2.0)      # the same VOP2 roof as the headline
+            pkf = probe.get(("v_pk_fma_f32 (VGPR pairs, independent)", 8))
+            pk_cyc = pkf["cycles_per_instruction_per_simd"] if pkf else 4.0
+            pk_peak = N_SIMD * LANES * 4 * CLOCK_HZ / pk_cyc       # a packed FMA: 2 rays x 2 flops per lane
             t = flat["kern_ms"] * 1e-3
             out["flat"] = {"ms_per_step": round(flat["ms_per_step"], 4), "value": round(rays / (flat["ms_per_step"] * 1e-3) / 1e6, 3), "unit": "Mrays/s",
                            "frame_crc_ok": flat["crc_ok"],
                            "roofline": {"bound": "valu_issue", "achieved": round(ops / t / 1e12, 2), "peak": round(pk_peak / 1e12, 1),
-                                        "unit": "TFLOP/s (un-fused f32 lane ops)", "frac": round(ops / t / pk_peak, 4),
+                                        "unit": "TFLOP/s (reference flops against the packed-FMA issue rate)", "frac": round(ops / t / pk_peak, 4),
                                         "kernel": "k_flat_primary_sc + k_flat_shadow_sc", "kernel_ms": round(flat["kern_ms"], 4),
                                         "tests_executed": fst["tests_executed"], "note": flat_note,
-                                        "peak_source": "probe: cycles per wave64 VOP2 instruction per SIMD at 8 waves per SIMD (a VOP2 whose SGPR operand changes "
-                                                       "from one instruction to the next issues at the VOP3 rate, 2.55: profiles/r02_valu_issue_probe.json)",
+                                        "peak_source": "1,024 SIMDs x 64 lanes x 4 flops x 2.4 GHz / %.3f cycles per wave64 v_pk_fma_f32 per SIMD at 8 waves per "
+                                                       "SIMD (profiles/r02_valu_issue_probe.json; the un-fused VOP2 roof of the headline is half of it "
+                                                       "at 2.22 cycles per instruction)" % pk_cyc,
                                         "from_profiles": from_profiles("k_flat_primary_sc", flat["kern_ms"])}}
         for k, e in extras.items():
             out[k] = summary(e, "config5" if k == "config5_tiles" else "1080p")

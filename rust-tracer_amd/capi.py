@@ -157,5 +157,16 @@ def debug(key, value):
         debug_set(key, -1)
 
 
+lib.rt_debug_flat_filter_check.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_ulonglong * 6)]
+
+
+def flat_filter_check(scene_handle, width, height, spp):
+    """rt_debug_flat_filter_check -> (pairs with disc >= 0, pairs with bound >= 0, pairs with disc >= 0 but bound < 0) for the primary
+    filter, then the same three for the shadow filter."""
+    counts = (C.c_ulonglong * 6)()
+    check(lib.rt_debug_flat_filter_check(scene_handle, width, height, spp, C.byref(counts)), "rt_debug_flat_filter_check")
+    return tuple(int(c) for c in counts)
+
+
 def wave_trace(path):
     check(lib.rt_debug_wave_trace(path.encode() if path else None), "rt_debug_wave_trace")

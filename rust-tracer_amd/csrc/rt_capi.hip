@@ -111,8 +111,9 @@ struct rt_scene {
     bool fused = false;            // every BOUND is followed by an ITEM with the same centre (rt_skip.hpp, Node)
     void *d_fprim = nullptr, *d_fprim_rr = nullptr, *d_fshad = nullptr;   // pre-formed per-item terms (RT_TRAVERSAL_FLAT)
     uint32_t n_padded = 0;
-    void *d_pg = nullptr, *d_sg = nullptr;      // f32: the same terms in 64-byte groups of three for the scalar-fed scan (rt_flat_sc.hpp)
-    uint32_t flat_sc_bytes = 0;                 // 128 x number of group pairs
+    void *d_pf = nullptr, *d_pe = nullptr, *d_sg = nullptr, *d_se = nullptr;   // f32, the scalar-fed scan (rt_flat_sc.hpp): filter groups of four
+                                                                               // items and exact records, primary / shadow
+    uint32_t flat_filter_bytes = 0;                                            // 128 x number of filter group pairs
     double light[3] = { 0, 0, 0 }, eye[3] = { 0, 0, 0 };   // exact copies of the REAL values
     std::mutex mu;
     std::vector<std::unique_ptr<Context>> pool;
@@ -262,14 +263,17 @@ rt_status upload_flat(rt_scene *s, const void *host_items)
                        static_cast<T *>(s->d_fprim_rr), static_cast<rt::Quad<T> *>(s->d_fshad));
     HIP_TRY(hipGetLastError());
     if constexpr (sizeof(T) == 4) {
-        const uint32_t n3 = (s->n_items + rt::kFlatGroupItems - 1) / rt::kFlatGroupItems, pairs = (n3 + 1) / 2;
-        const uint32_t n_groups = 2 * pairs + rt::kFlatPadGroups;            // pad groups: never hit; the scan loads one pair ahead
-        s->flat_sc_bytes = pairs * 128u;
-        HIP_TRY(hipMalloc(&s->d_pg, sizeof(rt::FGroup) * n_groups));
+        const uint32_t n4 = (s->n_items + rt::kFlatFilterItems - 1) / rt::kFlatFilterItems, pairs = (n4 + 1) / 2;
+        const uint32_t n_groups = 2 * pairs + rt::kFlatPadGroups;            // pad groups: never hit; the scans load one pair ahead
+        s->flat_filter_bytes = pairs * 128u;
+        HIP_TRY(hipMalloc(&s->d_pf, sizeof(rt::FGroup) * n_groups));
+        HIP_TRY(hipMalloc(&s->d_pe, sizeof(rt::FExact) * s->n_items));
         HIP_TRY(hipMalloc(&s->d_sg, sizeof(rt::FGroup) * n_groups));
-        hipLaunchKernelGGL(rt::k_build_flat_groups, dim3((n_groups * rt::kFlatGroupItems + 255) / 256), dim3(256), 0, nullptr,
-                           static_cast<const rt::Item<float> *>(s->d_items), d_order, s->n_items, n_groups, rt::V3<float>{ (float)s->eye[0], (float)s->eye[1], (float)s->eye[2] },
-                           static_cast<rt::FGroup *>(s->d_pg), static_cast<rt::FGroup *>(s->d_sg));
+        HIP_TRY(hipMalloc(&s->d_se, sizeof(rt::FExactShadow) * s->n_items));
+        hipLaunchKernelGGL(rt::k_build_flat_groups, dim3((n_groups * rt::kFlatFilterItems + 255) / 256), dim3(256), 0, nullptr,
+                           static_cast<const rt::Item<float> *>(s->d_items), d_order, s->n_items, n_groups,
+                           rt::V3<float>{ (float)s->eye[0], (float)s->eye[1], (float)s->eye[2] }, static_cast<rt::FGroup *>(s->d_pf),
+                           static_cast<rt::FExact *>(s->d_pe), static_cast<rt::FGroup *>(s->d_sg), static_cast<rt::FExactShadow *>(s->d_se));
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -279,11 +283,13 @@ rt_status upload_flat(rt_scene *s, const void *host_items)
 rt::FlatScView flat_sc_view_of(const rt_scene *s)
 {
     rt::FlatScView v;
-    v.pg = static_cast<const rt::FGroup *>(s->d_pg);
+    v.pf = static_cast<const rt::FGroup *>(s->d_pf);
+    v.pe = static_cast<const rt::FExact *>(s->d_pe);
     v.sg = static_cast<const rt::FGroup *>(s->d_sg);
+    v.se = static_cast<const rt::FExactShadow *>(s->d_se);
+    v.n_fbytes = s->flat_filter_bytes;
     v.items = static_cast<const rt::Item<float> *>(s->d_items);
     v.n_items = s->n_items;
-    v.n_bytes = s->flat_sc_bytes;
     v.light = { (float)s->light[0], (float)s->light[1], (float)s->light[2] };
     v.eye = { (float)s->eye[0], (float)s->eye[1], (float)s->eye[2] };
     return v;
@@ -746,10 +752,10 @@ rt_status launch_flat_wavefront(const rt_scene *s, Context *c, hipStream_t strea
     if constexpr (sizeof(T) == 4) {
         if (knob(RT_DEBUG_FLAT_KERNELS) != 0) {
             // f32: the scalar-fed scan (rt_flat_sc.hpp): two rays per lane, a workgroup = two 16x16-pixel blocks of two waves each (the resolve table serves both)
-            constexpr unsigned kFirstPassGroups = 342;                  // the 1,026 largest spheres (an even number of groups)
+            constexpr unsigned kFirstPassGroups = 256;                  // the 1,024 largest spheres (an even number of groups)
             const rt::FlatScView sv = flat_sc_view_of(s);
-            const unsigned first_bytes = std::min(kFirstPassGroups * 64u, sv.n_bytes);
-            c->flat_first_pass_items = first_bytes / 64u * rt::kFlatGroupItems;
+            const unsigned first_bytes = std::min(kFirstPassGroups * 64u, sv.n_fbytes);
+            c->flat_first_pass_items = first_bytes / 64u * rt::kFlatFilterItems;
             hipLaunchKernelGGL(rt::k_flat_primary_sc, dim3((blocks16 + 1) / 2, (unsigned)ns), dim3(rt::kFlatScPrimaryThreads), 0, stream, sv, w, h, spp,
                                d_tab16, nt, blocks16, sb, q1, c->d_queues, cnt);
             HIP_TRY(hipGetLastError());
@@ -1038,6 +1044,25 @@ long long rt_debug_count(int counter)
     return counter >= 0 && counter < RT_DEBUG_COUNTERS ? g_count[counter].load(std::memory_order_relaxed) : -1;
 }
 
+// Test infrastructure (csrc/rt_debug.h): the flat scan's conservative filter against the exact discriminant, for every primary
+// ray of a width x height x spp frame and every item.  counts: {disc >= 0, bound >= 0, disc >= 0 && bound < 0} primary, then shadow.
+rt_status rt_debug_flat_filter_check(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp, unsigned long long counts[6])
+{
+    if (!s || !counts || s->precision != RT_F32 || !s->d_pf || !width || !height || !spp) return RT_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(s->device));
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc(&d, 6 * sizeof(unsigned long long)));
+    struct Free { unsigned long long *p; ~Free() { (void)hipFree(p); } } fr{ d };
+    HIP_TRY(hipMemset(d, 0, 6 * sizeof(unsigned long long)));
+    const uint64_t px = (uint64_t)width * height;
+    hipLaunchKernelGGL(rt::k_flat_filter_check, dim3((unsigned)((px + rt::kBlockThreads - 1) / rt::kBlockThreads), spp * spp), dim3(rt::kBlockThreads), 0,
+                       nullptr, flat_sc_view_of(s), width, height, spp, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(counts, d, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 rt_status rt_debug_wave_trace(const char *path)
 {
     std::lock_guard<std::mutex> lk(g_trace_mu);
@@ -1169,8 +1194,10 @@ rt_status rt_scene_destroy(rt_scene *s)
     if (s->d_fprim) (void)hipFree(s->d_fprim);
     if (s->d_fprim_rr) (void)hipFree(s->d_fprim_rr);
     if (s->d_fshad) (void)hipFree(s->d_fshad);
-    if (s->d_pg) (void)hipFree(s->d_pg);
+    if (s->d_pf) (void)hipFree(s->d_pf);
+    if (s->d_pe) (void)hipFree(s->d_pe);
     if (s->d_sg) (void)hipFree(s->d_sg);
+    if (s->d_se) (void)hipFree(s->d_se);
     delete s;
     return RT_OK;
 }

@@ -54,6 +54,12 @@ long long rt_debug_count(int counter);
  * start / end / placement and writes the records to the file (synchronous, overwritten per launch).  NULL switches it off. */
 rt_status rt_debug_wave_trace(const char *path);
 
+/* Test infrastructure for the flat scan's conservative filter (rt_flat_sc.hpp, flat_filter_constant): evaluates, for every primary
+ * ray of a width x height x spp frame and every item of an f32 scene, the exact discriminant and the filter's bound.
+ * counts = { pairs with disc >= 0, pairs with bound >= 0, pairs with disc >= 0 but bound < 0 } for the primary filter, then the same
+ * three for the shadow filter on rays from a point of each primary ray towards the light: counts[2] and counts[5] must be 0. */
+rt_status rt_debug_flat_filter_check(rt_scene *scene, uint32_t width, uint32_t height, uint32_t spp, unsigned long long counts[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,69 +1,150 @@
 // rt_flat_sc.hpp -- RT_TRAVERSAL_FLAT for f32, the kernels the product runs: every item of the scene against every ray, with
-// the items fed through the SCALAR path.
+// the items fed through the SCALAR path, two rays per lane on packed math, and a conservative filter in front of the exact test.
 //
-// A linear scan is wave-uniform by construction: all 64 rays of a wave test the same item at the same moment.  On CDNA that
-// makes the item a scalar: records arrive by s_load (scalar cache, 466 KB for the 21,845 spheres in L2 behind it) and feed the
-// vector ALU as SGPR operands of plain 4-byte VOP2 instructions -- no LDS staging, no ds_read, no barrier, 8 waves per SIMD.
-// tools/valu_issue_probe.hip measured why this is the better shape here than the LDS + packed-math kernels of rt_flat_wf.hpp
-// (round 1; still what f64 runs, and selectable for f32 with csrc/rt_debug.h RT_DEBUG_FLAT_KERNELS = 0): a packed v_pk_mul/add_f32
-// issues in 2.55 cycles per wave at 8 waves per SIMD against 1.46 for a VOP2 -- 1.15x the lane-ops per cycle, not 2x -- while the
-// pair-interleaved operands cost registers (5.5 waves per SIMD) and five ds_read_b128 per 32 packed ops whose latency the
-// kernel waits for 65 % of the time.  The scan loops themselves are generated assembly (tools/gen_flat_asm.py ->
-// rt_flat_rot.hpp): as C++ the same scan compiled to 19 scalar / branch instructions per four items beside the 31 vector
-// ones and was slower than the LDS kernels.
+// A linear scan is wave-uniform by construction: all rays of a wave test the same item at the same moment.  On CDNA that makes
+// the item a scalar: records arrive by s_load (scalar cache, the scene's < 1 MB in L2 behind it) and feed the vector ALU as SGPR
+// operands -- no LDS staging, no ds_read, no barrier.  tools/valu_issue_probe.hip measured what the operand costs: a VOP2 that
+// reads a different SGPR than its predecessor occupies the SIMD for 4.1 cycles instead of 2.2, exactly what a packed
+// v_pk_mul/add/fma_f32 takes with its scalar operand (half of an SGPR pair, broadcast by op_sel) for free.  So a lane carries TWO
+// rays in VGPR pairs and every instruction of the scan is packed.  The scan loops are generated assembly (tools/gen_flat_asm.py
+// -> rt_flat_rot.hpp), which also documents the filter: almost every test ends in `disc < 0`, and for that only the sign of disc
+// is needed -- per item the loops form a bound of disc with 4 (primary) / 11 (shadow) packed FMAs whose margin covers every
+// rounding of both computations (disc >= 0 implies bound >= 0; flat_filter_constant / flat_shadow_filter_rr below, checked
+// exhaustively by k_flat_filter_check), reject a group of four items with one branch, and run the reference's eight / sixteen
+// individually rounded operations (primitive.rs:55-72) only for the items whose bound is >= 0 for some ray.  What is computed
+// for those is the reference's, bit for bit, in item order; the filter only decides what is looked at.
+// round 1's LDS + packed-math kernels (rt_flat_wf.hpp) remain what f64 runs and are selectable for f32 with csrc/rt_debug.h
+// RT_DEBUG_FLAT_KERNELS = 0.
 //
-//   k_flat_primary_sc  one thread per pixel x one sample: primary ray, nearest-hit scan of all items in DFS order (strict `<`:
-//                      the first item in DFS order wins ties, primitive.rs:79), shade; the sample's {state, n.light} is stored
-//                      and rays that need a shadow test are appended to queue 1 (one atomic per wave)
-//   k_flat_shadow_sc   one thread per queued shadow ray, any hit over a range of the RADIUS-SORTED item array (pass A: the 1,026
+//   k_flat_primary_sc  one lane = two pixels of one sample (a wave = a 16x8 patch): primary rays, nearest-hit scan of all items in
+//                      DFS order (strict `<`: the first item in DFS order wins ties, primitive.rs:79), shade; the sample's {state,
+//                      n.light} is stored and rays that need a shadow test are appended to queue 1 (one atomic per wave and half)
+//   k_flat_shadow_sc   one lane = two queued shadow rays, any hit over a range of the RADIUS-SORTED item array (pass A: the 1,024
 //                      largest spheres, which settle 89 % of the occluded rays; survivors re-packed into queue 2; pass B: the
 //                      rest); a wave leaves as soon as all its rays are settled
-//
-// Items are consumed three at a time (one 64-byte group = one s_load_dwordx16): the three discriminants are reduced with ONE
-// v_max3 and one branch rejects the group -- a ray's line meets a handful of the 21,845 spheres -- and the exact sqrt path
-// runs per item, in item order, only inside that rarely taken branch.  Per-item terms that do not depend on the ray are
-// pre-formed once per scene with the same individually rounded operations (v = c - eye, vv, rr): 8 VALU operations per
-// primary test, 16 per shadow test, every one of them the reference's (primitive.rs:55-72).
 #pragma once
 #include "rt_flat_wf.hpp"
 #include "rt_flat_rot.hpp"
 
 namespace rt {
 
-// Three items: primary {vx[3], vy[3], vz[3], vv[3], rr[3], pad}, shadow {cx[3], cy[3], cz[3], rr[3], pad[4]}.
+// Filter groups of FOUR items -- primary {vx[4], vy[4], vz[4], K[4]}, shadow {cx[4], cy[4], cz[4], rr'[4]} -- and one exact record per
+// item: primary {vx, vy, vz, vv, rr, 0, 0, 0}, shadow {cx, cy, cz, rr}.
 struct alignas(64) FGroup { float f[16]; };
-constexpr unsigned kFlatGroupItems = 3;
-constexpr unsigned kFlatPadGroups = 2;          // behind the last pair: the scan loads one pair ahead
+struct alignas(32) FExact { float f[8]; };
+struct alignas(16) FExactShadow { float f[4]; };
+constexpr unsigned kFlatFilterItems = 4;
+constexpr unsigned kFlatPadGroups = 2;          // behind the last pair: the scans load one pair ahead
 
 struct FlatScView {
-    const FGroup *pg;       // DFS order
-    const FGroup *sg;       // radius descending
+    const FGroup *pf;       // primary filter groups, DFS order
+    const FExact *pe;       // primary exact records, DFS order
+    const FGroup *sg;       // shadow filter groups, radius descending
+    const FExactShadow *se; // shadow exact records, radius descending
     const Item<float> *items;   // centres for the normal of the winning item
-    uint32_t n_items, n_bytes;  // n_bytes: 128 * number of group pairs
+    uint32_t n_items;
+    uint32_t n_fbytes;      // 128 * number of filter group pairs (both scans)
     V3<float> light, eye;
 };
 
-// shadow_order[i] = index of the item at position i of the shadow array.  Pad items (i >= n) can never be hit: rr = -inf
-// makes disc = (b*b - vv) + rr = -inf whatever the ray is.
+// The filter constant of an item (the proof is in tools/gen_flat_asm.py): the exact test forms, each operation rounded,
+//      b = (vx*dx + vy*dy) + vz*dz ; disc = (b*b - vv) + rr                              (primitive.rs:57-58)
+// and the filter b' = fma(vz, dz, fma(vy, dy, vx*dx)) ; bound = fma(b', b', K).  With eps = 2^-24 and |d| <= 1 + 2 eps, both b and
+// b' lie within 3.1 eps |v| of the exact dot product, so |b*b - b'*b'| <= 12.4 eps |v|^2; the three roundings of disc add at most
+// 1.1 eps |v|^2 + 2 eps rr, and the stored vv is within 4 eps of |v|^2.  Hence disc >= 0 implies b'*b' - vv + rr >= -(14 eps vv +
+// 3 eps rr) -- K = rr - vv + 2^-17 (vv + rr) + 2^-140, rounded UP, leaves a factor of eight on the relative term, and the absolute
+// term covers the results that are subnormal (scenes scaled to 1e-20: errors there are absolute, <= 2^-149 each).
+__device__ __forceinline__ float flat_filter_constant(float vv, float rr)
+{
+    const double k = ((double)rr - (double)vv) + ((double)vv + (double)rr) * 0x1p-17 + 0x1p-140;
+    float f = (float)k;
+    if ((double)f < k) f = __uint_as_float(__float_as_uint(f) + (f >= 0.f ? 1u : 0xFFFFFFFFu));      // next float up (f is finite and != -0)
+    return f;
+}
+
+// Shadow rays have their own origin, so vv is per ray: the filter forms b' and vv' as FMA chains from the SAME v = c - o the exact
+// test forms, and bound = fma(-vv', 1 - m, fma(b', b', rr')) with m = 2^-17.  |b*b - b'*b'| <= 12.4 eps |v|^2 as above (|dir| <= 1 +
+// 2 eps), vv and vv' are within 3 eps |v|^2 of |v|^2 each, the exact test's roundings add 1.1 eps |v|^2 + 2 eps rr and the filter's two
+// FMAs eps (vv' + rr'): disc >= 0 implies b'*b' - vv' + rr >= -(21 eps vv' + 3 eps rr), which m (vv' + rr) = 128 eps (vv' + rr)
+// covers six times over; 2^-140 covers the subnormal range.
+__device__ __forceinline__ float flat_shadow_filter_rr(float rr)
+{
+    const double k = (double)rr * (1.0 + 0x1p-17) + 0x1p-140;
+    float f = (float)k;
+    if ((double)f < k) f = __uint_as_float(__float_as_uint(f) + 1u);        // next float up (f > 0)
+    return f;
+}
+
+// shadow_order[i] = index of the item at position i of the shadow array.  Pad items (i >= n) can never be hit: rr = -inf makes
+// disc = (b*b - vv) + rr = -inf whatever the ray is, K = -inf the filter's bound.
 __global__ void k_build_flat_groups(const Item<float> *__restrict__ items, const unsigned *__restrict__ shadow_order, unsigned n, unsigned n_groups,
-                                    V3<float> eye, FGroup *__restrict__ pg, FGroup *__restrict__ sg)
+                                    V3<float> eye, FGroup *__restrict__ pf, FExact *__restrict__ pe, FGroup *__restrict__ sg,
+                                    FExactShadow *__restrict__ se)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_groups * kFlatGroupItems) return;
-    const unsigned g = i / kFlatGroupItems, k = i % kFlatGroupItems;
-    float *p = pg[g].f, *s = sg[g].f;
+    if (i >= n_groups * kFlatFilterItems) return;
+    const unsigned g = i / kFlatFilterItems, k = i % kFlatFilterItems;
+    float *p = pf[g].f, *s = sg[g].f;
     if (i < n) {
         const Item<float> it = items[i];
         const V3<float> v = { it.cx - eye.x, it.cy - eye.y, it.cz - eye.z };      // primitive.rs:56
-        p[0 + k] = v.x; p[3 + k] = v.y; p[6 + k] = v.z; p[9 + k] = dot(v, v);
-        p[12 + k] = it.r * it.r;                                                // primitive.rs:58
+        const float vv = dot(v, v), rr = it.r * it.r;                             // primitive.rs:58
+        p[0 + k] = v.x; p[4 + k] = v.y; p[8 + k] = v.z; p[12 + k] = flat_filter_constant(vv, rr);
+        float *e = pe[i].f;
+        e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = vv; e[4] = rr; e[5] = e[6] = e[7] = 0.f;
         const Item<float> sh = items[shadow_order[i]];
-        s[0 + k] = sh.cx; s[3 + k] = sh.cy; s[6 + k] = sh.cz; s[9 + k] = sh.r * sh.r;
+        const float srr = sh.r * sh.r;
+        s[0 + k] = sh.cx; s[4 + k] = sh.cy; s[8 + k] = sh.cz; s[12 + k] = flat_shadow_filter_rr(srr);
+        float *x = se[i].f;
+        x[0] = sh.cx; x[1] = sh.cy; x[2] = sh.cz; x[3] = srr;
     } else {
-        p[0 + k] = 0.f; p[3 + k] = 0.f; p[6 + k] = 0.f; p[9 + k] = 0.f; p[12 + k] = -inf<float>();
-        s[0 + k] = 0.f; s[3 + k] = 0.f; s[6 + k] = 0.f; s[9 + k] = -inf<float>();
+        p[0 + k] = 0.f; p[4 + k] = 0.f; p[8 + k] = 0.f; p[12 + k] = -inf<float>();
+        s[0 + k] = 0.f; s[4 + k] = 0.f; s[8 + k] = 0.f; s[12 + k] = -inf<float>();
     }
-    if (k == 0) { p[15] = 0.f; s[12] = s[13] = s[14] = s[15] = 0.f; }
+}
+
+// Test infrastructure of the filter's proof (rt_debug_flat_filter_check): for the primary rays of one frame and every item, the
+// exact discriminant and the filter's bound; counts the pairs with disc >= 0, with bound >= 0, and with disc >= 0 but bound < 0
+// (which must not exist); counts[3..5]: the same for the shadow filter on rays from a point of each primary ray towards the light.
+__global__ __launch_bounds__(kBlockThreads) void k_flat_filter_check(FlatScView sc, unsigned width, unsigned height, unsigned spp,
+                                                                    unsigned long long *__restrict__ counts)
+{
+    const unsigned px = blockIdx.x * kBlockThreads + threadIdx.x;
+    const unsigned x = px % width, y = px / width;
+    if (y >= height) return;
+    const float ssf = float(spp), fw = float(width), fh = float(height);
+    const float half_w = fw / 2.0f, half_h = fh / 2.0f;
+    const unsigned ssx = blockIdx.y / spp, ssy = blockIdx.y % spp;
+    const float xres = float(x) + float(ssx) / ssf, yres = float(y) + float(ssy) / ssf;
+    const V3<float> d = normalized(V3<float>{ xres - half_w, (fh - yres) - half_h, fw });
+    unsigned long long exact = 0, bound = 0, bad = 0, sexact = 0, sbound = 0, sbad = 0;
+    // shadow-type rays: from a point on the primary ray (0.75 .. 1 times the eye's distance from the origin along it) towards the light
+    const V3<float> o = add(sc.eye, mulf(d, sqrtf(dot(sc.eye, sc.eye)) * (0.75f + 0.0625f * float(blockIdx.y % 5u))));
+    const V3<float> l = mulf(sc.light, -1.0f);
+    for (unsigned i = 0; i < sc.n_items; ++i) {
+        const float *e = sc.pe[i].f;
+        const float b = (e[0] * d.x + e[1] * d.y) + e[2] * d.z;
+        const float disc = (b * b - e[3]) + e[4];
+        const float k = sc.pf[i / kFlatFilterItems].f[12 + i % kFlatFilterItems];
+        const float bf = __builtin_fmaf(e[2], d.z, __builtin_fmaf(e[1], d.y, e[0] * d.x));
+        const float bnd = __builtin_fmaf(bf, bf, k);
+        const bool ce = disc >= 0.f, cb = bnd >= 0.f;
+        exact += ce; bound += cb; bad += ce && !cb;
+        const float *x = sc.se[i].f;
+        const V3<float> v = { x[0] - o.x, x[1] - o.y, x[2] - o.z };
+        const float sb = dot(v, l);
+        const float sdisc = (sb * sb - dot(v, v)) + x[3];
+        const float rrp = sc.sg[i / kFlatFilterItems].f[12 + i % kFlatFilterItems];
+        const float sbf = __builtin_fmaf(l.z, v.z, __builtin_fmaf(l.y, v.y, l.x * v.x));
+        const float w = __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x));
+        const float sbnd = __builtin_fmaf(-w, 1.0f - 0x1p-17f, __builtin_fmaf(sbf, sbf, rrp));
+        const bool se = sdisc >= 0.f, sbb = sbnd >= 0.f;
+        sexact += se; sbound += sbb; sbad += se && !sbb;
+    }
+    exact = wave_sum((unsigned)exact); bound = wave_sum((unsigned)bound); bad = wave_sum((unsigned)bad);
+    sexact = wave_sum((unsigned)sexact); sbound = wave_sum((unsigned)sbound); sbad = wave_sum((unsigned)sbad);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&counts[3], sexact); atomicAdd(&counts[4], sbound); atomicAdd(&counts[5], sbad); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&counts[0], exact); atomicAdd(&counts[1], bound); atomicAdd(&counts[2], bad); }
 }
 
 constexpr unsigned kFlatScRays = 2;                       // rays per lane (one VGPR pair per quantity)
@@ -109,7 +190,7 @@ __global__ __launch_bounds__(kFlatScPrimaryThreads) void k_flat_primary_sc(FlatS
     // ---------------- primary rays: nearest hit, strict `<`, first item in DFS order wins ties ----------------
     T best[kFlatScRays];
     unsigned best_i[kFlatScRays];
-    flat_primary_scan(sc.pg, sc.n_bytes, dx, dy, dz, best, best_i);
+    flat_primary_scan(sc.pf, sc.n_fbytes, sc.pe, dx, dy, dz, best, best_i);
 
     // ---------------- shade (render.rs:190-199), store the samples, queue the shadow rays ----------------
     unsigned c_prim = 0, c_hits = 0, c_shadow = 0;
@@ -179,9 +260,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_flat_shadow_sc(FlatScView sc,
         }
     }
     const V3<T> sdir = mulf(sc.light, T(-1.0));                                // render.rs:206
-    const unsigned end = min(end_bytes, sc.n_bytes);
+    const unsigned end = min(end_bytes, sc.n_fbytes);
     if (begin_bytes < end)
-        flat_shadow_scan(sc.sg, begin_bytes, end, ox, oy, oz, sdir.x, sdir.y, sdir.z, have, occluded);
+        flat_shadow_scan(sc.sg, begin_bytes, end, sc.se, ox, oy, oz, sdir.x, sdir.y, sdir.z, have, occluded);
     unsigned c_occ = 0;
     for (unsigned h = 0; h < kFlatScRays; ++h) {
         const bool occ = have[h] && occluded[h];

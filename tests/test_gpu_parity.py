@@ -838,7 +838,7 @@ def test_dealing_blocks_to_workgroups_never_changes_a_pixel(size, policy):
     assert util.all_stats(st) == util.all_stats(rst)
 
 
-@pytest.mark.parametrize("n_items", [1, 2, 3, 5, 6, 7, 1025, 1026, 1027, 2053])
+@pytest.mark.parametrize("n_items", [1, 2, 3, 4, 5, 7, 8, 9, 1023, 1024, 1025, 2053])
 def test_scalar_fed_flat_scan_item_counts_around_the_group_and_pass_sizes(n_items):
     # f32 RT_TRAVERSAL_FLAT runs the scalar-fed scan (rt_flat_sc.hpp + generated rt_flat_rot.hpp): groups of three items, two groups
     # per loop iteration, the first shadow pass covers 342 groups = 1,026 items.  Item counts around every one of those boundaries,
@@ -856,6 +856,29 @@ def test_scalar_fed_flat_scan_item_counts_around_the_group_and_pass_sizes(n_item
         lds, lst = s.device().render_tiles((150, 70, 2), regs, FLAT)
     np.testing.assert_array_equal(lds, data)
     assert util.ray_stats(lst) == util.ray_stats(st)
+
+
+@pytest.mark.parametrize("scale", [1e-20, 1e-10, 1.0, 1e6, 5e13])
+def test_flat_scan_filter_never_rejects_a_candidate(scale):
+    # The f32 flat scan rejects items with a conservative bound of the discriminant (FMA chains, rt_flat_sc.hpp flat_filter_constant /
+    # flat_shadow_filter_rr; the error analysis is in tools/gen_flat_asm.py) and runs the reference's exact operations only on the
+    # survivors.  rt_debug_flat_filter_check evaluates both for every ray x item pair of a frame: no pair may have disc >= 0 with a
+    # negative bound -- on the default scene at 1080p (4.5e10 pairs) and on nested scenes scaled from the subnormal range to the
+    # validation bound -- and the bound must not be so loose that the exact path runs everywhere.
+    if scale == 1.0:
+        s = rta.Scene.default(8)
+        c = rta.capi.flat_filter_check(s.device()._h, 1920, 1080, 1)
+        assert c[0] > 5_000_000 and c[3] > 1_000_000
+        assert c[1] < 2 * c[0] and c[4] < 2 * c[3]
+        assert c[2] == 0 and c[5] == 0
+    for seed in (31, 32, 33):
+        items, bounds, ranges = util.random_nested_scene(seed, depth=3, fan=3, leaf_items=2, concentric=seed == 32)
+        sc = lambda a: (np.asarray(a, dtype=np.float64) * scale).astype(np.float32).astype(np.float64)
+        eye = tuple(float(v) for v in sc((0.07, -0.12, -3.1)))
+        s, _ = util.scene_pair_ranges(sc(items), sc(bounds), ranges, rta.RT_F32, eye=eye)
+        c = rta.capi.flat_filter_check(s.device()._h, 320, 240, 2)
+        assert c[0] > 50_000 and c[3] > 10_000, c
+        assert c[2] == 0 and c[5] == 0, c
 
 
 def test_scalar_fed_flat_scan_on_tiny_discriminants():

@@ -1,31 +1,50 @@
 #!/usr/bin/env python3
 """Generates rust-tracer_amd/csrc/rt_flat_rot.hpp: the inner loops of the scalar-fed flat scan (rt_flat_sc.hpp) in gfx950
-assembly, f32, TWO rays per lane on packed math.
+assembly, f32: TWO rays per lane on packed math, a conservative FMA filter in front of the reference's exact test.
 
 A linear scan is wave-uniform: all rays of a wave test the same item at the same moment, so the items are scalars.  A group
-of THREE items is one 64-byte record = one s_load_dwordx16 into one of two SGPR banks; the next group's load is issued before
-the current group's arithmetic.  Every arithmetic instruction of a test reads a scalar operand it shares with no neighbour, and
-tools/valu_issue_probe.hip measured what that costs on gfx950 at 8 waves per SIMD: a VOP2 whose SGPR operand differs from the
-previous instruction's issues in 2.55 cycles, not 1.46 -- exactly what a packed v_pk_mul/add_f32 costs, whose SGPR operand
-(either half of an aligned pair, broadcast to both results with op_sel) is free on top.  So each lane carries two rays in
-VGPR pairs and one packed instruction does one operation of the test for both: 8 x 2.55 = 20.4 cycles per item and 128 rays
-against 14.4 per item and 64 rays for the VOP2 form (profiles/r02_valu_issue_probe.json, the last rows), and the scalar load,
-the wait and the branch of a group are shared by twice the rays.
+of FOUR items is one 64-byte record = one s_load_dwordx16 into one of two SGPR banks; the next group's load is issued before the
+current group's arithmetic.
 
-The three discriminants of both rays are reduced with two v_max3_f32 + one v_max_f32 and one branch rejects the group; the
-exact path (root, t2, t1, d, strict `<` against hit.distance, in item order) runs per ray on the 32-bit halves, only when some
-lane's line meets one of the three spheres.  The halves of a register pair have to be named, which inline-asm operands cannot
-do, so the loops own FIXED registers (v[32:63], s[36:77]; listed as clobbers -- the kernels around them need 20 VGPRs) and move
-their operands in and out.
+What the instructions cost (tools/valu_issue_probe.hip, profiles/r02_valu_issue_probe.json; the time a SIMD needs per wave64
+instruction at 8 waves per SIMD, from the probe's LONGEST wave): a VOP2 2.2 cycles, but a VOP2 whose SGPR operand differs
+from the previous instruction's 4.1 -- what every VOP3 / VOP3P instruction takes, a packed v_pk_mul/add/fma_f32 included, whose
+scalar operand (either half of an aligned SGPR pair, broadcast to both results with op_sel) is free on top.  Every operation
+of a sphere test reads an item term no neighbour shares, so each lane carries two rays in VGPR pairs and one packed
+instruction does one operation of the test for both; the scalar load, the wait and the branch of a group serve 128 rays.
 
-Arithmetic, operation for operation (primitive.rs:55-72; each + - * rounded once, no FMA outside the exact root; a packed
+The filter.  The reference's test is eight (primary) / sixteen (shadow) individually rounded operations per ray and item.
+Almost every item is rejected by `disc < 0`, and a rejection does not need disc's bits, only its sign: the loops form a BOUND of
+disc with fused multiply-adds -- 4 (primary) / 11 (shadow) packed instructions per item instead of 8 / 16 -- plus a margin that
+covers every rounding of both computations, so that disc >= 0 implies bound >= 0.  A group none of whose bounds is >= 0 for any
+ray is skipped (three v_max3_f32, one v_max_f32, one compare, one branch per four items and 128 rays); otherwise the items
+whose bound is >= 0 for some ray get the reference's exact test, operation for operation, from their exact record (one more
+scalar load), in item order, with the exact root path behind it.  Results are the reference's bits; the filter only decides
+what is looked at.  Error analysis (eps = 2^-24, |dir| <= 1 + 2 eps, v the stored f32 centre - eye or the f32 centre - origin
+both computations start from; B = the exact dot product of v and dir):
+    exact     b  = fl(fl(fl(vx dx) + fl(vy dy)) + fl(vz dz))        |b  - B| <= 3.1 eps |v|
+    filter    b' = fma(vz, dz, fma(vy, dy, fl(vx dx)))              |b' - B| <= 3.1 eps |v|     so |b b - b' b'| <= 12.4 eps |v|^2
+    exact     disc = fl(fl(fl(b b) - vv) + rr) >= 0  implies  b b - vv + rr >= -(1.1 eps |v|^2 + 2 eps rr)
+    primary   vv is the stored f32 dot(v, v): within 4 eps of |v|^2.  Hence disc >= 0 implies b' b' - vv + rr >= -(14 eps vv + 3 eps rr),
+              and bound = fma(b', b', K) >= 0 for K = rr - vv + 2^-17 (vv + rr) + 2^-140 rounded UP (2^-17 = 128 eps: a factor of eight
+              in hand; 2^-140 covers subnormal results, whose errors are absolute, <= 2^-149 per operation)
+    shadow    vv is per ray: exact fl-sum of squares and the filter's FMA chain vv' are within 3 eps |v|^2 of |v|^2 each.  disc >= 0
+              implies b' b' - vv' + rr >= -(21 eps vv' + 3 eps rr); bound = fma(-vv', 1 - 2^-17, fma(b', b', rr')) with
+              rr' = rr (1 + 2^-17) + 2^-140 rounded UP adds 128 eps (vv' + rr) and loses at most 2 eps (vv' + rr') to its own roundings
+rt_debug_flat_filter_check evaluates both sides for every ray x item pair of a frame (tests/test_gpu_parity.py: 4.5e10 pairs of
+the default scene and scenes scaled from 1e-20 to 5e13, no pair with disc >= 0 and bound < 0; the bound lets through 1.3x the
+exact candidates).  A shadow ray that is settled (or a lane half without a ray) gets a NaN origin: every bound and
+discriminant it forms from then on is NaN, which is never `>= 0`, so it needs no mask of its own.
+
+The halves of a register pair have to be named, which inline-asm operands cannot do, so the loops own FIXED registers (v[32:63],
+s[36:89]; listed as clobbers -- the kernels around them need 20 VGPRs) and move their operands in and out.
+
+Exact arithmetic, operation for operation (primitive.rs:55-72; each + - * rounded once, no FMA outside the exact root; a packed
 subtraction is an addition with the IEEE sign flip of the neg modifier):
     primary   b = (vx*dx + vy*dy) + vz*dz ; disc = (b*b - vv) + rr            (v = c - eye, vv, rr pre-formed per item)
     shadow    v = c - o ; b = (v.x*l.x + v.y*l.y) + v.z*l.z ; vv = (v.x*v.x + v.y*v.y) + v.z*v.z ; disc = (b*b - vv) + rr
     exact     disc >= 0 ; root = correctly rounded sqrt(disc) (== sqrt_rn_lean) ; t2 = b + root >= 0 ; t1 = b - root ;
               d = t1 > 0 ? t1 : t2 ; primary: d < hit.distance -> hit.distance = d, item = index ; shadow: any hit retires the ray
-A shadow ray that is settled (or a lane half without a ray) gets a NaN origin: every discriminant it forms from then on is NaN,
-which is never `>= 0`, so it needs no mask of its own.
 
 Run:  python3 tools/gen_flat_asm.py   (writes the header; the build does not need this script)."""
 import os
@@ -36,8 +55,10 @@ OUT = os.path.join(ROOT, "rust-tracer_amd", "csrc", "rt_flat_rot.hpp")
 BANK = {"A": 36, "B": 52}            # s[36:51], s[52:67]
 OFF, IDX, EXS, TINY = "s68", "s69", "s[70:71]", "s[72:73]"
 LIGHT = 74                           # s74..s76: light direction of the shadow scan (s77 pads the pair)
+EXACT = 80                           # s[80:87]: the exact record of one item (slow path)
+SHRINK = 88                          # s88: 1 - 2^-17 (shadow filter; s89 pads the pair)
 STRIDE = 64
-SGPR_LAST = 77
+SGPR_LAST = 89
 VGPR_FIRST, VGPR_LAST = 32, 63
 
 
@@ -93,6 +114,23 @@ def pk(a, op, dst, x, y, sx=None, sy=None, neg_y=False, comment=None):
     a.op("v_pk_%s_f32 %s, %s, %s%s" % (op, dst, x, y, mods), comment)
 
 
+def pk_fma(a, dst, x, y, z, sx=None, sz=None, comment=None):
+    """dst = x * y + z on both rays, ONE rounding (the conservative filter only; never on the exact path)."""
+    sel, sel_hi = [0, 0, 0], [1, 1, 1]
+    if sx is not None:
+        x = "s[%d:%d]" % (sx & ~1, (sx & ~1) + 1)
+        sel[0] = sel_hi[0] = sx & 1
+    if sz is not None:
+        z = "s[%d:%d]" % (sz & ~1, (sz & ~1) + 1)
+        sel[2] = sel_hi[2] = sz & 1
+    mods = ""
+    if sel != [0, 0, 0]:
+        mods += " op_sel:[%d,%d,%d]" % tuple(sel)
+    if sel_hi != [1, 1, 1]:
+        mods += " op_sel_hi:[%d,%d,%d]" % tuple(sel_hi)
+    a.op("v_pk_fma_f32 %s, %s, %s, %s%s" % (dst, x, y, z, mods), comment)
+
+
 def load(a, bank, off, comment=None):
     a.op("s_load_dwordx16 s[%d:%d], %%[base], %s" % (BANK[bank], BANK[bank] + 15, off), comment)
 
@@ -146,37 +184,62 @@ class PrimaryRegs:
         self.DX, self.DY, self.DZ = Pair(v), Pair(v + 2), Pair(v + 4)
         self.BEST, self.BITEM = Pair(v + 6), Pair(v + 8)
         self.T0, self.T1, self.T2 = Pair(v + 10), Pair(v + 12), Pair(v + 14)
-        self.B = [Pair(v + 16), Pair(v + 18), Pair(v + 20)]
-        self.D = [Pair(v + 22), Pair(v + 24), Pair(v + 26)]
+        self.F = [Pair(v + 16), Pair(v + 18), Pair(v + 20), Pair(v + 22)]       # the filter's discriminant bounds of a group's 4 items
+        self.B, self.DISC = Pair(v + 24), Pair(v + 26)
         self.root = "v%d" % (v + 28)
-        # 32-bit temporaries of the exact path: the halves of T0 / T1 are free once the group's arithmetic is done
         self.t0, self.t1, self.t2 = self.T0.h[0], self.T0.h[1], self.T1.h[0]
 
 
+def fsreg(bank, field, k):
+    """SGPR number of item k's filter field (0..3: vx, vy, vz, K) in a bank of FOUR items: fields are stored [field][item]."""
+    return BANK[bank] + 4 * field + k
+
+
 def primary_group(a, bank, r):
-    for k in range(3):
-        pk(a, "mul", r.T0.p, None, r.DX.p, sx=sreg(bank, 0, k), comment="item %d: b = (vx*dx + vy*dy) + vz*dz, both rays" % k if k == 0 else None)
-        pk(a, "mul", r.T1.p, None, r.DY.p, sx=sreg(bank, 1, k))
-        pk(a, "mul", r.T2.p, None, r.DZ.p, sx=sreg(bank, 2, k))
-        pk(a, "add", r.T0.p, r.T0.p, r.T1.p)
-        pk(a, "add", r.B[k].p, r.T0.p, r.T2.p)
-        pk(a, "mul", r.T0.p, r.B[k].p, r.B[k].p, comment="disc = (b*b - vv) + rr" if k == 0 else None)
-        pk(a, "add", r.T0.p, r.T0.p, None, sy=sreg(bank, 3, k), neg_y=True)
-        pk(a, "add", r.D[k].p, None, r.T0.p, sx=sreg(bank, 4, k))
-    any_candidate(a, r, bank)
+    """The conservative filter for four items: bound = fma(b', b', K) with b' = fma(vz, dz, fma(vy, dy, vx*dx)) -- four packed
+    FMAs per item for both rays.  K = rr - vv + a margin that covers every rounding of both computations (tools/gen_flat_asm.py
+    docstring), so disc >= 0 implies bound >= 0: a group with no bound >= 0 holds no candidate."""
+    for k in range(4):
+        pk(a, "mul", r.T0.p, None, r.DX.p, sx=fsreg(bank, 0, k), comment="item %d: bound of disc, both rays" % k if k == 0 else None)
+        pk_fma(a, r.T0.p, None, r.DY.p, r.T0.p, sx=fsreg(bank, 1, k))
+        pk_fma(a, r.T0.p, None, r.DZ.p, r.T0.p, sx=fsreg(bank, 2, k))
+        pk_fma(a, r.F[k].p, r.T0.p, r.T0.p, None, sz=fsreg(bank, 3, k))
+    m = r.T0.h[0]
+    a.op("v_max3_f32 %s, %s, %s, %s" % (m, r.F[0].h[0], r.F[0].h[1], r.F[1].h[0]))
+    a.op("v_max3_f32 %s, %s, %s, %s" % (m, m, r.F[1].h[1], r.F[2].h[0]))
+    a.op("v_max3_f32 %s, %s, %s, %s" % (m, m, r.F[2].h[1], r.F[3].h[0]))
+    a.op("v_max_f32_e32 %s, %s, %s" % (m, m, r.F[3].h[1]))
+    a.op("v_cmp_le_f32_e32 vcc, 0, %s" % m)
+    a.op("s_cbranch_vccnz .Lfl_slow_%s_%%=" % bank, "some ray's line may meet one of the four spheres")
+    a.label(".Lfl_cont_%s_%%=" % bank)
 
 
 def primary_slow(a, bank, r):
+    """The exact test (primitive.rs:55-84, operation for operation) of the items whose bound is >= 0 for some ray, in item order."""
     a.label(".Lfl_slow_%s_%%=" % bank)
-    a.op("s_lshr_b32 %s, %s, 6" % (IDX, OFF), "index of the group's first item: 3 * (offset / 64)%s" % (" + 3" if bank == "B" else ""))
-    a.op("s_mul_i32 %s, %s, 3" % (IDX, IDX))
+    a.op("s_lshr_b32 %s, %s, 4" % (IDX, OFF), "index of the group's first item: 4 * (offset / 64)%s" % (" + 4" if bank == "B" else ""))
     if bank == "B":
-        a.op("s_add_u32 %s, %s, 3" % (IDX, IDX))
-    for k in range(3):
+        a.op("s_add_u32 %s, %s, 4" % (IDX, IDX))
+    for k in range(4):
+        nxt = ".Lfl_item_%s%d_%%=" % (bank, k)
+        a.op("v_max_f32_e32 %s, %s, %s" % (r.t0, r.F[k].h[0], r.F[k].h[1]), "item %d" % k)
+        a.op("v_cmp_le_f32_e32 vcc, 0, %s" % r.t0)
+        a.op("s_cbranch_vccz %s" % nxt)
+        a.op("s_lshl_b32 s76, %s, 5" % IDX)
+        a.op("s_load_dwordx8 s[%d:%d], %%[exact], s76" % (EXACT, EXACT + 7), "{vx, vy, vz, vv, rr} of the item")
+        a.op("s_waitcnt lgkmcnt(0)")
+        pk(a, "mul", r.T0.p, None, r.DX.p, sx=EXACT + 0, comment="b = (vx*dx + vy*dy) + vz*dz, both rays")
+        pk(a, "mul", r.T1.p, None, r.DY.p, sx=EXACT + 1)
+        pk(a, "mul", r.T2.p, None, r.DZ.p, sx=EXACT + 2)
+        pk(a, "add", r.T0.p, r.T0.p, r.T1.p)
+        pk(a, "add", r.B.p, r.T0.p, r.T2.p)
+        pk(a, "mul", r.T0.p, r.B.p, r.B.p, comment="disc = (b*b - vv) + rr")
+        pk(a, "add", r.T0.p, r.T0.p, None, sy=EXACT + 3, neg_y=True)
+        pk(a, "add", r.DISC.p, None, r.T0.p, sx=EXACT + 4)
         for h in range(2):
             tag = "%s%d%d" % (bank, k, h)
-            b, d, best, bitem = r.B[k].h[h], r.D[k].h[h], r.BEST.h[h], r.BITEM.h[h]
-            a.op("v_cmp_le_f32_e32 vcc, 0, %s" % d, "item %d, ray %d, in item order (primitive.rs:79: the first one keeps a tie)" % (k, h))
+            b, d, best, bitem = r.B.h[h], r.DISC.h[h], r.BEST.h[h], r.BITEM.h[h]
+            a.op("v_cmp_le_f32_e32 vcc, 0, %s" % d, "ray %d (primitive.rs:79: the first item keeps a tie)" % h)
             a.op("s_and_saveexec_b64 %s, vcc" % EXS)
             a.op("s_cbranch_execz .Lfl_next_%s_%%=" % tag)
             exact_root(a, d, tag, r)
@@ -190,12 +253,13 @@ def primary_slow(a, bank, r):
             a.op("v_mov_b32_e32 %s, %s" % (bitem, IDX))
             a.label(".Lfl_next_%s_%%=" % tag)
             a.op("s_mov_b64 exec, %s" % EXS)
-        if k < 2:
+        a.label(nxt)
+        if k < 3:
             a.op("s_add_u32 %s, %s, 1" % (IDX, IDX))
     a.op("s_branch .Lfl_cont_%s_%%=" % bank)
-    for k in range(3):
+    for k in range(4):
         for h in range(2):
-            exact_tiny(a, r.D[k].h[h], "%s%d%d" % (bank, k, h), r)
+            exact_tiny(a, r.DISC.h[h], "%s%d%d" % (bank, k, h), r)
 
 
 # ------------------------------------------------------------------------------------------------------------------- shadow
@@ -206,43 +270,74 @@ class ShadowRegs:
         self.OX, self.OY, self.OZ = Pair(v), Pair(v + 2), Pair(v + 4)
         self.VX, self.VY, self.VZ = Pair(v + 6), Pair(v + 8), Pair(v + 10)
         self.T0, self.T1 = Pair(v + 12), Pair(v + 14)
-        self.B = [Pair(v + 16), Pair(v + 18), Pair(v + 20)]
-        self.D = [Pair(v + 22), Pair(v + 24), Pair(v + 26)]
+        self.F = [Pair(v + 16), Pair(v + 18), Pair(v + 20), Pair(v + 22)]       # the filter's discriminant bounds of a group's 4 items
+        self.B, self.DISC = Pair(v + 24), Pair(v + 26)
         self.OCC = Pair(v + 28)
         self.root = "v%d" % (v + 30)
         self.t0, self.t1, self.t2 = self.T0.h[0], self.T0.h[1], self.T1.h[0]
 
 
 def shadow_group(a, bank, r):
-    for k in range(3):
-        pk(a, "add", r.VX.p, None, r.OX.p, sx=sreg(bank, 0, k), neg_y=True, comment="item %d: v = centre - origin, both rays" % k if k == 0 else None)
-        pk(a, "add", r.VY.p, None, r.OY.p, sx=sreg(bank, 1, k), neg_y=True)
-        pk(a, "add", r.VZ.p, None, r.OZ.p, sx=sreg(bank, 2, k), neg_y=True)
+    """The conservative filter for four items: v = centre - origin as the exact test forms it, then
+    bound = fma(-vv', 1 - 2^-17, fma(b', b', rr')) with b' and vv' as FMA chains and rr' = rr (1 + 2^-17) + 2^-140 rounded up:
+    eleven packed instructions per item for both rays, and disc >= 0 implies bound >= 0 (tools/gen_flat_asm.py docstring)."""
+    for k in range(4):
+        pk(a, "add", r.VX.p, None, r.OX.p, sx=fsreg(bank, 0, k), neg_y=True, comment="item %d: v = centre - origin, both rays" % k if k == 0 else None)
+        pk(a, "add", r.VY.p, None, r.OY.p, sx=fsreg(bank, 1, k), neg_y=True)
+        pk(a, "add", r.VZ.p, None, r.OZ.p, sx=fsreg(bank, 2, k), neg_y=True)
+        pk(a, "mul", r.T0.p, None, r.VX.p, sx=LIGHT + 0)
+        pk_fma(a, r.T0.p, None, r.VY.p, r.T0.p, sx=LIGHT + 1)
+        pk_fma(a, r.T0.p, None, r.VZ.p, r.T0.p, sx=LIGHT + 2)
+        pk(a, "mul", r.T1.p, r.VX.p, r.VX.p)
+        pk_fma(a, r.T1.p, r.VY.p, r.VY.p, r.T1.p)
+        pk_fma(a, r.T1.p, r.VZ.p, r.VZ.p, r.T1.p)
+        pk_fma(a, r.T0.p, r.T0.p, r.T0.p, None, sz=fsreg(bank, 3, k))
+        a.op("v_pk_fma_f32 %s, %s, s[%d:%d], %s op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" % (r.F[k].p, r.T1.p, SHRINK, SHRINK + 1, r.T0.p))
+    m = r.T0.h[0]
+    a.op("v_max3_f32 %s, %s, %s, %s" % (m, r.F[0].h[0], r.F[0].h[1], r.F[1].h[0]))
+    a.op("v_max3_f32 %s, %s, %s, %s" % (m, m, r.F[1].h[1], r.F[2].h[0]))
+    a.op("v_max3_f32 %s, %s, %s, %s" % (m, m, r.F[2].h[1], r.F[3].h[0]))
+    a.op("v_max_f32_e32 %s, %s, %s" % (m, m, r.F[3].h[1]))
+    a.op("v_cmp_le_f32_e32 vcc, 0, %s" % m)
+    a.op("s_cbranch_vccnz .Lfl_slow_%s_%%=" % bank, "some pending ray's line may meet one of the four spheres")
+    a.label(".Lfl_cont_%s_%%=" % bank)
+
+
+def shadow_slow(a, bank, r):
+    """The exact test of the items whose bound is >= 0 for some ray.  A ray that hits is settled: flagged, and its origin becomes
+    NaN.  A lane whose two rays are both settled leaves EXEC; the wave leaves the scan when EXEC is empty."""
+    a.label(".Lfl_slow_%s_%%=" % bank)
+    a.op("s_lshr_b32 %s, %s, 4" % (IDX, OFF), "index of the group's first item: 4 * (offset / 64)%s" % (" + 4" if bank == "B" else ""))
+    if bank == "B":
+        a.op("s_add_u32 %s, %s, 4" % (IDX, IDX))
+    for k in range(4):
+        nxt = ".Lfl_item_%s%d_%%=" % (bank, k)
+        a.op("v_max_f32_e32 %s, %s, %s" % (r.t0, r.F[k].h[0], r.F[k].h[1]), "item %d" % k)
+        a.op("v_cmp_le_f32_e32 vcc, 0, %s" % r.t0)
+        a.op("s_cbranch_vccz %s" % nxt)
+        a.op("s_lshl_b32 s78, %s, 4" % IDX)
+        a.op("s_load_dwordx4 s[%d:%d], %%[exact], s78" % (EXACT, EXACT + 3), "{cx, cy, cz, rr} of the item")
+        a.op("s_waitcnt lgkmcnt(0)")
+        pk(a, "add", r.VX.p, None, r.OX.p, sx=EXACT + 0, neg_y=True, comment="v = centre - origin, both rays")
+        pk(a, "add", r.VY.p, None, r.OY.p, sx=EXACT + 1, neg_y=True)
+        pk(a, "add", r.VZ.p, None, r.OZ.p, sx=EXACT + 2, neg_y=True)
         pk(a, "mul", r.T0.p, None, r.VX.p, sx=LIGHT + 0)
         pk(a, "mul", r.T1.p, None, r.VY.p, sx=LIGHT + 1)
         pk(a, "add", r.T0.p, r.T0.p, r.T1.p)
         pk(a, "mul", r.T1.p, None, r.VZ.p, sx=LIGHT + 2)
-        pk(a, "add", r.B[k].p, r.T0.p, r.T1.p, comment="b = dot(v, dir)" if k == 0 else None)
+        pk(a, "add", r.B.p, r.T0.p, r.T1.p, comment="b = dot(v, dir)")
         pk(a, "mul", r.VX.p, r.VX.p, r.VX.p)
         pk(a, "mul", r.VY.p, r.VY.p, r.VY.p)
         pk(a, "add", r.VX.p, r.VX.p, r.VY.p)
         pk(a, "mul", r.VZ.p, r.VZ.p, r.VZ.p)
-        pk(a, "add", r.VX.p, r.VX.p, r.VZ.p, comment="dot(v, v)" if k == 0 else None)
-        pk(a, "mul", r.T0.p, r.B[k].p, r.B[k].p)
+        pk(a, "add", r.VX.p, r.VX.p, r.VZ.p, comment="dot(v, v)")
+        pk(a, "mul", r.T0.p, r.B.p, r.B.p)
         pk(a, "add", r.T0.p, r.T0.p, r.VX.p, neg_y=True)
-        pk(a, "add", r.D[k].p, None, r.T0.p, sx=sreg(bank, 3, k), comment="disc = (b*b - vv) + rr" if k == 0 else None)
-    any_candidate(a, r, bank)
-
-
-def shadow_slow(a, bank, r):
-    """A ray that hits any of the three items is settled: flagged, and its origin becomes NaN.  A lane whose two rays are both
-    settled leaves EXEC; the wave leaves the scan when EXEC is empty."""
-    a.label(".Lfl_slow_%s_%%=" % bank)
-    for k in range(3):
+        pk(a, "add", r.DISC.p, None, r.T0.p, sx=EXACT + 3, comment="disc = (b*b - vv) + rr")
         for h in range(2):
             tag = "%s%d%d" % (bank, k, h)
-            b, d = r.B[k].h[h], r.D[k].h[h]
-            a.op("v_cmp_le_f32_e32 vcc, 0, %s" % d, "item %d, ray %d: disc >= 0 (NaN for a settled ray)" % (k, h))
+            b, d = r.B.h[h], r.DISC.h[h]
+            a.op("v_cmp_le_f32_e32 vcc, 0, %s" % d, "ray %d: disc >= 0 (NaN for a settled ray)" % h)
             a.op("s_and_saveexec_b64 %s, vcc" % EXS)
             a.op("s_cbranch_execz .Lfl_next_%s_%%=" % tag)
             exact_root(a, d, tag, r)
@@ -252,15 +347,18 @@ def shadow_slow(a, bank, r):
             a.op("v_mov_b32_e32 %s, 0x7fc00000" % r.OX.h[h], "settled")
             a.label(".Lfl_next_%s_%%=" % tag)
             a.op("s_mov_b64 exec, %s" % EXS)
+        a.label(nxt)
+        if k < 3:
+            a.op("s_add_u32 %s, %s, 1" % (IDX, IDX))
     a.op("v_cmp_o_f32_e32 vcc, %s, %s" % (r.OX.h[0], r.OX.h[0]), "lanes that still carry an unsettled ray")
     a.op("v_cmp_o_f32_e64 %s, %s, %s" % (TINY, r.OX.h[1], r.OX.h[1]))
     a.op("s_or_b64 vcc, vcc, %s" % TINY)
     a.op("s_and_b64 exec, exec, vcc")
     a.op("s_cbranch_execz .Lfl_exit_%=", "every ray of the wave is settled")
     a.op("s_branch .Lfl_cont_%s_%%=" % bank)
-    for k in range(3):
+    for k in range(4):
         for h in range(2):
-            exact_tiny(a, r.D[k].h[h], "%s%d%d" % (bank, k, h), r)
+            exact_tiny(a, r.DISC.h[h], "%s%d%d" % (bank, k, h), r)
 
 
 def loop(a, group, slow, r):
@@ -285,17 +383,20 @@ def loop(a, group, slow, r):
 HEADER = """// rt_flat_rot.hpp -- GENERATED by tools/gen_flat_asm.py; edit the generator, not this file.
 //
 // The inner loops of the scalar-fed flat scan (rt_flat_sc.hpp) in gfx950 assembly, f32, two rays per lane on packed math.  A
-// group of three items is one 64-byte record = one s_load_dwordx16 into one of two SGPR banks (s[36:51], s[52:67]); the next
-// group's load is issued before the current group's arithmetic.  Each operation of a test is ONE v_pk_mul/add_f32 for the lane's
-// two rays, its item term the low or high half of an aligned SGPR pair broadcast with op_sel (a VOP2 that reads a new SGPR
-// costs the same 2.55 issue cycles as the packed instruction: tools/valu_issue_probe.hip).  Two v_max3_f32 + one v_max_f32 and
-// one branch reject a group; the exact path (root == sqrt_rn_lean, t2, t1, d, strict `<`, item order) runs per ray on the 32-bit
-// halves, only when some ray's line meets one of the three spheres.  The loops own v[32:63] and s[36:77] (clobbers): s68 byte
-// offset of the current group pair, s69 scratch / item index, s[70:71] saved EXEC, s[72:73] mask scratch, s[74:76] the shadow
-// rays' direction.  64 VGPRs and 84 SGPRs keep 8 waves per SIMD.
+// group of four items is one 64-byte record = one s_load_dwordx16 into one of two SGPR banks (s[36:51], s[52:67]); the next
+// group's load is issued before the current group's arithmetic.  Per item the loops form a conservative BOUND of the
+// discriminant with packed FMAs (4 instructions primary, 11 shadow, for the lane's two rays; item terms are the low or high
+// half of an aligned SGPR pair broadcast with op_sel), whose margin covers every rounding of both computations: disc >= 0 implies
+// bound >= 0 (tools/gen_flat_asm.py has the analysis, rt_debug_flat_filter_check the exhaustive check).  Three v_max3_f32 + one
+// v_max_f32 and one branch reject a group; otherwise the items whose bound is >= 0 for some ray get the reference's exact test,
+// operation for operation, from their exact record, in item order (root == sqrt_rn_lean, t2, t1, d, strict `<`), per ray on the
+// 32-bit halves.  The loops own v[32:63] and s[36:89] (clobbers): s68 byte offset of the current group pair, s69 item index,
+// s[70:71] saved EXEC, s[72:73] mask scratch, s[74:76] the shadow rays' direction, s76 / s78 address scratch, s[80:87] the exact
+// record, s88 the shadow filter's 1 - 2^-17.
 //
-// Group record (rt_flat_sc.hpp, FGroup): primary {vx[3], vy[3], vz[3], vv[3], rr[3], pad}; shadow {cx[3], cy[3], cz[3], rr[3], pad[4]}.
-// The arrays end in pad groups (rr = -inf: never a candidate) so that the load issued one pair ahead stays inside them.
+// Filter group (rt_flat_sc.hpp, FGroup): primary {vx[4], vy[4], vz[4], K[4]}; shadow {cx[4], cy[4], cz[4], rr'[4]}.  Exact record:
+// primary FExact {vx, vy, vz, vv, rr, -, -, -}; shadow FExactShadow {cx, cy, cz, rr}.  The group arrays end in pad groups (K, rr' =
+// -inf: never a candidate) so that the load issued one pair ahead stays inside them.
 #pragma once
 #include "rt_kernels.hpp"
 
@@ -303,27 +404,27 @@ namespace rt {
 
 """
 
-PRIMARY = """// Nearest hit of all groups [0, n_bytes / 64) for the wave's 128 primary rays (n_bytes: a multiple of 128); ray h of a lane has
-// the direction (dx[h], dy[h], dz[h]).  Lane halves without a ray scan along (their result is ignored).  Returns hit.distance and
-// the index of the winning item per ray.
-__device__ __forceinline__ void flat_primary_scan(const void *groups, unsigned n_bytes, const float (&dx)[2], const float (&dy)[2],
-                                                  const float (&dz)[2], float (&best_out)[2], unsigned (&item_out)[2])
+PRIMARY = """// Nearest hit of all items for the wave's 128 primary rays: `groups` = the filter groups [0, n_bytes / 64) (n_bytes: a multiple
+// of 128), `exact` = the items' exact records (32 bytes each); ray h of a lane has the direction (dx[h], dy[h], dz[h]).  Lane halves
+// without a ray scan along (their result is ignored).  Returns hit.distance and the index of the winning item per ray.
+__device__ __forceinline__ void flat_primary_scan(const void *groups, unsigned n_bytes, const void *exact, const float (&dx)[2],
+                                                  const float (&dy)[2], const float (&dz)[2], float (&best_out)[2], unsigned (&item_out)[2])
 {
     const float tiny = 0x1p-96f;
     asm volatile(
 %(body)s
         : [best0] "=v"(best_out[0]), [best1] "=v"(best_out[1]), [item0] "=v"(item_out[0]), [item1] "=v"(item_out[1])
-        : [base] "s"(groups), [end] "s"(n_bytes), [dx0] "v"(dx[0]), [dx1] "v"(dx[1]), [dy0] "v"(dy[0]), [dy1] "v"(dy[1]), [dz0] "v"(dz[0]),
-          [dz1] "v"(dz[1]), [tiny] "s"(tiny)
+        : [base] "s"(groups), [end] "s"(n_bytes), [exact] "s"(exact), [dx0] "v"(dx[0]), [dx1] "v"(dx[1]), [dy0] "v"(dy[0]), [dy1] "v"(dy[1]),
+          [dz0] "v"(dz[0]), [dz1] "v"(dz[1]), [tiny] "s"(tiny)
         : %(clobbers)s);
 }
 
 """
 
-SHADOW = """// Any hit over the groups [begin_bytes / 64, end_bytes / 64) (multiples of 128) for the wave's 128 shadow rays; ray h of a lane
-// starts at (ox[h], oy[h], oz[h]) and counts only if pending[h] != 0.  Returns 1 in occluded[h] for an occluded ray.  The wave
-// leaves as soon as every pending ray is settled.
-__device__ __forceinline__ void flat_shadow_scan(const void *groups, unsigned begin_bytes, unsigned end_bytes, const float (&ox)[2],
+SHADOW = """// Any hit over the filter groups [begin_bytes / 64, end_bytes / 64) (multiples of 128; `exact`: the items' exact records, 16 bytes
+// each) for the wave's 128 shadow rays; ray h of a lane starts at (ox[h], oy[h], oz[h]) and counts only if pending[h] != 0.
+// Returns 1 in occluded[h] for an occluded ray.  The wave leaves as soon as every pending ray is settled.
+__device__ __forceinline__ void flat_shadow_scan(const void *groups, unsigned begin_bytes, unsigned end_bytes, const void *exact, const float (&ox)[2],
                                                  const float (&oy)[2], const float (&oz)[2], float lx, float ly, float lz,
                                                  const unsigned (&pending)[2], unsigned (&occluded)[2])
 {
@@ -332,7 +433,7 @@ __device__ __forceinline__ void flat_shadow_scan(const void *groups, unsigned be
     asm volatile(
 %(body)s
         : [occ0] "=v"(occluded[0]), [occ1] "=v"(occluded[1]), [saved] "=&s"(saved)
-        : [base] "s"(groups), [begin] "s"(begin_bytes), [end] "s"(end_bytes), [ox0] "v"(ox[0]), [ox1] "v"(ox[1]), [oy0] "v"(oy[0]),
+        : [base] "s"(groups), [begin] "s"(begin_bytes), [end] "s"(end_bytes), [exact] "s"(exact), [ox0] "v"(ox[0]), [ox1] "v"(ox[1]), [oy0] "v"(oy[0]),
           [oy1] "v"(oy[1]), [oz0] "v"(oz[0]), [oz1] "v"(oz[1]), [lx] "s"(lx), [ly] "s"(ly), [lz] "s"(lz), [pend0] "v"(pending[0]),
           [pend1] "v"(pending[1]), [tiny] "s"(tiny)
         : %(clobbers)s);
@@ -387,6 +488,7 @@ def shadow_body():
     a.op("s_mov_b32 s%d, %%[lx]" % (LIGHT + 0))
     a.op("s_mov_b32 s%d, %%[ly]" % (LIGHT + 1))
     a.op("s_mov_b32 s%d, %%[lz]" % (LIGHT + 2))
+    a.op("s_mov_b32 s%d, 0x3f7fff80" % SHRINK, "1 - 2^-17")
     a.op("v_cmp_o_f32_e32 vcc, %s, %s" % (r.OX.h[0], r.OX.h[0]))
     a.op("v_cmp_o_f32_e64 %s, %s, %s" % (TINY, r.OX.h[1], r.OX.h[1]))
     a.op("s_or_b64 vcc, vcc, %s" % TINY)
