@@ -310,14 +310,20 @@ def main():
                                       "note": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch (MI355X_MICROARCH.md gfx950 correction) over this run's kernel time"}
             else:
                 insts = sum(v.get(k) or 0 for k in ("valu_insts", "salu_insts", "smem_insts", "branch_insts", "other_insts"))
-                mix = probe.get(("traversal-step mix: 10 VALU + 12 SALU per 22", 8))
-                if insts and mix:
-                    peak = N_SIMD * CLOCK_HZ / mix["cycles_per_instruction_per_simd"]
+                ref = {name: (probe.get((kind, 8)) or {}).get("cycles_per_instruction_per_simd") for name, kind in (
+                    ("vop2", "v_mul_f32 (SGPR x VGPR, independent)"), ("vop2_new_sgpr_operand", "v_mul_f32 (a DIFFERENT SGPR x VGPR each instruction, independent)"),
+                    ("vop3_cmp_e64", "v_cmp_lt_f32_e64 -> SGPR pair"), ("packed", "v_pk_fma_f32 (VGPR pairs, independent)"),
+                    ("step_mix_10_valu_12_salu", "traversal-step mix: 10 VALU + 12 SALU per 22"))}
+                if insts:
                     out["instruction_issue"] = {
                         "wave_instructions_per_launch": insts, "valu": v.get("valu_insts"), "salu": v.get("salu_insts"), "smem": v.get("smem_insts"),
-                        "achieved_Ginst_s": round(insts / t / 1e9, 1), "peak_Ginst_s": round(peak / 1e9, 1), "frac": round(insts / t / peak, 4),
-                        "note": "wave-instructions per launch (SQ_INSTS_*) over this run's kernel time, against 1,024 SIMDs x 2.4 GHz / the probe's "
-                                "cycles per instruction of the traversal-step mix (10 VALU + 12 SALU) at 8 waves per SIMD"}
+                        "achieved_Ginst_s": round(insts / t / 1e9, 1),
+                        "simd_cycles_per_wave_instruction": round(N_SIMD * CLOCK_HZ * t / insts, 3),
+                        "probe_cycles_per_instruction": ref,
+                        "note": "wave-instructions per launch (SQ_INSTS_*) and the SIMD cycles this run's kernel time leaves for each "
+                                "(1,024 SIMDs x 2.4 GHz x kernel time / instructions), beside what the probe measured a SIMD needs per "
+                                "instruction of each class at 8 waves per SIMD: a launch whose average sits between those figures keeps its "
+                                "SIMDs issuing for its whole duration"}
         return out
 
     def roofline(m, kernel, flops_per_test, note):
@@ -427,7 +433,7 @@ def main():
                                         "peak_source": "1,024 SIMDs x 64 lanes x 4 flops x 2.4 GHz / %.3f cycles per wave64 v_pk_fma_f32 per SIMD at 8 waves per "
                                                        "SIMD (profiles/r02_valu_issue_probe.json; the un-fused VOP2 roof of the headline is half of it "
                                                        "at 2.22 cycles per instruction)" % pk_cyc,
-                                        "from_profiles": from_profiles("k_flat_primary_sc", flat["kern_ms"])}}
+                                        "from_profiles": from_profiles("k_flat_pipeline", flat["kern_ms"])}}
         for k, e in extras.items():
             out[k] = summary(e, "config5" if k == "config5_tiles" else "1080p")
             out[k]["scaling"] = "weak" if k == "weak_frames" else "strong"

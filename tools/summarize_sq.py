@@ -32,8 +32,8 @@ def main():
                 out[k]["duration_ns_while_counting_" + part] = sum(v) / len(v)
     for k, d in out.items():
         if "SQ_INSTS_VALU" in d and "duration_ns_while_counting_sq1" in d:
-            cyc = d["duration_ns_while_counting_sq1"] * 2.4          # shader cycles at 2.4 GHz
-            d["derived_avg_waves_per_simd"] = d["SQ_WAVE_CYCLES"] * 4 / cyc / 1024
+            # (SQ_WAVE_CYCLES is NOT a wave's lifetime: calibrated with tools/valu_issue_probe.hip it reads 1/4 of the cycles of a lone
+            # wave and 1/8 at 8 waves per SIMD, so no occupancy is derived from it)
             d["derived_valu_insts_per_wave"] = d["SQ_INSTS_VALU"] / d["SQ_WAVES"]
     # what bench.py quotes beside its live timing (instruction counts per launch do not depend on the clock)
     stamp = {"tag": tag, "git_head": git_head(), "kernel_src_sha": kernel_src_sha()}
@@ -45,6 +45,9 @@ def main():
             quote[k + "_n1"] = {"valu_insts": d["SQ_INSTS_VALU"], "salu_insts": d.get("SQ_INSTS_SALU"), "smem_insts": d.get("SQ_INSTS_SMEM"),
                                 "branch_insts": d.get("SQ_INSTS_BRANCH"), "other_insts": (d.get("SQ_INSTS_SENDMSG") or 0) + (d.get("SQ_INSTS_VMEM") or 0) +
                                 (d.get("SQ_INSTS_LDS") or 0), "waves": d.get("SQ_WAVES")}
+    a, b = quote.get("k_flat_primary_sc_n1"), quote.get("k_flat_shadow_sc_n1")
+    if a and b:                     # one flat frame = the primary pass + two shadow passes (the counters are per-launch averages)
+        quote["k_flat_pipeline_n1"] = {k: (a.get(k) or 0) + 2 * (b.get(k) or 0) for k in a}
     json.dump(quote, open(os.path.join(ROOT, "profiles", "roofline_sq.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))
 
