@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Soak / fuzz run for the generated assembly traversal loops (GPU box): bitwise stability over many launches, and random nested
-scenes where every loop flavour must agree with the counted C++ flavour (which the parity tests pin to the CPU path).
+"""Soak / fuzz run for the generated assembly loops (GPU box): bitwise stability over many launches, and random nested scenes on
+which every hierarchy-walk flavour (C++, assembly, fused assembly, two rays per lane) must agree with the counted C++ flavour
+(which the parity tests pin to the CPU path) and the filtered scalar-fed flat scan with round 1's LDS kernels.
 usage: soak.py [seconds]"""
 import os
 import sys
@@ -20,20 +21,24 @@ stream = torch.cuda.current_stream().cuda_stream
 # 1. bitwise stability of the default path, many launches back to back
 s = rta.Scene.default()
 d = s.device()
-for (w, h, spp) in ((1920, 1080, 1), (1024, 768, 4)):
+t_phase = time.time()
+for (w, h, spp, trav, share, batch) in ((1920, 1080, 1, rta.RT_TRAVERSAL_SKIP, 0.20, 200), (1024, 768, 4, rta.RT_TRAVERSAL_SKIP, 0.10, 200),
+                                       (3840, 2160, 1, rta.RT_TRAVERSAL_SKIP, 0.05, 50),           # k_render_skip2 by default
+                                       (1920, 1080, 1, rta.RT_TRAVERSAL_FLAT, 0.10, 10)):
     regs = d._regions([tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))])
     out = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
-    d.render_frame_device((w, h, spp), regs, out.data_ptr(), stream, rta.RT_TRAVERSAL_SKIP)
+    d.render_frame_device((w, h, spp), regs, out.data_ptr(), stream, trav)
     torch.cuda.synchronize()
     want = zlib.crc32(out.cpu().numpy().tobytes())
     n = 0
-    while time.time() < t_end - budget * 0.75 + (0 if spp == 1 else budget * 0.125):
-        for _ in range(200):
-            d.render_frame_device((w, h, spp), regs, out.data_ptr(), stream, rta.RT_TRAVERSAL_SKIP)
+    t_phase += budget * share
+    while time.time() < t_phase:
+        for _ in range(batch):
+            d.render_frame_device((w, h, spp), regs, out.data_ptr(), stream, trav)
         torch.cuda.synchronize()
         assert zlib.crc32(out.cpu().numpy().tobytes()) == want, "frame changed after %d launches" % n
-        n += 200
-    print("stable: %dx%d spp %d, %d launches" % (w, h, spp, n), flush=True)
+        n += batch
+    print("stable: %dx%d spp %d %s, %d launches" % (w, h, spp, "flat" if trav == rta.RT_TRAVERSAL_FLAT else "skip", n), flush=True)
 
 # 2. random nested scenes (every other one concentric): flavours 0/3/7 (no counters) vs flavour 1 with counters
 seed = 1000
@@ -55,9 +60,18 @@ while time.time() < t_end:
         got, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
         assert np.array_equal(got, ref), "seed %d: flavour %d differs" % (seed, v)
     rta.capi.debug_set(rta.capi.DEBUG_SKIP_VARIANT, -1)
+    if prec == rta.RT_F32:
+        if seed % 2 == 1:                                        # concentric = fused: the two-ray kernel exists (spp 1 and 2)
+            with rta.capi.debug(rta.capi.DEBUG_SKIP_RAYS, 2):
+                got, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
+            assert np.array_equal(got, ref), "seed %d: two rays per lane differ" % seed
+        flat, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_FLAT, want_stats=False)
+        with rta.capi.debug(rta.capi.DEBUG_FLAT_KERNELS, 0):
+            lds, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_FLAT, want_stats=False)
+        assert np.array_equal(flat, lds), "seed %d: filtered flat scan differs from the LDS kernels" % seed
     dv.close()
     checked += 1
     seed += 1
     if checked % 2000 == 0:
         print("fuzz: %d scenes so far" % checked, flush=True)        # a long run must not look hung
-print("fuzz: %d random scenes, all flavours identical" % checked)
+print("fuzz: %d random scenes, all flavours identical (hierarchy: C++ / assembly / fused / two rays; flat: filtered scan / LDS kernels)" % checked)
