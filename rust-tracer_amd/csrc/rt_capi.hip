@@ -113,7 +113,8 @@ struct rt_scene {
     uint32_t n_padded = 0;
     void *d_pf = nullptr, *d_pe = nullptr, *d_sg = nullptr, *d_se = nullptr;   // f32, the scalar-fed scan (rt_flat_sc.hpp): filter groups of four
                                                                                // items and exact records, primary / shadow
-    uint32_t flat_filter_bytes = 0;                                            // 128 x number of filter group pairs
+    uint32_t flat_filter_bytes = 0, flat_shadow_bytes = 0;                     // 128 x number of primary / shadow filter group pairs
+    float flat_centre[3] = { 0, 0, 0 };                                        // the shadow filter's reference point (centroid of the item centres)
     double light[3] = { 0, 0, 0 }, eye[3] = { 0, 0, 0 };   // exact copies of the REAL values
     std::mutex mu;
     std::vector<std::unique_ptr<Context>> pool;
@@ -263,16 +264,27 @@ rt_status upload_flat(rt_scene *s, const void *host_items)
                        static_cast<T *>(s->d_fprim_rr), static_cast<rt::Quad<T> *>(s->d_fshad));
     HIP_TRY(hipGetLastError());
     if constexpr (sizeof(T) == 4) {
-        const uint32_t n4 = (s->n_items + rt::kFlatFilterItems - 1) / rt::kFlatFilterItems, pairs = (n4 + 1) / 2;
-        const uint32_t n_groups = 2 * pairs + rt::kFlatPadGroups;            // pad groups: never hit; the scans load one pair ahead
-        s->flat_filter_bytes = pairs * 128u;
-        HIP_TRY(hipMalloc(&s->d_pf, sizeof(rt::FGroup) * n_groups));
+        const uint32_t n4 = (s->n_items + rt::kFlatFilterItems - 1) / rt::kFlatFilterItems, fpairs = (n4 + 1) / 2;
+        const uint32_t n3 = (s->n_items + rt::kFlatShadowItems - 1) / rt::kFlatShadowItems, spairs = (n3 + 1) / 2;
+        const uint32_t n_fgroups = 2 * fpairs + rt::kFlatPadGroups;          // pad groups: never hit; the scans load one pair ahead
+        const uint32_t n_sgroups = 2 * spairs + rt::kFlatPadGroups;
+        s->flat_filter_bytes = fpairs * 128u;
+        s->flat_shadow_bytes = spairs * 128u;
+        // the shadow filter takes centres and origins relative to a point inside the scene: the centroid of the item centres
+        double m0[3] = { 0, 0, 0 };
+        for (unsigned i = 0; i < s->n_items; ++i)
+            for (int k = 0; k < 3; ++k) m0[k] += (double)it[4 * i + k];
+        for (int k = 0; k < 3; ++k) s->flat_centre[k] = (float)(m0[k] / (double)s->n_items);
+        HIP_TRY(hipMalloc(&s->d_pf, sizeof(rt::FGroup) * n_fgroups));
         HIP_TRY(hipMalloc(&s->d_pe, sizeof(rt::FExact) * s->n_items));
-        HIP_TRY(hipMalloc(&s->d_sg, sizeof(rt::FGroup) * n_groups));
+        HIP_TRY(hipMalloc(&s->d_sg, sizeof(rt::FGroup) * n_sgroups));
         HIP_TRY(hipMalloc(&s->d_se, sizeof(rt::FExactShadow) * s->n_items));
-        hipLaunchKernelGGL(rt::k_build_flat_groups, dim3((n_groups * rt::kFlatFilterItems + 255) / 256), dim3(256), 0, nullptr,
-                           static_cast<const rt::Item<float> *>(s->d_items), d_order, s->n_items, n_groups,
-                           rt::V3<float>{ (float)s->eye[0], (float)s->eye[1], (float)s->eye[2] }, static_cast<rt::FGroup *>(s->d_pf),
+        const uint32_t n_threads = std::max(n_fgroups * rt::kFlatFilterItems, n_sgroups * rt::kFlatShadowItems);
+        hipLaunchKernelGGL(rt::k_build_flat_groups, dim3((n_threads + 255) / 256), dim3(256), 0, nullptr,
+                           static_cast<const rt::Item<float> *>(s->d_items), d_order, s->n_items, n_fgroups, n_sgroups,
+                           rt::V3<float>{ (float)s->eye[0], (float)s->eye[1], (float)s->eye[2] },
+                           rt::V3<float>{ s->flat_centre[0], s->flat_centre[1], s->flat_centre[2] },
+                           rt::V3<float>{ -(float)s->light[0], -(float)s->light[1], -(float)s->light[2] }, static_cast<rt::FGroup *>(s->d_pf),
                            static_cast<rt::FExact *>(s->d_pe), static_cast<rt::FGroup *>(s->d_sg), static_cast<rt::FExactShadow *>(s->d_se));
         HIP_TRY(hipGetLastError());
     }
@@ -288,6 +300,8 @@ rt::FlatScView flat_sc_view_of(const rt_scene *s)
     v.sg = static_cast<const rt::FGroup *>(s->d_sg);
     v.se = static_cast<const rt::FExactShadow *>(s->d_se);
     v.n_fbytes = s->flat_filter_bytes;
+    v.n_sbytes = s->flat_shadow_bytes;
+    v.centre = { s->flat_centre[0], s->flat_centre[1], s->flat_centre[2] };
     v.items = static_cast<const rt::Item<float> *>(s->d_items);
     v.n_items = s->n_items;
     v.light = { (float)s->light[0], (float)s->light[1], (float)s->light[2] };
@@ -752,10 +766,10 @@ rt_status launch_flat_wavefront(const rt_scene *s, Context *c, hipStream_t strea
     if constexpr (sizeof(T) == 4) {
         if (knob(RT_DEBUG_FLAT_KERNELS) != 0) {
             // f32: the scalar-fed scan (rt_flat_sc.hpp): two rays per lane, a workgroup = two 16x16-pixel blocks of two waves each (the resolve table serves both)
-            constexpr unsigned kFirstPassGroups = 256;                  // the 1,024 largest spheres (an even number of groups)
+            constexpr unsigned kFirstPassGroups = 342;                  // the 1,026 largest spheres (an even number of groups)
             const rt::FlatScView sv = flat_sc_view_of(s);
-            const unsigned first_bytes = std::min(kFirstPassGroups * 64u, sv.n_fbytes);
-            c->flat_first_pass_items = first_bytes / 64u * rt::kFlatFilterItems;
+            const unsigned first_bytes = std::min(kFirstPassGroups * 64u, sv.n_sbytes);
+            c->flat_first_pass_items = first_bytes / 64u * rt::kFlatShadowItems;
             hipLaunchKernelGGL(rt::k_flat_primary_sc, dim3((blocks16 + 1) / 2, (unsigned)ns), dim3(rt::kFlatScPrimaryThreads), 0, stream, sv, w, h, spp,
                                d_tab16, nt, blocks16, sb, q1, c->d_queues, cnt);
             HIP_TRY(hipGetLastError());

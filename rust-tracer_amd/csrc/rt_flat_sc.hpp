@@ -8,8 +8,8 @@
 // v_pk_mul/add/fma_f32 takes with its scalar operand (half of an SGPR pair, broadcast by op_sel) for free.  So a lane carries TWO
 // rays in VGPR pairs and every instruction of the scan is packed.  The scan loops are generated assembly (tools/gen_flat_asm.py
 // -> rt_flat_rot.hpp), which also documents the filter: almost every test ends in `disc < 0`, and for that only the sign of disc
-// is needed -- per item the loops form a bound of disc with 4 (primary) / 11 (shadow) packed FMAs whose margin covers every
-// rounding of both computations (disc >= 0 implies bound >= 0; flat_filter_constant / flat_shadow_filter_rr below, checked
+// is needed -- per item the loops form a bound of disc with 4 (primary) / 6 (shadow) packed instructions whose margin covers every
+// rounding of both computations (disc >= 0 implies bound >= 0; flat_filter_constant / flat_shadow_filter_g below, checked
 // exhaustively by k_flat_filter_check), reject a group of four items with one branch, and run the reference's eight / sixteen
 // individually rounded operations (primitive.rs:55-72) only for the items whose bound is >= 0 for some ray.  What is computed
 // for those is the reference's, bit for bit, in item order; the filter only decides what is looked at.
@@ -28,12 +28,13 @@
 
 namespace rt {
 
-// Filter groups of FOUR items -- primary {vx[4], vy[4], vz[4], K[4]}, shadow {cx[4], cy[4], cz[4], rr'[4]} -- and one exact record per
-// item: primary {vx, vy, vz, vv, rr, 0, 0, 0}, shadow {cx, cy, cz, rr}.
+// Filter groups -- primary: FOUR items {vx[4], vy[4], vz[4], K[4]}; shadow: THREE items {cx'[3], cy'[3], cz'[3], CL[3], G[3], -} with
+// c' = centre - scene centre -- and one exact record per item: primary {vx, vy, vz, vv, rr, 0, 0, 0}, shadow {cx, cy, cz, rr}.
 struct alignas(64) FGroup { float f[16]; };
 struct alignas(32) FExact { float f[8]; };
 struct alignas(16) FExactShadow { float f[4]; };
-constexpr unsigned kFlatFilterItems = 4;
+constexpr unsigned kFlatFilterItems = 4;        // primary filter groups
+constexpr unsigned kFlatShadowItems = 3;        // shadow filter groups
 constexpr unsigned kFlatPadGroups = 2;          // behind the last pair: the scans load one pair ahead
 
 struct FlatScView {
@@ -43,7 +44,9 @@ struct FlatScView {
     const FExactShadow *se; // shadow exact records, radius descending
     const Item<float> *items;   // centres for the normal of the winning item
     uint32_t n_items;
-    uint32_t n_fbytes;      // 128 * number of filter group pairs (both scans)
+    uint32_t n_fbytes;      // primary: 128 * number of filter group pairs
+    uint32_t n_sbytes;      // shadow: 128 * number of filter group pairs
+    V3<float> centre;       // shadow filter: the point the centres and origins are taken relative to
     V3<float> light, eye;
 };
 
@@ -62,44 +65,68 @@ __device__ __forceinline__ float flat_filter_constant(float vv, float rr)
     return f;
 }
 
-// Shadow rays have their own origin, so vv is per ray: the filter forms b' and vv' as FMA chains from the SAME v = c - o the exact
-// test forms, and bound = fma(-vv', 1 - m, fma(b', b', rr')) with m = 2^-17.  |b*b - b'*b'| <= 12.4 eps |v|^2 as above (|dir| <= 1 +
-// 2 eps), vv and vv' are within 3 eps |v|^2 of |v|^2 each, the exact test's roundings add 1.1 eps |v|^2 + 2 eps rr and the filter's two
-// FMAs eps (vv' + rr'): disc >= 0 implies b'*b' - vv' + rr >= -(21 eps vv' + 3 eps rr), which m (vv' + rr) = 128 eps (vv' + rr)
-// covers six times over; 2^-140 covers the subnormal range.
-__device__ __forceinline__ float flat_shadow_filter_rr(float rr)
+// Shadow rays have their own origin o, so nothing of vv can be pre-formed from v = c - o.  Relative to a point m0 inside the scene,
+// c' = fl(c - m0) and o' = fl(o - m0):  |c' - o'|^2 = |c'|^2 + |o'|^2 - 2 c'.o'  and  b = c'.l - o'.l, so per item only
+//      u = fma(cz', 2oz', fma(cy', 2oy', fma(cx', 2ox', -Pm))) ; b' = CL - OL ; bound = fma(b', b', u) + G
+// remain (six packed instructions), with CL = c'.l and G per item, OL = o'.l and Pm = |o'|^2 (1 - m) per ray, m = 2^-16.  With
+// S = |c'|^2 + |o'|^2: b' and the exact b are within 4.5 eps and 5.3 eps (|c'| + |o'|) of c'.l - o'.l (the re-centring costs
+// eps (|c'| + |o'|)), so b b and b' b' differ by <= 39.6 eps S; the exact vv and |c' - o'|^2 by <= 14.4 eps S; the exact test's roundings
+// add 2.2 eps S + 2 eps rr and the filter's own 21 eps S + eps rr: disc >= 0 implies bound >= -(77.2 eps S + 3 eps rr) + margin, and
+// the margin m (S + rr) = 256 eps (S + rr) (+ 2^-140 for subnormal results) is 3.3 times that.  Because S is taken about a point
+// inside the scene, the bound stays tight when the scene is far from the coordinate origin.
+__device__ __forceinline__ float flat_shadow_filter_g(double cc, float rr)
 {
-    const double k = (double)rr * (1.0 + 0x1p-17) + 0x1p-140;
+    const double k = ((double)rr - cc) + (cc + (double)rr) * 0x1p-16 + 0x1p-140;
     float f = (float)k;
-    if ((double)f < k) f = __uint_as_float(__float_as_uint(f) + 1u);        // next float up (f > 0)
+    if ((double)f < k) f = __uint_as_float(__float_as_uint(f) + (f >= 0.f ? 1u : 0xFFFFFFFFu));      // next float up (finite, != -0)
     return f;
+}
+
+// Per ray: -Pm = -(|o'|^2 (1 - m)) rounded towards zero (so that -Pm >= -|o'|^2 (1 - m)); p = the f32 |o'|^2 the kernel formed.
+__device__ __forceinline__ float flat_shadow_filter_npm(float p)
+{
+    float pm = p * (1.0f - 0x1p-16f);
+    if (pm > 0.f) pm = __uint_as_float(__float_as_uint(pm) - 1u);           // one step down covers the rounding of the product
+    return -pm;
 }
 
 // shadow_order[i] = index of the item at position i of the shadow array.  Pad items (i >= n) can never be hit: rr = -inf makes
 // disc = (b*b - vv) + rr = -inf whatever the ray is, K = -inf the filter's bound.
-__global__ void k_build_flat_groups(const Item<float> *__restrict__ items, const unsigned *__restrict__ shadow_order, unsigned n, unsigned n_groups,
-                                    V3<float> eye, FGroup *__restrict__ pf, FExact *__restrict__ pe, FGroup *__restrict__ sg,
-                                    FExactShadow *__restrict__ se)
+__global__ void k_build_flat_groups(const Item<float> *__restrict__ items, const unsigned *__restrict__ shadow_order, unsigned n, unsigned n_fgroups,
+                                    unsigned n_sgroups, V3<float> eye, V3<float> centre, V3<float> sdir, FGroup *__restrict__ pf, FExact *__restrict__ pe,
+                                    FGroup *__restrict__ sg, FExactShadow *__restrict__ se)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_groups * kFlatFilterItems) return;
-    const unsigned g = i / kFlatFilterItems, k = i % kFlatFilterItems;
-    float *p = pf[g].f, *s = sg[g].f;
-    if (i < n) {
-        const Item<float> it = items[i];
-        const V3<float> v = { it.cx - eye.x, it.cy - eye.y, it.cz - eye.z };      // primitive.rs:56
-        const float vv = dot(v, v), rr = it.r * it.r;                             // primitive.rs:58
-        p[0 + k] = v.x; p[4 + k] = v.y; p[8 + k] = v.z; p[12 + k] = flat_filter_constant(vv, rr);
-        float *e = pe[i].f;
-        e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = vv; e[4] = rr; e[5] = e[6] = e[7] = 0.f;
-        const Item<float> sh = items[shadow_order[i]];
-        const float srr = sh.r * sh.r;
-        s[0 + k] = sh.cx; s[4 + k] = sh.cy; s[8 + k] = sh.cz; s[12 + k] = flat_shadow_filter_rr(srr);
-        float *x = se[i].f;
-        x[0] = sh.cx; x[1] = sh.cy; x[2] = sh.cz; x[3] = srr;
-    } else {
-        p[0 + k] = 0.f; p[4 + k] = 0.f; p[8 + k] = 0.f; p[12 + k] = -inf<float>();
-        s[0 + k] = 0.f; s[4 + k] = 0.f; s[8 + k] = 0.f; s[12 + k] = -inf<float>();
+    if (i < n_fgroups * kFlatFilterItems) {
+        const unsigned g = i / kFlatFilterItems, k = i % kFlatFilterItems;
+        float *p = pf[g].f;
+        if (i < n) {
+            const Item<float> it = items[i];
+            const V3<float> v = { it.cx - eye.x, it.cy - eye.y, it.cz - eye.z };      // primitive.rs:56
+            const float vv = dot(v, v), rr = it.r * it.r;                             // primitive.rs:58
+            p[0 + k] = v.x; p[4 + k] = v.y; p[8 + k] = v.z; p[12 + k] = flat_filter_constant(vv, rr);
+            float *e = pe[i].f;
+            e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = vv; e[4] = rr; e[5] = e[6] = e[7] = 0.f;
+        } else {
+            p[0 + k] = 0.f; p[4 + k] = 0.f; p[8 + k] = 0.f; p[12 + k] = -inf<float>();
+        }
+    }
+    if (i < n_sgroups * kFlatShadowItems) {
+        const unsigned g = i / kFlatShadowItems, k = i % kFlatShadowItems;
+        float *s = sg[g].f;
+        if (i < n) {
+            const Item<float> sh = items[shadow_order[i]];
+            const float srr = sh.r * sh.r;
+            const float cx = sh.cx - centre.x, cy = sh.cy - centre.y, cz = sh.cz - centre.z;          // c', rounded once per component
+            const double cl = (double)cx * sdir.x + (double)cy * sdir.y + (double)cz * sdir.z;
+            const double cc = (double)cx * cx + (double)cy * cy + (double)cz * cz;
+            s[0 + k] = cx; s[3 + k] = cy; s[6 + k] = cz; s[9 + k] = (float)cl; s[12 + k] = flat_shadow_filter_g(cc, srr);
+            float *x = se[i].f;
+            x[0] = sh.cx; x[1] = sh.cy; x[2] = sh.cz; x[3] = srr;
+        } else {
+            s[0 + k] = 0.f; s[3 + k] = 0.f; s[6 + k] = 0.f; s[9 + k] = 0.f; s[12 + k] = -inf<float>();
+        }
+        if (k == 0) s[15] = 0.f;
     }
 }
 
@@ -118,9 +145,14 @@ __global__ __launch_bounds__(kBlockThreads) void k_flat_filter_check(FlatScView 
     const float xres = float(x) + float(ssx) / ssf, yres = float(y) + float(ssy) / ssf;
     const V3<float> d = normalized(V3<float>{ xres - half_w, (fh - yres) - half_h, fw });
     unsigned long long exact = 0, bound = 0, bad = 0, sexact = 0, sbound = 0, sbad = 0;
-    // shadow-type rays: from a point on the primary ray (0.75 .. 1 times the eye's distance from the origin along it) towards the light
-    const V3<float> o = add(sc.eye, mulf(d, sqrtf(dot(sc.eye, sc.eye)) * (0.75f + 0.0625f * float(blockIdx.y % 5u))));
+    // shadow-type rays: from a point on the primary ray (0.75 .. 1 times the eye's distance from the scene centre along it) towards the light
+    const V3<float> ec = sub(sc.eye, sc.centre);
+    const V3<float> o = add(sc.eye, mulf(d, sqrtf(dot(ec, ec)) * (0.75f + 0.0625f * float(blockIdx.y % 5u))));
     const V3<float> l = mulf(sc.light, -1.0f);
+    const V3<float> oc = sub(o, sc.centre);
+    const V3<float> o2 = mulf(oc, 2.0f);
+    const float ol = __builtin_fmaf(l.z, oc.z, __builtin_fmaf(l.y, oc.y, l.x * oc.x));
+    const float npm = flat_shadow_filter_npm(__builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, oc.x * oc.x)));
     for (unsigned i = 0; i < sc.n_items; ++i) {
         const float *e = sc.pe[i].f;
         const float b = (e[0] * d.x + e[1] * d.y) + e[2] * d.z;
@@ -134,10 +166,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_flat_filter_check(FlatScView 
         const V3<float> v = { x[0] - o.x, x[1] - o.y, x[2] - o.z };
         const float sb = dot(v, l);
         const float sdisc = (sb * sb - dot(v, v)) + x[3];
-        const float rrp = sc.sg[i / kFlatFilterItems].f[12 + i % kFlatFilterItems];
-        const float sbf = __builtin_fmaf(l.z, v.z, __builtin_fmaf(l.y, v.y, l.x * v.x));
-        const float w = __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x));
-        const float sbnd = __builtin_fmaf(-w, 1.0f - 0x1p-17f, __builtin_fmaf(sbf, sbf, rrp));
+        const float *g = sc.sg[i / kFlatShadowItems].f;
+        const unsigned gk = i % kFlatShadowItems;
+        const float u = __builtin_fmaf(g[6 + gk], o2.z, __builtin_fmaf(g[3 + gk], o2.y, __builtin_fmaf(g[0 + gk], o2.x, npm)));
+        const float bp = g[9 + gk] - ol;
+        const float sbnd = __builtin_fmaf(bp, bp, u) + g[12 + gk];
         const bool se = sdisc >= 0.f, sbb = sbnd >= 0.f;
         sexact += se; sbound += sbb; sbad += se && !sbb;
     }
@@ -260,9 +293,17 @@ __global__ __launch_bounds__(kBlockThreads) void k_flat_shadow_sc(FlatScView sc,
         }
     }
     const V3<T> sdir = mulf(sc.light, T(-1.0));                                // render.rs:206
-    const unsigned end = min(end_bytes, sc.n_fbytes);
+    // the filter's per-ray terms (flat_shadow_filter_g's comment): origin relative to the scene centre, FMAs welcome
+    T o2x[kFlatScRays], o2y[kFlatScRays], o2z[kFlatScRays], ol[kFlatScRays], npm[kFlatScRays];
+    for (unsigned h = 0; h < kFlatScRays; ++h) {
+        const V3<T> oc = { ox[h] - sc.centre.x, oy[h] - sc.centre.y, oz[h] - sc.centre.z };
+        o2x[h] = oc.x * T(2.0); o2y[h] = oc.y * T(2.0); o2z[h] = oc.z * T(2.0);
+        ol[h] = __builtin_fmaf(sdir.z, oc.z, __builtin_fmaf(sdir.y, oc.y, sdir.x * oc.x));
+        npm[h] = flat_shadow_filter_npm(__builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, oc.x * oc.x)));
+    }
+    const unsigned end = min(end_bytes, sc.n_sbytes);
     if (begin_bytes < end)
-        flat_shadow_scan(sc.sg, begin_bytes, end, sc.se, ox, oy, oz, sdir.x, sdir.y, sdir.z, have, occluded);
+        flat_shadow_scan(sc.sg, begin_bytes, end, sc.se, ox, oy, oz, o2x, o2y, o2z, ol, npm, sdir.x, sdir.y, sdir.z, have, occluded);
     unsigned c_occ = 0;
     for (unsigned h = 0; h < kFlatScRays; ++h) {
         const bool occ = have[h] && occluded[h];

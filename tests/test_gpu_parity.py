@@ -838,7 +838,7 @@ def test_dealing_blocks_to_workgroups_never_changes_a_pixel(size, policy):
     assert util.all_stats(st) == util.all_stats(rst)
 
 
-@pytest.mark.parametrize("n_items", [1, 2, 3, 4, 5, 7, 8, 9, 1023, 1024, 1025, 2053])
+@pytest.mark.parametrize("n_items", [1, 2, 3, 4, 5, 6, 7, 8, 9, 1023, 1024, 1025, 1026, 1027, 2053])
 def test_scalar_fed_flat_scan_item_counts_around_the_group_and_pass_sizes(n_items):
     # f32 RT_TRAVERSAL_FLAT runs the scalar-fed scan (rt_flat_sc.hpp + generated rt_flat_rot.hpp): groups of three items, two groups
     # per loop iteration, the first shadow pass covers 342 groups = 1,026 items.  Item counts around every one of those boundaries,
@@ -879,6 +879,22 @@ def test_flat_scan_filter_never_rejects_a_candidate(scale):
         c = rta.capi.flat_filter_check(s.device()._h, 320, 240, 2)
         assert c[0] > 50_000 and c[3] > 10_000, c
         assert c[2] == 0 and c[5] == 0, c
+    if scale == 1.0:
+        # a scene far from the coordinate origin: the shadow filter takes centres and origins relative to the scene's centroid, so
+        # its margin (relative to |c'|^2 + |o'|^2) stays tight; frames equal the oracle's flat semantics
+        items, bounds, ranges = util.random_nested_scene(34, depth=3, fan=3, leaf_items=2)
+        shift = np.array([3000.0, -2000.0, 5000.0])
+        mv = lambda a: np.concatenate([np.asarray(a, dtype=np.float64)[:, :3] + shift, np.asarray(a, dtype=np.float64)[:, 3:]], axis=1).astype(np.float32).astype(np.float64)
+        eye = tuple(float(v) for v in (np.array([0.07, -0.12, -3.1]) + shift).astype(np.float32))
+        s, o = util.scene_pair_ranges(mv(items), mv(bounds), ranges, rta.RT_F32, eye=eye)
+        c = rta.capi.flat_filter_check(s.device()._h, 320, 240, 2)
+        assert c[0] > 30_000 and c[3] > 10_000 and c[2] == 0 and c[5] == 0, c
+        assert c[1] < 2 * c[0] and c[4] < 2 * c[3], c
+        regs = bucket_list(160, 120, 2)
+        ref, rst, _ = o.render(160, 120, 2, os.cpu_count() or 1, oracle.MODE_FLAT)
+        data, st = s.device().render_tiles((160, 120, 2), regs, FLAT)
+        np.testing.assert_array_equal(util.stitch((160, 120), regs, data), ref)
+        assert util.ray_stats(st) == util.ray_stats(rst)
 
 
 def test_scalar_fed_flat_scan_on_tiny_discriminants():

@@ -15,7 +15,7 @@ instruction does one operation of the test for both; the scalar load, the wait a
 
 The filter.  The reference's test is eight (primary) / sixteen (shadow) individually rounded operations per ray and item.
 Almost every item is rejected by `disc < 0`, and a rejection does not need disc's bits, only its sign: the loops form a BOUND of
-disc with fused multiply-adds -- 4 (primary) / 11 (shadow) packed instructions per item instead of 8 / 16 -- plus a margin that
+disc with fused multiply-adds -- 4 (primary) / 6 (shadow) packed instructions per item instead of 8 / 16 -- plus a margin that
 covers every rounding of both computations, so that disc >= 0 implies bound >= 0.  A group none of whose bounds is >= 0 for any
 ray is skipped (three v_max3_f32, one v_max_f32, one compare, one branch per four items and 128 rays); otherwise the items
 whose bound is >= 0 for some ray get the reference's exact test, operation for operation, from their exact record (one more
@@ -28,16 +28,22 @@ both computations start from; B = the exact dot product of v and dir):
     primary   vv is the stored f32 dot(v, v): within 4 eps of |v|^2.  Hence disc >= 0 implies b' b' - vv + rr >= -(14 eps vv + 3 eps rr),
               and bound = fma(b', b', K) >= 0 for K = rr - vv + 2^-17 (vv + rr) + 2^-140 rounded UP (2^-17 = 128 eps: a factor of eight
               in hand; 2^-140 covers subnormal results, whose errors are absolute, <= 2^-149 per operation)
-    shadow    vv is per ray: exact fl-sum of squares and the filter's FMA chain vv' are within 3 eps |v|^2 of |v|^2 each.  disc >= 0
-              implies b' b' - vv' + rr >= -(21 eps vv' + 3 eps rr); bound = fma(-vv', 1 - 2^-17, fma(b', b', rr')) with
-              rr' = rr (1 + 2^-17) + 2^-140 rounded UP adds 128 eps (vv' + rr) and loses at most 2 eps (vv' + rr') to its own roundings
+    shadow    the origin o is per ray, so nothing of vv can be pre-formed from v = c - o.  Relative to a point m0 inside the scene,
+              c' = fl(c - m0), o' = fl(o - m0):  |c' - o'|^2 = |c'|^2 + |o'|^2 - 2 c'.o'  and  b = c'.l - o'.l, so per item only
+                  u = fma(cz', 2oz', fma(cy', 2oy', fma(cx', 2ox', -Pm))) ; b' = CL - OL ; bound = fma(b', b', u) + G
+              remain, with CL = c'.l (from double, rounded once) and G = rr - |c'|^2 + m (|c'|^2 + rr) + 2^-140 (rounded UP) per item,
+              OL = o'.l and Pm = |o'|^2 (1 - m) (rounded towards zero) per ray, m = 2^-16.  With S = |c'|^2 + |o'|^2: the exact b and b'
+              are within 5.3 eps and 4.5 eps (|c'| + |o'|) of c'.l - o'.l (re-centring costs eps (|c'| + |o'|)), so b b and b' b' differ
+              by <= 39.6 eps S; the exact vv and |c' - o'|^2 by <= 14.4 eps S; the exact test's roundings add 2.2 eps S + 2 eps rr, the
+              filter's own 21 eps S + eps rr.  disc >= 0 implies bound >= m (S + rr) - (77.2 eps S + 3 eps rr) >= 0: 256 eps against 77.
+              S is taken about a point inside the scene, so the bound stays tight for scenes far from the coordinate origin
 rt_debug_flat_filter_check evaluates both sides for every ray x item pair of a frame (tests/test_gpu_parity.py: 4.5e10 pairs of
-the default scene and scenes scaled from 1e-20 to 5e13, no pair with disc >= 0 and bound < 0; the bound lets through 1.3x the
-exact candidates).  A shadow ray that is settled (or a lane half without a ray) gets a NaN origin: every bound and
+the default scene, scenes scaled from 1e-20 to 5e13 and a scene 6,000 units from the origin: no pair with disc >= 0 and bound < 0;
+the bounds let through 1.33x (primary) / 1.13x (shadow) the exact candidates).  A shadow ray that is settled (or a lane half without a ray) gets a NaN origin: every bound and
 discriminant it forms from then on is NaN, which is never `>= 0`, so it needs no mask of its own.
 
 The halves of a register pair have to be named, which inline-asm operands cannot do, so the loops own FIXED registers (v[32:63],
-s[36:89]; listed as clobbers -- the kernels around them need 20 VGPRs) and move their operands in and out.
+s[36:87]; listed as clobbers -- the kernels around them need 20 VGPRs) and move their operands in and out.
 
 Exact arithmetic, operation for operation (primitive.rs:55-72; each + - * rounded once, no FMA outside the exact root; a packed
 subtraction is an addition with the IEEE sign flip of the neg modifier):
@@ -56,9 +62,8 @@ BANK = {"A": 36, "B": 52}            # s[36:51], s[52:67]
 OFF, IDX, EXS, TINY = "s68", "s69", "s[70:71]", "s[72:73]"
 LIGHT = 74                           # s74..s76: light direction of the shadow scan (s77 pads the pair)
 EXACT = 80                           # s[80:87]: the exact record of one item (slow path)
-SHRINK = 88                          # s88: 1 - 2^-17 (shadow filter; s89 pads the pair)
 STRIDE = 64
-SGPR_LAST = 89
+SGPR_LAST = 87
 VGPR_FIRST, VGPR_LAST = 32, 63
 
 
@@ -267,39 +272,40 @@ def primary_slow(a, bank, r):
 class ShadowRegs:
     def __init__(self):
         v = VGPR_FIRST
-        self.OX, self.OY, self.OZ = Pair(v), Pair(v + 2), Pair(v + 4)
-        self.VX, self.VY, self.VZ = Pair(v + 6), Pair(v + 8), Pair(v + 10)
-        self.T0, self.T1 = Pair(v + 12), Pair(v + 14)
-        self.F = [Pair(v + 16), Pair(v + 18), Pair(v + 20), Pair(v + 22)]       # the filter's discriminant bounds of a group's 4 items
-        self.B, self.DISC = Pair(v + 24), Pair(v + 26)
-        self.OCC = Pair(v + 28)
-        self.root = "v%d" % (v + 30)
+        self.OX, self.OY, self.OZ = Pair(v), Pair(v + 2), Pair(v + 4)            # origins (exact test); NaN once a ray is settled
+        self.O2X, self.O2Y, self.O2Z = Pair(v + 6), Pair(v + 8), Pair(v + 10)    # filter: 2 * (origin - scene centre)
+        self.OL, self.NPM = Pair(v + 12), Pair(v + 14)                           # filter: dir . (origin - centre); -|origin - centre|^2 (1 - m)
+        self.T0, self.T1 = Pair(v + 16), Pair(v + 18)
+        self.F = [Pair(v + 20), Pair(v + 22), Pair(v + 24)]                      # the filter's discriminant bounds of a group's 3 items
+        self.VX, self.VY, self.VZ = Pair(v + 26), Pair(v + 28), Pair(v + 30)
+        self.B, self.DISC = Pair(v + 32), Pair(v + 34)
+        self.OCC = Pair(v + 36)
+        self.root = "v%d" % (v + 38)
         self.t0, self.t1, self.t2 = self.T0.h[0], self.T0.h[1], self.T1.h[0]
 
 
+SHADOW_VGPR_LAST = VGPR_FIRST + 38
+
+
 def shadow_group(a, bank, r):
-    """The conservative filter for four items: v = centre - origin as the exact test forms it, then
-    bound = fma(-vv', 1 - 2^-17, fma(b', b', rr')) with b' and vv' as FMA chains and rr' = rr (1 + 2^-17) + 2^-140 rounded up:
-    eleven packed instructions per item for both rays, and disc >= 0 implies bound >= 0 (tools/gen_flat_asm.py docstring)."""
-    for k in range(4):
-        pk(a, "add", r.VX.p, None, r.OX.p, sx=fsreg(bank, 0, k), neg_y=True, comment="item %d: v = centre - origin, both rays" % k if k == 0 else None)
-        pk(a, "add", r.VY.p, None, r.OY.p, sx=fsreg(bank, 1, k), neg_y=True)
-        pk(a, "add", r.VZ.p, None, r.OZ.p, sx=fsreg(bank, 2, k), neg_y=True)
-        pk(a, "mul", r.T0.p, None, r.VX.p, sx=LIGHT + 0)
-        pk_fma(a, r.T0.p, None, r.VY.p, r.T0.p, sx=LIGHT + 1)
-        pk_fma(a, r.T0.p, None, r.VZ.p, r.T0.p, sx=LIGHT + 2)
-        pk(a, "mul", r.T1.p, r.VX.p, r.VX.p)
-        pk_fma(a, r.T1.p, r.VY.p, r.VY.p, r.T1.p)
-        pk_fma(a, r.T1.p, r.VZ.p, r.VZ.p, r.T1.p)
-        pk_fma(a, r.T0.p, r.T0.p, r.T0.p, None, sz=fsreg(bank, 3, k))
-        a.op("v_pk_fma_f32 %s, %s, s[%d:%d], %s op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" % (r.F[k].p, r.T1.p, SHRINK, SHRINK + 1, r.T0.p))
+    """The conservative filter for three items, six packed instructions per item for both rays.  With c' = centre - m0 and
+    o' = origin - m0 (m0: a point inside the scene), |c - o|^2 = |c'|^2 + |o'|^2 - 2 c'.o' and b = c'.l - o'.l, so
+        bound = (b'^2 + u) + G,   b' = CL - OL,   u = fma(cz', 2oz', fma(cy', 2oy', fma(cx', 2ox', -Pm)))
+    with CL = c'.l and G = rr - |c'|^2 + m (|c'|^2 + rr) + 2^-140 (rounded up) per item, OL = o'.l and Pm = |o'|^2 (1 - m)
+    (rounded down) per ray, m = 2^-16: disc >= 0 implies bound >= 0 (tools/gen_flat_asm.py docstring)."""
+    for k in range(3):
+        pk_fma(a, r.T0.p, None, r.O2X.p, r.NPM.p, sx=sreg(bank, 0, k), comment="item %d: bound of disc, both rays" % k if k == 0 else None)
+        pk_fma(a, r.T0.p, None, r.O2Y.p, r.T0.p, sx=sreg(bank, 1, k))
+        pk_fma(a, r.T0.p, None, r.O2Z.p, r.T0.p, sx=sreg(bank, 2, k))
+        pk(a, "add", r.T1.p, None, r.OL.p, sx=sreg(bank, 3, k), neg_y=True)
+        pk_fma(a, r.T0.p, r.T1.p, r.T1.p, r.T0.p)
+        pk(a, "add", r.F[k].p, None, r.T0.p, sx=sreg(bank, 4, k))
     m = r.T0.h[0]
     a.op("v_max3_f32 %s, %s, %s, %s" % (m, r.F[0].h[0], r.F[0].h[1], r.F[1].h[0]))
     a.op("v_max3_f32 %s, %s, %s, %s" % (m, m, r.F[1].h[1], r.F[2].h[0]))
-    a.op("v_max3_f32 %s, %s, %s, %s" % (m, m, r.F[2].h[1], r.F[3].h[0]))
-    a.op("v_max_f32_e32 %s, %s, %s" % (m, m, r.F[3].h[1]))
+    a.op("v_max_f32_e32 %s, %s, %s" % (m, m, r.F[2].h[1]))
     a.op("v_cmp_le_f32_e32 vcc, 0, %s" % m)
-    a.op("s_cbranch_vccnz .Lfl_slow_%s_%%=" % bank, "some pending ray's line may meet one of the four spheres")
+    a.op("s_cbranch_vccnz .Lfl_slow_%s_%%=" % bank, "some pending ray's line may meet one of the three spheres")
     a.label(".Lfl_cont_%s_%%=" % bank)
 
 
@@ -307,10 +313,11 @@ def shadow_slow(a, bank, r):
     """The exact test of the items whose bound is >= 0 for some ray.  A ray that hits is settled: flagged, and its origin becomes
     NaN.  A lane whose two rays are both settled leaves EXEC; the wave leaves the scan when EXEC is empty."""
     a.label(".Lfl_slow_%s_%%=" % bank)
-    a.op("s_lshr_b32 %s, %s, 4" % (IDX, OFF), "index of the group's first item: 4 * (offset / 64)%s" % (" + 4" if bank == "B" else ""))
+    a.op("s_lshr_b32 %s, %s, 6" % (IDX, OFF), "index of the group's first item: 3 * (offset / 64)%s" % (" + 3" if bank == "B" else ""))
+    a.op("s_mul_i32 %s, %s, 3" % (IDX, IDX))
     if bank == "B":
-        a.op("s_add_u32 %s, %s, 4" % (IDX, IDX))
-    for k in range(4):
+        a.op("s_add_u32 %s, %s, 3" % (IDX, IDX))
+    for k in range(3):
         nxt = ".Lfl_item_%s%d_%%=" % (bank, k)
         a.op("v_max_f32_e32 %s, %s, %s" % (r.t0, r.F[k].h[0], r.F[k].h[1]), "item %d" % k)
         a.op("v_cmp_le_f32_e32 vcc, 0, %s" % r.t0)
@@ -344,11 +351,12 @@ def shadow_slow(a, bank, r):
             a.op("v_add_f32_e32 %s, %s, %s" % (r.t0, b, r.root), "t2")
             a.op("v_cmpx_le_f32_e32 0, %s" % r.t0, "t2 >= 0: the ray is occluded (render.rs:208 only asks has_missed())")
             a.op("v_mov_b32_e32 %s, 1" % r.OCC.h[h])
-            a.op("v_mov_b32_e32 %s, 0x7fc00000" % r.OX.h[h], "settled")
+            a.op("v_mov_b32_e32 %s, 0x7fc00000" % r.OX.h[h], "settled: NaN discriminants and NaN bounds from now on")
+            a.op("v_mov_b32_e32 %s, 0x7fc00000" % r.NPM.h[h])
             a.label(".Lfl_next_%s_%%=" % tag)
             a.op("s_mov_b64 exec, %s" % EXS)
         a.label(nxt)
-        if k < 3:
+        if k < 2:
             a.op("s_add_u32 %s, %s, 1" % (IDX, IDX))
     a.op("v_cmp_o_f32_e32 vcc, %s, %s" % (r.OX.h[0], r.OX.h[0]), "lanes that still carry an unsettled ray")
     a.op("v_cmp_o_f32_e64 %s, %s, %s" % (TINY, r.OX.h[1], r.OX.h[1]))
@@ -356,7 +364,7 @@ def shadow_slow(a, bank, r):
     a.op("s_and_b64 exec, exec, vcc")
     a.op("s_cbranch_execz .Lfl_exit_%=", "every ray of the wave is settled")
     a.op("s_branch .Lfl_cont_%s_%%=" % bank)
-    for k in range(4):
+    for k in range(3):
         for h in range(2):
             exact_tiny(a, r.DISC.h[h], "%s%d%d" % (bank, k, h), r)
 
@@ -383,18 +391,18 @@ def loop(a, group, slow, r):
 HEADER = """// rt_flat_rot.hpp -- GENERATED by tools/gen_flat_asm.py; edit the generator, not this file.
 //
 // The inner loops of the scalar-fed flat scan (rt_flat_sc.hpp) in gfx950 assembly, f32, two rays per lane on packed math.  A
-// group of four items is one 64-byte record = one s_load_dwordx16 into one of two SGPR banks (s[36:51], s[52:67]); the next
+// group of four (primary) or three (shadow) items is one 64-byte record = one s_load_dwordx16 into one of two SGPR banks (s[36:51], s[52:67]); the next
 // group's load is issued before the current group's arithmetic.  Per item the loops form a conservative BOUND of the
-// discriminant with packed FMAs (4 instructions primary, 11 shadow, for the lane's two rays; item terms are the low or high
+// discriminant with packed FMAs (4 instructions primary, 6 shadow, for the lane's two rays; item terms are the low or high
 // half of an aligned SGPR pair broadcast with op_sel), whose margin covers every rounding of both computations: disc >= 0 implies
 // bound >= 0 (tools/gen_flat_asm.py has the analysis, rt_debug_flat_filter_check the exhaustive check).  Three v_max3_f32 + one
 // v_max_f32 and one branch reject a group; otherwise the items whose bound is >= 0 for some ray get the reference's exact test,
 // operation for operation, from their exact record, in item order (root == sqrt_rn_lean, t2, t1, d, strict `<`), per ray on the
-// 32-bit halves.  The loops own v[32:63] and s[36:89] (clobbers): s68 byte offset of the current group pair, s69 item index,
+// 32-bit halves.  The loops own v[32:63] (shadow: v[32:70]) and s[36:87] (clobbers): s68 byte offset of the current group pair, s69 item index,
 // s[70:71] saved EXEC, s[72:73] mask scratch, s[74:76] the shadow rays' direction, s76 / s78 address scratch, s[80:87] the exact
-// record, s88 the shadow filter's 1 - 2^-17.
+// record.
 //
-// Filter group (rt_flat_sc.hpp, FGroup): primary {vx[4], vy[4], vz[4], K[4]}; shadow {cx[4], cy[4], cz[4], rr'[4]}.  Exact record:
+// Filter group (rt_flat_sc.hpp, FGroup): primary {vx[4], vy[4], vz[4], K[4]}; shadow {cx'[3], cy'[3], cz'[3], CL[3], G[3], -}.  Exact record:
 // primary FExact {vx, vy, vz, vv, rr, -, -, -}; shadow FExactShadow {cx, cy, cz, rr}.  The group arrays end in pad groups (K, rr' =
 // -inf: never a candidate) so that the load issued one pair ahead stays inside them.
 #pragma once
@@ -422,10 +430,12 @@ __device__ __forceinline__ void flat_primary_scan(const void *groups, unsigned n
 """
 
 SHADOW = """// Any hit over the filter groups [begin_bytes / 64, end_bytes / 64) (multiples of 128; `exact`: the items' exact records, 16 bytes
-// each) for the wave's 128 shadow rays; ray h of a lane starts at (ox[h], oy[h], oz[h]) and counts only if pending[h] != 0.
-// Returns 1 in occluded[h] for an occluded ray.  The wave leaves as soon as every pending ray is settled.
+// each) for the wave's 128 shadow rays; ray h of a lane starts at (ox[h], oy[h], oz[h]) and counts only if pending[h] != 0.  For the
+// filter the caller passes, per ray, 2 (origin - scene centre), ol = dir . (origin - centre) and npm = -|origin - centre|^2 (1 - 2^-16)
+// rounded towards zero.  Returns 1 in occluded[h] for an occluded ray.  The wave leaves as soon as every pending ray is settled.
 __device__ __forceinline__ void flat_shadow_scan(const void *groups, unsigned begin_bytes, unsigned end_bytes, const void *exact, const float (&ox)[2],
-                                                 const float (&oy)[2], const float (&oz)[2], float lx, float ly, float lz,
+                                                 const float (&oy)[2], const float (&oz)[2], const float (&o2x)[2], const float (&o2y)[2],
+                                                 const float (&o2z)[2], const float (&ol)[2], const float (&npm)[2], float lx, float ly, float lz,
                                                  const unsigned (&pending)[2], unsigned (&occluded)[2])
 {
     const float tiny = 0x1p-96f;
@@ -434,16 +444,17 @@ __device__ __forceinline__ void flat_shadow_scan(const void *groups, unsigned be
 %(body)s
         : [occ0] "=v"(occluded[0]), [occ1] "=v"(occluded[1]), [saved] "=&s"(saved)
         : [base] "s"(groups), [begin] "s"(begin_bytes), [end] "s"(end_bytes), [exact] "s"(exact), [ox0] "v"(ox[0]), [ox1] "v"(ox[1]), [oy0] "v"(oy[0]),
-          [oy1] "v"(oy[1]), [oz0] "v"(oz[0]), [oz1] "v"(oz[1]), [lx] "s"(lx), [ly] "s"(ly), [lz] "s"(lz), [pend0] "v"(pending[0]),
-          [pend1] "v"(pending[1]), [tiny] "s"(tiny)
+          [oy1] "v"(oy[1]), [oz0] "v"(oz[0]), [oz1] "v"(oz[1]), [o2x0] "v"(o2x[0]), [o2x1] "v"(o2x[1]), [o2y0] "v"(o2y[0]), [o2y1] "v"(o2y[1]),
+          [o2z0] "v"(o2z[0]), [o2z1] "v"(o2z[1]), [ol0] "v"(ol[0]), [ol1] "v"(ol[1]), [npm0] "v"(npm[0]), [npm1] "v"(npm[1]), [lx] "s"(lx),
+          [ly] "s"(ly), [lz] "s"(lz), [pend0] "v"(pending[0]), [pend1] "v"(pending[1]), [tiny] "s"(tiny)
         : %(clobbers)s);
 }
 
 """
 
 
-def clobbers():
-    regs = ['"s%d"' % r for r in range(36, SGPR_LAST + 1)] + ['"v%d"' % r for r in range(VGPR_FIRST, VGPR_LAST + 1)]
+def clobbers(vgpr_last=VGPR_LAST):
+    regs = ['"s%d"' % r for r in range(36, SGPR_LAST + 1)] + ['"v%d"' % r for r in range(VGPR_FIRST, vgpr_last + 1)]
     lines, cur = [], '"memory", "vcc", "scc"'
     for r in regs:
         if len(cur) + len(r) + 2 > 118:
@@ -482,13 +493,17 @@ def shadow_body():
         a.op("v_cmp_ne_u32_e32 vcc, 0, %%[pend%d]" % h, "a lane half without a pending ray: NaN origin, never a candidate" if h == 0 else None)
         a.op("v_mov_b32_e32 %s, 0x7fc00000" % r.t0)
         a.op("v_cndmask_b32_e32 %s, %s, %%[ox%d], vcc" % (r.OX.h[h], r.t0, h))
+        a.op("v_cndmask_b32_e32 %s, %s, %%[npm%d], vcc" % (r.NPM.h[h], r.t0, h))
         a.op("v_mov_b32_e32 %s, %%[oy%d]" % (r.OY.h[h], h))
         a.op("v_mov_b32_e32 %s, %%[oz%d]" % (r.OZ.h[h], h))
+        a.op("v_mov_b32_e32 %s, %%[o2x%d]" % (r.O2X.h[h], h))
+        a.op("v_mov_b32_e32 %s, %%[o2y%d]" % (r.O2Y.h[h], h))
+        a.op("v_mov_b32_e32 %s, %%[o2z%d]" % (r.O2Z.h[h], h))
+        a.op("v_mov_b32_e32 %s, %%[ol%d]" % (r.OL.h[h], h))
         a.op("v_mov_b32_e32 %s, 0" % r.OCC.h[h])
     a.op("s_mov_b32 s%d, %%[lx]" % (LIGHT + 0))
     a.op("s_mov_b32 s%d, %%[ly]" % (LIGHT + 1))
     a.op("s_mov_b32 s%d, %%[lz]" % (LIGHT + 2))
-    a.op("s_mov_b32 s%d, 0x3f7fff80" % SHRINK, "1 - 2^-17")
     a.op("v_cmp_o_f32_e32 vcc, %s, %s" % (r.OX.h[0], r.OX.h[0]))
     a.op("v_cmp_o_f32_e64 %s, %s, %s" % (TINY, r.OX.h[1], r.OX.h[1]))
     a.op("s_or_b64 vcc, vcc, %s" % TINY)
@@ -510,7 +525,7 @@ def shadow_body():
 def main():
     text = HEADER
     text += PRIMARY % {"body": primary(), "clobbers": clobbers()}
-    text += SHADOW % {"body": shadow_body(), "clobbers": clobbers()}
+    text += SHADOW % {"body": shadow_body(), "clobbers": clobbers(SHADOW_VGPR_LAST)}
     text += "}  // namespace rt\n"
     with open(OUT, "w") as f:
         f.write(text)
