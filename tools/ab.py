@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of kernel tuning variants, interleaved in ONE process (cdna guide rule 24).  Checks every variant's frame
 and counters against the first variant.  usage: ab.py [rounds] [w h spp level]
-env: AB_TRAVERSAL=skip|flat  AB_KEY=skip_variant|block_order|narrow_max|packed_samples|host_copy (rt_debug.h)  AB_VARIANTS=1,3,7 (skip: 1 C++ loops, 3 generated assembly
+env: AB_TRAVERSAL=skip|flat  AB_KEY=skip_variant|block_order|narrow_max|packed_samples|host_copy|flat_kernels|skip_rays (rt_debug.h)  AB_VARIANTS=1,3,7 (skip: 1 C++ loops, 3 generated assembly
 loops, 7 their fused flavour)  AB_LAUNCHES=5"""
 import os
 import sys
