@@ -104,8 +104,8 @@ rt_status rt_device_count(int *n);
  *   bounds/ranges/n_bounds  optional (NULL/NULL/0): group bounds REAL[4*n_bounds] with their item ranges in DFS
  *               pre-order (outer group before the groups nested in it); required for RT_TRAVERSAL_SKIP.
  * REAL is float for RT_F32 and double for RT_F64.  All values must be finite, |coordinate| <= 1e15 (items, bounds, eye),
- * radius > 0, |light_unit component| <= 2: within these bounds no intermediate of the path overflows, so no NaN can arise
- * and every comparison agrees with the reference's whichever way it is written.
+ * radius > 0, light_unit of squared length within 2e-3 of 1 (RT_ERR_INVALID_ARGUMENT otherwise): within these bounds no
+ * intermediate of the path overflows, so no NaN can arise and every comparison agrees with the reference's whichever way it is written.
  * The caller keeps ownership of every host buffer; nothing is retained but the returned handle. */
 rt_status rt_scene_create(int device, rt_precision precision,
                           const void *dfs_items, uint32_t n_items,

@@ -1177,6 +1177,15 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
             return RT_ERR_INVALID_ARGUMENT;
         }
     }
+    {
+        // a unit vector as the host's `normalized` leaves it: the flat scan's shadow filter (rt_flat_sc.hpp) bounds its rounding
+        // errors with |light_unit| <= 1 + 1e-3
+        const double l2 = s->light[0] * s->light[0] + s->light[1] * s->light[1] + s->light[2] * s->light[2];
+        if (std::fabs(l2 - 1.0) > 2e-3) {
+            snprintf(g_err, sizeof g_err, "rt_scene_create: light_unit must be a unit vector (its squared length is %.6g)", l2);
+            return RT_ERR_INVALID_ARGUMENT;
+        }
+    }
     auto fail = [&](rt_status code) { rt_scene_destroy(s.release()); return code; };
     hipError_t e;
     if ((e = hipMalloc(&s->d_items, esz * 4 * n_items)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(items)", __LINE__));

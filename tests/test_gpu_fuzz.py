@@ -106,7 +106,8 @@ def test_two_rays_per_lane_walk_on_scaled_scenes(scale):
 def test_inputs_that_could_overflow_are_rejected():
     # the no-NaN argument rests on these bounds: coordinates and eye within 1e15, light a unit vector
     items = np.array([[0, 0, 0, 1.0]])
-    for kw in (dict(eye=(0, 0, -2e15)), dict(light=(0.0, -3.0, 0.0)), dict(items=np.array([[2e15, 0, 0, 1.0]]))):
+    for kw in (dict(eye=(0, 0, -2e15)), dict(light=(0.0, -3.0, 0.0)), dict(light=(0.0, -1.01, 0.0)), dict(light=(0.5, -0.5, 0.5)),
+               dict(items=np.array([[2e15, 0, 0, 1.0]]))):
         it = kw.pop("items", items)
         light = np.asarray(kw.pop("light", rta.normalized((-1, -3, 2), rta.RT_F32)), dtype=np.float64)
         s = rta.Scene(it, light, kw.pop("eye", (0, 0, -4)), np.array([[0, 0, 0, 3.0]]), np.array([[0, 1]], dtype=np.int32))
