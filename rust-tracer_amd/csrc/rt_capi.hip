@@ -447,11 +447,16 @@ bool packed_samples(unsigned spp)
     return (spp == 2 || spp == 4 || spp == 8) && knob(RT_DEBUG_PACKED_SAMPLES) != 0;
 }
 
-// Two rays per lane (rt_skip2.hpp) unless csrc/rt_debug.h RT_DEBUG_SKIP_RAYS says otherwise: for passes over at least 4 M pixels.
-// Measured: 3840x2160 spp 1 0.184 -> 0.173 ms, 4096x4096 spp 4 level 9 4.10 -> 3.84 ms; but a 1080p frame is as
-// long as its heaviest waves, and a wave of 128 rays walks the union of more paths: 54.8 -> 64.4 us (`make image`, 0.79 M
-// pixels: 0.289 -> 0.296 ms).
-bool skip2_by_default(uint64_t total_px) { return total_px >= (4ull << 20); }
+// Two rays per lane (rt_skip2.hpp) unless csrc/rt_debug.h RT_DEBUG_SKIP_RAYS says otherwise: for passes over at least 3.5 M pixels
+// at spp 1 or on scenes of 65,536 nodes and more.  Measured (one / two rays per lane): 2560x1440 spp 1 0.0926 / 0.0896 ms,
+// 3840x2160 spp 1 0.184 / 0.173, 4096x4096 spp 4 on 87,381 spheres 4.10 / 3.84 -- but 1920x1080 spp 1 54.8 / 64.4 us (a frame that is
+// as long as its heaviest waves, and a wave of 128 rays walks the union of more paths), and the sample-packed modes on the
+// 21,845-sphere scene lose 2-5 % at every size (2048x2048 spp 4: 1.048 / 1.076 ms): the halved scalar-cache traffic only pays
+// when the node stream is large.
+bool skip2_by_default(uint64_t total_px, unsigned spp, uint32_t n_nodes)
+{
+    return total_px >= 3500000ull && (spp == 1 || n_nodes >= 65536u);
+}
 
 constexpr size_t kMaxCachedTables = 32;
 
@@ -835,7 +840,7 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     bool two_rays = false;
     if constexpr (!COUNT && VAR == 7 && sizeof(T) == 4) {
         const long long k = knob(RT_DEBUG_SKIP_RAYS);
-        two_rays = k < 0 ? skip2_by_default(total_px) : k == 2;
+        two_rays = k < 0 ? skip2_by_default(total_px, spp, s->n_fnodes) : k == 2;
         two_rays = two_rays && (spp == 1 || (use_split(spp) && packed_samples(spp)));
     }
     const dim3 b2(rt::kSkip2Threads);

@@ -35,7 +35,7 @@ typedef enum rt_debug_key {
                                     runs) instead of the scalar-fed scan (rt_flat_sc.hpp) */
     RT_DEBUG_SKIP_RAYS = 12,     /* rays per lane of the f32 fused hierarchy walk: 1 = k_render_skip always; 2 = k_render_skip2 (two rays per lane on
                                     packed math, rt_skip2.hpp) wherever it exists (spp 1, 2, 4, 8; launches that do not count tests);
-                                    default: the library's choice per workload */
+                                    default: the library's choice per workload (large spp-1 frames, large scenes) */
     RT_DEBUG_KEYS = 13
 } rt_debug_key;
 

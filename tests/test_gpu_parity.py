@@ -922,7 +922,7 @@ def test_scalar_fed_flat_scan_on_tiny_discriminants():
 def test_two_rays_per_lane_walk_on_the_default_scene(w, h, spp, level):
     # k_render_skip2 against k_render_skip, byte for byte, on the reference's pyramid: cost-ordered and narrowed descriptors
     # (1080p), the sample-packed modes, a ragged frame, a pass dealt out over workgroups (2048 x 2048 spp 4: 262,144 descriptors)
-    # and the library's own choice -- frames of 4 M pixels and more take the two-ray kernel without being asked
+    # and the library's own choice -- spp-1 frames of 3.5 M pixels and more take the two-ray kernel without being asked
     s = rta.Scene.default(level)
     regs = bucket_list(w, h, spp)
     d = s.device()
