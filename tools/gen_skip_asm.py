@@ -181,8 +181,8 @@ class F32(Prec):
         a.op("s_and_b64 vcc, vcc, %s" % self.M56, "go")
 
     def item_update(self, a, c):
-        # by EXEC, not by v_cndmask: a v_cndmask_b32_e32 that reads VCC occupies the SIMD for 23 cycles (an e64 one with its mask
-        # in another SGPR pair for 4.2; tools/valu_issue_probe.hip), a v_mov for 2.2
+        # by EXEC, not by two v_cndmask_b32_e32 in a row: back to back they stall for 23 cycles each on VCC (an isolated one costs a
+        # VOP2's 2.2, an e64 one with its mask in another SGPR pair 4.2; tools/valu_issue_probe.hip)
         a.op("s_mov_b64 exec, vcc", "primitive.rs:80-83")
         a.op("v_mov_b32_e32 %[best], %[t4]")
         a.op("v_mov_b32_e32 %%[bitem], %s" % self.item(c))

@@ -34,7 +34,7 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 enum Kind { K_MUL, K_ADD, K_MUL_SGPR, K_FMA, K_PK_MUL, K_PK_ADD, K_PK_MUL_SGPR, K_CMP_E64, K_CNDMASK, K_SQRT, K_DEP_ADD, K_VALU_SALU,
-            K_STEP_MIX, K_PK_FMA, K_MUL_SGPR_ROT, K_ITEM_SGPR, K_ITEM_SGPR_R2, K_PK_MUL_SGPR_ROT, K_ITEM_PK, K_CND_E64, K_MOV, K_EXEC_MOV, K_CND_ZERO, K_COUNT };
+            K_STEP_MIX, K_PK_FMA, K_MUL_SGPR_ROT, K_ITEM_SGPR, K_ITEM_SGPR_R2, K_PK_MUL_SGPR_ROT, K_ITEM_PK, K_CND_E64, K_MOV, K_EXEC_MOV, K_CND_ZERO, K_CND_MIX, K_COUNT };
 
 static const char *kNames[K_COUNT] = {
     "v_mul_f32 (VGPR x VGPR, independent)", "v_add_f32 (independent)", "v_mul_f32 (SGPR x VGPR, independent)", "v_fma_f32 (independent)",
@@ -46,10 +46,11 @@ static const char *kNames[K_COUNT] = {
     "v_pk_mul_f32 (a DIFFERENT SGPR broadcast x VGPR pair each instruction, independent)",
     "flat-scan item for TWO rays per lane, packed: 8 dependent v_pk_*_f32, 5 distinct SGPR broadcast operands",
     "v_cndmask_b32_e64 (mask in an SGPR pair)", "v_mov_b32 (independent)", "select by EXEC: s_and_saveexec_b64 / v_mov_b32 / s_mov_b64 exec (per 3)",
-    "v_cndmask_b32_e64 (mask in an SGPR pair that is all zeros)" };
+    "v_cndmask_b32_e64 (mask in an SGPR pair that is all zeros)",
+    "one v_cndmask_b32_e32 (vcc) among three v_mul_f32 (per instruction)" };
 // vector instructions per 64-instruction block (the rest are scalar)
-static const int kValuPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 32, 30, 64, 64, 64, 64, 64, 64, 64, 64, 21, 64 };
-static const int kInstPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 66, 64, 64, 64, 64, 64, 64, 64, 64, 63, 64 };
+static const int kValuPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 32, 30, 64, 64, 64, 64, 64, 64, 64, 64, 21, 64, 64 };
+static const int kInstPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 66, 64, 64, 64, 64, 64, 64, 64, 64, 63, 64, 64 };
 
 #define R8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
 #define R64(M) R8(M) R8(M) R8(M) R8(M) R8(M) R8(M) R8(M) R8(M)
@@ -81,6 +82,8 @@ static const int kInstPerBlock[K_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 
 #define I_CND64(k) "v_cndmask_b32_e64 %" #k ", %8, %" #k ", s[20:21]\n"
 #define I_MOV(k) "v_mov_b32_e32 %" #k ", %8\n"
 #define I_XMOV(k) "s_and_saveexec_b64 s[22:23], s[20:21]\n" "v_mov_b32_e32 %" #k ", %8\n" "s_mov_b64 exec, s[22:23]\n"
+#define I_CNDMIX(k) "v_cndmask_b32_e32 %0, %8, %0, vcc\n" "v_mul_f32_e32 %1, %8, %1\n" "v_mul_f32_e32 %2, %8, %2\n" "v_mul_f32_e32 %3, %8, %3\n" \
+                    "v_cndmask_b32_e32 %4, %8, %4, vcc\n" "v_mul_f32_e32 %5, %8, %5\n" "v_mul_f32_e32 %6, %8, %6\n" "v_mul_f32_e32 %7, %8, %7\n"
 #define R21(M) R8(M) R8(M) M(0) M(1) M(2) M(3) M(4)
 // eight multiplies, each with its own SGPR operand (s20..s27 are never written: only which register is read matters)
 #define I_ROT(k) "v_mul_f32_e32 %0, s20, %0\n" "v_mul_f32_e32 %1, s21, %1\n" "v_mul_f32_e32 %2, s22, %2\n" "v_mul_f32_e32 %3, s23, %3\n" \
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(1024) void k_probe(int iters, Rec *rec, float *sink
     const float sone = __builtin_amdgcn_readfirstlane(one);
     unsigned long long sone2;
     { unsigned u = __float_as_uint(sone); sone2 = ((unsigned long long)u << 32) | u; }
-    if constexpr (KIND == K_CND_E64 || KIND == K_EXEC_MOV || KIND == K_CNDMASK) asm volatile("s_mov_b64 s[20:21], 0x5555\n s_mov_b64 vcc, 0x5555" ::: "s20", "s21", "vcc");
+    if constexpr (KIND == K_CND_E64 || KIND == K_EXEC_MOV || KIND == K_CNDMASK || KIND == K_CND_MIX) asm volatile("s_mov_b64 s[20:21], 0x5555\n s_mov_b64 vcc, 0x5555" ::: "s20", "s21", "vcc");
     if constexpr (KIND == K_CND_ZERO) asm volatile("s_mov_b64 s[20:21], 0" ::: "s20", "s21");
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
@@ -166,6 +169,8 @@ __global__ __launch_bounds__(1024) void k_probe(int iters, Rec *rec, float *sink
                          : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
         else if constexpr (KIND == K_CND_E64 || KIND == K_CND_ZERO)
             asm volatile(R64(I_CND64) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone));
+        else if constexpr (KIND == K_CND_MIX)
+            asm volatile(R8(I_CNDMIX) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone) : "vcc");
         else if constexpr (KIND == K_MOV)
             asm volatile(R64(I_MOV) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(one), "s"(sone));
         else if constexpr (KIND == K_EXEC_MOV)
@@ -272,6 +277,7 @@ int main(int argc, char **argv)
     run_kind<K_CND_ZERO>(n_cu, d_rec, d_sink, false);
     run_kind<K_MOV>(n_cu, d_rec, d_sink, false);
     run_kind<K_EXEC_MOV>(n_cu, d_rec, d_sink, false);
+    run_kind<K_CND_MIX>(n_cu, d_rec, d_sink, false);
     printf("\n ]}\n");
     CHECK(hipFree(d_rec)); CHECK(hipFree(d_sink));
     return 0;
