@@ -447,15 +447,17 @@ bool packed_samples(unsigned spp)
     return (spp == 2 || spp == 4 || spp == 8) && knob(RT_DEBUG_PACKED_SAMPLES) != 0;
 }
 
-// Two rays per lane (rt_skip2.hpp) unless csrc/rt_debug.h RT_DEBUG_SKIP_RAYS says otherwise: for passes over at least 3.5 M pixels
-// at spp 1 or on scenes of 65,536 nodes and more.  Measured (one / two rays per lane): 2560x1440 spp 1 0.0926 / 0.0896 ms,
-// 3840x2160 spp 1 0.184 / 0.173, 4096x4096 spp 4 on 87,381 spheres 4.10 / 3.84 -- but 1920x1080 spp 1 54.8 / 64.4 us (a frame that is
-// as long as its heaviest waves, and a wave of 128 rays walks the union of more paths), and the sample-packed modes on the
-// 21,845-sphere scene lose 2-5 % at every size (2048x2048 spp 4: 1.048 / 1.076 ms): the halved scalar-cache traffic only pays
-// when the node stream is large.
+// Two rays per lane (rt_skip2.hpp) unless csrc/rt_debug.h RT_DEBUG_SKIP_RAYS says otherwise.  Measured, one / two rays per lane
+// (DESIGN.md 4.1): on the 21,845-sphere scene spp 1 pays from 3.5 M pixels (2560x1440 0.0926 / 0.0896 ms, 3840x2160 0.184 / 0.173;
+// 1920x1080 54.8 / 64.4 us: a frame as long as its heaviest waves, and a wave of 128 rays walks the union of more paths) and the
+// sample-packed modes never do (2048x2048 spp 4: 1.048 / 1.076 ms); on the 87,381-sphere scene -- where the halved scalar-cache
+// traffic counts -- spp 4 pays from 2 M pixels (1920x1080 0.752 / 0.721, 4096x4096 4.10 / 3.84; 1024x768 0.333 / 0.341) and spp 1
+// from 6 M (2560x1440 0.104 / 0.115, 3840x2160 0.203 / 0.185).
 bool skip2_by_default(uint64_t total_px, unsigned spp, uint32_t n_nodes)
 {
-    return total_px >= 3500000ull && (spp == 1 || n_nodes >= 65536u);
+    const bool large_scene = n_nodes >= 65536u;
+    if (spp == 1) return total_px >= (large_scene ? 6000000ull : 3500000ull);
+    return large_scene && total_px >= 1500000ull;
 }
 
 constexpr size_t kMaxCachedTables = 32;
