@@ -193,6 +193,12 @@ def test_library_reads_no_environment_variable_and_keeps_diagnostics_out_of_the_
     assert capi.lib.rt_debug_set(999, 1) == capi.RT_ERR_INVALID_ARGUMENT
     for key in range(13):
         assert capi.lib.rt_debug_set(key, -1) == capi.RT_OK
+    # every function csrc/rt_debug.h declares is exported; the filter check refuses a null scene without touching a device
+    dbg = open(os.path.join(ROOT, "rust-tracer_amd", "csrc", "rt_debug.h")).read()
+    for name in re.findall(r"\b(rt_debug_\w+)\s*\(", dbg):
+        assert hasattr(capi.lib, name), name
+    import ctypes
+    assert capi.lib.rt_debug_flat_filter_check(None, 4, 4, 1, ctypes.byref((ctypes.c_ulonglong * 6)())) == capi.RT_ERR_INVALID_ARGUMENT
 
 
 def test_strict_64_and_writer_clock_on_the_host_mirror(tmp_path):
