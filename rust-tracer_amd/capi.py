@@ -139,7 +139,7 @@ lib.rt_debug_set.argtypes = [C.c_int, C.c_longlong]
 lib.rt_debug_wave_trace.argtypes = [C.c_char_p]
 lib.rt_debug_count.restype = C.c_longlong
 lib.rt_debug_count.argtypes = [C.c_int]
-DEBUG_COUNT_REGION_CALLS, DEBUG_COUNT_REGION_PASSES = 0, 1
+DEBUG_COUNT_REGION_CALLS, DEBUG_COUNT_REGION_PASSES, DEBUG_COUNT_FILTER_PASS, DEBUG_COUNT_FILTER_VIOLATIONS = 0, 1, 2, 3
 
 
 def debug_set(key, value=-1):

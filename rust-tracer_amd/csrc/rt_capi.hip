@@ -34,7 +34,7 @@ thread_local char g_err[512] = "";
 
 // Diagnostic controls (rt_debug.h): process-wide, -1 = default.  The library reads no environment variable.
 std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
-std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = { {0}, {0} };
+std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = { {0}, {0}, {0}, {0} };
 std::atomic<bool> g_trace_on{ false };
 std::mutex g_trace_mu;
 std::string g_trace_path;
@@ -107,6 +107,10 @@ struct rt_scene {
     void *d_items = nullptr;       // Item<REAL>[n_items], DFS order
     void *d_prim = nullptr, *d_shad = nullptr;   // Node<REAL>[n_nodes + kNodePad]: skip-pointer streams (RT_TRAVERSAL_SKIP)
     void *d_cprim = nullptr, *d_cshad = nullptr;   // fused scenes: the compacted streams of the fused assembly loops
+    // f32: FNode copies of the four streams for the filtered loops (rt_skip.hpp) and the compacted stream's own_item table
+    void *d_xprim = nullptr, *d_xshad = nullptr, *d_xcprim = nullptr, *d_xcshad = nullptr, *d_xown = nullptr;
+    rt::FilterConsts fc{};
+    void *d_fc = nullptr;          // device copy of fc
     uint32_t n_nodes = 0, n_fnodes = 0;
     bool fused = false;            // every BOUND is followed by an ITEM with the same centre (rt_skip.hpp, Node)
     void *d_fprim = nullptr, *d_fprim_rr = nullptr, *d_fshad = nullptr;   // pre-formed per-item terms (RT_TRAVERSAL_FLAT)
@@ -322,7 +326,73 @@ rt::SkipView<T> skip_view_of(const rt_scene *s)
     v.n_fnodes = s->n_fnodes;
     v.light = { (T)s->light[0], (T)s->light[1], (T)s->light[2] };
     v.eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
+    v.xprim = static_cast<const rt::FNode *>(s->d_xprim);
+    v.xshad = static_cast<const rt::FNodeS *>(s->d_xshad);
+    v.xfprim = static_cast<const rt::FNode *>(s->d_xcprim);
+    v.xfshad = static_cast<const rt::FNodeS *>(s->d_xcshad);
+    v.xown = static_cast<const uint32_t *>(s->d_xown);
+    v.fc = static_cast<const rt::FilterConsts *>(s->d_fc);
     return v;
+}
+
+// Constants of the filtered loops' shadow bounds (rt_skip.hpp FilterConsts, shadow_filter_bounds; derivation in DESIGN.md 4.1).
+// eps = 2^-24, eta = | |l|^2 - 1 | for the f32 shadow direction l, Rc = max |c - m0| over every node centre, Ro = the radius around
+// m0 the bounds cover ray origins in (a ray further out gets a NaN: no sure verdict, shadow_filter_origin), S = Rc + Ro (1 + 4 eps);
+// a0 = 11 eps S: a = cl - ol >= a0 proves b = dot(centre - origin, l) >= 0 as the reference rounds it.
+template <typename T>
+void filter_constants(rt_scene *s, const std::vector<rt::RawNode<T>> &raw, const T *items)
+{
+    double m0[3] = { 0, 0, 0 };
+    for (uint32_t i = 0; i < s->n_items; ++i)
+        for (int k = 0; k < 3; ++k) m0[k] += (double)items[4 * i + k];
+    rt::FilterConsts &fc = s->fc;
+    for (int k = 0; k < 3; ++k) { fc.m0[k] = (float)(m0[k] / (double)s->n_items); m0[k] = (double)fc.m0[k]; }
+    auto dist = [&](double x, double y, double z) { return std::sqrt((x - m0[0]) * (x - m0[0]) + (y - m0[1]) * (y - m0[1]) + (z - m0[2]) * (z - m0[2])); };
+    double rc = 0, rit = 0;
+    for (const rt::RawNode<T> &r : raw) rc = std::max(rc, dist((double)r.cx, (double)r.cy, (double)r.cz));
+    for (uint32_t i = 0; i < s->n_items; ++i)
+        rit = std::max(rit, dist((double)items[4 * i], (double)items[4 * i + 1], (double)items[4 * i + 2]) + (double)items[4 * i + 3]);
+    const double eye_d = dist(s->eye[0], s->eye[1], s->eye[2]);
+    const double eye_abs = std::fabs(s->eye[0]) + std::fabs(s->eye[1]) + std::fabs(s->eye[2]), m0_abs = std::fabs(m0[0]) + std::fabs(m0[1]) + std::fabs(m0[2]);
+    // shadow origins lie on an item's surface, pushed out by hit.distance * sqrt(eps) (render.rs:199): 1 % and a bit of room
+    const double ro = 1.01 * rit + 1e-3 * (eye_d + rit) + 1e-5 * (eye_abs + m0_abs);
+    const double eps = 0x1p-24;
+    // plane perpendicular to the shadow direction l = -light (f32 components)
+    const double l[3] = { -(double)(float)s->light[0], -(double)(float)s->light[1], -(double)(float)s->light[2] };
+    const double l2 = l[0] * l[0] + l[1] * l[1] + l[2] * l[2], ln = std::sqrt(l2);
+    const double lh[3] = { l[0] / ln, l[1] / ln, l[2] / ln };
+    int ax = 0;
+    for (int k = 1; k < 3; ++k) if (std::fabs(lh[k]) < std::fabs(lh[ax])) ax = k;
+    double a[3] = { 0, 0, 0 }; a[ax] = 1.0;
+    double e1[3] = { lh[1] * a[2] - lh[2] * a[1], lh[2] * a[0] - lh[0] * a[2], lh[0] * a[1] - lh[1] * a[0] };
+    const double n1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    for (int k = 0; k < 3; ++k) e1[k] /= n1;
+    const double e2[3] = { lh[1] * e1[2] - lh[2] * e1[1], lh[2] * e1[0] - lh[0] * e1[2], lh[0] * e1[1] - lh[1] * e1[0] };
+    for (int k = 0; k < 3; ++k) { fc.e1[k] = (float)e1[k]; fc.e2[k] = (float)e2[k]; }
+    for (int k = 0; k < 3; ++k) fc.l[k] = (float)l[k];
+    fc.eta = std::fabs(l2 - 1.0);
+    fc.S = (rc + ro * (1.0 + 4.0 * eps)) * (1.0 + 1e-9);
+    auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return std::nextafterf(f, INFINITY); };
+    fc.a0 = up(11.0 * eps * fc.S + 1e-37);
+    float ro2 = (float)(ro * ro);
+    if ((double)ro2 > ro * ro) ro2 = std::nextafterf(ro2, 0.0f);
+    fc.ro2 = ro2;
+}
+
+// FNode copies (rt_skip.hpp) of one pair of f32 Node streams, END nodes included.
+rt_status derive_fstreams(const rt_scene *s, const void *d_prim, const void *d_shad, size_t n_nodes, bool compacted, void **d_xprim, void **d_xshad,
+                          void **d_own)
+{
+    const size_t total = n_nodes + rt::kNodePad;
+    HIP_TRY(hipMalloc(d_xprim, sizeof(rt::FNode) * total));
+    HIP_TRY(hipMalloc(d_xshad, sizeof(rt::FNodeS) * total));
+    if (d_own) HIP_TRY(hipMalloc(d_own, sizeof(uint32_t) * total));
+    hipLaunchKernelGGL(rt::k_build_fstreams, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, static_cast<const rt::Node<float> *>(d_prim),
+                       static_cast<const rt::Node<float> *>(d_shad), (unsigned)total, compacted, s->fc, static_cast<rt::FNode *>(*d_xprim),
+                       static_cast<rt::FNodeS *>(*d_xshad), d_own ? static_cast<uint32_t *>(*d_own) : nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return RT_OK;
 }
 
 // Merges items and group bounds into the DFS pre-order node stream of rt_skip.hpp.  ranges must form a laminar
@@ -435,6 +505,13 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
         }
         s->n_fnodes = (uint32_t)compact.size();
         if ((st = derive_streams<T>(s, compact, true, &s->d_cprim, &s->d_cshad)) != RT_OK) return st;
+    }
+    if constexpr (sizeof(T) == 4) {
+        filter_constants<T>(s, raw, static_cast<const T *>(items));
+        HIP_TRY(hipMalloc(&s->d_fc, sizeof(rt::FilterConsts)));
+        HIP_TRY(hipMemcpy(s->d_fc, &s->fc, sizeof(rt::FilterConsts), hipMemcpyHostToDevice));
+        if ((st = derive_fstreams(s, s->d_prim, s->d_shad, s->n_nodes, false, &s->d_xprim, &s->d_xshad, nullptr)) != RT_OK) return st;
+        if (fused && (st = derive_fstreams(s, s->d_cprim, s->d_cshad, s->n_fnodes, true, &s->d_xcprim, &s->d_xcshad, &s->d_xown)) != RT_OK) return st;
     }
     return RT_OK;
 }
@@ -720,10 +797,11 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
 // is dropped for scenes that are not fused.
 int skip_variant(const rt_scene *s)
 {
-    int v = 1 | 2 | 4;
-    if (const long long o = knob(RT_DEBUG_SKIP_VARIANT); o >= 0) v = (int)o & 7;
+    int v = 1 | 2 | 4 | 16;
+    if (const long long o = knob(RT_DEBUG_SKIP_VARIANT); o >= 0) v = (int)o & 23;
     if (v & 2) v |= 1;                                  // the assembly loops imply the lean sqrt in what C++ remains
     if (!s->fused || !(v & 2)) v &= ~4;
+    if (s->precision != RT_F32 || !s->d_xprim || !(v & 2)) v &= ~16;      // the filtered loops exist in f32
     if ((v & 3) == 3 && g_trace_on.load(std::memory_order_relaxed)) v |= 8;      // diagnostic build of the assembly variants
     return v;
 }
@@ -840,14 +918,14 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     rt::SampleBuf<T> sb{ nullptr, nullptr, (unsigned)total_px };
     // two rays per lane (rt_skip2.hpp): f32, fused assembly loops, launches that neither count nor trace
     bool two_rays = false;
-    if constexpr (!COUNT && VAR == 7 && sizeof(T) == 4) {
+    if constexpr (!COUNT && (VAR & 15) == 7 && sizeof(T) == 4) {
         const long long k = knob(RT_DEBUG_SKIP_RAYS);
         two_rays = k < 0 ? skip2_by_default(total_px, spp, s->n_fnodes) : k == 2;
         two_rays = two_rays && (spp == 1 || (use_split(spp) && packed_samples(spp)));
     }
     const dim3 b2(rt::kSkip2Threads);
     if (!use_split(spp)) {
-        if constexpr (!COUNT && VAR == 7 && sizeof(T) == 4) {
+        if constexpr (!COUNT && (VAR & 15) == 7 && sizeof(T) == 4) {
             if (two_rays) {
                 hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipOne>), rgrid, b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt, d_out, sb, frame_w,
                                    order.d, order.wg_first);
@@ -871,7 +949,7 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     sb.state = c->d_sample_state;
     const bool packed = packed_samples(spp);
     bool done2 = false;
-    if constexpr (!COUNT && VAR == 7 && sizeof(T) == 4) {
+    if constexpr (!COUNT && (VAR & 15) == 7 && sizeof(T) == 4) {
         if (two_rays) {
             hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipPacked>), dim3(rgrid.x, (unsigned)ns), b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt,
                                d_out, sb, frame_w, order.d, order.wg_first);
@@ -905,10 +983,15 @@ rt_status launch_skip_var(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
         case 0: return launch_skip_one<T, false, 0>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
         case 3: return launch_skip_one<T, false, 3>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
         case 7: return launch_skip_one<T, false, 7>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+        case 19: if constexpr (sizeof(T) == 4) return launch_skip_one<T, false, 19>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order); else break;
+        case 23: if constexpr (sizeof(T) == 4) return launch_skip_one<T, false, 23>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order); else break;
+        case 27: if constexpr (sizeof(T) == 4) return launch_skip_one<T, false, 27>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order); else break;
+        case 31: if constexpr (sizeof(T) == 4) return launch_skip_one<T, false, 31>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order); else break;
         case 11: return launch_skip_one<T, false, 11>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
         case 15: return launch_skip_one<T, false, 15>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
-        default: return launch_skip_one<T, false, 1>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+        default: break;
         }
+        return launch_skip_one<T, false, 1>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     }
 }
 
@@ -1000,7 +1083,10 @@ rt_status read_stats(rt_scene *s, Context *c, hipStream_t stream, rt_traversal t
         h.max_wave_cycles = std::max(h.max_wave_cycles, k.max_wave_cycles);
         h.max_wave_ref100mhz = std::max(h.max_wave_ref100mhz, k.max_wave_ref100mhz);
         h.wave_item_steps += k.wave_item_steps;
+        h.filter_pass += k.filter_pass; h.filter_violations += k.filter_violations;
     }
+    g_count[RT_DEBUG_COUNT_FILTER_PASS].fetch_add((long long)h.filter_pass, std::memory_order_relaxed);
+    g_count[RT_DEBUG_COUNT_FILTER_VIOLATIONS].fetch_add((long long)h.filter_violations, std::memory_order_relaxed);
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     st->primary = h.primary; st->hits = h.hits; st->shadow = h.shadow; st->occluded = h.occluded;
@@ -1221,6 +1307,7 @@ rt_status rt_scene_destroy(rt_scene *s)
     if (s->d_shad) (void)hipFree(s->d_shad);
     if (s->d_cprim) (void)hipFree(s->d_cprim);
     if (s->d_cshad) (void)hipFree(s->d_cshad);
+    for (void *p : { s->d_xprim, s->d_xshad, s->d_xcprim, s->d_xcshad, s->d_xown, s->d_fc }) if (p) (void)hipFree(p);
     if (s->d_fprim) (void)hipFree(s->d_fprim);
     if (s->d_fprim_rr) (void)hipFree(s->d_fprim_rr);
     if (s->d_fshad) (void)hipFree(s->d_fshad);

@@ -16,7 +16,8 @@ extern "C" {
 
 typedef enum rt_debug_key {
     RT_DEBUG_SKIP_VARIANT = 0,   /* k_render_skip VAR bits (rt_skip.hpp): 0/1 C++ loops, 3 generated assembly loops, 7 their fused
-                                    flavour (dropped for scenes that are not concentric).  Default 7 */
+                                    flavour (dropped for scenes that are not concentric), + 16 the filtered loops (f32: a conservative
+                                    bound in front of every test).  Default 23 */
     RT_DEBUG_BLOCK_ORDER = 1,    /* 0: dispatch a pass's blocks in raster order instead of most-expensive-first.  Default 1 */
     RT_DEBUG_NARROW_MAX = 2,     /* cap on the number of blocks dealt out as narrow workgroups (read when a tile list is first seen) */
     RT_DEBUG_PACKED_SAMPLES = 3, /* 0: spp 2/4/8 use the plain sample-parallel mapping.  Default 1 */
@@ -46,7 +47,9 @@ rt_status rt_debug_set(int key, long long value);
 typedef enum rt_debug_counter {
     RT_DEBUG_COUNT_REGION_CALLS = 0,    /* rt_render_region calls that went through the merging path */
     RT_DEBUG_COUNT_REGION_PASSES = 1,   /* device passes they were rendered in */
-    RT_DEBUG_COUNTERS = 2
+    RT_DEBUG_COUNT_FILTER_PASS = 2,     /* f32 hierarchy walk, calls that return rt_stats: per-ray tests the filtered loops' bound lets through */
+    RT_DEBUG_COUNT_FILTER_VIOLATIONS = 3,   /* ... and tests with a finite distance that the bound would have ruled out: must stay 0 */
+    RT_DEBUG_COUNTERS = 4
 } rt_debug_counter;
 long long rt_debug_count(int counter);
 

@@ -64,6 +64,9 @@ struct Counters {          // same meaning as the reference-side ray statistics
     unsigned long long wave_steps, max_wave_steps;  // SKIP: node visits summed over waves / of the busiest wave (diagnostic)
     unsigned long long max_wave_cycles, max_wave_ref100mhz;   // diagnostic: s_memtime / s_memrealtime span of the longest wave
     unsigned long long wave_item_steps;                       // diagnostic: node visits that were ITEM nodes
+    // SKIP, f32, counting launches: per-ray tests the filtered loops' bound lets through / tests with a finite distance that
+    // the bound would have ruled out (must be 0: rt_debug_count(RT_DEBUG_COUNT_FILTER_VIOLATIONS))
+    unsigned long long filter_pass, filter_violations;
 };
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned v)

@@ -51,6 +51,68 @@ template <typename T> struct RawNode {
     uint32_t own_item, pad;
 };
 
+// FILTERED streams (f32; the *_filt loops of rt_skip_rot.hpp).  Same nodes, same order, same skip offsets as the
+// Node streams they are derived from, plus the terms of a conservative bound that is asked before the reference's test:
+//   primary  {vx, vy, vz, vv, rr, T, skip_off, tag}     the test can only return a finite distance if fma(vz,dz, fma(vy,dy, vx*dx)) >= T
+//   shadow   {w1, w2, cl, R2o, R2i, R2o_own, R2i_own, skip_off}   (FNodeS) TWO-sided: with P2 = (w1 - q1)^2 + (w2 - q2)^2 the squared distance of
+//            the centre from the ray in a plane perpendicular to the light ((w1, w2) / (q1, q2): centre / origin in that plane, relative to
+//            m0) and a = cl - ol the centre's coordinate along the ray: the reference's test says MISS if P2 > R2o and HIT if P2 <= R2i and
+//            (a >= a0 or P2 + a^2 <= R2i); only a lane in between runs the reference's arithmetic (terms from the Node stream).  R2*_own: the
+//            same for the group's own sphere (compacted stream).  Sign bit of R2o: ITEM (or END); sign bit of R2o_own: END.
+// primary tag: 0 for a BOUND (compacted stream: rr of the group's own sphere, a non-negative float), item | kNodeItem for an ITEM,
+// kNodeItem | kNodeEnd for END.  The own sphere's item index of a compacted BOUND lives in the stream's own_item table.
+struct alignas(32) FNode {
+    float a0, a1, a2, a3, a4, f5;
+    uint32_t skip_off, tag;
+};
+static_assert(sizeof(FNode) == 32, "one aligned s_load_dwordx8");
+struct alignas(32) FNodeS {
+    float w1, w2, cl, r2o, r2i, r2o_own, r2i_own;
+    uint32_t skip_off;
+};
+static_assert(sizeof(FNodeS) == 32, "one aligned s_load_dwordx8");
+
+// Constants of the shadow filter (derivation: DESIGN.md 4.1; computed by rt_capi.hip, filter_constants).
+struct FilterConsts {
+    float m0[3];            // reference point inside the scene (centroid of the item centres)
+    float e1[3], e2[3];     // f32 roundings of an orthonormal basis of the plane perpendicular to the light
+    float l[3];             // the shadow rays' direction (-light, the f32 values the reference uses)
+    float a0;               // a >= a0 proves b >= 0
+    float ro2;              // a ray whose origin is further than sqrt(ro2) from m0 is not covered: it fails every sure test (NaN)
+    double S, eta;          // Rc + Ro: bound of |c - m0| + |o - m0|;  | |l|^2 - 1 |
+};
+
+// Outer / inner bound of P2 for a sphere with squared radius rr (as the reference rounds it): DESIGN.md 4.1.
+__device__ __forceinline__ float next_f32_above(float f)      // finite f
+{
+    const uint32_t u = __float_as_uint(f);
+    if ((u << 1) == 0u) return __uint_as_float(0x00000001u);
+    return __uint_as_float((u >> 31) ? u - 1u : u + 1u);
+}
+__device__ __forceinline__ float next_f32_below(float f);
+__device__ __forceinline__ void shadow_filter_bounds(const FilterConsts &fc, float rr_f, float &r2o, float &r2i)
+{
+    const double eps = 0x1p-24, rr = rr_f, S2 = fc.S * fc.S, a9 = 9.7 * eps * fc.S;
+    if (!(rr < 1e300)) { r2o = r2i = __builtin_huge_valf(); return; }       // END: rr = +inf
+    const double so = __builtin_sqrt(rr * (1.0 + 1.01 * eps) + (fc.eta + 12.0 * eps) * S2) + a9;
+    const double o = so * so * (1.0 + 2.01 * eps) + 1e-36;
+    float of = (float)o;
+    if ((double)of < o) of = next_f32_above(of);
+    r2o = next_f32_above(of);
+    const double ain = rr * (1.0 - eps) - (2.0 * fc.eta + 32.0 * eps) * S2;
+    r2i = -1.0f;
+    if (ain > 0.0 && __builtin_sqrt(ain) > a9) {
+        const double si = (__builtin_sqrt(ain) - a9) / (1.0 + 1.01 * eps);
+        const double i = si * si * (1.0 - 40.0 * eps) - 1e-36;
+        if (i > 0.0) {
+            float inf_ = (float)i;
+            if ((double)inf_ > i) inf_ = next_f32_below(inf_);
+            inf_ = next_f32_below(inf_);
+            r2i = inf_ > 0.0f ? inf_ : -1.0f;
+        }
+    }
+}
+
 template <typename T> struct SkipView {
     const Node<T> *prim;    // primary-ray stream
     const Node<T> *shad;    // shadow-ray stream
@@ -59,7 +121,62 @@ template <typename T> struct SkipView {
     const Item<T> *items;   // DFS items (centre of the winning item for the normal)
     uint32_t n_nodes, n_fnodes;
     V3<T> light, eye;
+    // f32 only (else NULL): filtered copies of the four streams and the compacted stream's own_item table
+    const FNode *xprim, *xfprim;
+    const FNodeS *xshad, *xfshad;
+    const uint32_t *xown;
+    const FilterConsts *fc;  // device copy (read where a shadow walk starts: kernel arguments that stay live cost SGPRs, and occupancy)
 };
+
+// The primary filter's threshold for a node with the stored terms vv = dot(v, v), rr (both as the reference rounds them): any ray
+// direction d (a normalised f32 vector, | |d|^2 - 1 | <= 16 eps) for which Sphere::distance_from_ray returns a finite distance has
+// fma(vz, dz, fma(vy, dy, vx*dx)) >= T.  -inf (every ray passes) when the eye is not clearly outside the sphere or the squares are
+// near the subnormal range.  DESIGN.md 4.1 carries the derivation.
+__device__ __forceinline__ float next_f32_below(float f)      // finite f
+{
+    const uint32_t u = __float_as_uint(f);
+    if ((u << 1) == 0u) return __uint_as_float(0x80000001u);
+    return __uint_as_float((u >> 31) ? u + 1u : u - 1u);
+}
+__device__ __forceinline__ float primary_filter_threshold(float vv_f, float rr_f)
+{
+    const double eps = 0x1p-24, vv = vv_f, rr = rr_f;
+    if (!(vv >= 1e-30) || !(vv - rr >= 64.0 * eps * (vv + rr))) return -__builtin_huge_valf();
+    const double m0 = vv - rr * (1.0 + 2.0 * eps) - 1e-44;
+    const double t = __builtin_sqrt(m0 * (1.0 - 2.0 * eps)) - 8.0 * eps * __builtin_sqrt(vv);
+    float tf = (float)t;
+    if ((double)tf > t) tf = next_f32_below(tf);
+    return next_f32_below(tf);
+}
+
+// Filtered copies of a pair of Node<float> streams (plain or compacted; END nodes included).
+__global__ void k_build_fstreams(const Node<float> *__restrict__ prim, const Node<float> *__restrict__ shad, unsigned n_total, bool compacted,
+                                 FilterConsts fc, FNode *__restrict__ xprim, FNodeS *__restrict__ xshad, uint32_t *__restrict__ own_item)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    const Node<float> p = prim[i], s = shad[i];
+    const bool end = (p.item & kNodeEnd) != 0u, item = (p.item & kNodeItem) != 0u;
+    const uint32_t tag = end ? (kNodeItem | kNodeEnd) : item ? (kNodeItem | (p.item & kNodeIndexMask)) : compacted ? __float_as_uint(p.own_rr) : 0u;
+    FNode fp;
+    FNodeS fs;
+    fp.a0 = p.a0; fp.a1 = p.a1; fp.a2 = p.a2; fp.a3 = p.a3; fp.a4 = p.a4;
+    fp.f5 = end ? -__builtin_huge_valf() : primary_filter_threshold(p.a3, p.a4);
+    fp.skip_off = p.skip_off; fp.tag = tag;
+    const double cx = (double)s.a0 - (double)fc.m0[0], cy = (double)s.a1 - (double)fc.m0[1], cz = (double)s.a2 - (double)fc.m0[2];
+    fs.w1 = end ? 0.0f : (float)((cx * (double)fc.e1[0] + cy * (double)fc.e1[1]) + cz * (double)fc.e1[2]);
+    fs.w2 = end ? 0.0f : (float)((cx * (double)fc.e2[0] + cy * (double)fc.e2[1]) + cz * (double)fc.e2[2]);
+    fs.cl = end ? 3e38f : (float)((cx * (double)fc.l[0] + cy * (double)fc.l[1]) + cz * (double)fc.l[2]);
+    shadow_filter_bounds(fc, s.a3, fs.r2o, fs.r2i);                         // END: rr = +inf -> both +inf
+    if (end || item) fs.r2o = -fs.r2o;                                      // sign bit: ITEM or END
+    fs.r2o_own = 0.0f; fs.r2i_own = -1.0f;
+    if (compacted && !end && !item) shadow_filter_bounds(fc, s.own_rr, fs.r2o_own, fs.r2i_own);
+    if (end) fs.r2o_own = -0.0f;                                            // sign bit: END
+    fs.skip_off = s.skip_off;
+    xprim[i] = fp;
+    xshad[i] = fs;
+    if (own_item) own_item[i] = (compacted && !end && !item) ? p.item : 0u;
+}
 
 // Derives both streams from the raw one: exact IEEE ops, no contraction (same products the CPU path forms).  Threads
 // n .. n + kNodePad - 1 write the END nodes.
@@ -120,11 +237,40 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 
 constexpr unsigned kNever = 0xFFFFFFFFu;
 
+// A shadow ray's origin in the filter's plane: q = ((o - m0) . e1, (o - m0) . e2).  An origin the constants do not cover (further
+// than sqrt(ro2) from m0; none is on a scene the library built the constants for, but the bound must not depend on that) gets a NaN,
+// and a NaN passes every bound (v_cmp_ngt): such a ray simply runs the reference's test at every node.
+__device__ __forceinline__ void shadow_filter_origin(const FilterConsts &fc, float ox, float oy, float oz, float &q1, float &q2, float &ol)
+{
+    const float x = ox - fc.m0[0], y = oy - fc.m0[1], z = oz - fc.m0[2];
+    q1 = __builtin_fmaf(z, fc.e1[2], __builtin_fmaf(y, fc.e1[1], x * fc.e1[0]));
+    q2 = __builtin_fmaf(z, fc.e2[2], __builtin_fmaf(y, fc.e2[1], x * fc.e2[0]));
+    ol = __builtin_fmaf(z, fc.l[2], __builtin_fmaf(y, fc.l[1], x * fc.l[0]));
+    const float d2 = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+    if (!(d2 <= fc.ro2)) q1 = __builtin_nanf("");
+}
+// The two bounds as the *_filt loops evaluate them (the counting launches check them against the reference's test).
+__device__ __forceinline__ bool primary_filter_pass(const FNode &f, float dx, float dy, float dz)
+{
+    return f.f5 <= __builtin_fmaf(f.a2, dz, __builtin_fmaf(f.a1, dy, f.a0 * dx));
+}
+// 0: the bounds say MISS, 1: they cannot tell, 2: they say HIT
+__device__ __forceinline__ int shadow_filter_verdict(const FNodeS &f, const FilterConsts &fc, float q1, float q2, float ol)
+{
+    const float t0 = f.w1 - q1, t1 = f.w2 - q2;
+    const float p2 = __builtin_fmaf(t1, t1, t0 * t0);
+    if (p2 > __builtin_fabsf(f.r2o)) return 0;
+    const float av = f.cl - ol, inn = __builtin_fmaf(av, av, p2);
+    return (p2 <= f.r2i && (fc.a0 <= av || inn <= f.r2i)) ? 2 : 1;
+}
+
 // VAR bits (all bit-identical in output and counters):
 //   1 = sqrt_rn_lean in the C++ loops (same value as the IEEE sqrt for every input, about half the instructions)
 //   2 = (launches that do not count tests) the generated assembly traversal loops, rt_skip_rot.hpp
 //   4 = (with 2; fused scenes only) their fused flavour
 //   8 = wave trace (diagnostic, RT_WAVE_TRACE): every wave records when and where it ran into `lane_cost`
+//  16 = (with 2; f32) the FILTERED assembly loops over the FNode streams: a conservative bound in front of every test
+//       (launches that count tests: the C++ loops additionally evaluate the bounds and count any test they would have wrongly ruled out)
 //
 // SPLIT = false: one thread renders its pixel completely (all spp*spp samples in the reference's order) -- used for
 //   spp == 1, where it is a single pass.
@@ -225,6 +371,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     V3<T> g = { T(0.0), T(0.0), T(0.0) };
     T alpha = T(0.0);
     unsigned c_hits = 0, c_shadow = 0, c_occ = 0, c_items = 0, c_bounds = 0, c_steps = 0, c_isteps = 0;
+    [[maybe_unused]] unsigned c_fpass = 0, c_fviol = 0;
 
     const unsigned ss_first = SPLIT ? sample / spp : 0u, ss_last = SPLIT ? ss_first + 1 : spp;
     for (unsigned ssx = ss_first; ssx < ss_last; ++ssx) {
@@ -244,7 +391,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             constexpr unsigned kStride = (unsigned)sizeof(Node<T>);
             const unsigned nb = ((VAR & 4) ? sc.n_fnodes : sc.n_nodes) * kStride;
             if constexpr ((VAR & 2) && !COUNT) {
-                if constexpr ((VAR & 4) != 0) skip_primary_rot_fused(sc.fprim, nb, dir.x, dir.y, dir.z, inside ? 0u : nb, best, best_item);
+                if constexpr ((VAR & 16) != 0 && sizeof(T) == 4) {
+                    if constexpr ((VAR & 4) != 0) {
+                        skip_primary_rot_filt_fused(sc.xfprim, nb, dir.x, dir.y, dir.z, inside ? 0u : nb, best, best_item);
+                        // a group's own sphere won: the walk recorded the offset behind its BOUND node
+                        if (best_item != 0u && !(best_item & kNodeItem)) best_item = sc.xown[best_item / kStride - 1u];
+                    } else skip_primary_rot_filt(sc.xprim, nb, dir.x, dir.y, dir.z, inside ? 0u : nb, best, best_item);
+                } else if constexpr ((VAR & 4) != 0) skip_primary_rot_fused(sc.fprim, nb, dir.x, dir.y, dir.z, inside ? 0u : nb, best, best_item);
                 else skip_primary_rot(sc.prim, nb, dir.x, dir.y, dir.z, inside ? 0u : nb, best, best_item);
                 best_item &= kNodeIndexMask;
             } else {
@@ -264,6 +417,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                         if (!(t2 < T(0.0))) {
                             const T t1 = b - s;
                             d = t1 > T(0.0) ? t1 : t2;
+                        }
+                    }
+                    if constexpr (COUNT && sizeof(T) == 4) {
+                        if (sc.xprim && active) {
+                            const bool pass = primary_filter_pass(sc.xprim[i], dir.x, dir.y, dir.z);
+                            c_fpass += pass ? 1u : 0u;
+                            c_fviol += (!pass && d < inf<T>()) ? 1u : 0u;
                         }
                     }
                     if (nd.is_bound()) {                                // BOUND  group.rs:73
@@ -319,9 +479,19 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             if constexpr ((VAR & 2) && !COUNT) {
                 if (__ballot(need_shadow) != 0) {
                     resume = need_shadow ? 0u : nb;                 // lanes without a shadow ray sleep until END
+                    [[maybe_unused]] float q1 = 0.0f, q2 = 0.0f, fol = 0.0f, fa0 = 0.0f;
+                    if constexpr ((VAR & 16) != 0 && sizeof(T) == 4) {
+                        const FilterConsts fc = *sc.fc;
+                        shadow_filter_origin(fc, sp.x, sp.y, sp.z, q1, q2, fol);
+                        fa0 = fc.a0;
+                    }
                     while (i < nb) {
                         unsigned fin;
-                        if constexpr ((VAR & 4) != 0) i = skip_shadow_rot_fused(sc.fshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
+                        if constexpr ((VAR & 16) != 0 && sizeof(T) == 4) {
+                            if constexpr ((VAR & 4) != 0)
+                                i = skip_shadow_rot_filt_fused(sc.xfshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, q1, q2, fol, fa0, sc.fshad);
+                            else i = skip_shadow_rot_filt(sc.xshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, q1, q2, fol, fa0, sc.shad);
+                        } else if constexpr ((VAR & 4) != 0) i = skip_shadow_rot_fused(sc.fshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
                         else i = skip_shadow_rot(sc.shad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
                         if (i >= nb) break;
                         if (fin) { occluded = true; resume = nb; }
@@ -331,6 +501,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                     }
                 }
             } else if (__ballot(need_shadow) != 0) {
+                [[maybe_unused]] float fq1 = 0.0f, fq2 = 0.0f, fql = 0.0f;
+                [[maybe_unused]] FilterConsts cfc{};
+                if constexpr (COUNT && sizeof(T) == 4) { if (sc.xshad) { cfc = *sc.fc; shadow_filter_origin(cfc, sp.x, sp.y, sp.z, fq1, fq2, fql); } }
                 Node<T> nd = sc.shad[0];
                 for (;;) {
                     const bool active = i >= resume;
@@ -341,6 +514,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
                     {
                         const bool pos = !(disc < T(0.0));
                         if (pos) hit = !((b + ((VAR & 1) ? sqrt_rn_lean(disc) : rsqrt_exact(disc))) < T(0.0));
+                    }
+                    if constexpr (COUNT && sizeof(T) == 4) {
+                        if (sc.xshad && active) {
+                            const int verdict = shadow_filter_verdict(sc.xshad[i], cfc, fq1, fq2, fql);
+                            c_fpass += verdict == 1 ? 1u : 0u;              // tests the bounds leave to the reference's arithmetic
+                            c_fviol += ((verdict == 0 && hit) || (verdict == 2 && !hit)) ? 1u : 0u;
+                        }
                     }
                     unsigned ni;
                     if (nd.is_bound()) {
@@ -413,6 +593,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
         const unsigned long long prim = wave_sum(inside ? (SPLIT ? 1u : spp * spp) : 0u);
         const unsigned long long hits = wave_sum(c_hits), sh = wave_sum(c_shadow), oc = wave_sum(c_occ);
         const unsigned long long its = wave_sum(c_items), bds = wave_sum(c_bounds);
+        const unsigned long long fpass = wave_sum(c_fpass), fviol = wave_sum(c_fviol);
         if (lane == 0) {
             atomicAdd(&stripe->primary, prim);
             atomicAdd(&stripe->hits, hits);
@@ -422,6 +603,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             atomicAdd(&stripe->bound_tests, bds);
             atomicAdd(&stripe->wave_steps, (unsigned long long)c_steps);
             atomicAdd(&stripe->wave_item_steps, (unsigned long long)c_isteps);
+            if (fpass) atomicAdd(&stripe->filter_pass, fpass);
+            if (fviol) atomicAdd(&stripe->filter_violations, fviol);
             atomicMax(&stripe->max_wave_steps, (unsigned long long)c_steps);
             atomicMax(&stripe->max_wave_cycles, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start));
             atomicMax(&stripe->max_wave_ref100mhz, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r_start));

@@ -56,3 +56,6 @@ def _check_both_launch_flavours(request, monkeypatch):
 
     monkeypatch.setattr(rta.DeviceScene, "render_tiles", both)
     yield
+    # every counting launch of the f32 hierarchy walk also evaluated the filtered loops' bounds for each test it made
+    # (rt_skip.hpp): none that returned a finite distance may have been ruled out
+    assert rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_FILTER_VIOLATIONS) == 0, "the filtered loops' bound ruled out a hit"

@@ -36,7 +36,7 @@ def test_random_scene(seed):
     assert util.ray_stats(fst) == util.ray_stats(frst)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 7])
+@pytest.mark.parametrize("variant", [0, 1, 3, 7, 19, 23])
 @pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64], ids=["f32", "f64"])
 @pytest.mark.parametrize("scale", [1e-20, 1e-10, 1e6, 1e12, 5e13])
 def test_scaled_scenes_every_loop_flavour(scale, precision, variant):

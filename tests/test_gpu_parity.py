@@ -549,7 +549,7 @@ def test_more_distinct_tile_lists_than_the_table_cache_holds(trav):
         np.testing.assert_array_equal(data.reshape(t - b, r - l, 4), ref[b:t, l:r])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 7])
+@pytest.mark.parametrize("variant", [0, 1, 3, 7, 19, 23])
 @pytest.mark.parametrize("concentric", [False, True], ids=["nested", "concentric"])
 @pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64], ids=["f32", "f64"])
 @pytest.mark.parametrize("seed", [11, 12, 13])

@@ -159,13 +159,13 @@ def exact_root(a, disc, tag, r):
 
 def exact_tiny(a, disc, tag, r):
     a.label(".Lfl_tiny_%s_%%=" % tag)
-    a.op("v_mul_f32_e32 %s, 0x4f800000, %s" % (r.t0, disc), "root with the 2^32 / 2^-16 scaling for tiny lanes")
+    a.op("v_mul_f32_e32 %s, 0x5f800000, %s" % (r.t0, disc), "root with the 2^64 / 2^-32 scaling for tiny lanes (the scaled operand stays >= 2^-85: its residual is never subnormal)")
     a.op("v_cndmask_b32_e64 %s, %s, %s, %s" % (r.t2, disc, r.t0, TINY))
     a.op("v_rsq_f32_e32 %s, %s" % (r.t0, r.t2))
     a.op("v_cmp_eq_f32_e32 vcc, 0, %s" % r.t2, "sqrt(+-0) = +-0 (rsq would make it 0 * inf)")
     refine(a, r.t2, r.t0, r.t1, r.root)
     a.op("v_cndmask_b32_e32 %s, %s, %s, vcc" % (r.root, r.root, r.t2))
-    a.op("v_mul_f32_e32 %s, 0x37800000, %s" % (r.t0, r.root))
+    a.op("v_mul_f32_e32 %s, 0x2f800000, %s" % (r.t0, r.root))
     a.op("v_cndmask_b32_e64 %s, %s, %s, %s" % (r.root, r.root, r.t0, TINY))
     a.op("s_branch .Lfl_rooted_%s_%%=" % tag)
 

@@ -153,13 +153,13 @@ def root(a, r, disc, need_mask, done_label, tiny_label):
 
 def tiny(a, r, disc, tiny_label, done_label):
     a.label(tiny_label)
-    a.op("v_mul_f32_e32 %s, 0x4f800000, %s" % (r.t0, disc), "root with the 2^32 / 2^-16 scaling for tiny lanes")
+    a.op("v_mul_f32_e32 %s, 0x5f800000, %s" % (r.t0, disc), "root with the 2^64 / 2^-32 scaling for tiny lanes (the scaled operand stays >= 2^-85: its residual is never subnormal)")
     a.op("v_cndmask_b32_e64 %s, %s, %s, %s" % (r.t5, disc, r.t0, TINY))
     a.op("v_rsq_f32_e32 %s, %s" % (r.t0, r.t5))
     a.op("v_cmp_eq_f32_e64 %s, 0, %s" % (M2, r.t5), "sqrt(+-0) = +-0 (rsq would make it 0 * inf)")
     refine(a, r, r.t5)
     a.op("v_cndmask_b32_e64 %s, %s, %s, %s" % (r.root, r.root, r.t5, M2))
-    a.op("v_mul_f32_e32 %s, 0x37800000, %s" % (r.t0, r.root))
+    a.op("v_mul_f32_e32 %s, 0x2f800000, %s" % (r.t0, r.root))
     a.op("v_cndmask_b32_e64 %s, %s, %s, %s" % (r.root, r.root, r.t0, TINY))
     a.op("s_branch %s" % done_label)
 

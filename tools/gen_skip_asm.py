@@ -78,6 +78,17 @@ def sp(first, n=2):
 
 class Prec:
     """Register plan and the precision-dependent instruction sequences."""
+    filt = False
+    shadow_extra_in = ""
+    shadow_extra_out = ""
+    shadow_extra_decl = ""
+
+    def kind_test(self, a, c, lab):
+        a.op("s_cmp_gt_u32 %s, %s" % (self.item(c), FLAG_LIMIT), "an ITEM or the END node?  (flag bits of the item word)")
+        a.op("s_cbranch_scc1 %s" % lab("flagged"))
+
+    def own_item_update(self, a, c):
+        self.item_update(a, c)
 
     def bank(self, b):
         return self.bank_first[b]
@@ -159,13 +170,13 @@ class F32(Prec):
 
     def tiny(self, a, tiny_label, done_label):
         a.label(tiny_label)
-        a.op("v_mul_f32_e32 %[t0], 0x4f800000, %[disc]", "root with the 2^32 / 2^-16 scaling for tiny lanes")
+        a.op("v_mul_f32_e32 %[t0], 0x5f800000, %[disc]", "root with the 2^64 / 2^-32 scaling for tiny lanes (the scaled operand stays >= 2^-85: its residual is never subnormal)")
         a.op("v_cndmask_b32_e64 %%[t5], %%[disc], %%[t0], %s" % self.TINY)
         a.op("v_rsq_f32_e32 %[t0], %[t5]")
         a.op("v_cmp_eq_f32_e64 %s, 0, %%[t5]" % self.M58, "sqrt(+-0) = +-0 (rsq would make it 0 * inf)")
         self.refine(a, "%[t5]")
         a.op("v_cndmask_b32_e64 %%[root], %%[root], %%[t5], %s" % self.M58)
-        a.op("v_mul_f32_e32 %[t0], 0x37800000, %[root]")
+        a.op("v_mul_f32_e32 %[t0], 0x2f800000, %[root]")
         a.op("v_cndmask_b32_e64 %%[root], %%[root], %%[t0], %s" % self.TINY)
         a.op("s_branch %s" % done_label)
 
@@ -324,14 +335,80 @@ class F64(Prec):
     inf = "__builtin_huge_val()"
 
 
+class F32F(F32):
+    """f32 with the conservative FILTER in front of every test: the walk reads FNode streams (rt_skip.hpp) --
+    primary {vx, vy, vz, vv, rr, T, skip_off, tag}, shadow {cx, cy, cz, rr, w1, w2, skip_off, tag}; tag = 0 (BOUND), rr of the
+    group's own sphere (fused BOUND), item | bit 31 (ITEM), bits 31 + 30 (END).  A step first asks a bound of the test that is
+    proven to hold whenever the reference's test can return a finite distance (primary: fma-chain b' >= T; shadow: squared distance
+    of the sphere's centre from the ray in the plane perpendicular to the light <= rr * k1 + K0); only when some live lane passes
+    does it form the reference's own discriminant, operation for operation, exactly as the unfiltered loops do."""
+    name = "f32"
+    filt = True
+
+    def item(self, b):
+        return "s%d" % (self.bank(b) + 7)            # the tag word: an ITEM's index | bit 31
+
+    def thr(self, b):
+        return "s%d" % (self.bank(b) + 5)
+
+    def primary_filter(self, a, c):
+        a.op("v_mul_f32_e32 %%[t0], %s, %%[dx]" % self.fld(c, 0), "filter: b' = fma(vz, dz, fma(vy, dy, vx*dx)) >= T ?")
+        a.op("v_fma_f32 %%[disc], %s, %%[dy], %%[t0]" % self.fld(c, 1))
+        a.op("v_fma_f32 %%[disc], %s, %%[dz], %%[disc]" % self.fld(c, 2))
+        a.op("v_cmp_le_f32_e32 vcc, %s, %%[disc]" % self.thr(c))
+
+    def primary_terms_after_filter(self, a, c):
+        # t0 = vx*dx is the filter's first product: the same bits the reference forms (primitive.rs:57)
+        a.op("v_mul_f32_e32 %%[t1], %s, %%[dy]" % self.fld(c, 1), "b = (vx*dx + vy*dy) + vz*dz   primitive.rs:57")
+        a.op("v_mul_f32_e32 %%[t2], %s, %%[dz]" % self.fld(c, 2))
+        a.op("v_add_f32_e32 %[t0], %[t0], %[t1]")
+        a.op("v_add_f32_e32 %[b], %[t0], %[t2]")
+        a.op("v_mul_f32_e32 %[t0], %[b], %[b]", "disc = (b*b - vv) + rr   primitive.rs:58")
+        a.op("v_subrev_f32_e32 %%[q], %s, %%[t0]" % self.fld(c, 3))
+        a.op("v_add_f32_e32 %%[disc], %s, %%[q]" % self.fld(c, 4))
+
+    # ---- shadow stream (two-sided bound): {w1, w2, cl, R2o | ITEM flag, R2i, R2o_own | END flag, R2i_own, skip_off}
+    def s_w1(self, b): return "s%d" % (self.bank(b) + 0)
+    def s_w2(self, b): return "s%d" % (self.bank(b) + 1)
+    def s_cl(self, b): return "s%d" % (self.bank(b) + 2)
+    def s_r2o(self, b): return "s%d" % (self.bank(b) + 3)
+    def s_r2i(self, b): return "s%d" % (self.bank(b) + 4)
+    def s_r2o_own(self, b): return "s%d" % (self.bank(b) + 5)
+    def s_r2i_own(self, b): return "s%d" % (self.bank(b) + 6)
+    def s_skip(self, b): return "s%d" % (self.bank(b) + 7)
+
+    def shadow_filter(self, a, c):
+        a.op("v_sub_f32_e32 %%[t0], %s, %%[q1]" % self.s_w1(c), "P2 = |w - q|^2 in the plane perpendicular to the light")
+        a.op("v_sub_f32_e32 %%[t1], %s, %%[q2]" % self.s_w2(c))
+        a.op("v_mul_f32_e32 %[t0], %[t0], %[t0]")
+        a.op("v_fma_f32 %[p2], %[t1], %[t1], %[t0]")
+        a.op("v_cmp_ngt_f32_e64 vcc, %%[p2], |%s|" % self.s_r2o(c), "not beyond the outer bound (a NaN -- a ray the bounds do not cover -- passes)")
+
+    def kind_test(self, a, c, lab):
+        a.op("s_bitcmp1_b32 %s, 31" % self.item(c), "an ITEM or the END node?  (flag bits of the tag word)")
+        a.op("s_cbranch_scc1 %s" % lab("flagged"))
+
+    def own_item_update(self, a, c):
+        # the fused BOUND's tag is its own sphere's rr: the hit records WHERE it happened (NX = this node's offset + stride, bit 31
+        # clear) and the kernel looks the item up in the stream's own_item table afterwards
+        a.op("s_mov_b64 exec, vcc", "primitive.rs:80-83")
+        a.op("v_mov_b32_e32 %[best], %[t4]")
+        a.op("v_mov_b32_e32 %%[bitem], %s" % self.NX)
+        a.op("s_mov_b64 exec, %s" % self.EX)
+
+    shadow_extra_in = ', [q1] "v"(q1), [q2] "v"(q2), [ol] "v"(ol), [a0] "s"(a0), [base2] "s"(exact)'
+    shadow_extra_out = ', [p2] "=&v"(p2), [av] "=&v"(av), [inn] "=&v"(inn)'
+    shadow_extra_decl = "\n    float p2, av, inn;"
+
+
 def top_of(name):
     return ".Lrt_%s_top_%%=" % name
 
 
-def emit_skip(a, P, name, c, lab):
+def emit_skip(a, P, name, c, lab, skip_reg=None):
     """`skip` transition: the successor is the node behind the subtree (an ITEM's own successor)."""
     a.label(lab("skip"))
-    a.op("s_add_u32 %s, %s, %d" % (P.NX, P.skip(c), P.stride), "jump over the subtree")
+    a.op("s_add_u32 %s, %s, %d" % (P.NX, skip_reg or P.skip(c), P.stride), "jump over the subtree")
     a.op("s_waitcnt lgkmcnt(0)")
     nxt = SKIP_COPY[name]
     if LAYOUT.index(nxt) != LAYOUT.index(name) + 1:                # A -> C and C -> B fall through
@@ -344,13 +421,21 @@ def emit_next(a, P, name):
     a.op("s_branch %s" % top_of(NEXT_COPY[name]))
 
 
+def node_skip(P, c, terms):
+    return P.s_skip(c) if (P.filt and terms == P.shadow_terms) else P.skip(c)
+
+
 def step_top(a, P, c, n, s, terms):
     """The part of a step every node shares: fetch the likely successor, form the live mask and the discriminant."""
     # Only `skip` is fetched ahead: three of four BOUND tests end there, and an ITEM's `skip` IS its successor.  The first
     # child of a group is fetched when somebody enters (enter_group): fetched at the top of every BOUND step it doubled the
     # scalar-cache misses (most of those lines are never walked), which cost more than the late fetch on the entered quarter.
-    P.load(a, s, P.skip(c), "the likely successor, while this node is processed")
+    P.load(a, s, node_skip(P, c, terms), "the likely successor, while this node is processed")
     a.op("v_cmp_gt_u32_e64 %s, %s, %%[resume]" % (P.ACT, P.NX), "active = i >= resume  (NX = i + stride)")
+    if P.filt:
+        (P.primary_filter if terms == P.primary_terms else P.shadow_filter)(a, c)
+        a.op("s_and_b64 vcc, vcc, %s" % P.ACT, "live lanes the bound cannot rule out")
+        return
     terms(a, c)
     P.cand_cmp(a)
     a.op("s_and_b64 vcc, vcc, %s" % P.ACT, "live lanes whose line meets the sphere")
@@ -367,8 +452,17 @@ def sleep_culled(a, P, c):
 
 
 def kind_test(a, P, c, lab):
-    a.op("s_cmp_gt_u32 %s, %s" % (P.item(c), FLAG_LIMIT), "an ITEM or the END node?  (flag bits of the item word)")
-    a.op("s_cbranch_scc1 %s" % lab("flagged"))
+    P.kind_test(a, c, lab)
+
+
+def exact_after_filter(a, P, c, lab, terms):
+    """Filtered loops: some live lane passed the bound -- now the reference's own discriminant, for every lane."""
+    if not P.filt:
+        return
+    (P.primary_terms_after_filter if terms == P.primary_terms else terms)(a, c)
+    P.cand_cmp(a)
+    a.op("s_and_b64 vcc, vcc, %s" % P.ACT, "live lanes whose line meets the sphere")
+    a.op("s_cbranch_vccz %s" % lab("skip"), "the bound let it through, the test does not: nobody can hit the node")
 
 
 def primary_copy(P, name, fused):
@@ -381,6 +475,7 @@ def primary_copy(P, name, fused):
     emit_skip(m, P, name, c, lab)          # nobody can hit the node: a BOUND is jumped over, an ITEM changes nothing
     # ---------------- somebody's line meets the sphere ----------------
     k.label(lab("hit"))
+    exact_after_filter(k, P, c, lab, P.primary_terms)
     kind_test(k, P, c, lab)
     # BOUND (group.rs:73)
     P.root(k, "vcc", lab("brooted"), lab("btiny"))
@@ -397,7 +492,7 @@ def primary_copy(P, name, fused):
         k.op("s_cbranch_vccz %s" % lab("next"))
         P.root(k, "vcc", lab("frooted"), lab("ftiny"))
         P.primary_distance(k)
-        P.item_update(k, c)
+        P.own_item_update(k, c)
     k.label(lab("next"))
     emit_next(k, P, name)
     P.tiny(k, lab("btiny"), lab("brooted"))
@@ -436,6 +531,7 @@ def shadow_copy(P, name, fused):
     m.op("s_cbranch_vccnz %s" % lab("hit"))
     emit_skip(m, P, name, c, lab)
     k.label(lab("hit"))
+    exact_after_filter(k, P, c, lab, P.shadow_terms)
     kind_test(k, P, c, lab)
     # BOUND: hit.distance is INF, so a bound culls iff the ray misses it
     shadow_decide(k, P, lab, "b")
@@ -463,6 +559,102 @@ def shadow_copy(P, name, fused):
     k.op("s_cbranch_vccz %s" % lab("skip"), "an ITEM's `skip` is the node behind it")
     k.op("s_branch .Lrt_fin_%=")
     P.tiny(k, lab("itiny"), lab("irooted"))
+    return m, k
+
+
+def shadow_exact(k, P, src, lab, tag, rr_reg):
+    """The reference's own test (primitive.rs:55-72) for every lane, node terms from bank `src` (a Node<float> record of the exact stream):
+    vcc = live lanes (P.ACT) whose ray hits the sphere with squared radius rr_reg."""
+    a = k
+    a.op("v_sub_f32_e32 %%[vx], %s, %%[ox]" % P.fld(src, 0), "v = centre - origin   primitive.rs:56")
+    a.op("v_sub_f32_e32 %%[vy], %s, %%[oy]" % P.fld(src, 1))
+    a.op("v_sub_f32_e32 %%[vz], %s, %%[oz]" % P.fld(src, 2))
+    a.op("v_mul_f32_e32 %[t0], %[lx], %[vx]")
+    a.op("v_mul_f32_e32 %[t1], %[ly], %[vy]")
+    a.op("v_mul_f32_e32 %[t2], %[lz], %[vz]")
+    a.op("v_add_f32_e32 %[t0], %[t0], %[t1]")
+    a.op("v_add_f32_e32 %[b], %[t0], %[t2]", "b = dot(v, dir)   primitive.rs:57")
+    a.op("v_mul_f32_e32 %[t3], %[vx], %[vx]")
+    a.op("v_mul_f32_e32 %[t4], %[vy], %[vy]")
+    a.op("v_mul_f32_e32 %[t5], %[vz], %[vz]")
+    a.op("v_add_f32_e32 %[t3], %[t3], %[t4]")
+    a.op("v_add_f32_e32 %[t3], %[t3], %[t5]", "dot(v, v)")
+    a.op("v_mul_f32_e32 %[t0], %[b], %[b]")
+    a.op("v_sub_f32_e32 %[q], %[t0], %[t3]")
+    a.op("v_add_f32_e32 %%[disc], %s, %%[q]" % rr_reg, "disc = (b*b - vv) + rr   primitive.rs:58")
+    P.cand_cmp(a)
+    a.op("s_and_b64 vcc, vcc, %s" % P.ACT)
+    shadow_decide(a, P, lab, tag)
+
+
+def shadow_two_sided(a, P, r2i, exact_label, tag):
+    a.op("v_cmp_le_f32_e64 %s, %%[inn], %s" % (P.M56, r2i), "origin inside the sphere, by a margin")
+    a.op("s_or_b64 %s, %s, %s" % (P.M56, P.M56, P.M58), "... or b >= 0, by a margin")
+    a.op("v_cmp_le_f32_e64 %s, %%[p2], %s" % (P.M54, r2i), "inside the inner bound: disc >= 0, by a margin")
+    a.op("s_and_b64 %s, %s, %s" % (P.M54, P.M54, P.M56), "sure hits")
+    a.op("s_andn2_b64 %s, vcc, %s" % (P.M56, P.M54), "lanes between the bounds: the reference's test decides")
+    a.op("s_cbranch_scc1 %s" % exact_label)
+
+
+def shadow_copy_filt(P, name, fused):
+    """Two-sided flavour of shadow_copy (f32 filtered streams)."""
+    c, n, s = COPIES[name]
+    lab = lambda x: ".Lrt_%s_%s_%%=" % (name, x)
+    m, k = Asm(), Asm()
+    m.label(lab("top"))
+    step_top(m, P, c, n, s, P.shadow_terms)
+    m.op("s_cbranch_vccnz %s" % lab("hit"))
+    emit_skip(m, P, name, c, lab, P.s_skip(c))
+    # ---------------- some live lane is inside the outer bound ----------------
+    k.label(lab("hit"))
+    k.op("v_sub_f32_e32 %%[av], %s, %%[ol]" % P.s_cl(c), "a ~ b = dot(centre - origin, dir)")
+    k.op("v_cmp_le_f32_e64 %s, %%[a0], %%[av]" % P.M58, "b >= 0, by a margin")
+    k.op("v_fma_f32 %[inn], %[av], %[av], %[p2]", "~ |centre - origin|^2")
+    shadow_two_sided(k, P, P.s_r2i(c), lab("exact"), "")
+    k.label(lab("decided"))
+    k.op("s_bitcmp1_b32 %s, 31" % P.s_r2o(c), "an ITEM or the END node?  (sign bit of the outer bound)")
+    k.op("s_cbranch_scc1 %s" % lab("flagged"))
+    # BOUND: hit.distance is INF, so a bound culls iff the ray misses it
+    k.op("s_andn2_b64 exec, %s, vcc" % P.ACT, "lanes that may not enter sleep until `skip`")
+    k.op("v_mov_b32_e32 %%[resume], %s" % P.s_skip(c))
+    k.op("s_mov_b64 exec, %s" % P.EX)
+    if fused:
+        k.op("s_mov_b64 %s, vcc" % P.ACT, "the lanes that are live at the next node")
+        k.op("v_cmp_ngt_f32_e64 vcc, %%[p2], |%s|" % P.s_r2o_own(c), "the group's own sphere: same centre, its own bounds")
+        k.op("s_and_b64 vcc, vcc, %s" % P.ACT)
+        k.op("s_cbranch_vccz %s" % lab("next"))
+        shadow_two_sided(k, P, P.s_r2i_own(c), lab("exactown"), "own")
+        k.label(lab("owndecided"))
+        k.op("s_branch .Lrt_fin_%=", "any hit ends those rays; hand them to the caller (it starts again behind this node)")
+    k.label(lab("next"))
+    P.load(k, n, P.NX, "somebody entered: fetch the group's first child")
+    emit_next(k, P, name)
+    # ITEM or END
+    k.label(lab("flagged"))
+    k.op("s_bitcmp1_b32 %s, 31" % P.s_r2o_own(c))
+    k.op("s_cbranch_scc1 .Lrt_exit_%=", "END: every lane is awake here and hits it")
+    k.op("s_branch .Lrt_fin_%=")
+    # ---- the reference's test, for the steps whose lanes the bounds cannot settle: terms from the exact stream
+    k.label(lab("exact"))
+    tmp = "s" + P.M54[2:].split(":")[0]            # the masks are dead here: the reference's test forms the hit mask anew
+    k.op("s_sub_u32 %s, %s, %d" % (tmp, P.NX, P.stride), "this node's offset")
+    k.op("s_load_dwordx8 %s, %%[base2], %s" % (sp(P.bank(n), 8), tmp), "its Node record of the exact stream (the `next` bank is free until the group is entered)")
+    k.op("s_waitcnt lgkmcnt(0)")
+    shadow_exact(k, P, n, lab, "x", P.fld(n, 3))
+    k.op("s_cbranch_vccz %s" % lab("skip"))
+    k.op("v_cmp_le_f32_e64 %s, %%[a0], %%[av]" % P.M58, "(the root's scaled path may have used this mask: form `b >= 0 by a margin` again)")
+    k.op("s_branch %s" % lab("decided"))
+    P.tiny(k, lab("xtiny"), lab("xrooted"))
+    if fused:
+        k.label(lab("exactown"))
+        k.op("s_sub_u32 %s, %s, %d" % (tmp, P.NX, P.stride), "this node's offset")
+        k.op("s_waitcnt lgkmcnt(0)", "the skip successor's fetch may still be in flight INTO this bank, and scalar loads land out of order")
+        k.op("s_load_dwordx8 %s, %%[base2], %s" % (sp(P.bank(s), 8), tmp), "its Node record (the skip bank is free: the group is entered)")
+        k.op("s_waitcnt lgkmcnt(0)")
+        shadow_exact(k, P, s, lab, "y", P.own(s))
+        k.op("s_cbranch_vccz %s" % lab("next"))
+        k.op("s_branch %s" % lab("owndecided"))
+        P.tiny(k, lab("ytiny"), lab("yrooted"))
     return m, k
 
 
@@ -522,7 +714,7 @@ __device__ __forceinline__ void %(name)s(const void *nodes, unsigned n_bytes, %(
     asm volatile(
 %(body)s
         : [best] "+v"(best), [bitem] "+v"(bitem), [resume] "+v"(resume), %(out)s
-        : [base] "s"(nodes), [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz)%(extra_in)s
+        : [base] "s"(nodes), [n] "s"(n_bytes), [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz)%(extra_in)s
         : %(clobbers)s);
     best_out = best;
     item_out = bitem;
@@ -535,15 +727,15 @@ SHADOW_FN = """// Shadow-ray traversal (any hit, render.rs:202-208) from byte of
 // the byte offset it stopped at (n_bytes: stream finished); fin = 1 in the lanes that hit the ITEM there.  resume in bytes.
 // hit.distance is INF throughout, so a node is "hit" iff disc >= 0 and t2 = b + root >= 0.
 __device__ __forceinline__ unsigned %(name)s(const void *nodes, unsigned n_bytes, unsigned start, %(ctype)s ox, %(ctype)s oy, %(ctype)s oz,
-                                                   %(ctype)s lx, %(ctype)s ly, %(ctype)s lz, unsigned &resume_io, unsigned &fin_out)
+                                                   %(ctype)s lx, %(ctype)s ly, %(ctype)s lz, unsigned &resume_io, unsigned &fin_out%(shadow_extra_args)s)
 {
     unsigned resume = resume_io, fin = 0, stop;
-    %(decl)s
+    %(decl)s%(shadow_extra_decl)s
     asm volatile(
 %(body)s
-        : [resume] "+v"(resume), [fin] "+v"(fin), [stop] "=&s"(stop), %(out)s
+        : [resume] "+v"(resume), [fin] "+v"(fin), [stop] "=&s"(stop), %(out)s%(shadow_extra_out)s
         : [base] "s"(nodes), [n] "s"(n_bytes), [start] "s"(start), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [lx] "s"(lx), [ly] "s"(ly),
-          [lz] "s"(lz)%(extra_in)s
+          [lz] "s"(lz)%(extra_in)s%(shadow_extra_in)s
         : %(clobbers)s);
     resume_io = resume;
     fin_out = fin;
@@ -594,7 +786,7 @@ def shadow(P, fused):
     a.op("s_mov_b64 %s, exec" % P.EX)
     P.load(a, 0, "%[start]")
     a.op("s_waitcnt lgkmcnt(0)")
-    assemble(a, P, shadow_copy, fused)
+    assemble(a, P, shadow_copy_filt if P.filt else shadow_copy, fused)
     a.label(".Lrt_fin_%=")
     a.op("v_cndmask_b32_e64 %[fin], 0, 1, vcc", "the lanes whose ray hit the ITEM (or the group's own sphere) of the current node")
     a.op("s_sub_u32 %%[stop], %s, %d" % (P.NX, P.stride), "its position")
@@ -608,10 +800,12 @@ def shadow(P, fused):
 
 def main():
     text = HEADER
-    for P in (F32(), F64()):
+    for P in (F32(), F64(), F32F()):
         for fused in (False, True):
-            sfx = "_fused" if fused else ""
-            common = {"ctype": P.ctype, "stride": P.stride, "inf": P.inf, "extra_in": P.extra_in, "clobbers": clobbers(P)}
+            sfx = ("_filt" if P.filt else "") + ("_fused" if fused else "")
+            common = {"ctype": P.ctype, "stride": P.stride, "inf": P.inf, "extra_in": P.extra_in, "clobbers": clobbers(P),
+                      "shadow_extra_in": P.shadow_extra_in, "shadow_extra_out": P.shadow_extra_out, "shadow_extra_decl": P.shadow_extra_decl,
+                      "shadow_extra_args": ", float q1, float q2, float ol, float a0, const void *exact" if P.filt else ""}
             text += PRIMARY_FN % dict(common, name="skip_primary_rot" + sfx, body=primary(P, fused), decl=P.primary_decl, out=P.primary_out)
             text += SHADOW_FN % dict(common, name="skip_shadow_rot" + sfx, body=shadow(P, fused), decl=P.shadow_decl, out=P.shadow_out)
     text += "}  // namespace rt\n"
