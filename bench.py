@@ -19,11 +19,16 @@ vector (tests/golden/oracle_vectors.json) or the run fails.
 `roofline` (rank 0's render kernel): bound = VALU issue -- this path is un-fused f32 arithmetic on records that live in the
 scalar cache / L2, not an HBM stream.  achieved = SURVEY.md 8(d)'s 17 flops per ray x record test x the tests of one launch
 (counted by the kernel in this run, equal to the CPU path's) / the kernel's launch duration (HIP events on the launch
-stream, in this run); peak = 1,024 SIMDs x 64 lanes x 2.4 GHz / the measured cycles a SIMD needs per wave64 VOP2 instruction at
-8 waves per SIMD (profiles/r02_valu_issue_probe.json, tools/valu_issue_probe.hip: 2.22 -- the longest wave of the probe, not
-the median one; the first table of round 2 read 1.46 from the median and was wrong).  Figures that need rocprofv3 counters (instruction
-issue, HBM traffic) are quoted from profiles/ under `from_profiles`, stamped with the kernel sources they were collected on,
-and dropped when that stamp is not the sources' of this run.
+stream, in this run).  Two peaks are printed: `peak` = the guide's nominal 1,024 SIMDs x 64 lanes x 2.4 GHz / 2 cycles per wave64
+VALU op = 78.6 T un-fused lane-ops/s (`frac` is against this one), and `peak_probe` = the same with the cycles a SIMD was MEASURED to
+need per wave64 VOP2 instruction at 8 waves per SIMD (profiles/r02_valu_issue_probe.json, tools/valu_issue_probe.hip: 2.22 -> 70.9 T;
+`frac_probe`).  `path_arithmetic_frac`: what the path's arithmetic needs with the ray-independent terms pre-formed -- 8 lane-ops per
+primary test, 16 per shadow test (the kernel counts the two kinds separately) -- over the same time and nominal peak; the filtered
+loops (rt_skip.hpp, VAR 16) rule most tests out with 4 - 6 fused operations instead, so this is work the reference needs, not work the
+kernel issues.  `valu_lane_utilisation` = those lane-ops / (SQ_INSTS_VALU x 64), when profiles/ holds counters of these sources.
+Figures that need rocprofv3 counters (instruction issue, HBM traffic) are quoted from profiles/ under `from_profiles`, stamped with
+the kernel sources they were collected on, and dropped when that stamp is not the sources' of this run.
+The timed region is at least 0.2 s: when --steps x --repeats frames take less, more repetitions are run (a step stays one frame).
 
 `seam` (N = 1): the boundary the reference binds, timed from native threads by rust-tracer_amd/seam_bench (child process):
 host_tiles / host_region / end_to_end (render + D2H + PPM write).  `flat`: the north-star linear scan, same run.
@@ -49,7 +54,9 @@ if ROOT not in sys.path:
 # name -> (width, height, samples_per_pixel, pyramid level, golden case in tests/golden/oracle_vectors.json).  The default is the
 # configuration BASELINE.json's metric is quoted on; the others are BASELINE's neighbouring configs (never the headline).
 WORKLOADS = {"1080p": (1920, 1080, 1, 8, "config3_1920x1080_f32"), "config2": (800, 600, 1, 8, "config2_800x600"),
-             "make_image": (1024, 768, 4, 8, "make_image_1024x768_spp4"), "config5": (4096, 4096, 4, 9, "config5_4096x4096_spp4_L9")}
+             "make_image": (1024, 768, 4, 8, "make_image_1024x768_spp4"), "config5": (4096, 4096, 4, 9, "config5_4096x4096_spp4_L9"),
+             # BASELINE config 5 with EXACTLY 100,000 spheres: an arbitrary list (tests/scenes.py) with an automatically built hierarchy
+             "config5_100k": (4096, 4096, 4, "100k", "config5_100k_4096x4096_spp4")}
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_SIMD, LANES, CLOCK_HZ = 1024, 64, 2.4e9
 BYTES_PER_TEST, FLOPS_PER_TEST = 16, 17  # one ray x one {cx,cy,cz,r} record; 3 sub + 8 mul + 6 add/sub to the reject test
@@ -109,7 +116,14 @@ def cpu_baseline(width, height, spp, level, budget_s=12.0):
     """The oracle (CPU restatement of the reference's hierarchical path) timed on this host, same workload."""
     import oracle
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    o = oracle.Scene.default(oracle.F32, level)
+    if level == "100k":
+        import numpy as np
+        from rust_tracer_amd.scene import build_hierarchy
+        from tests.scenes import hundred_thousand_spheres
+        items, bounds, ranges, _ = build_hierarchy(hundred_thousand_spheres())
+        o = oracle.Scene.from_ranges(items.astype(np.float64), bounds.astype(np.float64), ranges)
+    else:
+        o = oracle.Scene.default(oracle.F32, level)
     t0 = time.perf_counter()
     # one single-threaded frame (the reference's default RTRACEMAXPROCS=1), unless the workload is far too big for that
     _, st, _ = o.render(width, height, spp, nthreads=1 if width * height * spp * spp <= 2.5e7 else cores)
@@ -124,9 +138,9 @@ def cpu_baseline(width, height, spp, level, budget_s=12.0):
         frames += 1
         spent += dt
     return {"value": round(rays / best / 1e6, 3), "unit": "Mrays/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
-            "sample": "%d full frames of the same %dx%d spp %d L%d workload on %d threads (64x64 buckets), reference "
+            "sample": "%d full frames of the same %dx%d spp %d %s workload on %d threads (64x64 buckets), reference "
                       "hierarchical traversal, best frame; 1 thread: %.3f Mrays/s"
-                      % (frames, width, height, spp, level, cores, rays / t_single / 1e6),
+                      % (frames, width, height, spp, "100,000 spheres" if level == "100k" else "L%d" % level, cores, rays / t_single / 1e6),
             "ms_per_frame": round(best * 1e3, 2), "single_core_value": round(rays / t_single / 1e6, 3)}
 
 
@@ -154,6 +168,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--repeats", type=int, default=5, help="repetitions of the timed --steps loop (median reported)")
+    ap.add_argument("--min-timed-region", type=float, default=0.2,
+                    help="seconds: more repetitions of the --steps loop are run until the timed region is at least this long")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flat", action="store_true", help="skip the secondary flat-scan measurement")
     ap.add_argument("--no-seam", action="store_true", help="skip the host-boundary legs (seam_bench child process)")
@@ -170,7 +186,7 @@ def main():
                     help="1080p = the headline workload; the others are BASELINE's neighbouring configs")
     args = ap.parse_args()
     width, height, spp, level, golden_name = WORKLOADS[args.workload]
-    n_items = (4 ** level - 1) // 3
+    n_items = 100000 if level == "100k" else (4 ** level - 1) // 3
 
     # Exactly ONE line may reach stdout.  RCCL prints a version banner on stdout (NCCL_DEBUG=VERSION is set on the GPU
     # boxes) whenever a communicator exists, so fd 1 is pointed at stderr for the whole run and the JSON line is written
@@ -214,10 +230,14 @@ def main():
 
     def scene_of(lv):
         if lv not in scenes:
-            scenes[lv] = rta.Scene.default(lv, rta.RT_F32)
+            if lv == "100k":
+                from tests.scenes import hundred_thousand_spheres
+                scenes[lv] = rta.Scene.from_spheres_auto(hundred_thousand_spheres())
+            else:
+                scenes[lv] = rta.Scene.default(lv, rta.RT_F32)
         return scenes[lv]
 
-    def measure(wl, traversal, steps, warmup, repeats, mode):
+    def measure(wl, traversal, steps, warmup, repeats, mode, min_region_s=0.0):
         """-> dict: whole-job ms per step of each repetition (max over ranks), this rank's kernel ms (HIP events), counters,
         and the CRC of the frame the timed launches left on rank 0."""
         w, h, k, lv, gname = WORKLOADS[wl]
@@ -225,6 +245,7 @@ def main():
         fs = FrameSharder(scene_of(lv), opts, rank, world, local, traversal, force_collective=args.force_collective, mode=mode,
                           frames_per_gather=args.frames_per_gather)
         st = fs.render_shard(want_stats=True)          # counters of this rank's shard (equal the oracle's; tests)
+        st = dict(st, primary_tests=(rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_PRIMARY_TESTS) if traversal == rta.RT_TRAVERSAL_SKIP else None))
         cnt = torch.tensor([st["primary"], st["shadow"]], dtype=torch.int64, device="cuda")
         if dist is not None:
             dist.all_reduce(cnt)
@@ -241,7 +262,9 @@ def main():
                 g.zero_()
         barrier()
         reps, kern = [], []
-        for _ in range(repeats):
+        rep = 0
+        while rep < repeats or (min_region_s and sum(r * steps for r in reps) / 1e3 < min_region_s and rep < 4000):
+            rep += 1
             # N = 1: the timed region is `steps` launches of the render kernel back to back on torch's current stream, which is the
             # stream handed to the C ABI -- two HIP events on that stream bracket exactly those launches, inside the timed region
             k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -329,28 +352,41 @@ def main():
     def roofline(m, kernel, flops_per_test, note):
         t = m["kern_ms"] * 1e-3
         vop2 = probe.get(("v_mul_f32 (SGPR x VGPR, independent)", 8))
-        cyc = vop2["cycles_per_instruction_per_simd"] if vop2 else 2.0
-        peak = N_SIMD * LANES * CLOCK_HZ / cyc / 1e12
+        cyc = vop2["cycles_per_instruction_per_simd"] if vop2 else None
+        peak = N_SIMD * LANES * CLOCK_HZ / 2.0 / 1e12              # MI355X_MICROARCH.md: SIMD-32, 2 cycles per wave64 VALU op
+        peak_probe = N_SIMD * LANES * CLOCK_HZ / cyc / 1e12 if cyc else None
         ach = m["my_tests"] * flops_per_test / t / 1e12
         logical = m["my_tests"] * BYTES_PER_TEST / t / 1e9
         out = {"bound": "valu_issue", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s (un-fused f32 lane ops)",
                "frac": round(ach / peak, 4), "traffic": None, "kernel": kernel, "kernel_ms": round(m["kern_ms"], 4),
                "tests_per_launch": m["my_tests"], "flops_per_test": flops_per_test,
-               "peak_source": "profiles/r02_valu_issue_probe.json: %.3f cycles per wave64 VOP2 instruction per SIMD at 8 waves per SIMD "
-                              "(1,024 SIMDs x 64 lanes x 2.4 GHz / that)" % cyc,
+               "peak_source": "MI355X_MICROARCH.md nominal: 1,024 SIMDs x 64 lanes x 2.4 GHz / 2 cycles per wave64 VALU op (un-fused: one lane-op per lane)",
+               "peak_probe": round(peak_probe, 1) if peak_probe else None, "frac_probe": round(ach / peak_probe, 4) if peak_probe else None,
+               "peak_probe_source": ("profiles/r02_valu_issue_probe.json: %.3f cycles per wave64 VOP2 instruction per SIMD measured at 8 waves per SIMD" % cyc) if cyc else None,
                "hbm_logical": {"GBs": round(logical, 1), "bytes_per_test": BYTES_PER_TEST,
                                "note": "16 B x tests / kernel time: a LOGICAL record rate -- the records come from the scalar cache / L2 / LDS, "
                                        "not from HBM, so it is not a fraction of the HBM peak (SURVEY.md H3)"},
                "note": note}
+        pt = m["my_stats"].get("primary_tests")
+        if pt is not None and kernel == "k_render_skip":
+            ops = 8 * pt + 16 * (m["my_tests"] - pt)
+            out["path_arithmetic"] = {"primary_tests": pt, "shadow_tests": m["my_tests"] - pt, "lane_ops": ops,
+                                      "frac": round(ops / t / 1e12 / peak, 4),
+                                      "note": "8 lane-ops per primary test (terms pre-formed against the shared eye), 16 per shadow test -- the arithmetic the reference's "
+                                              "tests need -- over the kernel time and the nominal peak.  The filtered loops rule most tests out with a cheaper proven "
+                                              "bound (4 - 6 fused operations), so the kernel issues fewer operations than this"}
         fp = from_profiles(kernel, m["kern_ms"])
         out["from_profiles"] = fp
         if "hbm_traffic" in fp:
             out["traffic"] = fp["hbm_traffic"]["bytes_per_launch"]
+        valu = (fp.get("instruction_issue") or {}).get("valu")
+        if valu and "path_arithmetic" in out:
+            out["valu_lane_utilisation"] = round(out["path_arithmetic"]["lane_ops"] / (valu * LANES), 4)
         return out
 
     head_trav = rta.RT_TRAVERSAL_SKIP if args.traversal == "skip" else rta.RT_TRAVERSAL_FLAT
     multi = args.multi if (world > 1 or args.force_collective) else "tiles"
-    m = measure(args.workload, head_trav, args.steps, args.warmup, max(1, args.repeats), multi)
+    m = measure(args.workload, head_trav, args.steps, args.warmup, max(1, args.repeats), multi, min_region_s=args.min_timed_region)
     flat = None
     if args.traversal == "skip" and not args.no_flat and world == 1:
         flat = measure(args.workload, rta.RT_TRAVERSAL_FLAT, max(2, min(5, args.steps)), 1, 3, multi)
@@ -366,7 +402,7 @@ def main():
         fr = e["frames_per_step"]
         rays = (e["primary"] + e["shadow"])
         srt = sorted(e["ms_reps"])
-        return {"workload": "%dx%d spp %d L%d" % (w, h, k, lv), "ms_per_step": round(e["ms_per_step"], 4), "ms_per_step_min_max": [round(srt[0], 4), round(srt[-1], 4)],
+        return {"workload": "%dx%d spp %d %s" % (w, h, k, "100k spheres" if lv == "100k" else "L%d" % lv), "ms_per_step": round(e["ms_per_step"], 4), "ms_per_step_min_max": [round(srt[0], 4), round(srt[-1], 4)],
                 "frames_per_step": fr, "value": round(rays / (e["ms_per_step"] * 1e-3) / 1e6, 3), "unit": "Mrays/s",
                 "rank0_kernel_ms": round(e["kern_ms"], 4), "frame_crc32": e["crc"], "frame_crc_ok": e["crc_ok"]}
 
@@ -394,14 +430,16 @@ def main():
         srt = sorted(m["ms_reps"])
         out = {
             "metric": "Mrays/sec + ms/frame, 1920x1080 20k-sphere scene" if args.workload == "1080p" else
-                      "Mrays/sec + ms/frame, %dx%d spp %d L%d (non-headline workload %s)" % (width, height, spp, level, args.workload),
+                      "Mrays/sec + ms/frame, %dx%d spp %d %s (non-headline workload %s)" % (width, height, spp, "100k spheres" if level == "100k" else "L%d" % level, args.workload),
             "value": round(rays / (ms_per_step * 1e-3) / 1e6, 3),      # rays of every frame of a step (summed over ranks) / step time
             "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak" if (multi == "frames" and world > 1) else "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (the reference's deterministic default scene: pyramid level %d)" % level,
-            "config": {"workload": "%dx%d, %d spheres (pyramid L%d), spp %d, f32, %s traversal, %d 64x64 buckets per frame; %s"
-                                   % (width, height, n_items, level, spp, args.traversal, -(-width // 64) * -(-height // 64), layout),
+            "data": ("synthetic (100,000 seeded random spheres, tests/scenes.py; hierarchy built by the host)" if level == "100k" else
+                     "synthetic (the reference's deterministic default scene: pyramid level %d)" % level),
+            "config": {"workload": "%dx%d, %d spheres (%s), spp %d, f32, %s traversal, %d 64x64 buckets per frame; %s"
+                                   % (width, height, n_items, "random list, auto hierarchy" if level == "100k" else "pyramid L%d" % level, spp, args.traversal,
+                                      -(-width // 64) * -(-height // 64), layout),
                        "width": width, "height": height, "samples_per_pixel": spp, "n_spheres": n_items,
                        "primary_rays": m["primary"], "shadow_rays": m["shadow"], "traversal": args.traversal,
                        "frames_per_step": m["frames_per_step"],
@@ -424,16 +462,25 @@ def main():
             pk_cyc = pkf["cycles_per_instruction_per_simd"] if pkf else 4.0
             pk_peak = N_SIMD * LANES * 4 * CLOCK_HZ / pk_cyc       # a packed FMA: 2 rays x 2 flops per lane
             t = flat["kern_ms"] * 1e-3
+            fp_flat = from_profiles("k_flat_pipeline", flat["kern_ms"])
+            issue = fp_flat.get("instruction_issue") or {}
+            survey_ops = FLOPS_PER_TEST * (fst["primary"] + fst["shadow"]) * n_items        # 17 flops x every ray x every item
             out["flat"] = {"ms_per_step": round(flat["ms_per_step"], 4), "value": round(rays / (flat["ms_per_step"] * 1e-3) / 1e6, 3), "unit": "Mrays/s",
                            "frame_crc_ok": flat["crc_ok"],
-                           "roofline": {"bound": "valu_issue", "achieved": round(ops / t / 1e12, 2), "peak": round(pk_peak / 1e12, 1),
-                                        "unit": "TFLOP/s (reference flops against the packed-FMA issue rate)", "frac": round(ops / t / pk_peak, 4),
+                           "roofline": {"bound": "valu_issue",
+                                        "simd_cycles_per_wave_instruction": issue.get("simd_cycles_per_wave_instruction"),
+                                        "probe_cycles_per_packed_instruction": round(pk_cyc, 3),
+                                        "survey_8d_frac": round(survey_ops / t / 1e12 / (N_SIMD * LANES * CLOCK_HZ / 2.0 / 1e12), 3),
+                                        "reference_flops_over_packed_fma_peak": round(ops / t / pk_peak, 4),
                                         "kernel": "k_flat_primary_sc + k_flat_shadow_sc", "kernel_ms": round(flat["kern_ms"], 4),
-                                        "tests_executed": fst["tests_executed"], "note": flat_note,
-                                        "peak_source": "1,024 SIMDs x 64 lanes x 4 flops x 2.4 GHz / %.3f cycles per wave64 v_pk_fma_f32 per SIMD at 8 waves per "
-                                                       "SIMD (profiles/r02_valu_issue_probe.json; the un-fused VOP2 roof of the headline is half of it "
-                                                       "at 2.22 cycles per instruction)" % pk_cyc,
-                                        "from_profiles": from_profiles("k_flat_pipeline", flat["kern_ms"])}}
+                                        "tests_executed": fst["tests_executed"],
+                                        "note": "What bounds the scan is instruction issue: the counters (when profiles/ holds them for these sources) give the SIMD cycles "
+                                                "the launch leaves per wave-instruction, to be read against the probe's cost of a packed instruction -- equal means the "
+                                                "SIMDs issue back to back.  survey_8d_frac = SURVEY 8(d)'s 17 flops x rays x items / time / the nominal un-fused peak: "
+                                                "it exceeds 1 because the kernel provably does not perform most of those operations -- a conservative bound of the "
+                                                "discriminant (4 - 6 packed FMAs per item and ray pair; margin proven, checked exhaustively by rt_debug_flat_filter_check) "
+                                                "rejects items and the reference's individually rounded operations run only for the survivors.  " + flat_note,
+                                        "from_profiles": fp_flat}}
         for k, e in extras.items():
             out[k] = summary(e, "config5" if k == "config5_tiles" else "1080p")
             out[k]["scaling"] = "weak" if k == "weak_frames" else "strong"

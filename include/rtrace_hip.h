@@ -123,6 +123,14 @@ rt_status rt_scene_destroy(rt_scene *scene);
 enum { RT_SCENE_HAS_BOUNDS = 1u, RT_SCENE_CONCENTRIC = 2u };
 rt_status rt_scene_traits(const rt_scene *scene, uint32_t *traits);
 
+/* rt_render_tiles with delivery in completion order (the reference's channel, render.rs:271,301-307): the buckets are rendered in
+ * batches that are all enqueued at once, and `callback` is invoked -- on the calling thread -- for every bucket of a batch as soon
+ * as that batch is complete, while later batches are still rendering.  tile_index: the bucket's position in `tiles`; rgba: its
+ * RGBABuffer bytes (row 0 = region.b), valid only during the callback.  Returns when every bucket has been delivered. */
+typedef void (*rt_tile_callback)(void *user, uint32_t tile_index, const rt_region *region, const uint8_t *rgba);
+rt_status rt_render_tiles_stream(rt_scene *scene, const rt_options *options, rt_traversal traversal,
+                                 const rt_region *tiles, uint32_t n_tiles, rt_tile_callback callback, void *user);
+
 /* Host memory for RGBABuffer storage (render.rs:74-90 allocates it with vec![0; area * 4]) that the device can reach
  * directly.  rt_render_tiles / rt_render_region recognise such memory by address (any pointer inside a range this library
  * pinned -- memory pinned by other means counts as pageable) and then
@@ -195,6 +203,13 @@ rt_status rt_gang_size(const rt_gang *gang, int *n_devices);
  * device_ms = the slowest device's render. */
 rt_status rt_gang_render_frame(rt_gang *gang, const rt_options *options, rt_traversal traversal,
                                const rt_region *tiles, uint32_t n_tiles, uint8_t *frame_rgba_host, rt_stats *stats);
+/* n_frames frames of the same tile list, frame f to frames_rgba_host[f] (each as for rt_gang_render_frame): the gather, the blit and
+ * the copy of frame f run under the render of frame f + 1 (double-buffered shards; what dist.py's run_pipeline does across
+ * processes).  A frame buffer from rt_host_alloc / rt_host_register is written by the root GPU's blit kernel directly.
+ * stats (may be NULL): the counters of ONE frame. */
+rt_status rt_gang_render_frames(rt_gang *gang, const rt_options *options, rt_traversal traversal,
+                                const rt_region *tiles, uint32_t n_tiles, uint8_t *const *frames_rgba_host, uint32_t n_frames,
+                                rt_stats *stats);
 
 /* Bytes rt_render_tiles writes for this tile list (4 * total area), or 0 on an invalid list. */
 uint64_t rt_tiles_rgba_bytes(const rt_region *tiles, uint32_t n_tiles);

@@ -18,7 +18,7 @@ ABI_VERSION = 2
 SYMBOLS = ("rt_abi_version", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_scene_traits", "rt_render_tiles",
            "rt_render_tiles_device", "rt_render_frame_device", "rt_render_region", "rt_blit_tiles_device", "rt_selftest_sqrt", "rt_tiles_rgba_bytes", "rt_strerror", "rt_last_error_message",
            "rt_host_alloc", "rt_host_free", "rt_host_register", "rt_host_unregister",
-           "rt_gang_create", "rt_gang_destroy", "rt_gang_size", "rt_gang_render_frame")
+           "rt_gang_create", "rt_gang_destroy", "rt_gang_size", "rt_gang_render_frame", "rt_gang_render_frames", "rt_render_tiles_stream")
 
 
 class Options(C.Structure):      # rt_options / RenderOptions render.rs:33-38
@@ -74,6 +74,9 @@ lib.rt_gang_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p,
 lib.rt_gang_destroy.argtypes = [C.c_void_p]
 lib.rt_gang_size.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
 lib.rt_gang_render_frame.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
+lib.rt_gang_render_frames.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(Stats)]
+TILE_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.POINTER(Region), C.POINTER(C.c_uint8))      # rt_tile_callback
+lib.rt_render_tiles_stream.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_void_p, C.c_uint32, TILE_CALLBACK, C.c_void_p]
 lib.rt_selftest_sqrt.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
 lib.rt_scene_traits.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
 RT_SCENE_HAS_BOUNDS, RT_SCENE_CONCENTRIC = 1, 2
@@ -103,26 +106,23 @@ def device_count():
 
 
 class HostBuffer:
-    """rt_host_alloc'd bytes as a numpy uint8 array (`.array`): RGBABuffer storage the render kernel writes directly."""
+    """rt_host_alloc'd bytes as a numpy uint8 array (`.array`): RGBABuffer storage the render kernel writes directly.
+
+    The allocation lives as long as ANY array derived from `.array` (views, slices, what render_tiles returns): the array's base is
+    a ctypes block whose finalizer calls rt_host_free, so `render_tiles(..., out=capi.HostBuffer(n).array)` is safe.  close() only
+    drops this object's own reference."""
 
     def __init__(self, nbytes):
+        import weakref
         import numpy as np
         p = C.c_void_p()
         check(lib.rt_host_alloc(nbytes, C.byref(p)), "rt_host_alloc")
-        self._p = p
-        self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p.value))
+        block = (C.c_uint8 * nbytes).from_address(p.value)
+        weakref.finalize(block, lib.rt_host_free, C.c_void_p(p.value))      # runs when the last array over the block is gone
+        self.array = np.ctypeslib.as_array(block)                            # .base chain keeps `block` alive
 
     def close(self):
-        if getattr(self, "_p", None):
-            self.array = None
-            lib.rt_host_free(self._p)
-            self._p = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        self.array = None
 
 
 def selftest_sqrt(device=0):
@@ -134,12 +134,14 @@ def selftest_sqrt(device=0):
 
 # ---- csrc/rt_debug.h: diagnostic controls (not part of the drop-in ABI; the library reads no environment variable) ----
 (DEBUG_SKIP_VARIANT, DEBUG_BLOCK_ORDER, DEBUG_NARROW_MAX, DEBUG_PACKED_SAMPLES, DEBUG_PRINT_STEPS, DEBUG_PRINT_COSTS,
- DEBUG_HOST_COPY, DEBUG_COALESCE, DEBUG_LDS_BYTES, DEBUG_WG_POLICY, DEBUG_NARROW_L2, DEBUG_FLAT_KERNELS, DEBUG_SKIP_RAYS) = range(13)
+ DEBUG_HOST_COPY, DEBUG_COALESCE, DEBUG_LDS_BYTES, DEBUG_WG_POLICY, DEBUG_NARROW_L2, DEBUG_FLAT_KERNELS, DEBUG_SKIP_RAYS,
+ DEBUG_FRAME_AHEAD) = range(14)
 lib.rt_debug_set.argtypes = [C.c_int, C.c_longlong]
 lib.rt_debug_wave_trace.argtypes = [C.c_char_p]
 lib.rt_debug_count.restype = C.c_longlong
 lib.rt_debug_count.argtypes = [C.c_int]
-DEBUG_COUNT_REGION_CALLS, DEBUG_COUNT_REGION_PASSES, DEBUG_COUNT_FILTER_PASS, DEBUG_COUNT_FILTER_VIOLATIONS = 0, 1, 2, 3
+(DEBUG_COUNT_REGION_CALLS, DEBUG_COUNT_REGION_PASSES, DEBUG_COUNT_FILTER_PASS, DEBUG_COUNT_FILTER_VIOLATIONS, DEBUG_COUNT_PRIMARY_TESTS,
+ DEBUG_COUNT_FRAME_AHEAD_PASSES) = range(6)
 
 
 def debug_set(key, value=-1):
@@ -166,6 +168,33 @@ def flat_filter_check(scene_handle, width, height, spp):
     counts = (C.c_ulonglong * 6)()
     check(lib.rt_debug_flat_filter_check(scene_handle, width, height, spp, C.byref(counts)), "rt_debug_flat_filter_check")
     return tuple(int(c) for c in counts)
+
+
+lib.rt_debug_gang_layout.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+lib.rt_debug_shard_costs.argtypes = [C.c_void_p, C.POINTER(Options), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+
+
+def gang_layout(regions, n_devices):
+    """rt_debug_gang_layout (no device needed) -> (device of each bucket, its first pixel inside that device's shard, pixels of
+    each device's shard, padded shard length in pixels)."""
+    import numpy as np
+    arr = (Region * len(regions))(*[Region(*r) for r in regions])
+    dev = np.zeros(len(regions), dtype=np.uint32)
+    off = np.zeros(len(regions), dtype=np.uint32)
+    px = np.zeros(n_devices, dtype=np.uint64)
+    padded = C.c_uint64(0)
+    check(lib.rt_debug_gang_layout(arr, len(regions), n_devices, dev.ctypes.data, off.ctypes.data, px.ctypes.data, C.byref(padded)), "rt_debug_gang_layout")
+    return dev, off, px, int(padded.value)
+
+
+def shard_costs(scene_handle, options, regions, n_devices):
+    """rt_debug_shard_costs -> float64[n_devices]: the cost map's prediction for each device's shard (tests, arbitrary scale)."""
+    import numpy as np
+    arr = (Region * len(regions))(*[Region(*r) for r in regions])
+    cost = np.zeros(n_devices, dtype=np.float64)
+    o = Options(*options)
+    check(lib.rt_debug_shard_costs(scene_handle, C.byref(o), arr, len(regions), n_devices, cost.ctypes.data), "rt_debug_shard_costs")
+    return cost
 
 
 def wave_trace(path):

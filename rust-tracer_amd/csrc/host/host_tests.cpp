@@ -106,8 +106,33 @@ static void basic_rendering()                                     // render.rs:4
     CHECK(dw.write_count == 2);
 }
 
-int main()
+// `host_tests --hierarchy <scene file>`: prints the flattened arrays of Scene::from_file's automatically built hierarchy as
+// "<n items> <n groups> <crc32 of the item bytes> <crc32 of the bound bytes> <crc32 of the range bytes>" -- the Python mirror's
+// build_hierarchy must give the same five numbers (tests/test_host_and_abi.py).
+static uint32_t crc32_of(const void *data, size_t n)
 {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+        init = true;
+    }
+    uint32_t c = 0xFFFFFFFFu;
+    const uint8_t *p = static_cast<const uint8_t *>(data);
+    for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc == 3 && std::string(argv[1]) == "--hierarchy") {
+        try {
+            const FlatScene f = Scene::from_file(argv[2]).flatten();
+            printf("%zu %zu %u %u %u\n", f.items.size() / 4, f.ranges.size() / 2, crc32_of(f.items.data(), f.items.size() * sizeof(RFloat)),
+                   crc32_of(f.bounds.data(), f.bounds.size() * sizeof(RFloat)), crc32_of(f.ranges.data(), f.ranges.size() * sizeof(int32_t)));
+            return 0;
+        } catch (const std::exception &e) { fprintf(stderr, "%s\n", e.what()); return 2; }
+    }
     vec_basics();
     vec_default_and_normalize();
     sphere_default();

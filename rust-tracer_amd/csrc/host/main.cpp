@@ -44,8 +44,11 @@ const char *USAGE =
     "        --device <N>                    first GPU to render on [default: 0]\n"
     "        --devices <N>                   number of GPUs; buckets are dealt round-robin and gathered over RCCL [default: 1]\n"
     "        --gather <rccl|host>            N > 1: one RCCL gather to the first GPU (default), or per-GPU host copies\n"
-    "        --traversal <skip|flat>         hierarchy walk (default) or flat DFS scan; identical pixels\n"
+    "        --traversal <skip|flat>         hierarchy walk (default: the reference on every scene) or flat DFS scan (every item,\n"
+    "                                        no culling: the same pixels when every bound encloses its group and the eye is outside)\n"
     "        --level <N>                     pyramid level of the default scene [default: 8]\n"
+    "        --scene <file>                  render a sphere list instead (text: `cx cy cz r` per line, optional `light x y z` /\n"
+    "                                        `eye x y z` lines; *.f32: raw f32 quadruples); a bounding-sphere hierarchy is built for it\n"
     "        --stats                         print ray counters and device time on stderr\n"
     "        --strict-64                     panic like the reference unless width and height are multiples of 64\n\n"
     "ARGS:\n"
@@ -100,7 +103,7 @@ int main(int argc, char **argv)
     }
 
     std::string width = "1024", height = "1024", ssp = "1", numcores = "1", output;
-    std::string device = "0", devices = "1", traversal = "skip", level = "8", gather = "";
+    std::string device = "0", devices = "1", traversal = "skip", level = "8", gather = "", scene_file = "";
     bool have_output = false, stats = false, strict64 = false;
     auto take = [&](int &i, const std::string &arg, const char *name, std::string &dst) -> bool {
         const std::string flag = std::string("--") + name;
@@ -120,7 +123,7 @@ int main(int argc, char **argv)
         if (a == "--strict-64") { strict64 = true; continue; }
         if (take(i, a, "width", width) || take(i, a, "height", height) || take(i, a, "samples-per-pixel", ssp) ||
             take(i, a, "num-cores", numcores) || take(i, a, "device", device) || take(i, a, "devices", devices) ||
-            take(i, a, "traversal", traversal) || take(i, a, "level", level) || take(i, a, "gather", gather))
+            take(i, a, "traversal", traversal) || take(i, a, "level", level) || take(i, a, "gather", gather) || take(i, a, "scene", scene_file))
             continue;
         if (a.size() > 1 && a[0] == '-' && a != "-") {
             fprintf(stderr, "error: Found argument '%s' which wasn't expected, or isn't valid in this context\n\nFor more information try --help\n", a.c_str());
@@ -162,7 +165,8 @@ int main(int argc, char **argv)
 
     int status = 0;
     try {
-        const Scene scene = Scene::with_level(parse_or_panic<uint32_t>(level));          // Arc::new(Default::default())  main.rs:23
+        // Arc::new(Default::default())  main.rs:23 -- or, not in the reference, a sphere list with an automatically built hierarchy
+        const Scene scene = scene_file.empty() ? Scene::with_level(parse_or_panic<uint32_t>(level)) : Scene::from_file(scene_file);
         Backend be;
         be.strict_64 = strict64;
         be.want_stats = stats;
@@ -177,7 +181,15 @@ int main(int argc, char **argv)
         if (gather == "rccl" || (gather.empty() && ndev > 1)) {
             std::vector<int> ids;
             for (int d = 0; d < ndev; ++d) ids.push_back(dev0 + d);
-            be.gang = std::make_shared<DeviceGang>(scene, ids);
+            rt_status gst = RT_OK;
+            be.gang = DeviceGang::try_create(scene, ids, &gst);
+            if (!be.gang && gst == RT_ERR_UNSUPPORTED && gather.empty()) {
+                // no RCCL on this machine: the per-device host copies still work
+                fprintf(stderr, "rtrace: RCCL is not available (%s); gathering the buckets through host memory instead\n", rt_last_error_message());
+                for (int d = 0; d < ndev; ++d) be.devices.push_back(std::make_shared<DeviceScene>(scene, dev0 + d));
+            } else if (!be.gang) {
+                throw std::runtime_error(std::string("rt_gang_create: ") + rt_strerror(gst) + " -- " + rt_last_error_message());
+            }
         } else {
             for (int d = 0; d < ndev; ++d) be.devices.push_back(std::make_shared<DeviceScene>(scene, dev0 + d));
         }

@@ -28,15 +28,58 @@ DeviceScene::DeviceScene(const Scene &scene, int device)
           "rt_scene_create");
 }
 
-DeviceGang::DeviceGang(const Scene &scene, const std::vector<int> &devices)
+static rt_status gang_create(const Scene &scene, const std::vector<int> &devices, rt_gang **h)
 {
     const FlatScene f = scene.flatten();
     const RFloat light[3] = { scene.directional_light.x, scene.directional_light.y, scene.directional_light.z };
     const RFloat eye[3] = { scene.eye.x, scene.eye.y, scene.eye.z };
     const rt_precision prec = sizeof(RFloat) == 4 ? RT_F32 : RT_F64;
-    check(rt_gang_create(devices.data(), (int)devices.size(), prec, f.items.data(), (uint32_t)(f.items.size() / 4), light, eye, f.bounds.data(),
-                         reinterpret_cast<const rt_range *>(f.ranges.data()), (uint32_t)(f.ranges.size() / 2), &h_),
-          "rt_gang_create");
+    return rt_gang_create(devices.data(), (int)devices.size(), prec, f.items.data(), (uint32_t)(f.items.size() / 4), light, eye, f.bounds.data(),
+                          reinterpret_cast<const rt_range *>(f.ranges.data()), (uint32_t)(f.ranges.size() / 2), h);
+}
+
+DeviceGang::DeviceGang(const Scene &scene, const std::vector<int> &devices) { check(gang_create(scene, devices, &h_), "rt_gang_create"); }
+
+std::shared_ptr<DeviceGang> DeviceGang::try_create(const Scene &scene, const std::vector<int> &devices, rt_status *status)
+{
+    rt_gang *h = nullptr;
+    *status = gang_create(scene, devices, &h);
+    return *status == RT_OK ? std::make_shared<DeviceGang>(h) : nullptr;
+}
+
+// RGBA -> RGB for n pixels (alpha dropped, render.rs:392-396).  The SSSE3 body moves 4 pixels per shuffle.
+__attribute__((target("ssse3"))) static void rgba_to_rgb_ssse3(const uint8_t *b, uint8_t *w, size_t n)
+{
+    typedef char v16 __attribute__((vector_size(16)));
+    const v16 mask = { 0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14, -1, -1, -1, -1 };
+    size_t i = 0;
+    for (; i + 8 <= n; i += 4, b += 16, w += 12) {            // the 16-byte store writes 4 bytes past the 12 it means: keep a margin
+        v16 v;
+        memcpy(&v, b, 16);
+        v = __builtin_ia32_pshufb128(v, mask);
+        memcpy(w, &v, 16);
+    }
+    for (; i < n; ++i, b += 4, w += 3) { w[0] = b[0]; w[1] = b[1]; w[2] = b[2]; }
+}
+
+static void rgba_to_rgb(const uint8_t *b, uint8_t *w, size_t n)
+{
+    static const bool ssse3 = __builtin_cpu_supports("ssse3");
+    if (ssse3) { rgba_to_rgb_ssse3(b, w, n); return; }
+    for (size_t i = 0; i < n; ++i, b += 4, w += 3) { w[0] = b[0]; w[1] = b[1]; w[2] = b[2]; }
+}
+
+void PPMStdoutRGBABufferWriter::blit_encoded(const RGBABuffer &b)
+{
+    const ImageRegion &r = b.region();
+    if (!width_ || !height_ || r.r > *width_ || r.t > *height_) throw std::runtime_error("assertion failed: self.reg.contains(&b.reg)");
+    const size_t bpp = rgb_ ? 3 : 1, pitch = (size_t)*width_ * bpp;
+    const uint8_t *src = b.data();
+    for (uint16_t y = r.b; y < r.t; ++y, src += (size_t)r.width() * 4) {
+        uint8_t *dst = encoded_.data() + (size_t)y * pitch + (size_t)r.l * bpp;
+        if (rgb_) rgba_to_rgb(src, dst, r.width());
+        else for (size_t i = 0; i < r.width(); ++i) dst[i] = (uint8_t)(((float)src[4 * i] + (float)src[4 * i + 1] + (float)src[4 * i + 2]) / 3.0f);      // render.rs:399
+    }
 }
 
 void PPMStdoutRGBABufferWriter::write_buffer_with_header()
@@ -50,17 +93,7 @@ void PPMStdoutRGBABufferWriter::write_buffer_with_header()
     }
     if (!width_ || !height_) throw std::runtime_error("begin() called");
     fprintf(out, "%s\n%u %u\n255\n", rgb_ ? "P6" : "P5", (unsigned)*width_, (unsigned)*height_);
-    const std::vector<uint8_t> &buf = image_->buffer();
-    const size_t n_px = buf.size() / RGBABuffer::components();
-    std::vector<uint8_t> line(n_px * (rgb_ ? 3 : 1));
-    const uint8_t *b = buf.data();
-    uint8_t *w = line.data();
-    if (rgb_) {
-        for (size_t i = 0; i < n_px; ++i, b += 4, w += 3) { w[0] = b[0]; w[1] = b[1]; w[2] = b[2]; }      // alpha dropped, render.rs:392-396
-    } else {
-        for (size_t i = 0; i < n_px; ++i, b += 4) w[i] = (uint8_t)(((float)b[0] + (float)b[1] + (float)b[2]) / 3.0f);      // render.rs:399
-    }
-    if (fwrite(line.data(), 1, line.size(), out) != line.size()) throw std::runtime_error("called `Result::unwrap()` on an `Err` value: write");
+    if (fwrite(encoded_.data(), 1, encoded_.size(), out) != encoded_.size()) throw std::runtime_error("called `Result::unwrap()` on an `Err` value: write");
     fflush(out);
     buffer_dirty_ = false;
 }
@@ -86,29 +119,62 @@ RenderStats Renderer::render(const RenderOptions &o, const Backend &be, RGBABuff
 
     const std::vector<ImageRegion> all = buckets(o);
     size_t count = all.size();
+    static_assert(sizeof(ImageRegion) == sizeof(rt_region), "ImageRegion is layout-compatible with rt_region");
     if (be.gang) {
-        // Several GPUs: the whole bucket list in one gang call (bucket i -> GPU i % N, one RCCL gather of the u8 shards to the
-        // root GPU, blit there); the writer still receives the frame bucket by bucket, like the channel's consumer loop.
-        static_assert(sizeof(ImageRegion) == sizeof(rt_region), "ImageRegion is layout-compatible with rt_region");
+        // Several GPUs: gang calls of at most 64 buckets per GPU (bucket i -> GPU i % N, one RCCL gather of the u8 shards to the
+        // root GPU, blit there -- straight into this pinned frame); after every call its buckets go to the writer, like the
+        // channel's consumer loop: a long render still delivers tiles while it runs (render.rs:301-307, 427-432).
         const rt_options gopts{ o.width, o.height, o.samples_per_pixel };
-        std::vector<uint8_t> frame((size_t)o.width * o.height * 4);
-        rt_stats st{};
-        check(rt_gang_render_frame(be.gang->handle(), &gopts, be.traversal, reinterpret_cast<const rt_region *>(all.data()), (uint32_t)all.size(),
-                                   frame.data(), be.want_stats ? &st : nullptr),
-              "rt_gang_render_frame");
+        const size_t frame_bytes = (size_t)o.width * o.height * 4;
+        void *pinned = nullptr;
+        check(rt_host_alloc(frame_bytes, &pinned), "rt_host_alloc");
+        struct Free { void *p; ~Free() { rt_host_free(p); } } free_frame{ pinned };
+        uint8_t *frame = static_cast<uint8_t *>(pinned);
+        int n_gpus = 1;
+        check(rt_gang_size(be.gang->handle(), &n_gpus), "rt_gang_size");
+        const size_t per_call = be.buckets_per_call ? be.buckets_per_call : kMaxBucketsPerCall * (size_t)n_gpus;
         RenderStats total;
-        total.primary = st.primary; total.hits = st.hits; total.shadow = st.shadow; total.occluded = st.occluded;
-        total.sphere_tests = st.sphere_tests; total.bound_tests = st.bound_tests; total.device_ms = st.device_ms;
         std::vector<uint8_t> tile;
-        for (const ImageRegion &r : all) {
-            tile.resize(r.area() * 4);
-            for (uint16_t y = r.b; y < r.t; ++y)
-                memcpy(tile.data() + (size_t)(y - r.b) * r.width() * 4, frame.data() + ((size_t)y * o.width + r.l) * 4, (size_t)r.width() * 4);
-            writer.write_rgba_buffer(RGBABuffer(r, tile.data()));
-            count -= 1;
+        for (size_t first = 0; first < all.size(); first += per_call) {
+            const size_t cnt = std::min(per_call, all.size() - first);
+            rt_stats st{};
+            check(rt_gang_render_frame(be.gang->handle(), &gopts, be.traversal, reinterpret_cast<const rt_region *>(all.data() + first), (uint32_t)cnt,
+                                       frame, be.want_stats ? &st : nullptr),
+                  "rt_gang_render_frame");
+            total.primary += st.primary; total.hits += st.hits; total.shadow += st.shadow; total.occluded += st.occluded;
+            total.sphere_tests += st.sphere_tests; total.bound_tests += st.bound_tests; total.device_ms += st.device_ms;
+            for (size_t i = first; i < first + cnt; ++i) {
+                const ImageRegion &r = all[i];
+                tile.resize(r.area() * 4);
+                for (uint16_t y = r.b; y < r.t; ++y)
+                    memcpy(tile.data() + (size_t)(y - r.b) * r.width() * 4, frame + ((size_t)y * o.width + r.l) * 4, (size_t)r.width() * 4);
+                writer.write_rgba_buffer(RGBABuffer(r, tile.data(), RGBABuffer::View{}));
+                count -= 1;
+            }
         }
         if (count != 0) throw std::runtime_error("We really should have processed all chunks here");
         return total;
+    }
+    if (be.devices.size() == 1 && !be.want_stats && be.buckets_per_call == 0) {
+        // One GPU, no counters: the whole bucket list in ONE streaming call.  The device renders batch after batch into pinned
+        // staging and the callback -- this thread, the channel's consumer (render.rs:301-307) -- receives each bucket as a view of
+        // that staging as soon as its batch is complete, while later batches are still rendering: no per-batch host call, no
+        // intermediate copies.  (The pool keeps its meaning for the paths below; here the producers are the GPU's workgroups.)
+        struct Ctx { RGBABufferWriter *writer; size_t delivered = 0; std::exception_ptr err; } ctx{ &writer, 0, nullptr };
+        const rt_options opts1{ o.width, o.height, o.samples_per_pixel };
+        check(rt_render_tiles_stream(be.devices[0]->handle(), &opts1, be.traversal, reinterpret_cast<const rt_region *>(all.data()), (uint32_t)all.size(),
+                                     [](void *user, uint32_t, const rt_region *region, const uint8_t *rgba) {
+                                         Ctx *c = static_cast<Ctx *>(user);
+                                         if (c->err) return;                       // a failing writer: keep draining, report at the end
+                                         try {
+                                             c->writer->write_rgba_buffer(RGBABuffer(ImageRegion{ region->l, region->t, region->r, region->b }, rgba, RGBABuffer::View{}));
+                                             c->delivered += 1;
+                                         } catch (...) { c->err = std::current_exception(); }
+                                     }, &ctx),
+              "rt_render_tiles_stream");
+        if (ctx.err) std::rethrow_exception(ctx.err);
+        if (ctx.delivered != all.size()) throw std::runtime_error("We really should have processed all chunks here");
+        return RenderStats{};
     }
     // Deal buckets round-robin over the devices, then cut each device's list into batches: one rt_render_tiles call
     // per batch (a launch per 64x64 bucket would leave 255 of 256 CUs idle).
@@ -139,7 +205,6 @@ RenderStats Renderer::render(const RenderOptions &o, const Backend &be, RGBABuff
         pool.execute([&, b] {
             std::exception_ptr err;
             try {
-                static_assert(sizeof(ImageRegion) == sizeof(rt_region), "ImageRegion is layout-compatible with rt_region");
                 size_t px = 0;
                 for (const ImageRegion &r : b.regs) px += r.area();
                 std::vector<uint8_t> rgba(px * 4);

@@ -36,26 +36,35 @@ struct ImageRegion {                                              // render.rs:4
 
 class RGBABuffer {                                                // render.rs:74-135
 public:
+    struct View {};                                               // tag: the buffer does not own its bytes
     explicit RGBABuffer(const ImageRegion &r) : buf_(r.area() * components(), 0), reg_(r) {}
     RGBABuffer(const ImageRegion &r, const uint8_t *src) : buf_(src, src + r.area() * components()), reg_(r) {}
+    // A bucket as the device delivered it (pinned staging of rt_render_tiles_stream): valid while the writer is being called with
+    // it, which is all the reference's consumer loop needs (render.rs:301-307 drops each buffer after write_rgba_buffer).
+    RGBABuffer(const ImageRegion &r, const uint8_t *src, View) : view_(src), reg_(r) {}
     static size_t components() { return 4; }
+    const uint8_t *data() const { return view_ ? view_ : buf_.data(); }
+    size_t size() const { return reg_.area() * components(); }
 
     void set_pixels_from_buffer(const RGBABuffer &b)              // render.rs:112-126
     {
         if (!reg_.contains(b.reg_)) throw std::runtime_error("assertion failed: self.reg.contains(&b.reg)");
+        if (view_) throw std::runtime_error("set_pixels_from_buffer on a view");
         const size_t w = (size_t)b.reg_.width() * components();
-        if (reg_ == b.reg_) { buf_ = b.buf_; return; }
+        const uint8_t *src = b.data();
+        if (reg_ == b.reg_) { buf_.assign(src, src + b.size()); return; }
         for (uint16_t y = b.reg_.b; y < b.reg_.t; ++y) {
             const size_t bl = reg_.buffer_offset(b.reg_.l, y) * components();
             const size_t their = b.reg_.buffer_offset(b.reg_.l, y) * components();
-            std::copy(b.buf_.begin() + their, b.buf_.begin() + their + w, buf_.begin() + bl);
+            std::copy(src + their, src + their + w, buf_.begin() + bl);
         }
     }
-    const std::vector<uint8_t> &buffer() const { return buf_; }
+    const std::vector<uint8_t> &buffer() const { return buf_; }   // owned buffers only
     const ImageRegion &region() const { return reg_; }
 
 private:
     std::vector<uint8_t> buf_;
+    const uint8_t *view_ = nullptr;
     ImageRegion reg_;
 };
 
@@ -81,11 +90,14 @@ public:
     void begin(uint16_t x, uint16_t y) override                   // render.rs:411-420
     {
         width_ = x; height_ = y;
-        image_.emplace(ImageRegion{ 0, y, x, 0 });
+        // The reference keeps the frame as an RGBABuffer and turns it into P6 / P5 bytes on every write of the file
+        // (render.rs:373-401).  Here the frame is kept in the file's own pixel format: a bucket is converted once, when it
+        // arrives (while the device is still rendering the next ones), and a write of the file is the header plus one write.
+        encoded_.assign((size_t)x * y * (rgb_ ? 3 : 1), 0);
     }
     void write_rgba_buffer(const RGBABuffer &buffer) override     // render.rs:422-433
     {
-        image_->set_pixels_from_buffer(buffer);
+        blit_encoded(buffer);                                     // set_pixels_from_buffer (render.rs:112-126) + the conversion of render.rs:392-399
         buffer_dirty_ = true;
         const auto now = std::chrono::steady_clock::now();
         if (out_.is_file && (!last_written_at_ || *last_written_at_ + std::chrono::seconds(1) <= now)) {
@@ -96,9 +108,10 @@ public:
     void write_buffer_with_header();                              // render.rs:359-407
 
 private:
+    void blit_encoded(const RGBABuffer &b);
     FileOrAnyWriter &out_;
     std::optional<uint16_t> width_, height_;
-    std::optional<RGBABuffer> image_;
+    std::vector<uint8_t> encoded_;                                // the frame as the file holds it: RGB (P6) or grey (P5), row-major
     bool rgb_;
     std::optional<std::chrono::steady_clock::time_point> last_written_at_;
     bool buffer_dirty_ = false;
@@ -121,6 +134,9 @@ private:
 class DeviceGang {
 public:
     DeviceGang(const Scene &scene, const std::vector<int> &devices);
+    // nullptr + *status when the gang cannot be created (RT_ERR_UNSUPPORTED: no RCCL on this machine)
+    static std::shared_ptr<DeviceGang> try_create(const Scene &scene, const std::vector<int> &devices, rt_status *status);
+    explicit DeviceGang(rt_gang *h) : h_(h) {}
     ~DeviceGang() { rt_gang_destroy(h_); }
     DeviceGang(const DeviceGang &) = delete;
     DeviceGang &operator=(const DeviceGang &) = delete;

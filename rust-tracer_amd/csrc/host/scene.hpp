@@ -2,9 +2,16 @@
 // owned on the host exactly as the reference does; flatten() turns the group tree into the DFS arrays the C ABI
 // consumes (items in traversal order + each group's bound and item range, pre-order).
 #pragma once
+#include <algorithm>
+#include <array>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <memory>
+#include <numeric>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "vec.hpp"
@@ -57,6 +64,20 @@ struct SphericalGroup {                                           // TypedGroup<
         return std::move(pyramid_recursive(level, origin, radius).group);
     }
 
+    // Bounding-sphere hierarchy for an ARBITRARY sphere list (not in the reference, whose only builder is `pyramid`):
+    // median splits along the longest axis of the centres until at most leaf_size spheres remain; a group's bound encloses its whole
+    // subtree (centre = box centre, radius = max(|c_i - centre| + r_i), inflated by 1e-4 so that it still encloses after rounding to
+    // RFloat).  The result is an ordinary TypedGroup tree.  Same arithmetic, in double, as scene.py's build_hierarchy: both hosts
+    // produce the same items, bounds and ranges bit for bit (tests/test_host_and_abi.py).
+    using Sphere4 = std::array<double, 4>;
+    static std::unique_ptr<SphericalGroup> from_spheres_auto(const std::vector<Sphere4> &sp, size_t leaf_size = 4)
+    {
+        if (sp.empty()) throw std::invalid_argument("build_hierarchy needs at least one sphere");
+        std::vector<size_t> idx(sp.size());
+        std::iota(idx.begin(), idx.end(), (size_t)0);
+        return build_auto(sp, idx, std::max<size_t>(1, leaf_size));
+    }
+
     // TypedGroup::count  group.rs:93-109 -> (num_groups, num_items)
     void count(size_t &ng, size_t &ni) const
     {
@@ -64,6 +85,47 @@ struct SphericalGroup {                                           // TypedGroup<
         for (const Pair &c : children) {
             if (c.is_group) c.group->count(ng, ni); else ni += 1;
         }
+    }
+
+private:
+    static std::unique_ptr<SphericalGroup> build_auto(const std::vector<Sphere4> &sp, std::vector<size_t> &idx, size_t leaf_size)
+    {
+        auto g = std::make_unique<SphericalGroup>();
+        double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 }, cmin[3] = { 1e300, 1e300, 1e300 }, cmax[3] = { -1e300, -1e300, -1e300 };
+        for (size_t i : idx)
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = std::min(lo[k], sp[i][k] - sp[i][3]); hi[k] = std::max(hi[k], sp[i][k] + sp[i][3]);
+                cmin[k] = std::min(cmin[k], sp[i][k]); cmax[k] = std::max(cmax[k], sp[i][k]);
+            }
+        const double c[3] = { (lo[0] + hi[0]) * 0.5, (lo[1] + hi[1]) * 0.5, (lo[2] + hi[2]) * 0.5 };
+        double rad = 0.0;
+        for (size_t i : idx) {
+            const double dx = sp[i][0] - c[0], dy = sp[i][1] - c[1], dz = sp[i][2] - c[2];
+            rad = std::max(rad, std::sqrt(dx * dx + dy * dy + dz * dz) + sp[i][3]);
+        }
+        rad = rad * (1.0 + 1e-4) + 1e-30;
+        g->bound.center = Vector{ (RFloat)c[0], (RFloat)c[1], (RFloat)c[2] };
+        g->bound.radius = (RFloat)rad;
+        if (idx.size() <= leaf_size) {
+            for (size_t i : idx) {
+                Pair p;
+                p.item = Sphere{ Vector{ (RFloat)sp[i][0], (RFloat)sp[i][1], (RFloat)sp[i][2] }, (RFloat)sp[i][3] };
+                g->children.push_back(std::move(p));
+            }
+            return g;
+        }
+        int axis = 0;                                             // first axis of the largest extent (numpy argmax)
+        for (int k = 1; k < 3; ++k) if (cmax[k] - cmin[k] > cmax[axis] - cmin[axis]) axis = k;
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return sp[a][axis] < sp[b][axis]; });
+        const size_t half = idx.size() / 2;
+        std::vector<size_t> first(idx.begin(), idx.begin() + half), second(idx.begin() + half, idx.end());
+        for (std::vector<size_t> *part : { &first, &second }) {
+            Pair p;
+            p.is_group = true;
+            p.group = build_auto(sp, *part, leaf_size);
+            g->children.push_back(std::move(p));
+        }
+        return g;
     }
 };
 
@@ -87,6 +149,57 @@ struct Scene {                                                    // render.rs:1
         return s;
     }
     static Scene default_scene() { return with_level(8); }
+
+    // A sphere list from a file, with an automatically built hierarchy (SphericalGroup::from_spheres_auto).  Text: one sphere per
+    // line `cx cy cz r`; optional lines `light x y z` (direction the light travels, normalised here like Scene::default does,
+    // render.rs:154-159) and `eye x y z`; `#` starts a comment.  A file whose name ends in .f32 holds raw little-endian f32
+    // quadruples instead.
+    static Scene from_file(const std::string &path, size_t leaf_size = 4)
+    {
+        std::vector<SphericalGroup::Sphere4> sp;
+        Vector light{ -1.0, -3.0, 2.0 }, eye{ 0.0, 0.0, -4.0 };
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) throw std::runtime_error("cannot open scene file " + path);
+        const bool raw = path.size() > 4 && path.compare(path.size() - 4, 4, ".f32") == 0;
+        if (raw) {
+            float q[4];
+            while (fread(q, sizeof(float), 4, f) == 4) sp.push_back({ (double)q[0], (double)q[1], (double)q[2], (double)q[3] });
+        } else {
+            char line[512];
+            size_t ln = 0;
+            while (fgets(line, sizeof line, f)) {
+                ++ln;
+                if (char *h = strchr(line, '#')) *h = '\0';
+                char *p = line;
+                while (*p == ' ' || *p == '\t') ++p;
+                if (*p == '\0' || *p == '\n' || *p == '\r') continue;
+                double v[4];
+                int n = 0;
+                const bool is_light = strncmp(p, "light", 5) == 0, is_eye = strncmp(p, "eye", 3) == 0;
+                if (is_light) p += 5; else if (is_eye) p += 3;
+                for (; n < 4; ++n) {
+                    char *end = nullptr;
+                    v[n] = strtod(p, &end);
+                    if (end == p) break;
+                    p = end;
+                }
+                if ((is_light || is_eye) ? n != 3 : n != 4) {
+                    fclose(f);
+                    throw std::runtime_error(path + ":" + std::to_string(ln) + ": expected `cx cy cz r`, `light x y z` or `eye x y z`");
+                }
+                if (is_light) light = Vector{ (RFloat)v[0], (RFloat)v[1], (RFloat)v[2] };
+                else if (is_eye) eye = Vector{ (RFloat)v[0], (RFloat)v[1], (RFloat)v[2] };
+                else sp.push_back({ v[0], v[1], v[2], v[3] });
+            }
+        }
+        fclose(f);
+        if (sp.empty()) throw std::runtime_error("scene file " + path + " holds no sphere");
+        Scene s;
+        s.group = SphericalGroup::from_spheres_auto(sp, leaf_size);
+        s.directional_light = light.normalized();
+        s.eye = eye;
+        return s;
+    }
 
     FlatScene flatten() const
     {

@@ -33,8 +33,8 @@ namespace {
 thread_local char g_err[512] = "";
 
 // Diagnostic controls (rt_debug.h): process-wide, -1 = default.  The library reads no environment variable.
-std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
-std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = { {0}, {0}, {0}, {0} };
+std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
+std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = { {0}, {0}, {0}, {0}, {0}, {0} };
 std::atomic<bool> g_trace_on{ false };
 std::mutex g_trace_mu;
 std::string g_trace_path;
@@ -136,6 +136,12 @@ struct rt_scene {
     // whoever finds no pass running becomes its leader and renders every request that is waiting at that moment.
     struct RegionReq { rt_options o; rt_traversal trav; rt_region region; uint8_t *out; rt_status st = RT_OK; bool taken = false, done = false; char err[256] = "";
                        std::condition_variable cv; };      // signalled when the request is done, or when its owner should lead
+    // Frame-ahead for rt_render_region (render.rs:283-294 calls it once per 64x64 bucket): the first request for a bucket of the
+    // scheduler's grid renders the WHOLE grid in one pass into pinned staging, and the following requests of that frame are a 16 KB
+    // copy each.  A bucket is handed out once per rendered frame: asking for one again means the caller has started its next frame,
+    // and the grid is rendered again -- every byte a caller receives was rendered for the frame it belongs to.
+    struct FrameAhead { rt_options o{}; rt_traversal trav = RT_TRAVERSAL_SKIP; uint8_t *h = nullptr; size_t cap = 0; std::vector<size_t> off;
+                        std::vector<rt_region> grid; std::vector<uint8_t> served; bool valid = false; std::mutex mu; } ahead;
     std::mutex comb_mu;
     std::vector<RegionReq *> comb_pending;
     int comb_leaders = 0;              // passes being led right now (<= kMaxRegionLeaders)
@@ -1083,10 +1089,11 @@ rt_status read_stats(rt_scene *s, Context *c, hipStream_t stream, rt_traversal t
         h.max_wave_cycles = std::max(h.max_wave_cycles, k.max_wave_cycles);
         h.max_wave_ref100mhz = std::max(h.max_wave_ref100mhz, k.max_wave_ref100mhz);
         h.wave_item_steps += k.wave_item_steps;
-        h.filter_pass += k.filter_pass; h.filter_violations += k.filter_violations;
+        h.filter_pass += k.filter_pass; h.filter_violations += k.filter_violations; h.primary_tests += k.primary_tests;
     }
     g_count[RT_DEBUG_COUNT_FILTER_PASS].fetch_add((long long)h.filter_pass, std::memory_order_relaxed);
     g_count[RT_DEBUG_COUNT_FILTER_VIOLATIONS].fetch_add((long long)h.filter_violations, std::memory_order_relaxed);
+    g_count[RT_DEBUG_COUNT_PRIMARY_TESTS].store((long long)h.primary_tests, std::memory_order_relaxed);
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     st->primary = h.primary; st->hits = h.hits; st->shadow = h.shadow; st->occluded = h.occluded;
@@ -1308,6 +1315,7 @@ rt_status rt_scene_destroy(rt_scene *s)
     if (s->d_cprim) (void)hipFree(s->d_cprim);
     if (s->d_cshad) (void)hipFree(s->d_cshad);
     for (void *p : { s->d_xprim, s->d_xshad, s->d_xcprim, s->d_xcshad, s->d_xown, s->d_fc }) if (p) (void)hipFree(p);
+    if (s->ahead.h) (void)rt_host_free(s->ahead.h);
     if (s->d_fprim) (void)hipFree(s->d_fprim);
     if (s->d_fprim_rr) (void)hipFree(s->d_fprim_rr);
     if (s->d_fshad) (void)hipFree(s->d_fshad);
@@ -1549,6 +1557,72 @@ rt_status rt_render_tiles(rt_scene *s, const rt_options *o, rt_traversal trav, c
     return render_tiles_host(s, o, trav, tiles, n, rgba_out, nullptr, stats, true);
 }
 
+
+// rt_render_tiles with delivery in completion order: the list is cut into batches that are ALL enqueued at once (kernels storing
+// into pinned staging), and each batch's buckets are handed to the callback as soon as that batch's event has fired -- while the
+// later batches are still rendering.  What render.rs:301-307 does with its channel, without serialising launches behind host calls.
+rt_status rt_render_tiles_stream(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n,
+                                 rt_tile_callback callback, void *user)
+{
+    if (!callback) { snprintf(g_err, sizeof g_err, "rt_render_tiles_stream: NULL callback"); return RT_ERR_INVALID_ARGUMENT; }
+    if (!check_common(s, o, tiles, n, tiles)) return RT_ERR_INVALID_ARGUMENT;
+    rt_status st = check_traversal(s, trav);
+    if (st != RT_OK) return st;
+    const bool flat2 = trav == RT_TRAVERSAL_FLAT;
+    // batches: at least kStreamBatch buckets (enough workgroups to fill the device), at most kStreamMaxBatches of them (each batch keeps
+    // a cached tile table on the device)
+    constexpr uint32_t kStreamBatch = 64, kStreamMaxBatches = 16;
+    const uint32_t per = std::max(kStreamBatch, (n + kStreamMaxBatches - 1) / kStreamMaxBatches), n_batches = (n + per - 1) / per;
+    struct Batch { std::vector<rt::TileDev> tab, tab16; uint64_t px = 0; uint32_t blocks = 0, blocks16 = 0; size_t byte_off = 0; };
+    std::vector<Batch> batches(n_batches);
+    size_t total_bytes = 0;
+    for (uint32_t k = 0; k < n_batches; ++k) {
+        Batch &b = batches[k];
+        const uint32_t first = k * per, cnt = std::min(per, n - first);
+        if ((st = build_tile_table(o, tiles + first, cnt, b.tab, &b.px, &b.blocks, flat2 ? rt::kFlatBlockW : rt::kBlockW, flat2 ? rt::kFlatBlockH : rt::kBlockH)) != RT_OK) return st;
+        if (flat2) { uint64_t px16 = 0; if ((st = build_tile_table(o, tiles + first, cnt, b.tab16, &px16, &b.blocks16)) != RT_OK) return st; }
+        b.byte_off = total_bytes;
+        total_bytes += (size_t)b.px * 4;
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    Context *c = nullptr;
+    if ((st = acquire(s, &c)) != RT_OK) return st;
+    Lease lease{ s, c };
+    if (c->h_out_cap < total_bytes) {
+        if (c->h_out) HIP_TRY(hipHostFree(c->h_out));
+        c->h_out = nullptr; c->h_out_cap = 0;
+        HIP_TRY(hipHostMalloc(&c->h_out, std::max(total_bytes, (size_t)1 << 20), hipHostMallocDefault));
+        c->h_out_cap = std::max(total_bytes, (size_t)1 << 20);
+    }
+    void *alias = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&alias, c->h_out, 0));
+    while (c->chunk_ev.size() < n_batches) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->chunk_ev.push_back(e);
+    }
+    auto drain = [&](rt_status code) { (void)hipStreamSynchronize(c->stream); (void)hipGetLastError(); return code; };   // nothing may still be writing the staging
+    for (uint32_t k = 0; k < n_batches; ++k) {
+        Batch &b = batches[k];
+        st = enqueue_pass(s, c, o, trav, b.tab, b.blocks, b.px, static_cast<uint8_t *>(alias) + b.byte_off, 0u, c->stream, false, flat2 ? &b.tab16 : nullptr,
+                          b.blocks16, true);
+        if (st != RT_OK) return drain(st);
+        hipError_t e = hipEventRecord(c->chunk_ev[k], c->stream);
+        if (e != hipSuccess) return drain(hip_fail(e, "hipEventRecord(stream batch)", __LINE__));
+    }
+    for (uint32_t k = 0; k < n_batches; ++k) {
+        hipError_t e = hipEventSynchronize(c->chunk_ev[k]);
+        if (e != hipSuccess) return drain(hip_fail(e, "hipEventSynchronize(stream batch)", __LINE__));
+        const uint32_t first = k * per, cnt = std::min(per, n - first);
+        size_t off = batches[k].byte_off;
+        for (uint32_t i = first; i < first + cnt; ++i) {
+            callback(user, i, &tiles[i], c->h_out + off);
+            off += (size_t)(tiles[i].r - tiles[i].l) * (tiles[i].t - tiles[i].b) * 4;
+        }
+    }
+    return RT_OK;
+}
+
 rt_status rt_host_alloc(size_t bytes, void **out)
 {
     if (!out || bytes == 0) { snprintf(g_err, sizeof g_err, "rt_host_alloc: NULL argument or 0 bytes"); return RT_ERR_INVALID_ARGUMENT; }
@@ -1705,10 +1779,64 @@ static void run_region_batch(rt_scene *s, const std::vector<rt_scene::RegionReq 
     for (rt_scene::RegionReq *r : batch) { r->st = st; snprintf(r->err, sizeof r->err, "%s", g_err); }
 }
 
+// rt_render_region through the scene's frame-ahead (rt_scene::FrameAhead).  false: the request is not a bucket of the scheduler's
+// grid (render.rs:273-298: 64x64, edge buckets clipped) or the frame is too large to keep -- the caller renders it on its own.
+constexpr unsigned kBucket = 64;
+constexpr size_t kFrameAheadMaxBytes = (size_t)1 << 28;
+static bool region_from_frame_ahead(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *region, uint8_t *out, rt_status *st)
+{
+    const unsigned w = o->width, h = o->height;
+    if (region->l % kBucket || region->b % kBucket || region->r != std::min<unsigned>(region->l + kBucket, w) ||
+        region->t != std::min<unsigned>(region->b + kBucket, h) || region->l >= w || region->b >= h)
+        return false;
+    const size_t frame_bytes = (size_t)w * h * 4;
+    if (frame_bytes > kFrameAheadMaxBytes || check_traversal(s, trav) != RT_OK) return false;
+    const unsigned nbx = (w + kBucket - 1) / kBucket, idx = (region->b / kBucket) * nbx + region->l / kBucket;
+    rt_scene::FrameAhead &a = s->ahead;
+    std::lock_guard<std::mutex> lk(a.mu);
+    const bool same = a.valid && a.trav == trav && a.o.width == o->width && a.o.height == o->height && a.o.samples_per_pixel == o->samples_per_pixel;
+    if (!same || a.served[idx]) {
+        if (!same) {
+            a.valid = false;
+            a.grid.clear(); a.off.clear();
+            size_t off = 0;
+            for (unsigned y = 0; y < h; y += kBucket)
+                for (unsigned x = 0; x < w; x += kBucket) {
+                    const rt_region r{ (uint16_t)x, (uint16_t)std::min(y + kBucket, h), (uint16_t)std::min(x + kBucket, w), (uint16_t)y };
+                    a.grid.push_back(r);
+                    a.off.push_back(off);
+                    off += (size_t)(r.r - r.l) * (r.t - r.b) * 4;
+                }
+            if (a.cap < frame_bytes) {
+                if (a.h) (void)rt_host_free(a.h);
+                a.h = nullptr; a.cap = 0;
+                void *p = nullptr;
+                if ((*st = rt_host_alloc(frame_bytes, &p)) != RT_OK) return true;
+                a.h = static_cast<uint8_t *>(p); a.cap = frame_bytes;
+            }
+            a.o = *o; a.trav = trav;
+        }
+        // the whole grid in one pass, the kernel storing into the pinned staging (rt_host_alloc'd memory is recognised by address)
+        *st = render_tiles_host(s, o, trav, a.grid.data(), (uint32_t)a.grid.size(), a.h, nullptr, nullptr, true);
+        if (*st != RT_OK) { a.valid = false; return true; }
+        a.served.assign(a.grid.size(), 0);
+        a.valid = true;
+        g_count[RT_DEBUG_COUNT_FRAME_AHEAD_PASSES].fetch_add(1, std::memory_order_relaxed);
+    }
+    memcpy(out, a.h + a.off[idx], (size_t)(region->r - region->l) * (region->t - region->b) * 4);
+    a.served[idx] = 1;
+    *st = RT_OK;
+    return true;
+}
+
 rt_status rt_render_region(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *region, uint8_t *rgba_out,
                            rt_stats *stats)
 {
     if (!check_common(s, o, region, 1, rgba_out)) return RT_ERR_INVALID_ARGUMENT;
+    if (!stats && knob(RT_DEBUG_FRAME_AHEAD) != 0) {
+        rt_status fst = RT_OK;
+        if (region_from_frame_ahead(s, o, trav, region, rgba_out, &fst)) return fst;
+    }
     if (stats || knob(RT_DEBUG_COALESCE) == 0) return render_tiles_host(s, o, trav, region, 1, rgba_out, &rgba_out, stats, false);
     // Group commit: the reference calls this from up to RTRACEMAXPROCS pool threads at once (render.rs:283-294), and one
     // 64x64 bucket per device pass would leave 255 of 256 CUs idle.  A caller that finds no pass running leads the next
@@ -1806,18 +1934,59 @@ static rt_status rccl_fail(ncclResult_t e, const char *what, int line)
 
 }  // namespace
 
+// Where bucket i of a frame goes when its buckets are dealt over nd devices: device i % nd in the caller's (the
+// scheduler's row-major, render.rs:273-298) order, tile-major inside the device's shard; shards padded to the longest one so the
+// gather moves equal counts.  Pure arithmetic (no device needed): rt_debug_gang_layout exposes it to the CPU tests, which hold it
+// against dist.shard_layout.
+struct GangLayout {
+    std::vector<std::vector<rt_region>> shard;      // per device: its buckets
+    std::vector<uint64_t> shard_px;                 // per device: pixels of its shard (before padding)
+    uint64_t max_px = 0;                            // padded shard length in pixels
+    std::vector<rt_region> gathered_regs;           // every bucket, in gathered order (device-major)
+    std::vector<uint32_t> gathered_off;             // its first pixel in the gathered [nd][max_px] buffer
+    std::vector<uint32_t> device_of, px_offset;     // per input bucket: its device and its first pixel inside that device's shard
+};
+
+static void gang_layout(const rt_region *tiles, uint32_t n, size_t nd, GangLayout &L)
+{
+    L = GangLayout{};
+    L.shard.resize(nd); L.shard_px.assign(nd, 0); L.device_of.resize(n); L.px_offset.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const size_t d = i % nd;
+        L.device_of[i] = (uint32_t)d;
+        L.px_offset[i] = (uint32_t)L.shard_px[d];
+        L.shard[d].push_back(tiles[i]);
+        L.shard_px[d] += (uint64_t)(tiles[i].r - tiles[i].l) * (tiles[i].t - tiles[i].b);
+    }
+    for (size_t d = 0; d < nd; ++d) L.max_px = std::max(L.max_px, L.shard_px[d]);
+    for (size_t d = 0; d < nd; ++d) {
+        uint64_t px = 0;
+        for (const rt_region &t : L.shard[d]) {
+            L.gathered_regs.push_back(t);
+            L.gathered_off.push_back((uint32_t)(d * L.max_px + px));
+            px += (uint64_t)(t.r - t.l) * (t.t - t.b);
+        }
+    }
+}
+
 struct rt_gang {
     std::vector<int> devices;
     std::vector<rt_scene *> scenes;
     std::vector<ncclComm_t> comms;
-    std::vector<hipStream_t> streams;
-    std::vector<uint8_t *> d_shard;           // per device: its tile-major shard
+    std::vector<hipStream_t> streams;         // per device: renders
+    std::vector<hipStream_t> comm_streams;    // per device: the gather (and on the root the blit and the copy to the host) -- a frame's
+                                              // gather runs under the next frame's render (rt_gang_render_frames)
+    std::vector<hipEvent_t> ev_rendered[2], ev_gathered[2];      // per shard-buffer parity and device
+    std::vector<uint8_t *> d_shard[2];        // per device: its tile-major shard, double-buffered
     size_t shard_cap = 0;                     // bytes of each d_shard
-    uint8_t *d_gathered = nullptr;            // root: [n_devices][shard bytes]
+    uint8_t *d_gathered[2] = { nullptr, nullptr };   // root: [n_devices][shard bytes]
     size_t gathered_cap = 0;
-    uint8_t *d_frame = nullptr;               // root: row-major RGBA frame
+    uint8_t *d_frame = nullptr;               // root: row-major RGBA frame (pageable destinations)
     size_t frame_cap = 0;
-    std::mutex mu;                            // one frame at a time per gang
+    // the layout of the last tile list (a scheduler submits the same bucket list every frame)
+    std::vector<rt_region> last_tiles;
+    GangLayout layout;
+    std::mutex mu;                            // one call at a time per gang
 };
 
 rt_status rt_gang_create(const int *devices, int n_devices, rt_precision precision, const void *dfs_items, uint32_t n_items,
@@ -1848,7 +2017,17 @@ rt_status rt_gang_create(const int *devices, int n_devices, rt_precision precisi
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
         if (e != hipSuccess) return fail(hip_fail(e, "hipStreamCreate(gang)", __LINE__));
         g->streams.push_back(stream);
-        g->d_shard.push_back(nullptr);
+        hipStream_t cs = nullptr;
+        if ((e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking)) != hipSuccess) return fail(hip_fail(e, "hipStreamCreate(gang)", __LINE__));
+        g->comm_streams.push_back(cs);
+        for (int p = 0; p < 2; ++p) {
+            hipEvent_t a = nullptr, b2 = nullptr;
+            if ((e = hipEventCreateWithFlags(&a, hipEventDisableTiming)) != hipSuccess) return fail(hip_fail(e, "hipEventCreate(gang)", __LINE__));
+            g->ev_rendered[p].push_back(a);
+            if ((e = hipEventCreateWithFlags(&b2, hipEventDisableTiming)) != hipSuccess) return fail(hip_fail(e, "hipEventCreate(gang)", __LINE__));
+            g->ev_gathered[p].push_back(b2);
+            g->d_shard[p].push_back(nullptr);
+        }
     }
     g->comms.assign((size_t)n_devices, nullptr);
     ncclResult_t ne = r->CommInitAll(g->comms.data(), n_devices, g->devices.data());       // one communicator per device, this process
@@ -1864,10 +2043,15 @@ rt_status rt_gang_destroy(rt_gang *g)
         if (c) (void)rccl()->CommDestroy(c);
     for (size_t d = 0; d < g->devices.size(); ++d) {
         (void)hipSetDevice(g->devices[d]);
-        if (d < g->d_shard.size() && g->d_shard[d]) (void)hipFree(g->d_shard[d]);
+        for (int p = 0; p < 2; ++p) {
+            if (d < g->d_shard[p].size() && g->d_shard[p][d]) (void)hipFree(g->d_shard[p][d]);
+            if (d < g->ev_rendered[p].size() && g->ev_rendered[p][d]) (void)hipEventDestroy(g->ev_rendered[p][d]);
+            if (d < g->ev_gathered[p].size() && g->ev_gathered[p][d]) (void)hipEventDestroy(g->ev_gathered[p][d]);
+        }
         if (d < g->streams.size() && g->streams[d]) (void)hipStreamDestroy(g->streams[d]);
+        if (d < g->comm_streams.size() && g->comm_streams[d]) (void)hipStreamDestroy(g->comm_streams[d]);
         if (d == 0) {
-            if (g->d_gathered) (void)hipFree(g->d_gathered);
+            for (int p = 0; p < 2; ++p) if (g->d_gathered[p]) (void)hipFree(g->d_gathered[p]);
             if (g->d_frame) (void)hipFree(g->d_frame);
         }
     }
@@ -1883,6 +2067,134 @@ rt_status rt_gang_size(const rt_gang *g, int *n_devices)
     return RT_OK;
 }
 
+// The gang's frames: `k` frames of the same tile list, frame f to frames_host[f].  Per device a render stream and a communication
+// stream: render(f) -> [event] -> gather(f) on the communication streams -> blit(f) (+ copy to the host) on the root's, while
+// render(f + 1) already runs into the other shard buffer (it waits for gather(f - 1), the last reader of that buffer).
+static rt_status gang_sync_all(rt_gang *g)
+{
+    for (size_t d = 0; d < g->devices.size(); ++d) {
+        (void)hipSetDevice(g->devices[d]);
+        (void)hipStreamSynchronize(g->streams[d]);
+        (void)hipStreamSynchronize(g->comm_streams[d]);
+    }
+    (void)hipGetLastError();
+    return RT_OK;
+}
+
+static rt_status gang_render(rt_gang *g, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n, uint8_t *const *frames_host,
+                             uint32_t k, rt_stats *stats)
+{
+    Rccl *r = rccl();
+    const size_t nd = g->devices.size();
+    // the layout of this tile list (cached: a scheduler submits the same list every frame)
+    bool new_list = false;
+    if (g->last_tiles.size() != n || memcmp(g->last_tiles.data(), tiles, sizeof(rt_region) * n) != 0) {
+        gang_layout(tiles, n, nd, g->layout);
+        g->last_tiles.assign(tiles, tiles + n);
+        new_list = true;
+    }
+    const GangLayout &L = g->layout;
+    if (L.max_px * nd > 0xFFFFFFFFull) { snprintf(g_err, sizeof g_err, "rt_gang_render_frame: tile list too large for one pass"); return RT_ERR_INVALID_ARGUMENT; }
+    const size_t shard_bytes = (size_t)L.max_px * 4, frame_bytes = (size_t)o->width * o->height * 4;
+    // buffers
+    if (g->shard_cap < shard_bytes) {
+        for (size_t d = 0; d < nd; ++d) {
+            HIP_TRY(hipSetDevice(g->devices[d]));
+            for (int p = 0; p < 2; ++p) {
+                if (g->d_shard[p][d]) HIP_TRY(hipFree(g->d_shard[p][d]));
+                g->d_shard[p][d] = nullptr;
+                HIP_TRY(hipMalloc(&g->d_shard[p][d], shard_bytes));
+                HIP_TRY(hipMemset(g->d_shard[p][d], 0, shard_bytes));          // the padding behind a short shard travels too
+            }
+        }
+        g->shard_cap = shard_bytes;
+    }
+    HIP_TRY(hipSetDevice(g->devices[0]));
+    if (g->gathered_cap < shard_bytes * nd) {
+        for (int p = 0; p < 2; ++p) {
+            if (g->d_gathered[p]) HIP_TRY(hipFree(g->d_gathered[p]));
+            g->d_gathered[p] = nullptr;
+        }
+        g->gathered_cap = 0;
+        for (int p = 0; p < 2; ++p) HIP_TRY(hipMalloc(&g->d_gathered[p], shard_bytes * nd));
+        g->gathered_cap = shard_bytes * nd;
+    }
+    // destinations: memory this library pinned is written by the root's blit kernel itself (no device copy of the frame, no D2H)
+    std::vector<uint8_t *> alias(k, nullptr);
+    bool need_dev_frame = false;
+    for (uint32_t f = 0; f < k; ++f) {
+        const HostDest dest = classify_host_pointer(frames_host[f]);
+        if (dest.bad) { snprintf(g_err, sizeof g_err, "rt_gang_render_frame: the frame pointer is device memory"); return RT_ERR_INVALID_ARGUMENT; }
+        if (dest.pinned && dest.dev_alias && dest.room >= frame_bytes && knob(RT_DEBUG_HOST_COPY) != kCopyDirect) alias[f] = dest.dev_alias;
+        else need_dev_frame = true;
+    }
+    if (need_dev_frame && g->frame_cap < frame_bytes) {
+        if (g->d_frame) HIP_TRY(hipFree(g->d_frame));
+        g->d_frame = nullptr; g->frame_cap = 0;
+        HIP_TRY(hipMalloc(&g->d_frame, frame_bytes));
+        HIP_TRY(hipMemset(g->d_frame, 0, frame_bytes));        // pixels outside the listed buckets: zero, never stale device memory
+        g->frame_cap = frame_bytes;
+    } else if (need_dev_frame && new_list) {
+        HIP_TRY(hipMemsetAsync(g->d_frame, 0, g->frame_cap, g->comm_streams[0]));      // ... nor what an earlier tile list left there
+    }
+    rt_stats total{};
+    auto fail = [&](rt_status st) { gang_sync_all(g); return st; };      // nothing of this gang may still be running when an error returns
+    for (uint32_t f = 0; f < k; ++f) {
+        const int p = (int)(f & 1u);
+        // 1. every device renders its shard (asynchronous unless counters are wanted)
+        for (size_t d = 0; d < nd; ++d) {
+            hipError_t e = hipSetDevice(g->devices[d]);
+            if (e == hipSuccess && f >= 2) e = hipStreamWaitEvent(g->streams[d], g->ev_gathered[p][d], 0);      // the buffer's last reader
+            if (e != hipSuccess) return fail(hip_fail(e, "gang render", __LINE__));
+            if (!L.shard[d].empty()) {
+                rt_stats st{};
+                rt_status rs = rt_render_tiles_device(g->scenes[d], o, trav, L.shard[d].data(), (uint32_t)L.shard[d].size(), g->d_shard[p][d], g->streams[d],
+                                                      (stats && f == 0) ? &st : nullptr);
+                if (rs != RT_OK) return fail(rs);
+                if (stats && f == 0) {
+                    total.primary += st.primary; total.hits += st.hits; total.shadow += st.shadow; total.occluded += st.occluded;
+                    total.sphere_tests += st.sphere_tests; total.bound_tests += st.bound_tests; total.tests_executed += st.tests_executed;
+                    total.device_ms = std::max(total.device_ms, st.device_ms);
+                }
+            }
+            if ((e = hipEventRecord(g->ev_rendered[p][d], g->streams[d])) != hipSuccess) return fail(hip_fail(e, "gang render", __LINE__));
+            if ((e = hipStreamWaitEvent(g->comm_streams[d], g->ev_rendered[p][d], 0)) != hipSuccess) return fail(hip_fail(e, "gang render", __LINE__));
+        }
+        // 2. the one collective on the data path: equal-length u8 shards to the root GPU
+        ncclResult_t ne = r->GroupStart();
+        if (ne != ncclSuccess) return fail(rccl_fail(ne, "ncclGroupStart", __LINE__));
+        for (size_t d = 0; d < nd; ++d) {
+            ne = r->Gather(g->d_shard[p][d], d == 0 ? g->d_gathered[p] : nullptr, shard_bytes, ncclUint8, 0, g->comms[d], g->comm_streams[d]);
+            if (ne != ncclSuccess) { (void)r->GroupEnd(); return fail(rccl_fail(ne, "ncclGather", __LINE__)); }
+        }
+        if ((ne = r->GroupEnd()) != ncclSuccess) return fail(rccl_fail(ne, "ncclGroupEnd", __LINE__));
+        for (size_t d = 0; d < nd; ++d) {
+            hipError_t e = hipSetDevice(g->devices[d]);
+            if (e == hipSuccess) e = hipEventRecord(g->ev_gathered[p][d], g->comm_streams[d]);
+            if (e != hipSuccess) return fail(hip_fail(e, "gang gather", __LINE__));
+        }
+        // 3. root: set_pixels_from_buffer for every bucket (render.rs:112-126, 422-424) -- straight into the caller's frame when it is pinned
+        hipError_t e = hipSetDevice(g->devices[0]);
+        if (e != hipSuccess) return fail(hip_fail(e, "gang blit", __LINE__));
+        uint8_t *target = alias[f] ? alias[f] : g->d_frame;
+        rt_status bs = rt_blit_tiles_device(g->scenes[0], o, L.gathered_regs.data(), (uint32_t)L.gathered_regs.size(), L.gathered_off.data(), g->d_gathered[p],
+                                            target, g->comm_streams[0]);
+        if (bs != RT_OK) return fail(bs);
+        if (!alias[f]) {
+            if ((e = hipMemcpyAsync(frames_host[f], g->d_frame, frame_bytes, hipMemcpyDeviceToHost, g->comm_streams[0])) != hipSuccess)
+                return fail(hip_fail(e, "gang copy", __LINE__));
+        }
+    }
+    for (size_t d = 0; d < nd; ++d) {
+        hipError_t e = hipSetDevice(g->devices[d]);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->streams[d]);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->comm_streams[d]);
+        if (e != hipSuccess) return fail(hip_fail(e, "gang synchronize", __LINE__));
+    }
+    if (stats) *stats = total;
+    return RT_OK;
+}
+
 rt_status rt_gang_render_frame(rt_gang *g, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n,
                                uint8_t *frame_rgba_host, rt_stats *stats)
 {
@@ -1892,88 +2204,61 @@ rt_status rt_gang_render_frame(rt_gang *g, const rt_options *o, rt_traversal tra
     }
     if (rt_tiles_rgba_bytes(tiles, n) == 0) { snprintf(g_err, sizeof g_err, "rt_gang_render_frame: empty region in the tile list"); return RT_ERR_INVALID_REGION; }
     std::lock_guard<std::mutex> lk(g->mu);
-    Rccl *r = rccl();
-    const size_t nd = g->devices.size();
-    // bucket i -> device i % N in the caller's (the scheduler's row-major, render.rs:273-298) order; shards padded to equal length
-    std::vector<std::vector<rt_region>> shard(nd);
-    std::vector<rt_region> gathered_regs;
-    std::vector<uint32_t> gathered_off;
-    std::vector<uint64_t> shard_px(nd, 0);
-    for (uint32_t i = 0; i < n; ++i) shard[i % nd].push_back(tiles[i]);
-    uint64_t max_px = 0;
-    for (size_t d = 0; d < nd; ++d) {
-        for (const rt_region &t : shard[d]) shard_px[d] += (uint64_t)(t.r - t.l) * (t.t - t.b);
-        max_px = std::max(max_px, shard_px[d]);
+    return gang_render(g, o, trav, tiles, n, &frame_rgba_host, 1, stats);
+}
+
+rt_status rt_gang_render_frames(rt_gang *g, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n,
+                                uint8_t *const *frames_rgba_host, uint32_t n_frames, rt_stats *stats)
+{
+    if (!g || !frames_rgba_host || n_frames == 0 || !check_common(g->scenes.empty() ? nullptr : g->scenes[0], o, tiles, n, frames_rgba_host[0])) {
+        if (!g || !frames_rgba_host || n_frames == 0) snprintf(g_err, sizeof g_err, "rt_gang_render_frames: NULL argument or no frames");
+        return RT_ERR_INVALID_ARGUMENT;
     }
-    if (max_px * nd > 0xFFFFFFFFull) { snprintf(g_err, sizeof g_err, "rt_gang_render_frame: tile list too large for one pass"); return RT_ERR_INVALID_ARGUMENT; }
-    for (size_t d = 0; d < nd; ++d) {
-        uint64_t px = 0;
-        for (const rt_region &t : shard[d]) {
-            gathered_regs.push_back(t);
-            gathered_off.push_back((uint32_t)(d * max_px + px));
-            px += (uint64_t)(t.r - t.l) * (t.t - t.b);
-        }
+    for (uint32_t f = 0; f < n_frames; ++f)
+        if (!frames_rgba_host[f]) { snprintf(g_err, sizeof g_err, "rt_gang_render_frames: frame %u is NULL", f); return RT_ERR_INVALID_ARGUMENT; }
+    if (rt_tiles_rgba_bytes(tiles, n) == 0) { snprintf(g_err, sizeof g_err, "rt_gang_render_frames: empty region in the tile list"); return RT_ERR_INVALID_REGION; }
+    std::lock_guard<std::mutex> lk(g->mu);
+    return gang_render(g, o, trav, tiles, n, frames_rgba_host, n_frames, stats);
+}
+
+// Test infrastructure (rt_debug.h): the gang's sharding arithmetic without a device.
+rt_status rt_debug_gang_layout(const rt_region *tiles, uint32_t n, uint32_t n_devices, uint32_t *device_of, uint32_t *px_offset, uint64_t *shard_px,
+                               uint64_t *padded_px)
+{
+    if (!tiles || n == 0 || n_devices == 0 || !device_of || !px_offset || !shard_px || !padded_px) {
+        snprintf(g_err, sizeof g_err, "rt_debug_gang_layout: NULL argument");
+        return RT_ERR_INVALID_ARGUMENT;
     }
-    const size_t shard_bytes = (size_t)max_px * 4, frame_bytes = (size_t)o->width * o->height * 4;
-    // buffers
-    for (size_t d = 0; d < nd; ++d) {
-        HIP_TRY(hipSetDevice(g->devices[d]));
-        if (g->shard_cap < shard_bytes || !g->d_shard[d]) {
-            if (g->d_shard[d]) HIP_TRY(hipFree(g->d_shard[d]));
-            g->d_shard[d] = nullptr;
-            HIP_TRY(hipMalloc(&g->d_shard[d], shard_bytes));
-        }
+    GangLayout L;
+    gang_layout(tiles, n, n_devices, L);
+    memcpy(device_of, L.device_of.data(), sizeof(uint32_t) * n);
+    memcpy(px_offset, L.px_offset.data(), sizeof(uint32_t) * n);
+    memcpy(shard_px, L.shard_px.data(), sizeof(uint64_t) * n_devices);
+    *padded_px = L.max_px;
+    return RT_OK;
+}
+
+// Test infrastructure (rt_debug.h): what the scene's cost map (tests per primary ray, its shadow ray included) predicts for the
+// shards of a frame dealt over n_devices: cost[d] = sum over device d's buckets of the map's value under every 4th pixel x 16.
+rt_status rt_debug_shard_costs(rt_scene *s, const rt_options *o, const rt_region *tiles, uint32_t n, uint32_t n_devices, double *cost)
+{
+    if (!s || !o || !tiles || !cost || n_devices == 0) { snprintf(g_err, sizeof g_err, "rt_debug_shard_costs: NULL argument"); return RT_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipSetDevice(s->device));
+    const std::vector<uint32_t> *map = cost_map_of(s);
+    if (!map) { snprintf(g_err, sizeof g_err, "rt_debug_shard_costs: the scene has no cost map (no hierarchy)"); return RT_ERR_UNSUPPORTED; }
+    constexpr int R = (int)kCostRes;
+    const unsigned w = o->width, h = o->height;
+    for (uint32_t d = 0; d < n_devices; ++d) cost[d] = 0.0;
+    for (uint32_t i = 0; i < n; ++i) {
+        double c = 0.0;
+        for (unsigned y = tiles[i].b; y < tiles[i].t; y += 4)
+            for (unsigned x = tiles[i].l; x < tiles[i].r; x += 4) {
+                const int X = std::clamp((int)((uint64_t)x * R / w), 0, R - 1);
+                const int Y = std::clamp((int)std::floor(((double)y - h / 2.0) * R / w + R / 2.0), 0, R - 1);
+                c += 16.0 * ((*map)[(size_t)Y * R + X] + kFixedBlockCost / 256.0);
+            }
+        cost[i % n_devices] += c;
     }
-    g->shard_cap = std::max(g->shard_cap, shard_bytes);
-    HIP_TRY(hipSetDevice(g->devices[0]));
-    if (g->gathered_cap < shard_bytes * nd) {
-        if (g->d_gathered) HIP_TRY(hipFree(g->d_gathered));
-        g->d_gathered = nullptr; g->gathered_cap = 0;
-        HIP_TRY(hipMalloc(&g->d_gathered, shard_bytes * nd));
-        g->gathered_cap = shard_bytes * nd;
-    }
-    if (g->frame_cap < frame_bytes) {
-        if (g->d_frame) HIP_TRY(hipFree(g->d_frame));
-        g->d_frame = nullptr; g->frame_cap = 0;
-        HIP_TRY(hipMalloc(&g->d_frame, frame_bytes));
-        g->frame_cap = frame_bytes;
-    }
-    // 1. every device renders its shard (asynchronous unless counters are wanted)
-    rt_stats total{};
-    for (size_t d = 0; d < nd; ++d) {
-        if (shard[d].empty()) continue;
-        rt_stats st{};
-        rt_status rs = rt_render_tiles_device(g->scenes[d], o, trav, shard[d].data(), (uint32_t)shard[d].size(), g->d_shard[d], g->streams[d],
-                                              stats ? &st : nullptr);
-        if (rs != RT_OK) {
-            for (size_t k = 0; k <= d; ++k) { (void)hipSetDevice(g->devices[k]); (void)hipStreamSynchronize(g->streams[k]); }
-            return rs;
-        }
-        if (stats) {
-            total.primary += st.primary; total.hits += st.hits; total.shadow += st.shadow; total.occluded += st.occluded;
-            total.sphere_tests += st.sphere_tests; total.bound_tests += st.bound_tests; total.tests_executed += st.tests_executed;
-            total.device_ms = std::max(total.device_ms, st.device_ms);
-        }
-    }
-    // 2. the one collective on the data path: equal-length u8 shards to the root GPU
-    RCCL_TRY(r->GroupStart());
-    for (size_t d = 0; d < nd; ++d) {
-        ncclResult_t e = r->Gather(g->d_shard[d], d == 0 ? g->d_gathered : nullptr, shard_bytes, ncclUint8, 0, g->comms[d], g->streams[d]);
-        if (e != ncclSuccess) { (void)r->GroupEnd(); return rccl_fail(e, "ncclGather", __LINE__); }
-    }
-    RCCL_TRY(r->GroupEnd());
-    // 3. root: set_pixels_from_buffer for every bucket (render.rs:112-126, 422-424), then the frame goes to the host
-    HIP_TRY(hipSetDevice(g->devices[0]));
-    rt_status bs = rt_blit_tiles_device(g->scenes[0], o, gathered_regs.data(), (uint32_t)gathered_regs.size(), gathered_off.data(), g->d_gathered,
-                                        g->d_frame, g->streams[0]);
-    if (bs != RT_OK) { (void)hipStreamSynchronize(g->streams[0]); return bs; }
-    HIP_TRY(hipSetDevice(g->devices[0]));
-    HIP_TRY(hipMemcpyAsync(frame_rgba_host, g->d_frame, frame_bytes, hipMemcpyDeviceToHost, g->streams[0]));
-    for (size_t d = 0; d < nd; ++d) {
-        HIP_TRY(hipSetDevice(g->devices[d]));
-        HIP_TRY(hipStreamSynchronize(g->streams[d]));
-    }
-    if (stats) *stats = total;
     return RT_OK;
 }
 

@@ -37,7 +37,9 @@ typedef enum rt_debug_key {
     RT_DEBUG_SKIP_RAYS = 12,     /* rays per lane of the f32 fused hierarchy walk: 1 = k_render_skip always; 2 = k_render_skip2 (two rays per lane on
                                     packed math, rt_skip2.hpp) wherever it exists (spp 1, 2, 4, 8; launches that do not count tests);
                                     default: the library's choice per workload (large spp-1 frames, large scenes) */
-    RT_DEBUG_KEYS = 13
+    RT_DEBUG_FRAME_AHEAD = 13,   /* 0: rt_render_region never serves a bucket from a whole-grid pass rendered ahead (every call its own device pass,
+                                    or merged with concurrent ones: RT_DEBUG_COALESCE).  Default 1 */
+    RT_DEBUG_KEYS = 14
 } rt_debug_key;
 
 /* value < 0 restores the default. */
@@ -49,7 +51,10 @@ typedef enum rt_debug_counter {
     RT_DEBUG_COUNT_REGION_PASSES = 1,   /* device passes they were rendered in */
     RT_DEBUG_COUNT_FILTER_PASS = 2,     /* f32 hierarchy walk, calls that return rt_stats: per-ray tests the filtered loops' bound lets through */
     RT_DEBUG_COUNT_FILTER_VIOLATIONS = 3,   /* ... and tests with a finite distance that the bound would have ruled out: must stay 0 */
-    RT_DEBUG_COUNTERS = 4
+    RT_DEBUG_COUNT_PRIMARY_TESTS = 4,   /* hierarchy walk: of the LAST call that returned rt_stats, the tests (items + bounds) made for primary rays
+                                           (the rest of sphere_tests + bound_tests were made for shadow rays); not cumulative */
+    RT_DEBUG_COUNT_FRAME_AHEAD_PASSES = 5,  /* whole-grid passes rendered for rt_render_region's frame-ahead */
+    RT_DEBUG_COUNTERS = 6
 } rt_debug_counter;
 long long rt_debug_count(int counter);
 
@@ -62,6 +67,14 @@ rt_status rt_debug_wave_trace(const char *path);
  * counts = { pairs with disc >= 0, pairs with bound >= 0, pairs with disc >= 0 but bound < 0 } for the primary filter, then the same
  * three for the shadow filter on rays from a point of each primary ray towards the light: counts[2] and counts[5] must be 0. */
 rt_status rt_debug_flat_filter_check(rt_scene *scene, uint32_t width, uint32_t height, uint32_t spp, unsigned long long counts[6]);
+
+/* Test infrastructure for the multi-GPU paths.  rt_debug_gang_layout: the sharding arithmetic of rt_gang_render_frame(s) without a
+ * device -- for bucket i its device (i % n_devices) and its first pixel inside that device's tile-major shard; per device the pixels
+ * of its shard; the padded shard length every device sends.  rt_debug_shard_costs: what the scene's cost map predicts for the shards
+ * (sum of tests per pixel under each device's buckets): cost[n_devices]. */
+rt_status rt_debug_gang_layout(const rt_region *tiles, uint32_t n_tiles, uint32_t n_devices, uint32_t *device_of, uint32_t *px_offset,
+                               uint64_t *shard_px, uint64_t *padded_px);
+rt_status rt_debug_shard_costs(rt_scene *scene, const rt_options *options, const rt_region *tiles, uint32_t n_tiles, uint32_t n_devices, double *cost);
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,7 @@ struct Counters {          // same meaning as the reference-side ray statistics
     // SKIP, f32, counting launches: per-ray tests the filtered loops' bound lets through / tests with a finite distance that
     // the bound would have ruled out (must be 0: rt_debug_count(RT_DEBUG_COUNT_FILTER_VIOLATIONS))
     unsigned long long filter_pass, filter_violations;
+    unsigned long long primary_tests;                         // SKIP: the part of sphere_tests + bound_tests made for primary rays
 };
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned v)

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     V3<T> g = { T(0.0), T(0.0), T(0.0) };
     T alpha = T(0.0);
     unsigned c_hits = 0, c_shadow = 0, c_occ = 0, c_items = 0, c_bounds = 0, c_steps = 0, c_isteps = 0;
-    [[maybe_unused]] unsigned c_fpass = 0, c_fviol = 0;
+    [[maybe_unused]] unsigned c_fpass = 0, c_fviol = 0, c_ptotal = 0;
 
     const unsigned ss_first = SPLIT ? sample / spp : 0u, ss_last = SPLIT ? ss_first + 1 : spp;
     for (unsigned ssx = ss_first; ssx < ss_last; ++ssx) {
@@ -381,6 +381,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             V3<T> dir = { xres - half_w, (fh - yres) - half_h, fw };
             dir = normalized(dir);
 
+            [[maybe_unused]] const unsigned t_before = c_items + c_bounds;
             // ---------------- primary ray: s.group.intersect(&mut h, r)  render.rs:188-189 ----------------
             T best = inf<T>();
             unsigned best_item = 0;
@@ -444,6 +445,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             }
             }
 
+            if (COUNT) c_ptotal += c_items + c_bounds - t_before;      // tests of this sample's primary ray
             // ---------------- shade  render.rs:190-199 ----------------
             bool need_shadow = false;
             T gdot = T(0.0);
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
         const unsigned long long prim = wave_sum(inside ? (SPLIT ? 1u : spp * spp) : 0u);
         const unsigned long long hits = wave_sum(c_hits), sh = wave_sum(c_shadow), oc = wave_sum(c_occ);
         const unsigned long long its = wave_sum(c_items), bds = wave_sum(c_bounds);
-        const unsigned long long fpass = wave_sum(c_fpass), fviol = wave_sum(c_fviol);
+        const unsigned long long fpass = wave_sum(c_fpass), fviol = wave_sum(c_fviol), ptot = wave_sum(c_ptotal);
         if (lane == 0) {
             atomicAdd(&stripe->primary, prim);
             atomicAdd(&stripe->hits, hits);
@@ -603,6 +605,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             atomicAdd(&stripe->bound_tests, bds);
             atomicAdd(&stripe->wave_steps, (unsigned long long)c_steps);
             atomicAdd(&stripe->wave_item_steps, (unsigned long long)c_isteps);
+            atomicAdd(&stripe->primary_tests, ptot);
             if (fpass) atomicAdd(&stripe->filter_pass, fpass);
             if (fviol) atomicAdd(&stripe->filter_violations, fviol);
             atomicMax(&stripe->max_wave_steps, (unsigned long long)c_steps);

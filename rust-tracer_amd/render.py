@@ -147,8 +147,13 @@ class Renderer:
     def render_region(o, scene, buf, device=0, traversal=None):
         """Renderer::render_region(o, scene, buf) render.rs:218 -- fills buf for buf.region() on the GPU.
         traversal: None = the reference's hierarchy walk when the scene has bounds (else the flat scan)."""
-        _, stats = scene.device(device).render_region(tuple(o), tuple(buf.region()), traversal, want_stats=True,
-                                                      out=buf.buf.reshape(-1))
+        # straight into the RGBABuffer's storage when that is one contiguous block; a buffer that wraps a strided view (a
+        # sub-rectangle of a frame, say) is filled through a temporary -- reshape(-1) of such a view would be a silent copy
+        direct = buf.buf.dtype == np.uint8 and buf.buf.flags.c_contiguous
+        data, stats = scene.device(device).render_region(tuple(o), tuple(buf.region()), traversal, want_stats=True,
+                                                         out=buf.buf.reshape(-1) if direct else None)
+        if not direct:
+            buf.buf[...] = data.reshape(buf.buf.shape)
         return stats
 
     @staticmethod

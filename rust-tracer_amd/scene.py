@@ -190,7 +190,8 @@ class DeviceScene:
 
     def render_tiles(self, options, regions, traversal=None, want_stats=True, out=None):
         """rt_render_tiles: regions = [(l, t, r, b), ...] -> (uint8[total_px*4] tile-major, stats dict | None).
-        out: optional uint8 array to render into (e.g. capi.HostBuffer(n).array: pinned, written by the kernel directly)."""
+        out: optional uint8 array to render into.  Pinned memory is written by the kernel directly: keep the allocation in a
+        variable while its array is in use -- `hb = capi.HostBuffer(n); dev.render_tiles(..., out=hb.array)`."""
         traversal = self.default_traversal() if traversal is None else traversal
         arr = regions if isinstance(regions, C.Array) else self._regions(regions)
         nbytes = capi.lib.rt_tiles_rgba_bytes(arr, len(arr))
@@ -210,13 +211,39 @@ class DeviceScene:
         traversal = self.default_traversal() if traversal is None else traversal
         l, t, r, b = region
         reg = capi.Region(l, t, r, b)
+        nbytes = (t - b) * (r - l) * 4
         if out is None:
-            out = np.empty((t - b) * (r - l) * 4, dtype=np.uint8)
+            out = np.empty(nbytes, dtype=np.uint8)
+        elif out.dtype != np.uint8 or not out.flags.c_contiguous or out.size < nbytes:
+            raise ValueError("out must be a contiguous uint8 array of at least %d bytes" % nbytes)
         st = capi.Stats()
         o = capi.Options(*options)
         rc = capi.lib.rt_render_region(self._h, C.byref(o), traversal, C.byref(reg), out.ctypes.data, C.byref(st) if want_stats else None)
         capi.check(rc, "rt_render_region")
-        return out.reshape(t - b, r - l, 4), (st.as_dict() if want_stats else None)
+        return out.reshape(-1)[:nbytes].reshape(t - b, r - l, 4), (st.as_dict() if want_stats else None)
+
+    def render_tiles_stream(self, options, regions, on_tile, traversal=None):
+        """rt_render_tiles_stream: on_tile(index, (l, t, r, b), uint8[h, w, 4] view valid during the call) for every bucket, in
+        completion order, while later batches are still rendering (the reference's channel consumer, render.rs:301-307)."""
+        traversal = self.default_traversal() if traversal is None else traversal
+        arr = regions if isinstance(regions, C.Array) else self._regions(regions)
+        err = []
+
+        def cb(_user, index, region, rgba):
+            if err:
+                return
+            try:
+                reg = region.contents
+                h, w = reg.t - reg.b, reg.r - reg.l
+                on_tile(int(index), (reg.l, reg.t, reg.r, reg.b), np.ctypeslib.as_array(rgba, shape=(h * w * 4,)).reshape(h, w, 4))
+            except BaseException as e:      # noqa: BLE001  (must not unwind through the C frames)
+                err.append(e)
+
+        o = capi.Options(*options)
+        rc = capi.lib.rt_render_tiles_stream(self._h, C.byref(o), traversal, arr, len(arr), capi.TILE_CALLBACK(cb), None)
+        if err:
+            raise err[0]
+        capi.check(rc, "rt_render_tiles_stream")
 
     def default_traversal(self):
         """The reference's hierarchy walk whenever the scene has bounds; the flat scan otherwise."""
@@ -285,6 +312,23 @@ class Gang:
         rc = capi.lib.rt_gang_render_frame(self._h, C.byref(o), traversal, arr, len(arr), out.ctypes.data, C.byref(st) if want_stats else None)
         capi.check(rc, "rt_gang_render_frame")
         return out.reshape(o.height, o.width, 4), (st.as_dict() if want_stats else None)
+
+    def render_frames(self, options, regions, n_frames, traversal=capi.RT_TRAVERSAL_SKIP, want_stats=False, out=None):
+        """rt_gang_render_frames -> (list of n_frames uint8[h, w, 4] frames, stats dict | None): frame f's gather runs under the
+        render of frame f + 1.  out: optional list of contiguous uint8 arrays (pinned ones are written by the root GPU directly)."""
+        arr = regions if isinstance(regions, C.Array) else DeviceScene._regions(regions)
+        o = capi.Options(*options)
+        nbytes = o.width * o.height * 4
+        if out is None:
+            out = [np.zeros(nbytes, dtype=np.uint8) for _ in range(n_frames)]
+        for a in out:
+            if a.dtype != np.uint8 or not a.flags.c_contiguous or a.size < nbytes:
+                raise ValueError("every frame must be a contiguous uint8 array of at least %d bytes" % nbytes)
+        ptrs = (C.c_void_p * n_frames)(*[a.ctypes.data for a in out])
+        st = capi.Stats()
+        rc = capi.lib.rt_gang_render_frames(self._h, C.byref(o), traversal, arr, len(arr), ptrs, n_frames, C.byref(st) if want_stats else None)
+        capi.check(rc, "rt_gang_render_frames")
+        return [a.reshape(-1)[:nbytes].reshape(o.height, o.width, 4) for a in out], (st.as_dict() if want_stats else None)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Adds (or refreshes) the case `config5_100k_4096x4096_spp4` of oracle_vectors.json: BASELINE config 5 with EXACTLY 100,000 spheres
+(tests/scenes.py hundred_thousand_spheres, hierarchy built by scene.py build_hierarchy), 4096x4096, spp 4, rendered by the CPU
+oracle (pinned on the reference's image first, like every vector in that file).  Takes a while: 268 M primary rays on the host."""
+import json
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from rust_tracer_amd.scene import build_hierarchy  # noqa: E402  (host code only: no device is touched)
+from tests.scenes import hundred_thousand_spheres  # noqa: E402
+from tests.golden.make_oracle_vectors import tile_crcs  # noqa: E402
+
+
+def main():
+    w, h, spp = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (4096, 4096, 4)
+    items, bounds, ranges, _ = build_hierarchy(hundred_thousand_spheres())
+    o = oracle.Scene.from_ranges(items.astype(np.float64), bounds.astype(np.float64), ranges)
+    t0 = time.time()
+    frame, st, n = o.render(w, h, spp, nthreads=os.cpu_count() or 1, mode=oracle.MODE_HIERARCHY | oracle.MODE_ANYHIT_EXIT)
+    print("rendered in %.1f s" % (time.time() - t0), st)
+    name = "config5_100k_%dx%d_spp%d" % (w, h, spp)
+    case = {"name": name, "width": w, "height": h, "spp": spp, "buckets": n, "stats": st,
+            "frame_crc32": zlib.crc32(frame.tobytes()) & 0xFFFFFFFF, "tile_crc32": tile_crcs(frame), "scene": "hundred_thousand_spheres", "precision": "f32"}
+    path = os.path.join(HERE, "oracle_vectors.json")
+    d = json.load(open(path))
+    d["cases"] = [c for c in d["cases"] if c["name"] != name] + [case]
+    with open(path, "w") as f:
+        json.dump(d, f, indent=1)
+    print("wrote", name)
+
+
+if __name__ == "__main__":
+    main()

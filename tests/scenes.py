@@ -30,3 +30,11 @@ def random_nested_scene(seed, depth=3, fan=3, leaf_items=3, concentric=False):
     rec(depth, np.array([0.0, 0.0, 0.0]), 1.2)
     f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
     return f32(items), f32(bounds), np.asarray(ranges, dtype=np.int32)
+
+
+def hundred_thousand_spheres(seed=5, n=100000):
+    """BASELINE config 5's "100k spheres" as an arbitrary list: n spheres in a box in front of the default eye,
+    f32-representable values.  The hierarchy is built by the host (scene.py build_hierarchy / csrc/host/scene.hpp)."""
+    rng = np.random.default_rng(seed)
+    sp = np.concatenate([rng.uniform([-3, -2, 0], [3, 2, 6], (n, 3)), rng.uniform(0.01, 0.03, (n, 1))], axis=1)
+    return sp.astype(np.float32).astype(np.float64)

@@ -137,7 +137,7 @@ def test_bench_collective_path_checks_its_own_frame(multi):
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-collective", "--multi", multi, "--steps", "4",
-                        "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--no-flat", "--no-seam"], capture_output=True, text=True, env=env,
+                        "--warmup", "2", "--repeats", "2", "--min-timed-region", "0", "--no-cpu-baseline", "--no-flat", "--no-seam"], capture_output=True, text=True, env=env,
                        timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]

@@ -1,0 +1,218 @@
+"""The host-facing seam added in round 3, through the C ABI on an MI355X: delivery in completion order (rt_render_tiles_stream),
+the frame-ahead of rt_render_region, pipelined gang frames, pinned-buffer lifetime and the `--scene` path of the native host."""
+import gc
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+import rust_tracer_amd as rta
+from tests import util
+
+pytestmark = pytest.mark.gpu
+SKIP, FLAT = rta.RT_TRAVERSAL_SKIP, rta.RT_TRAVERSAL_FLAT
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bucket_list(w, h, spp=1):
+    return [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
+
+
+@pytest.mark.parametrize("size,trav", [((800, 600, 1), SKIP), ((333, 200, 2), SKIP), ((256, 192, 1), FLAT), ((2048, 1600, 1), SKIP)])
+def test_stream_call_delivers_every_bucket_once_with_the_reference_bytes(size, trav):
+    # rt_render_tiles_stream: batches enqueued at once, buckets handed to the callback batch by batch in list order
+    s, o = util.scene_pair_default()
+    w, h, spp = size
+    regs = bucket_list(w, h, spp)
+    ref, _, _ = o.render(w, h, spp, nthreads=os.cpu_count() or 1)
+    frame = np.zeros((h, w, 4), dtype=np.uint8)
+    seen = []
+
+    def on_tile(i, reg, px):
+        assert reg == regs[i]
+        l, t, r, b = reg
+        frame[b:t, l:r] = px
+        seen.append(i)
+
+    s.device().render_tiles_stream(size, regs, on_tile, trav)
+    assert seen == list(range(len(regs)))
+    np.testing.assert_array_equal(frame, ref)
+
+
+def test_stream_call_propagates_a_failing_consumer_and_bad_regions():
+    s, _ = util.scene_pair_default()
+    regs = bucket_list(256, 192)
+
+    def boom(i, reg, px):
+        if i == 3:
+            raise KeyError("writer failed")
+
+    with pytest.raises(KeyError):
+        s.device().render_tiles_stream((256, 192, 1), regs, boom, SKIP)
+    with pytest.raises(rta.RtError) as e:
+        s.device().render_tiles_stream((256, 192, 1), regs + [(0, 300, 64, 236)], lambda *a: None, SKIP)
+    assert e.value.status == rta.capi.RT_ERR_INVALID_REGION
+    # the context is usable afterwards
+    data, _ = s.device().render_tiles((256, 192, 1), regs, SKIP, want_stats=False)
+    assert data.size == 256 * 192 * 4
+
+
+def test_render_region_frame_ahead_serves_a_frame_from_one_pass():
+    # render.rs:283-294 calls render_region once per bucket.  From one thread that used to be one device pass per call; now the first
+    # call of a frame renders the whole bucket grid and the others are copies -- and a bucket is only handed out once per pass: asking
+    # for it again (the next frame) renders again.
+    s, o = util.scene_pair_default()
+    d = s.device()
+    w, h = 800, 600
+    regs = bucket_list(w, h)
+    ref, _, _ = o.render(w, h, 1, nthreads=os.cpu_count() or 1)
+    count = lambda: rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_FRAME_AHEAD_PASSES)
+    c0 = count()
+    for frame in range(3):
+        for (l, t, r, b) in regs:
+            got, _ = d.render_region((w, h, 1), (l, t, r, b), SKIP)
+            np.testing.assert_array_equal(got, ref[b:t, l:r])
+    assert count() - c0 == 3
+    # other options: a new grid; a region that is not a bucket of the grid: its own pass; with stats: the counting path
+    got, _ = d.render_region((w, h, 2), regs[7], SKIP)
+    ref2, _ = o.render_region(w, h, 2, *regs[7])
+    np.testing.assert_array_equal(got, ref2)
+    c1 = count()
+    got, _ = d.render_region((w, h, 1), (10, 90, 70, 30), SKIP)
+    np.testing.assert_array_equal(got, ref[30:90, 10:70])
+    got, st = d.render_region((w, h, 1), regs[0], SKIP, want_stats=True)
+    assert st["primary"] == 64 * 64
+    assert count() == c1
+    # switched off: every call its own pass
+    with rta.capi.debug(rta.capi.DEBUG_FRAME_AHEAD, 0):
+        got, _ = d.render_region((w, h, 1), regs[5], SKIP)
+        np.testing.assert_array_equal(got, ref[regs[5][3]:regs[5][1], regs[5][0]:regs[5][2]])
+    assert count() == c1
+
+
+def test_render_region_frame_ahead_under_concurrent_callers():
+    s, o = util.scene_pair_default()
+    d = s.device()
+    w, h = 512, 384
+    regs = bucket_list(w, h)
+    ref, _, _ = o.render(w, h, 1, nthreads=os.cpu_count() or 1)
+    out = {}
+    jobs = [(f, i) for f in range(4) for i in range(len(regs))]
+    nxt, lock = [0], threading.Lock()
+
+    def work():
+        while True:
+            with lock:
+                k = nxt[0]
+                nxt[0] += 1
+            if k >= len(jobs):
+                return
+            out[jobs[k]] = d.render_region((w, h, 1), regs[jobs[k][1]], SKIP)[0]
+
+    th = [threading.Thread(target=work) for _ in range(12)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for (f, i), got in out.items():
+        l, t, r, b = regs[i]
+        np.testing.assert_array_equal(got, ref[b:t, l:r])
+
+
+def test_render_region_validates_out_and_renderer_fills_strided_buffers():
+    s, o = util.scene_pair_default()
+    d = s.device()
+    with pytest.raises(ValueError):
+        d.render_region((128, 128, 1), (0, 64, 64, 0), SKIP, out=np.zeros(100, dtype=np.uint8))
+    with pytest.raises(ValueError):
+        d.render_region((128, 128, 1), (0, 64, 64, 0), SKIP, out=np.zeros(64 * 64 * 4, dtype=np.float32))
+    ref, _ = o.render_region(128, 128, 1, 0, 64, 64, 0)
+    # an RGBABuffer over a sub-rectangle of a frame (a strided view): filled through a temporary, not silently skipped
+    frame = np.zeros((128, 128, 4), dtype=np.uint8)
+    buf = rta.RGBABuffer(rta.ImageRegion(0, 64, 64, 0))
+    buf.buf = frame[0:64, 0:64]
+    assert not buf.buf.flags.c_contiguous
+    rta.Renderer.render_region(rta.RenderOptions(128, 128, 1), s, buf)
+    np.testing.assert_array_equal(frame[0:64, 0:64], ref)
+
+
+def test_a_temporary_host_buffer_lives_as_long_as_its_array():
+    s, o = util.scene_pair_default()
+    regs = bucket_list(320, 200)
+    ref, _, _ = o.render(320, 200, 1, nthreads=4)
+    data, _ = s.device().render_tiles((320, 200, 1), regs, SKIP, want_stats=False, out=rta.capi.HostBuffer(320 * 200 * 4).array)
+    gc.collect()
+    junk = [rta.capi.HostBuffer(320 * 200 * 4) for _ in range(4)]       # would reuse the freed range
+    for j in junk:
+        j.array[:] = 0xAB
+    np.testing.assert_array_equal(util.stitch((320, 200), regs, data), ref)
+
+
+def test_gang_pipelined_frames_one_rank():
+    # rt_gang_render_frames on a one-rank communicator (what a 1-GPU box can run): gather(f) under render(f + 1), double-buffered
+    # shards; pinned destinations are written by the root's blit kernel, pageable ones copied
+    s, o = util.scene_pair_default()
+    try:
+        g = rta.Gang(s, [0])
+    except rta.RtError as e:
+        if e.status == rta.capi.RT_ERR_UNSUPPORTED:
+            pytest.skip("no RCCL")
+        raise
+    w, h = 800, 600
+    regs = bucket_list(w, h)
+    ref, rst, _ = o.render(w, h, 1, nthreads=os.cpu_count() or 1)
+    frames, st = g.render_frames((w, h, 1), regs, 5, want_stats=True)
+    for f in frames:
+        np.testing.assert_array_equal(f, ref)
+    assert util.ray_stats(st) == util.ray_stats(rst)
+    pinned = [rta.capi.HostBuffer(w * h * 4) for _ in range(3)]
+    frames, _ = g.render_frames((w, h, 1), regs, 3, out=[p.array for p in pinned])
+    for f in frames:
+        np.testing.assert_array_equal(f, ref)
+    # a partial tile list leaves the other pixels of a fresh frame zero, never stale device memory
+    part, _ = g.render_frame((w, h, 1), regs[:7])
+    assert not part[64:].any() and np.array_equal(part[0:64, 0:448], ref[0:64, 0:448])
+    g.close()
+
+
+def test_rtrace_scene_file_with_an_automatically_built_hierarchy(tmp_path):
+    # SURVEY.md 8f.4 on the native host: `rtrace --scene <file>` builds the bounding-sphere hierarchy itself (csrc/host/scene.hpp);
+    # the oracle renders the Python mirror's hierarchy of the same list (both builders agree bit for bit: test_host_and_abi.py)
+    rng = np.random.default_rng(9)
+    n = 2000
+    sp = np.concatenate([rng.uniform([-2, -1.5, 0], [2, 1.5, 4], (n, 3)), rng.uniform(0.02, 0.12, (n, 1))], axis=1).astype(np.float32).astype(np.float64)
+    path = tmp_path / "spheres.txt"
+    with open(path, "w") as f:
+        f.write("eye 0.1 -0.2 -4.5\nlight -1 -2 1.5\n")
+        for q in sp:
+            f.write("%r %r %r %r\n" % tuple(float(v) for v in q))
+    out = str(tmp_path / "out.tga")
+    exe = os.path.join(ROOT, "rust-tracer_amd", "rtrace")
+    r = subprocess.run([exe, "--width=400", "--height=300", "--samples-per-pixel=2", "--scene=" + str(path), out], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    from rust_tracer_amd.scene import build_hierarchy
+    items, bounds, ranges, _ = build_hierarchy(sp)
+    o = oracle.Scene.from_ranges(items.astype(np.float64), bounds.astype(np.float64), ranges, (-1.0, -2.0, 1.5), (0.1, -0.2, -4.5))
+    img, st, _ = o.render(400, 300, 2, nthreads=os.cpu_count() or 1)
+    assert st["hits"] > 10000
+    ref = str(tmp_path / "ref.ppm")
+    oracle.write_ppm(ref, img)
+    assert open(out, "rb").read() == open(ref, "rb").read()
+
+
+@pytest.mark.parametrize("scale", [1.0 - 1.9e-3, 1.0 + 1.9e-3])
+def test_filter_bounds_hold_at_the_edges_of_the_accepted_light_length(scale):
+    # rt_scene_create accepts a light_unit whose squared length is within 2e-3 of 1; the filtered loops' shadow bounds carry that
+    # deviation (eta).  At both edges: the counting launch evaluates the bounds for every test it makes (violations are asserted 0
+    # by the autouse fixture) and the filtered assembly loops render the same bytes as the reference loops.
+    items, bounds, ranges = util.random_nested_scene(35, depth=3, fan=3, leaf_items=2, concentric=True)
+    light = rta.normalized((-1.0, -3.0, 2.0), rta.RT_F32).astype(np.float64) * np.sqrt(scale)
+    s = rta.Scene(items, light, (0.05, -0.1, -3.2), bounds, ranges, rta.RT_F32)
+    regs = bucket_list(192, 160, 2)
+    counted, st = s.device().render_tiles((192, 160, 2), regs, SKIP, want_stats=True)
+    assert st["shadow"] > 1000
+    for variant in (3, 7, 19, 23):
+        with rta.capi.debug(rta.capi.DEBUG_SKIP_VARIANT, variant):
+            plain, _ = s.device().render_tiles((192, 160, 2), regs, SKIP, want_stats=False)
+        np.testing.assert_array_equal(plain, counted)

@@ -231,3 +231,50 @@ def test_strict_64_and_writer_clock_on_the_host_mirror(tmp_path):
     assert (on_disk()[64:, 64:] == 0).all()
     w.close()                                                                                              # Drop writes the final image
     assert (on_disk()[64:, 64:] == fill[3]).all()
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (800, 600), (4096, 4096), (64, 64)])
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_native_gang_sharding_equals_the_python_shard_layout(size, world):
+    # rt_gang_render_frame(s) and dist.FrameSharder must deal a frame's buckets identically (bucket i -> GPU i % N, tile-major inside
+    # the shard, shards padded to the longest): the native side's arithmetic is a pure function (rt_debug_gang_layout, no device)
+    from rust_tracer_amd import dist
+    o = rta.RenderOptions(size[0], size[1], 1)
+    regs = [tuple(r) for r in rta.buckets(o)]
+    dev, off, px, padded = capi.gang_layout(regs, world)
+    bl, per_rank, shard_px = dist.shard_layout(o, world)
+    assert padded == shard_px
+    for r, (idx, offs, p) in enumerate(per_rank):
+        assert list(dev[idx]) == [r] * len(idx)
+        assert list(off[idx]) == offs
+        assert int(px[r]) == p
+    # the gathered table the root blits from
+    regions, offsets, _ = dist.gathered_tile_table(o, world)
+    mine = sorted(range(len(regs)), key=lambda i: (int(dev[i]), int(off[i])))
+    assert [regs[i] for i in mine] == regions
+    assert [int(dev[i]) * padded + int(off[i]) for i in mine] == [int(v) for v in offsets]
+
+
+def test_native_and_python_hierarchy_builders_agree_bit_for_bit(tmp_path):
+    # SURVEY.md 8f.4 on both hosts: `rtrace --scene <file>` (csrc/host/scene.hpp, Scene::from_file) and scene.py's build_hierarchy
+    # must produce the same items, bounds and ranges -- host_tests --hierarchy prints CRCs of the C++ side's flattened arrays
+    import subprocess
+    import zlib
+    rng = np.random.default_rng(77)
+    n = 5000
+    sp = np.concatenate([rng.uniform([-3, -2, 0], [3, 2, 6], (n, 3)), rng.uniform(0.01, 0.2, (n, 1))], axis=1).astype(np.float32).astype(np.float64)
+    path = tmp_path / "scene.txt"
+    with open(path, "w") as f:
+        f.write("# %d random spheres\nlight -1 -3 2\n" % n)
+        for s in sp:
+            f.write("%r %r %r %r\n" % tuple(float(v) for v in s))
+    exe = os.path.join(ROOT, "rust-tracer_amd", "host_tests")
+    out = subprocess.run([exe, "--hierarchy", str(path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    from rust_tracer_amd.scene import build_hierarchy
+    items, bounds, ranges, _ = build_hierarchy(sp)
+    want = "%d %d %d %d %d" % (items.shape[0], bounds.shape[0], zlib.crc32(items.tobytes()), zlib.crc32(bounds.tobytes()), zlib.crc32(ranges.tobytes()))
+    assert out.stdout.strip() == want
+    bad = tmp_path / "bad.txt"
+    bad.write_text("1 2 3\n")
+    assert subprocess.run([exe, "--hierarchy", str(bad)], capture_output=True, text=True, timeout=60).returncode == 2
