@@ -380,6 +380,7 @@ void filter_constants(rt_scene *s, const std::vector<rt::RawNode<T>> &raw, const
     fc.S = (rc + ro * (1.0 + 4.0 * eps)) * (1.0 + 1e-9);
     auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return std::nextafterf(f, INFINITY); };
     fc.a0 = up(11.0 * eps * fc.S + 1e-37);
+    fc.k1 = up((fc.eta + 10.2 * eps) * (1.0 + fc.eta) * (1.0 + 12.0 * eps));
     float ro2 = (float)(ro * ro);
     if ((double)ro2 > ro * ro) ro2 = std::nextafterf(ro2, 0.0f);
     fc.ro2 = ro2;

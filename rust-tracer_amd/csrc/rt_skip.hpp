@@ -56,8 +56,9 @@ template <typename T> struct RawNode {
 //   primary  {vx, vy, vz, vv, rr, T, skip_off, tag}     the test can only return a finite distance if fma(vz,dz, fma(vy,dy, vx*dx)) >= T
 //   shadow   {w1, w2, cl, R2o, R2i, R2o_own, R2i_own, skip_off}   (FNodeS) TWO-sided: with P2 = (w1 - q1)^2 + (w2 - q2)^2 the squared distance of
 //            the centre from the ray in a plane perpendicular to the light ((w1, w2) / (q1, q2): centre / origin in that plane, relative to
-//            m0) and a = cl - ol the centre's coordinate along the ray: the reference's test says MISS if P2 > R2o and HIT if P2 <= R2i and
-//            (a >= a0 or P2 + a^2 <= R2i); only a lane in between runs the reference's arithmetic (terms from the Node stream).  R2*_own: the
+//            m0) and a = cl - ol the centre's coordinate along the ray: the reference's test says MISS if P2 > R2o and HIT if
+//            P2 + k1 (P2 + a^2) <= R2i and (a >= a0 or P2 + a^2 <= R2i); only a lane in between runs the reference's arithmetic (terms from
+//            the Node stream).  R2*_own: the
 //            same for the group's own sphere (compacted stream).  Sign bit of R2o: ITEM (or END); sign bit of R2o_own: END.
 // primary tag: 0 for a BOUND (compacted stream: rr of the group's own sphere, a non-negative float), item | kNodeItem for an ITEM,
 // kNodeItem | kNodeEnd for END.  The own sphere's item index of a compacted BOUND lives in the stream's own_item table.
@@ -78,6 +79,7 @@ struct FilterConsts {
     float e1[3], e2[3];     // f32 roundings of an orthonormal basis of the plane perpendicular to the light
     float l[3];             // the shadow rays' direction (-light, the f32 values the reference uses)
     float a0;               // a >= a0 proves b >= 0
+    float k1;               // inner bound: P2 + k1 * (P2 + a^2) <= R2i (the reference's rounding of disc grows with |centre - origin|^2)
     float ro2;              // a ray whose origin is further than sqrt(ro2) from m0 is not covered: it fails every sure test (NaN)
     double S, eta;          // Rc + Ro: bound of |c - m0| + |o - m0|;  | |l|^2 - 1 |
 };
@@ -99,17 +101,17 @@ __device__ __forceinline__ void shadow_filter_bounds(const FilterConsts &fc, flo
     float of = (float)o;
     if ((double)of < o) of = next_f32_above(of);
     r2o = next_f32_above(of);
-    const double ain = rr * (1.0 - eps) - (2.0 * fc.eta + 32.0 * eps) * S2;
+    // inner bound, for the test  P2 + k1 (P2 + a^2) <= R2i  (FilterConsts::k1 carries the part that grows with the ray's own distance)
+    const double tau = 0x1p-10, es2 = eps * fc.S * eps * fc.S;
+    const double c2 = 102.7 * (1.0 + 1.0 / tau) * es2 * (1.0 + fc.eta);
+    const double X = (1.0 + fc.eta + 10.2 * eps) * c2 * (1.0 + 6.0 * eps) + 94.1 * es2 * (1.0 + 1.0 / tau);
+    const double i = (rr * (1.0 - eps) - X) / ((1.0 + tau) * (1.0 + 2.1 * eps) * (1.0 + fc.eta) * (1.0 + 40.0 * eps)) * (1.0 - 8.0 * eps) - 1e-36;
     r2i = -1.0f;
-    if (ain > 0.0 && __builtin_sqrt(ain) > a9) {
-        const double si = (__builtin_sqrt(ain) - a9) / (1.0 + 1.01 * eps);
-        const double i = si * si * (1.0 - 40.0 * eps) - 1e-36;
-        if (i > 0.0) {
-            float inf_ = (float)i;
-            if ((double)inf_ > i) inf_ = next_f32_below(inf_);
-            inf_ = next_f32_below(inf_);
-            r2i = inf_ > 0.0f ? inf_ : -1.0f;
-        }
+    if (i > 0.0) {
+        float inf_ = (float)i;
+        if ((double)inf_ > i) inf_ = next_f32_below(inf_);
+        inf_ = next_f32_below(inf_);
+        r2i = inf_ > 0.0f ? inf_ : -1.0f;
     }
 }
 
@@ -261,7 +263,7 @@ __device__ __forceinline__ int shadow_filter_verdict(const FNodeS &f, const Filt
     const float p2 = __builtin_fmaf(t1, t1, t0 * t0);
     if (p2 > __builtin_fabsf(f.r2o)) return 0;
     const float av = f.cl - ol, inn = __builtin_fmaf(av, av, p2);
-    return (p2 <= f.r2i && (fc.a0 <= av || inn <= f.r2i)) ? 2 : 1;
+    return (__builtin_fmaf(inn, fc.k1, p2) <= f.r2i && (fc.a0 <= av || inn <= f.r2i)) ? 2 : 1;
 }
 
 // VAR bits (all bit-identical in output and counters):
@@ -481,18 +483,18 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             if constexpr ((VAR & 2) && !COUNT) {
                 if (__ballot(need_shadow) != 0) {
                     resume = need_shadow ? 0u : nb;                 // lanes without a shadow ray sleep until END
-                    [[maybe_unused]] float q1 = 0.0f, q2 = 0.0f, fol = 0.0f, fa0 = 0.0f;
+                    [[maybe_unused]] float q1 = 0.0f, q2 = 0.0f, fol = 0.0f, fa0 = 0.0f, fk1 = 0.0f;
                     if constexpr ((VAR & 16) != 0 && sizeof(T) == 4) {
                         const FilterConsts fc = *sc.fc;
                         shadow_filter_origin(fc, sp.x, sp.y, sp.z, q1, q2, fol);
-                        fa0 = fc.a0;
+                        fa0 = fc.a0; fk1 = fc.k1;
                     }
                     while (i < nb) {
                         unsigned fin;
                         if constexpr ((VAR & 16) != 0 && sizeof(T) == 4) {
                             if constexpr ((VAR & 4) != 0)
-                                i = skip_shadow_rot_filt_fused(sc.xfshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, q1, q2, fol, fa0, sc.fshad);
-                            else i = skip_shadow_rot_filt(sc.xshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, q1, q2, fol, fa0, sc.shad);
+                                i = skip_shadow_rot_filt_fused(sc.xfshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, q1, q2, fol, fa0, fk1, sc.fshad);
+                            else i = skip_shadow_rot_filt(sc.xshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, q1, q2, fol, fa0, fk1, sc.shad);
                         } else if constexpr ((VAR & 4) != 0) i = skip_shadow_rot_fused(sc.fshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
                         else i = skip_shadow_rot(sc.shad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
                         if (i >= nb) break;

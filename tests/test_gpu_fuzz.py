@@ -34,6 +34,11 @@ def test_random_scene(seed):
     fref, frst, _ = o.render(w, h, spp, os.cpu_count() or 1, oracle.MODE_FLAT)
     np.testing.assert_array_equal(util.stitch((w, h), regs, flat), fref)
     assert util.ray_stats(fst) == util.ray_stats(frst)
+    if precision == rta.RT_F32:
+        # the flat scan's conservative filter, pair by pair (every ray x every item of this frame): no candidate rejected.  (The hierarchy
+        # walk's bounds were checked test by test by the counting launch above: conftest asserts rt_debug_count(FILTER_VIOLATIONS) == 0.)
+        c = rta.capi.flat_filter_check(s.device()._h, w, h, spp)
+        assert c[2] == 0 and c[5] == 0, c
 
 
 @pytest.mark.parametrize("variant", [0, 1, 3, 7, 19, 23])

@@ -624,6 +624,8 @@ def test_100k_arbitrary_spheres_with_auto_built_hierarchy():
     flat, fst = s.device().render_tiles((512, 384, 1), regs, FLAT)
     frame = util.stitch((512, 384), regs, flat)
     assert int((frame != ref).sum()) <= 8
+    c = rta.capi.flat_filter_check(s.device()._h, 160, 120, 1)            # 100,000 items x every ray of a small frame, pair by pair
+    assert c[0] > 10_000 and c[2] == 0 and c[5] == 0, c
     for (l, t, r, b) in ((192, 256, 256, 192), (320, 128, 384, 64)):
         fref, _ = o.render_region(512, 384, 1, l, t, r, b, oracle.MODE_FLAT)
         np.testing.assert_array_equal(frame[b:t, l:r], fref)

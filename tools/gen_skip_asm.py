@@ -396,7 +396,7 @@ class F32F(F32):
         a.op("v_mov_b32_e32 %%[bitem], %s" % self.NX)
         a.op("s_mov_b64 exec, %s" % self.EX)
 
-    shadow_extra_in = ', [q1] "v"(q1), [q2] "v"(q2), [ol] "v"(ol), [a0] "s"(a0), [base2] "s"(exact)'
+    shadow_extra_in = ', [q1] "v"(q1), [q2] "v"(q2), [ol] "v"(ol), [a0] "s"(a0), [k1] "s"(k1), [base2] "s"(exact)'
     shadow_extra_out = ', [p2] "=&v"(p2), [av] "=&v"(av), [inn] "=&v"(inn)'
     shadow_extra_decl = "\n    float p2, av, inn;"
 
@@ -590,7 +590,8 @@ def shadow_exact(k, P, src, lab, tag, rr_reg):
 def shadow_two_sided(a, P, r2i, exact_label, tag):
     a.op("v_cmp_le_f32_e64 %s, %%[inn], %s" % (P.M56, r2i), "origin inside the sphere, by a margin")
     a.op("s_or_b64 %s, %s, %s" % (P.M56, P.M56, P.M58), "... or b >= 0, by a margin")
-    a.op("v_cmp_le_f32_e64 %s, %%[p2], %s" % (P.M54, r2i), "inside the inner bound: disc >= 0, by a margin")
+    a.op("v_fma_f32 %[t0], %[inn], %[k1], %[p2]", "P2 + k1 |centre - origin|^2: the reference's rounding of disc grows with the distance")
+    a.op("v_cmp_le_f32_e64 %s, %%[t0], %s" % (P.M54, r2i), "inside the inner bound: disc >= 0, by a margin")
     a.op("s_and_b64 %s, %s, %s" % (P.M54, P.M54, P.M56), "sure hits")
     a.op("s_andn2_b64 %s, vcc, %s" % (P.M56, P.M54), "lanes between the bounds: the reference's test decides")
     a.op("s_cbranch_scc1 %s" % exact_label)
@@ -805,7 +806,7 @@ def main():
             sfx = ("_filt" if P.filt else "") + ("_fused" if fused else "")
             common = {"ctype": P.ctype, "stride": P.stride, "inf": P.inf, "extra_in": P.extra_in, "clobbers": clobbers(P),
                       "shadow_extra_in": P.shadow_extra_in, "shadow_extra_out": P.shadow_extra_out, "shadow_extra_decl": P.shadow_extra_decl,
-                      "shadow_extra_args": ", float q1, float q2, float ol, float a0, const void *exact" if P.filt else ""}
+                      "shadow_extra_args": ", float q1, float q2, float ol, float a0, float k1, const void *exact" if P.filt else ""}
             text += PRIMARY_FN % dict(common, name="skip_primary_rot" + sfx, body=primary(P, fused), decl=P.primary_decl, out=P.primary_out)
             text += SHADOW_FN % dict(common, name="skip_shadow_rot" + sfx, body=shadow(P, fused), decl=P.shadow_decl, out=P.shadow_out)
     text += "}  // namespace rt\n"
