@@ -1506,25 +1506,32 @@ static rt_status render_tiles_host(rt_scene *s, const rt_options *o, rt_traversa
     }
     st = enqueue_pass(s, c, o, trav, tab, total_blocks, total_px, d_target, 0u, c->stream, stats != nullptr, wavefront ? &tab16 : nullptr, blocks16,
                       cacheable);
+    // from here on kernels of this pass may be running: an error return first waits for them (they write d_out / h_out or the caller's
+    // pinned buffer), so that the context is not handed to the next caller with work in flight
+#define HIP_DRAIN(expr)                                                                                                   \
+    do {                                                                                                                  \
+        hipError_t e__ = (expr);                                                                                          \
+        if (e__ != hipSuccess) { (void)hipStreamSynchronize(c->stream); return hip_fail(e__, #expr, __LINE__); }          \
+    } while (0)
     if (st != RT_OK) { (void)hipStreamSynchronize(c->stream); (void)hipGetLastError(); return st; }
     if (mode == kCopyDirect) {
-        HIP_TRY(hipMemcpyAsync(rgba_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_DRAIN(hipMemcpyAsync(rgba_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
     } else if (mode == kCopyStaged) {
         const size_t chunks = (bytes + kStageChunk - 1) / kStageChunk;
         while (c->chunk_ev.size() < chunks) {
             hipEvent_t e = nullptr;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIP_DRAIN(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             c->chunk_ev.push_back(e);
         }
         for (size_t k = 0; k < chunks; ++k) {
             const size_t off = k * kStageChunk, len = std::min(kStageChunk, bytes - off);
-            HIP_TRY(hipMemcpyAsync(c->h_out + off, c->d_out + off, len, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipEventRecord(c->chunk_ev[k], c->stream));
+            HIP_DRAIN(hipMemcpyAsync(c->h_out + off, c->d_out + off, len, hipMemcpyDeviceToHost, c->stream));
+            HIP_DRAIN(hipEventRecord(c->chunk_ev[k], c->stream));
         }
         // the CPU copy of chunk k runs while the DMA engine moves chunk k + 1
         size_t tile = 0, tile_off = 0;                    // scatter cursor: current tile and bytes of it already delivered
         for (size_t k = 0; k < chunks; ++k) {
-            HIP_TRY(hipEventSynchronize(c->chunk_ev[k]));
+            HIP_DRAIN(hipEventSynchronize(c->chunk_ev[k]));
             const size_t off = k * kStageChunk, len = std::min(kStageChunk, bytes - off);
             if (!scatter) { memcpy(rgba_out + off, c->h_out + off, len); continue; }
             size_t pos = off;
@@ -1539,7 +1546,8 @@ static rt_status render_tiles_host(rt_scene *s, const rt_options *o, rt_traversa
     }
     rt_status rst = RT_OK;
     if (stats) rst = read_stats(s, c, c->stream, trav, stats);          // synchronises the stream
-    else HIP_TRY(hipStreamSynchronize(c->stream));
+    else HIP_DRAIN(hipStreamSynchronize(c->stream));
+#undef HIP_DRAIN
     if (rst == RT_OK && mode == kCopyZeroStaged) {
         size_t off = 0;
         for (uint32_t i = 0; i < n; ++i) {
