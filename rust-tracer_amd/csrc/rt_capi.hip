@@ -381,6 +381,7 @@ void filter_constants(rt_scene *s, const std::vector<rt::RawNode<T>> &raw, const
     auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return std::nextafterf(f, INFINITY); };
     fc.a0 = up(11.0 * eps * fc.S + 1e-37);
     fc.k1 = up((fc.eta + 10.2 * eps) * (1.0 + fc.eta) * (1.0 + 12.0 * eps));
+    { float kc = (float)(1.0 / (1.0 + 4.0 * 0x1p-10)); if ((double)kc > 1.0 / (1.0 + 4.0 * 0x1p-10)) kc = std::nextafterf(kc, 0.0f); fc.kc = std::nextafterf(kc, 0.0f); }
     float ro2 = (float)(ro * ro);
     if ((double)ro2 > ro * ro) ro2 = std::nextafterf(ro2, 0.0f);
     fc.ro2 = ro2;
@@ -536,11 +537,14 @@ bool packed_samples(unsigned spp)
 // 1920x1080 54.8 / 64.4 us: a frame as long as its heaviest waves, and a wave of 128 rays walks the union of more paths) and the
 // sample-packed modes never do (2048x2048 spp 4: 1.048 / 1.076 ms); on the 87,381-sphere scene -- where the halved scalar-cache
 // traffic counts -- spp 4 pays from 2 M pixels (1920x1080 0.752 / 0.721, 4096x4096 4.10 / 3.84; 1024x768 0.333 / 0.341) and spp 1
-// from 6 M (2560x1440 0.104 / 0.115, 3840x2160 0.203 / 0.185).
+// from 6 M (2560x1440 0.104 / 0.115, 3840x2160 0.203 / 0.185).  Round 3, both kernels with the conservative bound in front of their
+// primary tests (the one-ray kernel in front of its shadow tests too): 21,845 spheres 2560x1440 0.0850 / 0.0900, 3840x2160 0.161 / 0.157,
+// 2048x2048 spp 4 0.956 / 0.961; 87,381 spheres 3840x2160 0.186 / 0.173, 1920x1080 spp 4 0.729 / 0.684, 4096x4096 spp 4 4.21 / 3.75 --
+// spp 1 from 6 M pixels on either scene.
 bool skip2_by_default(uint64_t total_px, unsigned spp, uint32_t n_nodes)
 {
     const bool large_scene = n_nodes >= 65536u;
-    if (spp == 1) return total_px >= (large_scene ? 6000000ull : 3500000ull);
+    if (spp == 1) return total_px >= 6000000ull;
     return large_scene && total_px >= 1500000ull;
 }
 
@@ -2113,7 +2117,9 @@ static rt_status gang_render(rt_gang *g, const rt_options *o, rt_traversal trav,
                 if (g->d_shard[p][d]) HIP_TRY(hipFree(g->d_shard[p][d]));
                 g->d_shard[p][d] = nullptr;
                 HIP_TRY(hipMalloc(&g->d_shard[p][d], shard_bytes));
-                HIP_TRY(hipMemset(g->d_shard[p][d], 0, shard_bytes));          // the padding behind a short shard travels too
+                // the padding behind a short shard travels too.  On the stream that renders into the buffer: the device's streams do not
+                // synchronise with the null stream, where a plain hipMemset would run
+                HIP_TRY(hipMemsetAsync(g->d_shard[p][d], 0, shard_bytes, g->streams[d]));
             }
         }
         g->shard_cap = shard_bytes;
@@ -2141,7 +2147,8 @@ static rt_status gang_render(rt_gang *g, const rt_options *o, rt_traversal trav,
         if (g->d_frame) HIP_TRY(hipFree(g->d_frame));
         g->d_frame = nullptr; g->frame_cap = 0;
         HIP_TRY(hipMalloc(&g->d_frame, frame_bytes));
-        HIP_TRY(hipMemset(g->d_frame, 0, frame_bytes));        // pixels outside the listed buckets: zero, never stale device memory
+        // pixels outside the listed buckets: zero, never stale device memory (on the stream of the blit that writes the frame)
+        HIP_TRY(hipMemsetAsync(g->d_frame, 0, frame_bytes, g->comm_streams[0]));
         g->frame_cap = frame_bytes;
     } else if (need_dev_frame && new_list) {
         HIP_TRY(hipMemsetAsync(g->d_frame, 0, g->frame_cap, g->comm_streams[0]));      // ... nor what an earlier tile list left there

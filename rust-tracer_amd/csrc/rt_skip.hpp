@@ -80,6 +80,7 @@ struct FilterConsts {
     float l[3];             // the shadow rays' direction (-light, the f32 values the reference uses)
     float a0;               // a >= a0 proves b >= 0
     float k1;               // inner bound: P2 + k1 * (P2 + a^2) <= R2i (the reference's rounding of disc grows with |centre - origin|^2)
+    float kc;               // 1 / (1 + 4 tau): (P2 + a^2) kc >= R2o proves the origin clearly outside the sphere (then b < 0 means miss)
     float ro2;              // a ray whose origin is further than sqrt(ro2) from m0 is not covered: it fails every sure test (NaN)
     double S, eta;          // Rc + Ro: bound of |c - m0| + |o - m0|;  | |l|^2 - 1 |
 };
@@ -263,7 +264,8 @@ __device__ __forceinline__ int shadow_filter_verdict(const FNodeS &f, const Filt
     const float p2 = __builtin_fmaf(t1, t1, t0 * t0);
     if (p2 > __builtin_fabsf(f.r2o)) return 0;
     const float av = f.cl - ol, inn = __builtin_fmaf(av, av, p2);
-    return (__builtin_fmaf(inn, fc.k1, p2) <= f.r2i && (fc.a0 <= av || inn <= f.r2i)) ? 2 : 1;
+    if (__builtin_fmaf(inn, fc.k1, p2) <= f.r2i && (fc.a0 <= av || inn <= f.r2i)) return 2;
+    return (av <= -fc.a0 && __builtin_fabsf(f.r2o) <= fc.kc * inn) ? 0 : 1;      // behind the origin, origin outside: t2 < 0
 }
 
 // VAR bits (all bit-identical in output and counters):
@@ -483,18 +485,18 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             if constexpr ((VAR & 2) && !COUNT) {
                 if (__ballot(need_shadow) != 0) {
                     resume = need_shadow ? 0u : nb;                 // lanes without a shadow ray sleep until END
-                    [[maybe_unused]] float q1 = 0.0f, q2 = 0.0f, fol = 0.0f, fa0 = 0.0f, fk1 = 0.0f;
+                    [[maybe_unused]] float q1 = 0.0f, q2 = 0.0f, fol = 0.0f, fa0 = 0.0f, fk1 = 0.0f, fkc = 0.0f;
                     if constexpr ((VAR & 16) != 0 && sizeof(T) == 4) {
                         const FilterConsts fc = *sc.fc;
                         shadow_filter_origin(fc, sp.x, sp.y, sp.z, q1, q2, fol);
-                        fa0 = fc.a0; fk1 = fc.k1;
+                        fa0 = fc.a0; fk1 = fc.k1; fkc = fc.kc;
                     }
                     while (i < nb) {
                         unsigned fin;
                         if constexpr ((VAR & 16) != 0 && sizeof(T) == 4) {
                             if constexpr ((VAR & 4) != 0)
-                                i = skip_shadow_rot_filt_fused(sc.xfshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, q1, q2, fol, fa0, fk1, sc.fshad);
-                            else i = skip_shadow_rot_filt(sc.xshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, q1, q2, fol, fa0, fk1, sc.shad);
+                                i = skip_shadow_rot_filt_fused(sc.xfshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, q1, q2, fol, fa0, fk1, fkc, sc.fshad);
+                            else i = skip_shadow_rot_filt(sc.xshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, q1, q2, fol, fa0, fk1, fkc, sc.shad);
                         } else if constexpr ((VAR & 4) != 0) i = skip_shadow_rot_fused(sc.fshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
                         else i = skip_shadow_rot(sc.shad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
                         if (i >= nb) break;

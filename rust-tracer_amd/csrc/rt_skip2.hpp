@@ -102,7 +102,9 @@ __global__ __launch_bounds__(kSkip2Threads) void k_render_skip2(SkipView<float> 
         // ---------------- primary rays: s.group.intersect(&mut h, r)  render.rs:188-189 ----------------
         T best[R];
         unsigned best_item[R];
-        skip2_primary_rot_fused(sc.fprim, dx, dy, dz, resume, best, best_item);
+        skip2_primary_rot_fused(sc.xfprim, dx, dy, dz, resume, best, best_item);
+        for (unsigned h = 0; h < R; ++h)  // a group's own sphere won: the walk recorded the offset behind its BOUND node
+            if (best_item[h] != 0u && !(best_item[h] & kNodeItem)) best_item[h] = sc.xown[best_item[h] / (unsigned)sizeof(FNode) - 1u];
 
         // ---------------- shade  render.rs:190-199 ----------------
         bool need_shadow[R];

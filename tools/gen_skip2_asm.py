@@ -84,6 +84,14 @@ def item(b):
     return "s%d" % (BANK[b] + 5)
 
 
+def thr(b):                     # primary FNode: the filter's threshold T sits where Node has its item word
+    return "s%d" % (BANK[b] + 5)
+
+
+def tag(b):                     # primary FNode: own rr (BOUND) / item | bit 31 (ITEM) / bits 31 + 30 (END)
+    return "s%d" % (BANK[b] + 7)
+
+
 def skip(b):
     return "s%d" % (BANK[b] + 6)
 
@@ -113,6 +121,20 @@ def pk(a, op, dst, x, y, sx=None, sy=None, neg_y=False, comment=None):
     if neg_y:
         mods += " neg_lo:[0,1] neg_hi:[0,1]"
     a.op("v_pk_%s_f32 %s, %s, %s%s" % (op, dst, x, y, mods), comment)
+
+
+def pk_fma(a, dst, x, y, z, sx=None, comment=None):
+    """dst = x * y + z on both rays; sx: SGPR NUMBER broadcast to both rays in place of x."""
+    sel, sel_hi = [0, 0, 0], [1, 1, 1]
+    if sx is not None:
+        x = "s[%d:%d]" % (sx & ~1, (sx & ~1) + 1)
+        sel[0] = sel_hi[0] = sx & 1
+    mods = ""
+    if sel != [0, 0, 0]:
+        mods += " op_sel:[%d,%d,%d]" % tuple(sel)
+    if sel_hi != [1, 1, 1]:
+        mods += " op_sel_hi:[%d,%d,%d]" % tuple(sel_hi)
+    a.op("v_pk_fma_f32 %s, %s, %s, %s%s" % (dst, x, y, z, mods), comment)
 
 
 class Regs:
@@ -231,6 +253,28 @@ def primary_terms(a, r, c):
     pk(a, "add", r.DISC.p, None, r.Q.p, sx=fld(c, 4))
 
 
+def primary_filter(a, r, c):
+    """The conservative bound of rt_skip_rot.hpp's filtered loops for both rays: b' = fma(vz, dz, fma(vy, dy, vx*dx)) >= T, or the
+    reference's test returns INF for that ray.  Three packed instructions instead of eight; T0 keeps vx*dx."""
+    pk(a, "mul", r.T0.p, None, r.DX.p, sx=fld(c, 0), comment="filter: b' = fma(vz, dz, fma(vy, dy, vx*dx)) >= T for some ray?")
+    pk_fma(a, r.DISC.p, None, r.DY.p, r.T0.p, sx=fld(c, 1))
+    pk_fma(a, r.DISC.p, None, r.DZ.p, r.DISC.p, sx=fld(c, 2))
+    a.op("v_max_f32_e32 %s, %s, %s" % (r.root, r.DISC.h[0], r.DISC.h[1]))
+    a.op("v_cmp_le_f32_e32 vcc, %s, %s" % (thr(c), r.root))
+
+
+def primary_terms_after_filter(a, r, c):
+    pk(a, "mul", r.T1.p, None, r.DY.p, sx=fld(c, 1), comment="b = (vx*dx + vy*dy) + vz*dz, both rays   primitive.rs:57 (vx*dx is the filter's)")
+    pk(a, "mul", r.T2.p, None, r.DZ.p, sx=fld(c, 2))
+    pk(a, "add", r.T0.p, r.T0.p, r.T1.p)
+    pk(a, "add", r.B.p, r.T0.p, r.T2.p)
+    pk(a, "mul", r.T0.p, r.B.p, r.B.p, comment="disc = (b*b - vv) + rr   primitive.rs:58")
+    pk(a, "add", r.Q.p, r.T0.p, None, sy=fld(c, 3), neg_y=True)
+    pk(a, "add", r.DISC.p, None, r.Q.p, sx=fld(c, 4))
+    a.op("v_max_f32_e32 %s, %s, %s" % (r.t0, r.DISC.h[0], r.DISC.h[1]))
+    a.op("v_cmp_le_f32_e32 vcc, 0, %s" % r.t0)
+
+
 def primary_go(a, r, h, tag, lab, tinies):
     """C[h] (awake rays of half h with disc >= 0) -> C[h] = go: t2 >= 0 and d < hit.distance; d left in t4.  Skipped when the
     half has no candidate."""
@@ -250,10 +294,12 @@ def primary_go(a, r, h, tag, lab, tinies):
     return done
 
 
-def primary_update(a, r, h, c, done):
+def primary_update(a, r, h, c, done, own=False):
+    # an ITEM records its tag (item | bit 31); a group's own sphere records WHERE it was hit (NX = the BOUND's offset + stride, bit 31
+    # clear) and the kernel looks the item up in the stream's own_item table afterwards (the BOUND's tag word is the sphere's rr)
     a.op("s_mov_b64 exec, %s" % C[h], "primitive.rs:80-83")
     a.op("v_mov_b32_e32 %s, %s" % (r.BEST.h[h], r.t4))
-    a.op("v_mov_b32_e32 %s, %s" % (r.BITEM.h[h], item(c)))
+    a.op("v_mov_b32_e32 %s, %s" % (r.BITEM.h[h], NX if own else tag(c)))
     a.op("s_mov_b64 exec, %s" % EX)
     a.label(done)
 
@@ -263,13 +309,17 @@ def primary_copy(r, name):
     lab = lambda x: ".Lr2_%s_%s_%%=" % (name, x)
     m, k, tinies = Asm(), Asm(), []
     m.label(lab("top"))
-    step_top(m, r, c, s, primary_terms)
+    load(m, s, skip(c), "the likely successor, while this node is processed")
+    primary_filter(m, r, c)
     m.op("s_cbranch_vccnz %s" % lab("hit"))
     emit_skip(m, name, c, lab)
-    # ---------------- some ray's line meets the sphere ----------------
+    # ---------------- the bound cannot rule the node out for some ray: the reference's discriminant, for every ray ----------------
     k.label(lab("hit"))
+    primary_terms_after_filter(k, r, c)
+    k.op("s_cbranch_vccz %s" % lab("skip"), "the bound let it through, the test does not: nobody can hit the node")
     wake_check(k, r, lab)
-    kind_test(k, c, lab)
+    k.op("s_bitcmp1_b32 %s, 31" % tag(c), "an ITEM or the END node?  (flag bits of the tag word)")
+    k.op("s_cbranch_scc1 %s" % lab("flagged"))
     # BOUND (group.rs:73)
     for h in range(2):
         k.label(primary_go(k, r, h, "b", lab, tinies))
@@ -286,12 +336,12 @@ def primary_copy(r, name):
     k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
     k.op("s_cbranch_scc0 %s" % lab("next"))
     for h in range(2):
-        primary_update(k, r, h, c, primary_go(k, r, h, "f", lab, tinies))
+        primary_update(k, r, h, c, primary_go(k, r, h, "f", lab, tinies), own=True)
     k.label(lab("next"))
     emit_next(k, name)
     # ITEM (primitive.rs:77-84) or END
     k.label(lab("flagged"))
-    k.op("s_bitcmp1_b32 %s, 30" % item(c))
+    k.op("s_bitcmp1_b32 %s, 30" % tag(c))
     k.op("s_cbranch_scc1 .Lr2_exit_%=", "END: every ray is awake here and hits it")
     for h in range(2):
         primary_update(k, r, h, c, primary_go(k, r, h, "i", lab, tinies))
@@ -463,9 +513,11 @@ namespace rt {
 
 """
 
-PRIMARY_FN = """// Primary-ray traversal: s.group.intersect(&mut h, r) for the wave's 128 rays.  nodes: compacted Node<float>[n + 3], END at [n].
-// resume[h]: 0 for a ray, n * 32 for a lane half without one (it sleeps until END).  Returns hit.distance / item word per ray (mask
-// the item with kNodeIndexMask).
+PRIMARY_FN = """// Primary-ray traversal: s.group.intersect(&mut h, r) for the wave's 128 rays.  nodes: the compacted FILTERED stream FNode[n + 3]
+// (rt_skip.hpp: {vx, vy, vz, vv, rr, T, skip_off, tag}), END at [n]: a step first asks the conservative bound b' >= T for both rays
+// (three packed instructions) and forms the reference's discriminant only when some ray passes.
+// resume[h]: 0 for a ray, n * 32 for a lane half without one (it sleeps until END).  Returns hit.distance and, per ray, either
+// item | bit 31 or -- bit 31 clear, a group's own sphere -- the byte offset behind its BOUND node (look the item up in own_item).
 __device__ __forceinline__ void skip2_primary_rot_fused(const void *nodes, const float (&dx)[2], const float (&dy)[2], const float (&dz)[2],
                                                         const unsigned (&resume)[2], float (&best_out)[2], unsigned (&item_out)[2])
 {

@@ -396,7 +396,7 @@ class F32F(F32):
         a.op("v_mov_b32_e32 %%[bitem], %s" % self.NX)
         a.op("s_mov_b64 exec, %s" % self.EX)
 
-    shadow_extra_in = ', [q1] "v"(q1), [q2] "v"(q2), [ol] "v"(ol), [a0] "s"(a0), [k1] "s"(k1), [base2] "s"(exact)'
+    shadow_extra_in = ', [q1] "v"(q1), [q2] "v"(q2), [ol] "v"(ol), [a0] "s"(a0), [k1] "s"(k1), [kc] "v"(kc), [base2] "s"(exact)'
     shadow_extra_out = ', [p2] "=&v"(p2), [av] "=&v"(av), [inn] "=&v"(inn)'
     shadow_extra_decl = "\n    float p2, av, inn;"
 
@@ -597,6 +597,21 @@ def shadow_two_sided(a, P, r2i, exact_label, tag):
     a.op("s_cbranch_scc1 %s" % exact_label)
 
 
+def shadow_second_chance(k, P, r2o, exact2, none_label, some_label):
+    """Lanes between the bounds before the reference's arithmetic is fetched: most of them have the sphere BEHIND them -- b < 0 by a
+    margin while the origin is clearly outside the sphere (P2 + a^2 >= R2o (1 + 4 tau)): disc < 0, or the root is smaller than |b| and
+    t2 = b + root < 0 -- the reference's test says miss.  vcc = lanes inside the outer bound, M56 = those not settled yet."""
+    k.op("v_mul_f32_e32 %[t0], %[kc], %[inn]", "(P2 + a^2) / (1 + 4 tau)")
+    k.op("v_cmp_le_f32_e64 %s, |%s|, %%[t0]" % (P.TINY, r2o), "the origin is clearly outside the sphere")
+    k.op("v_cmp_le_f32_e64 %s, %%[av], -%%[a0]" % P.M54, "b < 0, by a margin")
+    k.op("s_and_b64 %s, %s, %s" % (P.TINY, P.TINY, P.M54), "sure misses")
+    k.op("s_andn2_b64 %s, %s, %s" % (P.M56, P.M56, P.TINY), "still between the bounds")
+    k.op("s_cbranch_scc1 %s" % exact2)
+    k.op("s_andn2_b64 vcc, vcc, %s" % P.TINY, "every lane is settled: the hits are the lanes inside the outer bound that are not sure misses")
+    k.op("s_cbranch_vccz %s" % none_label)
+    k.op("s_branch %s" % some_label)
+
+
 def shadow_copy_filt(P, name, fused):
     """Two-sided flavour of shadow_copy (f32 filtered streams)."""
     c, n, s = COPIES[name]
@@ -637,6 +652,8 @@ def shadow_copy_filt(P, name, fused):
     k.op("s_branch .Lrt_fin_%=")
     # ---- the reference's test, for the steps whose lanes the bounds cannot settle: terms from the exact stream
     k.label(lab("exact"))
+    shadow_second_chance(k, P, P.s_r2o(c), lab("exact2"), lab("skip"), lab("decided"))
+    k.label(lab("exact2"))
     tmp = "s" + P.M54[2:].split(":")[0]            # the masks are dead here: the reference's test forms the hit mask anew
     k.op("s_sub_u32 %s, %s, %d" % (tmp, P.NX, P.stride), "this node's offset")
     k.op("s_load_dwordx8 %s, %%[base2], %s" % (sp(P.bank(n), 8), tmp), "its Node record of the exact stream (the `next` bank is free until the group is entered)")
@@ -648,6 +665,8 @@ def shadow_copy_filt(P, name, fused):
     P.tiny(k, lab("xtiny"), lab("xrooted"))
     if fused:
         k.label(lab("exactown"))
+        shadow_second_chance(k, P, P.s_r2o_own(c), lab("exactown2"), lab("next"), lab("owndecided"))
+        k.label(lab("exactown2"))
         k.op("s_sub_u32 %s, %s, %d" % (tmp, P.NX, P.stride), "this node's offset")
         k.op("s_waitcnt lgkmcnt(0)", "the skip successor's fetch may still be in flight INTO this bank, and scalar loads land out of order")
         k.op("s_load_dwordx8 %s, %%[base2], %s" % (sp(P.bank(s), 8), tmp), "its Node record (the skip bank is free: the group is entered)")
@@ -806,7 +825,7 @@ def main():
             sfx = ("_filt" if P.filt else "") + ("_fused" if fused else "")
             common = {"ctype": P.ctype, "stride": P.stride, "inf": P.inf, "extra_in": P.extra_in, "clobbers": clobbers(P),
                       "shadow_extra_in": P.shadow_extra_in, "shadow_extra_out": P.shadow_extra_out, "shadow_extra_decl": P.shadow_extra_decl,
-                      "shadow_extra_args": ", float q1, float q2, float ol, float a0, float k1, const void *exact" if P.filt else ""}
+                      "shadow_extra_args": ", float q1, float q2, float ol, float a0, float k1, float kc, const void *exact" if P.filt else ""}
             text += PRIMARY_FN % dict(common, name="skip_primary_rot" + sfx, body=primary(P, fused), decl=P.primary_decl, out=P.primary_out)
             text += SHADOW_FN % dict(common, name="skip_shadow_rot" + sfx, body=shadow(P, fused), decl=P.shadow_decl, out=P.shadow_out)
     text += "}  // namespace rt\n"
