@@ -149,31 +149,54 @@ def test_a_temporary_host_buffer_lives_as_long_as_its_array():
     np.testing.assert_array_equal(util.stitch((320, 200), regs, data), ref)
 
 
-def test_gang_pipelined_frames_one_rank():
+_GANG_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import oracle
+import rust_tracer_amd as rta
+from tests import util
+
+s, o = util.scene_pair_default()
+try:
+    g = rta.Gang(s, [0])
+except rta.RtError as e:
+    if e.status == rta.capi.RT_ERR_UNSUPPORTED:
+        print("SKIP no RCCL")
+        sys.exit(0)
+    raise
+w, h = 800, 600
+regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, 1))]
+ref, rst, _ = o.render(w, h, 1, nthreads=os.cpu_count() or 1)
+frames, st = g.render_frames((w, h, 1), regs, 5, want_stats=True)
+for f in frames:
+    np.testing.assert_array_equal(f, ref)
+assert util.ray_stats(st) == util.ray_stats(rst)
+pinned = [rta.capi.HostBuffer(w * h * 4) for _ in range(3)]
+frames, _ = g.render_frames((w, h, 1), regs, 3, out=[p.array for p in pinned])
+for f in frames:
+    np.testing.assert_array_equal(f, ref)
+# a partial tile list leaves the other pixels of a fresh frame zero, never stale device memory
+part, _ = g.render_frame((w, h, 1), regs[:7])
+assert not part[64:].any() and np.array_equal(part[0:64, 0:448], ref[0:64, 0:448])
+g.close()
+print("OK")
+"""
+
+
+def test_gang_pipelined_frames_one_rank(tmp_path):
     # rt_gang_render_frames on a one-rank communicator (what a 1-GPU box can run): gather(f) under render(f + 1), double-buffered
-    # shards; pinned destinations are written by the root's blit kernel, pageable ones copied
-    s, o = util.scene_pair_default()
-    try:
-        g = rta.Gang(s, [0])
-    except rta.RtError as e:
-        if e.status == rta.capi.RT_ERR_UNSUPPORTED:
-            pytest.skip("no RCCL")
-        raise
-    w, h = 800, 600
-    regs = bucket_list(w, h)
-    ref, rst, _ = o.render(w, h, 1, nthreads=os.cpu_count() or 1)
-    frames, st = g.render_frames((w, h, 1), regs, 5, want_stats=True)
-    for f in frames:
-        np.testing.assert_array_equal(f, ref)
-    assert util.ray_stats(st) == util.ray_stats(rst)
-    pinned = [rta.capi.HostBuffer(w * h * 4) for _ in range(3)]
-    frames, _ = g.render_frames((w, h, 1), regs, 3, out=[p.array for p in pinned])
-    for f in frames:
-        np.testing.assert_array_equal(f, ref)
-    # a partial tile list leaves the other pixels of a fresh frame zero, never stale device memory
-    part, _ = g.render_frame((w, h, 1), regs[:7])
-    assert not part[64:].any() and np.array_equal(part[0:64, 0:448], ref[0:64, 0:448])
-    g.close()
+    # shards; pinned destinations are written by the root's blit kernel, pageable ones copied.  In a process of its own: the gang
+    # creates its communicator with ncclCommInitAll inside whatever RCCL instance the process has loaded, and this session's other
+    # tests have created and destroyed torch.distributed process groups in it.
+    import sys
+    script = tmp_path / "gang_frames.py"
+    script.write_text(_GANG_SCRIPT)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    if "SKIP" in r.stdout:
+        pytest.skip("no RCCL")
+    assert "OK" in r.stdout
 
 
 def test_rtrace_scene_file_with_an_automatically_built_hierarchy(tmp_path):
