@@ -217,6 +217,9 @@ uint64_t rt_tiles_rgba_bytes(const rt_region *tiles, uint32_t n_tiles);
 /* Device self-test: compares the traversal loops' lean correctly-rounded f32 sqrt with the compiler's IEEE sqrt on
  * ALL 2^32 bit patterns; *mismatches must come back 0 (first_bad_bits = 0xFFFFFFFF).  ~10 ms on an MI355X. */
 rt_status rt_selftest_sqrt(int device, uint64_t *mismatches, uint32_t *first_bad_bits);
+/* The same for the lean reciprocal of Vector::normalized (vec.rs:87-95, `len.recip()`): against the compiler's IEEE division
+ * 1.0f / x on all 2^32 bit patterns, and through normalized() itself. */
+rt_status rt_selftest_rcp(int device, uint64_t *mismatches, uint32_t *first_bad_bits);
 
 const char *rt_strerror(rt_status status);
 /* Detail of the last RT_ERR_HIP on the calling thread (static thread-local storage; never NULL). */

@@ -16,7 +16,7 @@ ABI_VERSION = 2
 
 # every symbol include/rtrace_hip.h declares
 SYMBOLS = ("rt_abi_version", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_scene_traits", "rt_render_tiles",
-           "rt_render_tiles_device", "rt_render_frame_device", "rt_render_region", "rt_blit_tiles_device", "rt_selftest_sqrt", "rt_tiles_rgba_bytes", "rt_strerror", "rt_last_error_message",
+           "rt_render_tiles_device", "rt_render_frame_device", "rt_render_region", "rt_blit_tiles_device", "rt_selftest_sqrt", "rt_selftest_rcp", "rt_tiles_rgba_bytes", "rt_strerror", "rt_last_error_message",
            "rt_host_alloc", "rt_host_free", "rt_host_register", "rt_host_unregister",
            "rt_gang_create", "rt_gang_destroy", "rt_gang_size", "rt_gang_render_frame", "rt_gang_render_frames", "rt_render_tiles_stream")
 
@@ -78,6 +78,7 @@ lib.rt_gang_render_frames.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C
 TILE_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.POINTER(Region), C.POINTER(C.c_uint8))      # rt_tile_callback
 lib.rt_render_tiles_stream.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_void_p, C.c_uint32, TILE_CALLBACK, C.c_void_p]
 lib.rt_selftest_sqrt.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+lib.rt_selftest_rcp.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
 lib.rt_scene_traits.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
 RT_SCENE_HAS_BOUNDS, RT_SCENE_CONCENTRIC = 1, 2
 lib.rt_tiles_rgba_bytes.restype = C.c_uint64
@@ -129,6 +130,13 @@ def selftest_sqrt(device=0):
     """rt_selftest_sqrt -> (mismatches, first_bad_bits) over all 2^32 f32 bit patterns."""
     bad, first = C.c_uint64(0), C.c_uint32(0)
     check(lib.rt_selftest_sqrt(device, C.byref(bad), C.byref(first)), "rt_selftest_sqrt")
+    return bad.value, first.value
+
+
+def selftest_rcp(device=0):
+    """rt_selftest_rcp -> (mismatches, first_bad_bits) over all 2^32 f32 bit patterns."""
+    bad, first = C.c_uint64(0), C.c_uint32(0)
+    check(lib.rt_selftest_rcp(device, C.byref(bad), C.byref(first)), "rt_selftest_rcp")
     return bad.value, first.value
 
 

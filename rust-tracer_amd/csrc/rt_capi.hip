@@ -532,20 +532,20 @@ bool packed_samples(unsigned spp)
     return (spp == 2 || spp == 4 || spp == 8) && knob(RT_DEBUG_PACKED_SAMPLES) != 0;
 }
 
-// Two rays per lane (rt_skip2.hpp) unless csrc/rt_debug.h RT_DEBUG_SKIP_RAYS says otherwise.  Measured, one / two rays per lane
-// (DESIGN.md 4.1): on the 21,845-sphere scene spp 1 pays from 3.5 M pixels (2560x1440 0.0926 / 0.0896 ms, 3840x2160 0.184 / 0.173;
-// 1920x1080 54.8 / 64.4 us: a frame as long as its heaviest waves, and a wave of 128 rays walks the union of more paths) and the
-// sample-packed modes never do (2048x2048 spp 4: 1.048 / 1.076 ms); on the 87,381-sphere scene -- where the halved scalar-cache
-// traffic counts -- spp 4 pays from 2 M pixels (1920x1080 0.752 / 0.721, 4096x4096 4.10 / 3.84; 1024x768 0.333 / 0.341) and spp 1
-// from 6 M (2560x1440 0.104 / 0.115, 3840x2160 0.203 / 0.185).  Round 3, both kernels with the conservative bound in front of their
-// primary tests (the one-ray kernel in front of its shadow tests too): 21,845 spheres 2560x1440 0.0850 / 0.0900, 3840x2160 0.161 / 0.157,
-// 2048x2048 spp 4 0.956 / 0.961; 87,381 spheres 3840x2160 0.186 / 0.173, 1920x1080 spp 4 0.729 / 0.684, 4096x4096 spp 4 4.21 / 3.75 --
-// spp 1 from 6 M pixels on either scene.
+// Two rays per lane (rt_skip2.hpp) unless csrc/rt_debug.h RT_DEBUG_SKIP_RAYS says otherwise.  A wave of 128 rays walks the union of more
+// paths and a frame is as long as its heaviest waves, so the second ray pays once there is enough work to be throughput-bound.
+// Measured with both kernels' walks behind their conservative bounds (round 3: tools/skip2_sweep.sh, profiles/r03d_skip2_sweep.log;
+// one / two rays per lane, us per launch).  21,845 spheres, spp 1: 1920x1080 45.5 / 57.5, 2304x1296 65.6 / 61.7, 2560x1440 77.8 / 71.1,
+// 3840x2160 153.9 / 131.6; sample-packed: 1024x768 spp 2 108.5 / 121.2, 640x480 spp 4 147.8 / 152.6, 800x600 spp 4 202.0 / 192.5,
+// 1024x768 spp 4 (`make image`) 263.6 / 244.0, 2048x2048 spp 4 952 / 828.  87,381 spheres, spp 1: 2560x1440 92.4 / 115.8, 3200x1800
+// 138.5 / 131.7, 3840x2160 181.5 / 153.8; sample-packed: 1280x720 spp 2 163.3 / 175.1, 640x480 spp 4 187.9 / 194.6, 800x600 spp 4
+// 247.7 / 242.5, 1920x1080 spp 4 724 / 625, 4096x4096 spp 4 4206 / 3420.  (Round 2, before the bounds: spp 1 from 3.5 M / 6 M pixels,
+// sample-packed modes only on the large scene.)
 bool skip2_by_default(uint64_t total_px, unsigned spp, uint32_t n_nodes)
 {
     const bool large_scene = n_nodes >= 65536u;
-    if (spp == 1) return total_px >= 6000000ull;
-    return large_scene && total_px >= 1500000ull;
+    if (spp == 1) return total_px >= (large_scene ? 5000000ull : 2900000ull);
+    return total_px * spp * spp >= 6000000ull;
 }
 
 constexpr size_t kMaxCachedTables = 32;
@@ -938,7 +938,7 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     if (!use_split(spp)) {
         if constexpr (!COUNT && (VAR & 15) == 7 && sizeof(T) == 4) {
             if (two_rays) {
-                hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipOne>), rgrid, b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt, d_out, sb, frame_w,
+                hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipOne, (VAR & 16) != 0>), rgrid, b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt, d_out, sb, frame_w,
                                    order.d, order.wg_first);
                 return RT_OK;
             }
@@ -962,7 +962,7 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     bool done2 = false;
     if constexpr (!COUNT && (VAR & 15) == 7 && sizeof(T) == 4) {
         if (two_rays) {
-            hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipPacked>), dim3(rgrid.x, (unsigned)ns), b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt,
+            hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipPacked, (VAR & 16) != 0>), dim3(rgrid.x, (unsigned)ns), b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt,
                                d_out, sb, frame_w, order.d, order.wg_first);
             done2 = true;
         }
@@ -1736,7 +1736,8 @@ rt_status rt_scene_traits(const rt_scene *s, uint32_t *traits)
     return RT_OK;
 }
 
-rt_status rt_selftest_sqrt(int device, uint64_t *mismatches, uint32_t *first_bad_bits)
+typedef void (*selftest_kernel)(unsigned, unsigned long long, unsigned long long *, unsigned *);
+static rt_status selftest_all_f32(int device, selftest_kernel kernel, const char *what, uint64_t *mismatches, uint32_t *first_bad_bits)
 {
     if (!mismatches || !first_bad_bits) return RT_ERR_INVALID_ARGUMENT;
     int ndev = 0;
@@ -1751,16 +1752,26 @@ rt_status rt_selftest_sqrt(int device, uint64_t *mismatches, uint32_t *first_bad
     HIP_TRY(hipMemset(d_bad, 0, sizeof *d_bad));
     HIP_TRY(hipMemset(d_first, 0xFF, sizeof *d_first));
     // all 2^32 bit patterns: non-negative values, negatives, infinities and NaNs
-    hipLaunchKernelGGL(rt::k_selftest_sqrt, dim3(256 * 32), dim3(256), 0, nullptr, 0u, 1ull << 32, d_bad, d_first);
+    hipLaunchKernelGGL(kernel, dim3(256 * 32), dim3(256), 0, nullptr, 0u, 1ull << 32, d_bad, d_first);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     unsigned long long bad = 0; unsigned first = 0;
     if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(&first, d_first, sizeof first, hipMemcpyDeviceToHost);
     (void)hipFree(d_bad); (void)hipFree(d_first);
-    if (e != hipSuccess) return hip_fail(e, "rt_selftest_sqrt", __LINE__);
+    if (e != hipSuccess) return hip_fail(e, what, __LINE__);
     *mismatches = bad; *first_bad_bits = first;
     return RT_OK;
+}
+
+rt_status rt_selftest_sqrt(int device, uint64_t *mismatches, uint32_t *first_bad_bits)
+{
+    return selftest_all_f32(device, rt::k_selftest_sqrt, "rt_selftest_sqrt", mismatches, first_bad_bits);
+}
+
+rt_status rt_selftest_rcp(int device, uint64_t *mismatches, uint32_t *first_bad_bits)
+{
+    return selftest_all_f32(device, rt::k_selftest_rcp, "rt_selftest_rcp", mismatches, first_bad_bits);
 }
 
 constexpr int kMaxRegionLeaders = 2;

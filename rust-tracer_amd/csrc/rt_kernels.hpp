@@ -93,6 +93,25 @@ __global__ void k_selftest_sqrt(unsigned first, unsigned long long count, unsign
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// The same for rcp_rn_lean against the compiler's IEEE division 1.0f / x.
+__global__ void k_selftest_rcp(unsigned first, unsigned long long count, unsigned long long *mismatches, unsigned *first_bad)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
+        const unsigned bits = first + (unsigned)k;
+        const float x = __uint_as_float(bits);
+        const float a = rcp_rn_lean(x), b = 1.0f / x;
+        bool same = __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
+        // normalized<float> inlines both lean sequences behind one range test: the same comparison for the value it multiplies by
+        const V3<float> n = normalized(V3<float>{ x, 0.0f, 0.0f });
+        const float ref = x * (1.0f / rsqrt_exact(x * x + 0.0f * 0.0f + 0.0f * 0.0f));
+        same = same && (__float_as_uint(n.x) == __float_as_uint(ref) || (n.x != n.x && ref != ref));
+        if (!same) { ++bad; atomicMin(first_bad, bits); }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 // RGBABuffer::set_pixels_from_buffer (render.rs:112-126): tile-major tiles -> row-major frame, 4 B per lane.
 __global__ __launch_bounds__(kBlockThreads) void k_blit_tiles(unsigned width, const TileDev *__restrict__ tiles, unsigned n_tiles,
                                                              const unsigned *__restrict__ src, unsigned *__restrict__ frame)

@@ -19,7 +19,9 @@ namespace rt {
 constexpr unsigned kSkip2Rays = 2;
 constexpr unsigned kSkip2Threads = kBlockThreads / kSkip2Rays;
 
-template <int MODE>
+// FILT: the shadow walk reads the two-sided bounds of the filtered streams (skip2_shadow_rot_filt_fused) instead of forming the
+// reference's sixteen operations at every node; the primary walk is filtered in both flavours.
+template <int MODE, bool FILT>
 __global__ __launch_bounds__(kSkip2Threads) void k_render_skip2(SkipView<float> sc, unsigned width, unsigned height, unsigned spp_arg,
                                                                const TileDev *__restrict__ tiles, unsigned n_tiles, uint8_t *__restrict__ out,
                                                                SampleBuf<float> sb, unsigned frame_w, const BlockDesc *__restrict__ order,
@@ -135,19 +137,25 @@ __global__ __launch_bounds__(kSkip2Threads) void k_render_skip2(SkipView<float> 
         bool occluded[R] = { false, false };
         if (__ballot(need_shadow[0] || need_shadow[1]) != 0) {
             for (unsigned h = 0; h < R; ++h) resume[h] = need_shadow[h] ? 0u : nb;      // rays without a shadow ray sleep until END
-            unsigned i = 0;
-            while (i < nb) {
-                unsigned fin[R];
-                i = (unsigned)__builtin_amdgcn_readfirstlane((int)skip2_shadow_rot_fused(sc.fshad, nb, i, ox, oy, oz, sdir.x, sdir.y, sdir.z, resume, fin));
-                if (i >= nb) break;
-                unsigned want = nb;
-                for (unsigned h = 0; h < R; ++h) {
-                    if (fin[h]) { occluded[h] = true; resume[h] = nb; }
-                    const unsigned w = resume[h] >= nb ? nb : (resume[h] > i ? resume[h] : i + kStride);
-                    want = w < want ? w : want;
+            if constexpr (FILT) {
+                // one invocation: rays retire inside the loop (resume = nb + 1) and the walk goes on at the next wanted node
+                skip2_shadow_rot_filt_fused(sc.xfshad, nb, ox, oy, oz, resume, sc.fc, sc.fshad);
+                for (unsigned h = 0; h < R; ++h) occluded[h] = resume[h] == nb + 1u;
+            } else {
+                unsigned i = 0;
+                while (i < nb) {
+                    unsigned fin[R];
+                    i = (unsigned)__builtin_amdgcn_readfirstlane((int)skip2_shadow_rot_fused(sc.fshad, nb, i, ox, oy, oz, sdir.x, sdir.y, sdir.z, resume, fin));
+                    if (i >= nb) break;
+                    unsigned want = nb;
+                    for (unsigned h = 0; h < R; ++h) {
+                        if (fin[h]) { occluded[h] = true; resume[h] = nb; }
+                        const unsigned w = resume[h] >= nb ? nb : (resume[h] > i ? resume[h] : i + kStride);
+                        want = w < want ? w : want;
+                    }
+                    // some ray retired at the node at i: go straight to the next node any ray still wants (nb: nobody is left)
+                    i = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_min_u32(want));
                 }
-                // some ray retired at the node at i: go straight to the next node any ray still wants (nb: nobody is left)
-                i = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_min_u32(want));
             }
         }
 

@@ -370,6 +370,12 @@ def test_lean_sqrt_is_correctly_rounded_for_every_f32():
     assert bad == 0, "first differing input bits: 0x%08x" % first
 
 
+def test_lean_reciprocal_is_correctly_rounded_for_every_f32():
+    # Vector::normalized multiplies by len.recip(): the kernels' 3-instruction reciprocal must equal 1.0f / x on all 2^32 inputs
+    bad, first = rta.capi.selftest_rcp(0)
+    assert bad == 0, "first differing input bits: 0x%08x" % first
+
+
 # ----------------------------------------------------------------------------------------------------------
 # Committed vectors (tests/golden/oracle_vectors.json): the expected bytes are data in the repository, so these
 # checks do not depend on running the oracle at test time.

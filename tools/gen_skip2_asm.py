@@ -156,6 +156,35 @@ class Regs:
         self.t0, self.t1, self.t3, self.t4, self.t5 = self.T0.h[0], self.T0.h[1], self.T1.h[0], self.T1.h[1], self.T2.h[0]
 
 
+U = (TINY, sp(82))             # filtered shadow walk, per half: the candidates the bounds cannot settle (TINY is only the root's scratch)
+K1 = LIGHT + 3                  # s81: k1 of the inner bound (the pad of the light's pair)
+A0, KC = "s84", "s85"           # a >= a0 proves b >= 0;  (P2 + a^2) kc >= R2o proves the origin clearly outside
+SGPR_LAST_FILT = 85
+FC = 36                         # FilterConsts (rt_skip.hpp) arrive in s[36:51] before the walk starts: m0, e1, e2, l, a0, k1, kc, ro2
+
+
+class RegsSF:
+    """v[32:63] of the FILTERED shadow walk.  Ray-persistent: the origin (D, for the reference's arithmetic), its coordinates in the
+    plane perpendicular to the light (Q1, Q2) and along it (OL), RES.  Step-persistent: P2, AV.  E0..E6: temporaries -- of the bounds
+    (differences, INN = P2 + AV^2, TT = P2 + k1 INN) and, when the bounds cannot settle a ray, of the reference's sixteen operations
+    (V = E0..E2, products E3..E5, B = E6, then vv -> E0, Q -> E2, DISC -> E1) and of the root (halves of E3..E5)."""
+
+    def __init__(self):
+        v = VGPR_FIRST
+        self.DX, self.DY, self.DZ = Pair(v), Pair(v + 2), Pair(v + 4)
+        self.RES = Pair(v + 6)
+        self.Q1, self.Q2, self.OL = Pair(v + 8), Pair(v + 10), Pair(v + 12)
+        self.P2, self.AV = Pair(v + 14), Pair(v + 16)
+        E = [Pair(v + 18 + 2 * k) for k in range(7)]
+        self.E = E
+        self.INN, self.TT = E[2], E[3]
+        self.VX, self.VY, self.VZ = E[0], E[1], E[2]
+        self.T0, self.T1, self.T2 = E[3], E[4], E[5]
+        self.B, self.Q, self.DISC = E[6], E[2], E[1]
+        self.t0, self.t1, self.t3, self.t4, self.t5 = E[3].h[0], E[3].h[1], E[4].h[0], E[4].h[1], E[5].h[0]
+        self.root = E[5].h[1]
+
+
 def refine(a, r, x):
     a.op("v_mul_f32_e32 %s, %s, %s" % (r.root, x, r.t0), "g = x*y")
     a.op("v_mul_f32_e32 %s, 0.5, %s" % (r.t0, r.t0), "h = y/2")
@@ -430,6 +459,250 @@ def shadow_copy(r, name):
         tiny(k, r, disc, tl, dl)
     return m, k
 
+# ---------------------------------------------------------------------------------------------------------- shadow, filtered
+
+def fs(b, k):
+    """FNodeS (rt_skip.hpp): {w1, w2, cl, R2o | ITEM flag, R2i, R2o_own | END flag, R2i_own, skip_off}."""
+    return BANK[b] + k
+
+
+def s_r2o(b): return "s%d" % fs(b, 3)
+def s_r2i(b): return "s%d" % fs(b, 4)
+def s_r2o_own(b): return "s%d" % fs(b, 5)
+def s_r2i_own(b): return "s%d" % fs(b, 6)
+def s_skip(b): return "s%d" % fs(b, 7)
+
+
+def outer_cmp(a, r, r2o):
+    """C[h] = the rays of half h that are NOT beyond the outer bound (a NaN -- a ray the bounds do not cover -- passes)."""
+    for h in range(2):
+        a.op("v_cmp_ngt_f32_e64 %s, %s, |%s|" % (C[h], r.P2.h[h], r2o), "P2 > R2o: the reference's test says miss" if h == 0 else None)
+
+
+def inner_terms(a, r):
+    pk_fma(a, r.INN.p, r.AV.p, r.AV.p, r.P2.p, comment="~ |centre - origin|^2")
+    pk_fma(a, r.TT.p, None, r.INN.p, r.P2.p, sx=K1, comment="P2 + k1 |centre - origin|^2: the reference's rounding of disc grows with the distance")
+
+
+def two_sided(a, r, r2i, exact_label):
+    """C[h] = awake rays inside the outer bound.  A ray is a SURE hit if it is inside the inner bound (disc >= 0 by a margin) and
+    t2 = b + root >= 0 for certain (b >= 0 by a margin, or the origin inside the sphere).  U[h] = the candidates that are not sure."""
+    for h in range(2):
+        a.op("v_cmp_le_f32_e64 %s, %s, %s" % (M, A0, r.AV.h[h]), "b >= 0, by a margin")
+        a.op("v_cmp_le_f32_e64 %s, %s, %s" % (M2, r.INN.h[h], r2i), "origin inside the sphere, by a margin")
+        a.op("s_or_b64 %s, %s, %s" % (M, M, M2))
+        a.op("v_cmp_le_f32_e64 %s, %s, %s" % (M2, r.TT.h[h], r2i), "inside the inner bound")
+        a.op("s_and_b64 %s, %s, %s" % (M, M, M2), "sure hits")
+        a.op("s_andn2_b64 %s, %s, %s" % (U[h], C[h], M), "candidates between the bounds")
+    a.op("s_or_b64 %s, %s, %s" % (M, U[0], U[1]))
+    a.op("s_cbranch_scc1 %s" % exact_label)
+
+
+def second_chance(k, r, r2o, exact2, none_label, some_label):
+    """Most rays between the bounds have the sphere BEHIND them: b < 0 by a margin while the origin is clearly outside -- the
+    reference's test says miss.  Settles U[h]; sure misses leave C[h]."""
+    for h in range(2):
+        k.op("v_mul_f32_e32 %s, %s, %s" % (r.T1.h[h], KC, r.INN.h[h]), "(P2 + a^2) / (1 + 4 tau)")
+        k.op("v_cmp_le_f32_e64 %s, |%s|, %s" % (M, r2o, r.T1.h[h]), "the origin is clearly outside the sphere")
+        k.op("v_cmp_le_f32_e64 %s, %s, -%s" % (M2, r.AV.h[h], A0), "b < 0, by a margin")
+        k.op("s_and_b64 %s, %s, %s" % (M, M, M2), "sure misses")
+        k.op("s_andn2_b64 %s, %s, %s" % (U[h], U[h], M))
+        k.op("s_andn2_b64 %s, %s, %s" % (C[h], C[h], M))
+    k.op("s_or_b64 %s, %s, %s" % (M, U[0], U[1]))
+    k.op("s_cbranch_scc1 %s" % exact2, "still between the bounds: the reference's arithmetic decides")
+    k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+    k.op("s_cbranch_scc0 %s" % none_label)
+    k.op("s_branch %s" % some_label)
+
+
+def exact_packed(k, r, src, rr, lab, tag, tinies):
+    """The reference's own test (primitive.rs:55-72) for both rays of every lane, node terms from bank `src` (a Node<float> record of
+    the exact stream): C[h] = awake rays (ACT[h]) that hit the sphere with squared radius SGPR number `rr`."""
+    pk(k, "add", r.VX.p, None, r.DX.p, sx=fld(src, 0), neg_y=True, comment="v = centre - origin, both rays   primitive.rs:56")
+    pk(k, "add", r.VY.p, None, r.DY.p, sx=fld(src, 1), neg_y=True)
+    pk(k, "add", r.VZ.p, None, r.DZ.p, sx=fld(src, 2), neg_y=True)
+    pk(k, "mul", r.T0.p, None, r.VX.p, sx=LIGHT + 0)
+    pk(k, "mul", r.T1.p, None, r.VY.p, sx=LIGHT + 1)
+    pk(k, "mul", r.T2.p, None, r.VZ.p, sx=LIGHT + 2)
+    pk(k, "add", r.T0.p, r.T0.p, r.T1.p)
+    pk(k, "add", r.B.p, r.T0.p, r.T2.p, comment="b = dot(v, dir)   primitive.rs:57")
+    pk(k, "mul", r.VX.p, r.VX.p, r.VX.p)
+    pk(k, "mul", r.VY.p, r.VY.p, r.VY.p)
+    pk(k, "mul", r.VZ.p, r.VZ.p, r.VZ.p)
+    pk(k, "add", r.VX.p, r.VX.p, r.VY.p)
+    pk(k, "add", r.VX.p, r.VX.p, r.VZ.p, comment="dot(v, v)")
+    pk(k, "mul", r.T0.p, r.B.p, r.B.p)
+    pk(k, "add", r.Q.p, r.T0.p, r.VX.p, neg_y=True)
+    pk(k, "add", r.DISC.p, None, r.Q.p, sx=rr, comment="disc = (b*b - vv) + rr   primitive.rs:58")
+    k.op("v_cmp_le_f32_e64 %s, 0, %s" % (C[0], r.DISC.h[0]))
+    k.op("v_cmp_le_f32_e32 vcc, 0, %s" % r.DISC.h[1])
+    k.op("s_and_b64 %s, %s, %s" % (C[0], C[0], ACT[0]))
+    k.op("s_and_b64 %s, vcc, %s" % (C[1], ACT[1]))
+    for h in range(2):
+        shadow_decide(k, r, h, tag, lab, tinies)
+
+
+def shadow_copy_filt(r, name):
+    """Two-sided flavour of shadow_copy: the walk reads the FNodeS stream (%[base]); a step that leaves some ray between the bounds
+    fetches the node's Node record from the exact stream (%[base2]) and runs the reference's arithmetic for every ray."""
+    c, n, s = COPIES[name]
+    lab = lambda x: ".Lr2_%s_%s_%%=" % (name, x)
+    m, k, tinies = Asm(), Asm(), []
+    m.label(lab("top"))
+    load(m, s, s_skip(c), "the likely successor, while this node is processed")
+    pk(m, "add", r.E[0].p, None, r.Q1.p, sx=fs(c, 0), neg_y=True, comment="P2 = |w - q|^2 in the plane perpendicular to the light, both rays")
+    pk(m, "add", r.E[1].p, None, r.Q2.p, sx=fs(c, 1), neg_y=True)
+    pk(m, "mul", r.E[0].p, r.E[0].p, r.E[0].p)
+    pk_fma(m, r.P2.p, r.E[1].p, r.E[1].p, r.E[0].p)
+    outer_cmp(m, r, s_r2o(c))
+    m.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+    m.op("s_cbranch_scc1 %s" % lab("hit"))
+    m.label(lab("skip"))
+    m.op("s_add_u32 %s, %s, %d" % (NX, s_skip(c), STRIDE), "jump over the subtree")
+    m.op("s_waitcnt lgkmcnt(0)")
+    if LAYOUT.index(SKIP_COPY[name]) != LAYOUT.index(name) + 1:
+        m.op("s_branch %s" % top_of(SKIP_COPY[name]))
+    # ---------------- some ray (awake or not) is inside the outer bound ----------------
+    k.label(lab("hit"))
+    for h in range(2):
+        k.op("v_cmp_gt_u32_e64 %s, %s, %s" % (ACT[h], NX, r.RES.h[h]), "active = i >= resume  (NX = i + stride)" if h == 0 else None)
+    for h in range(2):
+        k.op("s_and_b64 %s, %s, %s" % (C[h], C[h], ACT[h]))
+    k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+    k.op("s_cbranch_scc0 %s" % lab("skip"), "only sleeping rays: a BOUND is jumped over, an ITEM changes nothing")
+    pk(k, "add", r.AV.p, None, r.OL.p, sx=fs(c, 2), neg_y=True, comment="a ~ b = dot(centre - origin, dir)")
+    inner_terms(k, r)
+    two_sided(k, r, s_r2i(c), lab("exact"))
+    k.label(lab("decided"))
+    k.op("s_bitcmp1_b32 %s, 31" % s_r2o(c), "an ITEM or the END node?  (sign bit of the outer bound)")
+    k.op("s_cbranch_scc1 %s" % lab("flagged"))
+    # BOUND: hit.distance is INF, so a bound culls iff the ray misses it
+    for h in range(2):
+        k.op("s_andn2_b64 exec, %s, %s" % (ACT[h], C[h]), "rays that may not enter sleep until `skip`" if h == 0 else None)
+        k.op("v_mov_b32_e32 %s, %s" % (r.RES.h[h], s_skip(c)))
+    k.op("s_mov_b64 exec, %s" % EX)
+    for h in range(2):
+        k.op("s_mov_b64 %s, %s" % (ACT[h], C[h]), "the rays that are awake at the next node" if h == 0 else None)
+    outer_cmp(k, r, s_r2o_own(c))
+    for h in range(2):
+        k.op("s_and_b64 %s, %s, %s" % (C[h], C[h], ACT[h]), "the group's own sphere: same centre, its own bounds" if h == 0 else None)
+    k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+    k.op("s_cbranch_scc0 %s" % lab("next"))
+    two_sided(k, r, s_r2i_own(c), lab("exactown"))
+    k.label(lab("owndecided"))
+    k.op("s_branch .Lr2_fin_%=", "any hit ends those rays; hand them to the caller (it starts again behind this node)")
+    k.label(lab("next"))
+    load(k, n, NX, "somebody entered: fetch the group's first child")
+    emit_next(k, name)
+    # ITEM or END
+    k.label(lab("flagged"))
+    k.op("s_bitcmp1_b32 %s, 31" % s_r2o_own(c))
+    k.op("s_cbranch_scc1 .Lr2_exit_%=", "END: every ray is awake here and hits it")
+    k.op("s_branch .Lr2_fin_%=")
+    # ---- rays between the bounds
+    tmp = "s" + M[2:].split(":")[0]                 # the scratch mask is dead here
+    k.label(lab("exact"))
+    second_chance(k, r, s_r2o(c), lab("exact2"), lab("skip"), lab("decided"))
+    k.label(lab("exact2"))
+    k.op("s_sub_u32 %s, %s, %d" % (tmp, NX, STRIDE), "this node's offset")
+    k.op("s_load_dwordx8 s[%d:%d], %%[base2], %s" % (BANK[n], BANK[n] + 7, tmp), "its Node record of the exact stream (the `next` bank is free until the group is entered)")
+    k.op("s_waitcnt lgkmcnt(0)")
+    exact_packed(k, r, n, fld(n, 3), lab, "x", tinies)
+    k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+    k.op("s_cbranch_scc0 %s" % lab("skip"))
+    inner_terms(k, r)                                # the own sphere's bounds read INN and TT again
+    k.op("s_branch %s" % lab("decided"))
+    k.label(lab("exactown"))
+    second_chance(k, r, s_r2o_own(c), lab("exactown2"), lab("next"), lab("owndecided"))
+    k.label(lab("exactown2"))
+    k.op("s_sub_u32 %s, %s, %d" % (tmp, NX, STRIDE), "this node's offset")
+    k.op("s_waitcnt lgkmcnt(0)", "the skip successor's fetch may still be in flight INTO this bank, and scalar loads land out of order")
+    k.op("s_load_dwordx8 s[%d:%d], %%[base2], %s" % (BANK[s], BANK[s] + 7, tmp), "its Node record (the skip bank is free: the group is entered)")
+    k.op("s_waitcnt lgkmcnt(0)")
+    exact_packed(k, r, s, own(s), lab, "y", tinies)
+    k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+    k.op("s_cbranch_scc0 %s" % lab("next"))
+    k.op("s_branch %s" % lab("owndecided"))
+    for disc, tl, dl in tinies:
+        tiny(k, r, disc, tl, dl)
+    return m, k
+
+
+def shadow_filt():
+    """One invocation walks the whole stream: a ray that hits an ITEM (or a group's own sphere) retires INSIDE the loop -- resume =
+    n + 1 (asleep at every node, told apart from the rays that never had a shadow ray: resume = n) -- and the walk goes on at the first
+    node any ray still wants (the wave minimum of max(resume, NX), a DPP reduction).  The operands are dead once copied in."""
+    a, r = Asm(), RegsSF()
+    a.op("s_load_dwordx16 s[%d:%d], %%[fc], 0x0" % (FC, FC + 15), "FilterConsts: m0, e1, e2, l, a0, k1, kc, ro2")
+    for h in range(2):
+        a.op("v_mov_b32_e32 %s, %%[ox%d]" % (r.DX.h[h], h), "operands into the loop's own registers" if h == 0 else None)
+        a.op("v_mov_b32_e32 %s, %%[oy%d]" % (r.DY.h[h], h))
+        a.op("v_mov_b32_e32 %s, %%[oz%d]" % (r.DZ.h[h], h))
+        a.op("v_mov_b32_e32 %s, %%[res%d]" % (r.RES.h[h], h))
+    a.op("v_mov_b32_e32 %s, 0x7fc00000" % r.E[4].h[0])
+    a.op("s_mov_b64 %s, exec" % EX)
+    a.op("s_waitcnt lgkmcnt(0)")
+    # shadow_filter_origin (rt_skip.hpp) for both rays: q = ((o - m0) . e1, (o - m0) . e2), ol = (o - m0) . l, FMA chains in its order
+    x, y, z, d2 = r.E[0], r.E[1], r.E[2], r.E[3]
+    pk(a, "add", x.p, r.DX.p, None, sy=FC + 0, neg_y=True, comment="o - m0")
+    pk(a, "add", y.p, r.DY.p, None, sy=FC + 1, neg_y=True)
+    pk(a, "add", z.p, r.DZ.p, None, sy=FC + 2, neg_y=True)
+    for dst, k0 in ((r.Q1, FC + 3), (r.Q2, FC + 6), (r.OL, FC + 9)):
+        pk(a, "mul", dst.p, None, x.p, sx=k0)
+        pk_fma(a, dst.p, None, y.p, dst.p, sx=k0 + 1)
+        pk_fma(a, dst.p, None, z.p, dst.p, sx=k0 + 2)
+    pk(a, "mul", d2.p, x.p, x.p)
+    pk_fma(a, d2.p, y.p, y.p, d2.p)
+    pk_fma(a, d2.p, z.p, z.p, d2.p)
+    for h in range(2):
+        a.op("v_cmp_nle_f32_e64 %s, %s, s%d" % (M, d2.h[h], FC + 15), "an origin the constants do not cover: q1 = NaN passes every outer bound and fails every sure test" if h == 0 else None)
+        a.op("s_nop 1")
+        a.op("v_cndmask_b32_e64 %s, %s, %s, %s" % (r.Q1.h[h], r.Q1.h[h], r.E[4].h[0], M))
+    for k in range(3):
+        a.op("s_mov_b32 s%d, s%d" % (LIGHT + k, FC + 9 + k), "the shadow rays' direction, -light (render.rs:206)" if k == 0 else None)
+    a.op("s_mov_b32 %s, s%d" % (A0, FC + 12))
+    a.op("s_mov_b32 s%d, s%d" % (K1, FC + 13))
+    a.op("s_mov_b32 %s, s%d" % (KC, FC + 14))
+    a.op("s_mov_b32 %s, %d" % (NX, STRIDE))
+    load(a, 0, "0x0")
+    a.op("s_waitcnt lgkmcnt(0)")
+    assemble(a, r, shadow_copy_filt)
+    # ---- some ray hit the ITEM (or the group's own sphere) of the current node: C[h]
+    tmp = "s" + M[2:].split(":")[0]
+    w, t = r.E[0].h[0], (r.E[0].h[1], r.E[1].h[0])
+    a.label(".Lr2_fin_%=")
+    a.op("s_waitcnt lgkmcnt(0)", "a successor fetch may still be in flight into the bank the walk restarts in")
+    a.op("s_add_u32 %s, %%[n], 1" % tmp)
+    for h in range(2):
+        a.op("s_mov_b64 exec, %s" % C[h], "render.rs:208 only asks has_missed(): the ray is done" if h == 0 else None)
+        a.op("v_mov_b32_e32 %s, %s" % (r.RES.h[h], tmp))
+    a.op("s_mov_b64 exec, -1")
+    a.op("v_mov_b32_e32 %s, %%[n]" % w, "lanes the wave entered without take no part")
+    a.op("s_mov_b64 exec, %s" % EX)
+    for h in range(2):
+        a.op("v_max_u32_e32 %s, %s, %s" % (t[h], NX, r.RES.h[h]), "the next node the ray wants: resume > i ? resume : i + stride" if h == 0 else None)
+    a.op("v_min_u32_e32 %s, %s, %s" % (w, t[0], t[1]))
+    a.op("v_min_u32_e32 %s, %%[n], %s" % (w, w), "retired rays (n, n + 1) want nothing")
+    a.op("s_mov_b64 exec, -1")
+    for ctrl in ("row_shr:1 row_mask:0xf", "row_shr:2 row_mask:0xf", "row_shr:4 row_mask:0xf", "row_shr:8 row_mask:0xf",
+                 "row_bcast:15 row_mask:0xa", "row_bcast:31 row_mask:0xc"):
+        a.op("s_nop 1")
+        a.op("v_min_u32_dpp %s, %s, %s %s bank_mask:0xf" % (w, w, w, ctrl))
+    a.op("s_nop 1")
+    a.op("v_readlane_b32 %s, %s, 63" % (tmp, w), "the wave's minimum")
+    a.op("s_mov_b64 exec, %s" % EX)
+    a.op("s_cmp_ge_u32 %s, %%[n]" % tmp)
+    a.op("s_cbranch_scc1 .Lr2_exit_%=", "nobody is left")
+    a.op("s_add_u32 %s, %s, %d" % (NX, tmp, STRIDE))
+    load(a, 0, tmp)
+    a.op("s_waitcnt lgkmcnt(0)")
+    a.op("s_branch %s" % top_of("A"))
+    a.label(".Lr2_exit_%=")
+    a.op("s_waitcnt lgkmcnt(0)")
+    for h in range(2):
+        a.op("v_mov_b32_e32 %%[rout%d], %s" % (h, r.RES.h[h]))
+    return a.render()
+
 
 def assemble(a, r, copy_fn):
     mains, colds = {}, {}
@@ -556,8 +829,29 @@ __device__ __forceinline__ unsigned skip2_shadow_rot_fused(const void *nodes, un
 """
 
 
-def clobbers():
-    regs = ['"s%d"' % r for r in range(36, SGPR_LAST + 1)] + ['"v%d"' % r for r in range(VGPR_FIRST, VGPR_LAST + 1)]
+SHADOW_FN_FILT = """// The shadow walk over the FILTERED stream (FNodeS[n + 3], rt_skip.hpp: the two-sided bounds of rt_skip_rot.hpp's filtered loops,
+// DESIGN.md 4.1), start to END in one invocation: a step forms P2 for both rays with four packed instructions and asks the outer
+// bound; a node some awake ray is inside of is settled by the inner bound (sure hit) or the behind-the-origin test (sure miss), and
+// only when a ray stays between the bounds does the step fetch the node's Node record from `exact` (the compacted exact stream, same
+// offsets) and run the reference's arithmetic for every ray.  fc: the scene's FilterConsts (its l is the rays' direction).
+// resume[h] in: 0 for a shadow ray, n_bytes for a lane half without one.  resume[h] out: n_bytes + 1 iff the ray hit something.
+__device__ __forceinline__ void skip2_shadow_rot_filt_fused(const void *nodes, unsigned n_bytes, const float (&ox)[2], const float (&oy)[2],
+                                                            const float (&oz)[2], unsigned (&resume)[2], const void *fc, const void *exact)
+{
+    const float tiny = 0x1p-96f;
+    asm volatile(
+%(body)s
+        : [rout0] "=v"(resume[0]), [rout1] "=v"(resume[1])
+        : [base] "s"(nodes), [n] "s"(n_bytes), [ox0] "v"(ox[0]), [ox1] "v"(ox[1]), [oy0] "v"(oy[0]), [oy1] "v"(oy[1]),
+          [oz0] "v"(oz[0]), [oz1] "v"(oz[1]), [res0] "v"(resume[0]), [res1] "v"(resume[1]), [tiny] "s"(tiny), [fc] "s"(fc), [base2] "s"(exact)
+        : %(clobbers)s);
+}
+
+"""
+
+
+def clobbers(last=SGPR_LAST):
+    regs = ['"s%d"' % r for r in range(36, last + 1)] + ['"v%d"' % r for r in range(VGPR_FIRST, VGPR_LAST + 1)]
     lines, cur = [], '"memory", "vcc", "scc"'
     for r in regs:
         if len(cur) + len(r) + 2 > 118:
@@ -573,6 +867,7 @@ def main():
     text = HEADER
     text += PRIMARY_FN % {"body": primary(), "clobbers": clobbers()}
     text += SHADOW_FN % {"body": shadow(), "clobbers": clobbers()}
+    text += SHADOW_FN_FILT % {"body": shadow_filt(), "clobbers": clobbers(SGPR_LAST_FILT)}
     text += "}  // namespace rt\n"
     with open(OUT, "w") as f:
         f.write(text)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak / fuzz run for the generated assembly loops (GPU box): bitwise stability over many launches, and random nested scenes on
-which every hierarchy-walk flavour (C++, assembly, fused assembly, two rays per lane) must agree with the counted C++ flavour
+which every hierarchy-walk flavour (C++, assembly, fused assembly, filtered, two rays per lane) must agree with the counted C++ flavour
 (which the parity tests pin to the CPU path) and the filtered scalar-fed flat scan with round 1's LDS kernels.
 usage: soak.py [seconds]"""
 import os
@@ -43,22 +43,38 @@ for (w, h, spp, trav, share, batch) in ((1920, 1080, 1, rta.RT_TRAVERSAL_SKIP, 0
 # 2. random nested scenes (every other one concentric): flavours 0/3/7 (no counters) vs flavour 1 with counters
 seed = 1000
 checked = 0
+filter_tests = 0
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
     depth, fan, leaf = int(rng.integers(2, 6)), int(rng.integers(2, 5)), int(rng.integers(1, 4))
     items, bounds, ranges = util.random_nested_scene(seed, depth=depth, fan=fan, leaf_items=leaf, concentric=seed % 2 == 1)
+    # round 3: the filtered loops' constants depend on the light, the eye and the scene's extent -- vary all three.  One scene in
+    # eight puts the eye inside the hierarchy, one in four scales every coordinate (margins are relative, subnormals are not).
     eye = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-4.5, -1.0)))
+    if seed % 8 == 6:
+        eye = tuple(float(v) for v in rng.uniform(-0.8, 0.8, 3))
+    light = rng.normal(size=3)
+    if seed % 3 == 0 or np.linalg.norm(light) < 0.2:
+        light = np.array((-1.0, -3.0, 2.0))
+    k = float(2.0 ** int(rng.integers(-30, 31))) if seed % 4 == 2 else 1.0
+    items, bounds, eye = items * k, bounds * k, tuple(v * k for v in eye)
     prec = rta.RT_F64 if seed % 4 == 3 else rta.RT_F32
-    sc = rta.Scene(items, rta.normalized((-1, -3, 2), prec), eye, bounds, ranges, prec)
+    sc = rta.Scene(items, rta.normalized(tuple(light), prec), eye, bounds, ranges, prec)
     dv = sc.device()
     w, h, spp = int(rng.integers(3, 9)) * 32, int(rng.integers(3, 9)) * 24, int(rng.integers(1, 3))
     regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
     rta.capi.debug_set(rta.capi.DEBUG_SKIP_VARIANT, 1)
     ref, st = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=True)
-    for v in (0, 3, 7):
+    flavours = (0, 3, 7) if prec == rta.RT_F64 else (0, 3, 7, 19, 23)
+    for v in flavours:
         rta.capi.debug_set(rta.capi.DEBUG_SKIP_VARIANT, v)
         got, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
         assert np.array_equal(got, ref), "seed %d: flavour %d differs" % (seed, v)
+    if prec == rta.RT_F32:
+        # the counting launch evaluated the filtered loops' bounds NEXT TO the reference's arithmetic for every test it made and
+        # counts a violation whenever a bound rules out what the arithmetic finds (rt_skip.hpp, COUNT mode)
+        assert rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_FILTER_VIOLATIONS) == 0, "seed %d: a bound ruled out a hit" % seed
+        filter_tests += st["sphere_tests"] + st["bound_tests"]
     rta.capi.debug_set(rta.capi.DEBUG_SKIP_VARIANT, -1)
     if prec == rta.RT_F32:
         if seed % 2 == 1:                                        # concentric = fused: the two-ray kernel exists (spp 1 and 2)
@@ -74,4 +90,5 @@ while time.time() < t_end:
     seed += 1
     if checked % 2000 == 0:
         print("fuzz: %d scenes so far" % checked, flush=True)        # a long run must not look hung
-print("fuzz: %d random scenes, all flavours identical (hierarchy: C++ / assembly / fused / two rays; flat: filtered scan / LDS kernels)" % checked)
+print("fuzz: %d random scenes, all flavours identical (hierarchy: C++ / assembly / fused / filtered / two rays; flat: filtered scan / LDS kernels); "
+      "0 filter violations in %d counted tests" % (checked, filter_tests))
