@@ -33,7 +33,7 @@ namespace {
 thread_local char g_err[512] = "";
 
 // Diagnostic controls (rt_debug.h): process-wide, -1 = default.  The library reads no environment variable.
-std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
+std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
 std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = { {0}, {0}, {0}, {0}, {0}, {0} };
 std::atomic<bool> g_trace_on{ false };
 std::mutex g_trace_mu;
@@ -361,7 +361,8 @@ void filter_constants(rt_scene *s, const std::vector<rt::RawNode<T>> &raw, const
     const double eye_d = dist(s->eye[0], s->eye[1], s->eye[2]);
     const double eye_abs = std::fabs(s->eye[0]) + std::fabs(s->eye[1]) + std::fabs(s->eye[2]), m0_abs = std::fabs(m0[0]) + std::fabs(m0[1]) + std::fabs(m0[2]);
     // shadow origins lie on an item's surface, pushed out by hit.distance * sqrt(eps) (render.rs:199): 1 % and a bit of room
-    const double ro = 1.01 * rit + 1e-3 * (eye_d + rit) + 1e-5 * (eye_abs + m0_abs);
+    double ro = 1.01 * rit + 1e-3 * (eye_d + rit) + 1e-5 * (eye_abs + m0_abs);
+    if (const long long pc = g_knob[RT_DEBUG_FILTER_RO_PERCENT].load(std::memory_order_relaxed); pc >= 0) ro *= (double)pc / 100.0;   // tests only
     const double eps = 0x1p-24;
     // plane perpendicular to the shadow direction l = -light (f32 components)
     const double l[3] = { -(double)(float)s->light[0], -(double)(float)s->light[1], -(double)(float)s->light[2] };
@@ -975,6 +976,15 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
         hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipSplit>), dim3(rgrid.x, (unsigned)ns), b, lds, stream, skip_view_of<T>(s), w, h, spp,
                            d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost, order.wg_first);
     HIP_TRY(hipGetLastError());
+    if constexpr (sizeof(T) == 4) {
+        if (packed) {        // one word per sample, [pixel][sample] (rt_kernels.hpp sample_word)
+            const uint4 *words = reinterpret_cast<const uint4 *>(sb.gdot);
+            if (ns == 4) hipLaunchKernelGGL((rt::k_resolve_words<4>), grid, b, 0, stream, words, d_tab, nt, d_out, frame_w);
+            else if (ns == 16) hipLaunchKernelGGL((rt::k_resolve_words<16>), grid, b, 0, stream, words, d_tab, nt, d_out, frame_w);
+            else hipLaunchKernelGGL((rt::k_resolve_words<64>), grid, b, 0, stream, words, d_tab, nt, d_out, frame_w);
+            return RT_OK;
+        }
+    }
     hipLaunchKernelGGL((rt::k_resolve_samples<T>), grid, b, 0, stream, sb, spp, d_tab, nt, d_out, frame_w, packed);
     return RT_OK;
 }

@@ -39,7 +39,10 @@ typedef enum rt_debug_key {
                                     default: the library's choice per workload (large spp-1 frames, large scenes) */
     RT_DEBUG_FRAME_AHEAD = 13,   /* 0: rt_render_region never serves a bucket from a whole-grid pass rendered ahead (every call its own device pass,
                                     or merged with concurrent ones: RT_DEBUG_COALESCE).  Default 1 */
-    RT_DEBUG_KEYS = 14
+    RT_DEBUG_FILTER_RO_PERCENT = 14, /* read by rt_scene_create: the radius around the scene's centroid in which the filtered loops' bounds cover
+                                    shadow-ray origins, in percent of the library's own value.  A small value leaves real origins
+                                    uncovered -- they must then fall back to the reference's arithmetic at every node (tests).  Default 100 */
+    RT_DEBUG_KEYS = 15
 } rt_debug_key;
 
 /* value < 0 restores the default. */

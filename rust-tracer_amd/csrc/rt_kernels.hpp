@@ -41,6 +41,18 @@ struct BlockList { const BlockDesc *d = nullptr; uint32_t n = 0; const uint32_t 
 // accumulation order: the four exits of Renderer::raytrace (render.rs:190-213) and n.light where it is needed.
 enum SampleState : uint8_t { kMiss = 0, kAmbient = 1, kLit = 2, kShadowed = 3 };
 
+// f32 sample-packed passes of the hierarchy walk ([pixel][sample] order) store ONE word per sample in the gdot array and leave the state
+// array alone: a sample needs n.light only when a shadow ray was cast, i.e. when n.light < 0 (render.rs:196-199) -- its sign bit is
+// known, so the bit says whether the shadow ray was occluded; the two other exits are NaN payloads (no n.light is a NaN: DESIGN.md 2).
+constexpr uint32_t kSampleMiss = 0x7fc00001u, kSampleAmbient = 0x7fc00002u;
+__device__ __forceinline__ uint32_t sample_word(uint8_t state, float gdot)
+{
+    if (state == 0) return kSampleMiss;                 // kMiss
+    if (state == 1) return kSampleAmbient;              // kAmbient
+    const uint32_t b = __float_as_uint(gdot);           // sign bit set
+    return state == 2 ? b : (b & 0x7fffffffu);          // kLit : kShadowed
+}
+
 template <typename T> struct SampleBuf {
     T *gdot;             // [spp*spp][n_px]  n.light of the sample (meaningful for kLit / kShadowed)
     uint8_t *state;      // [spp*spp][n_px]

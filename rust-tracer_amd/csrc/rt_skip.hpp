@@ -569,8 +569,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             if (SPLIT && inside) {
                 const size_t px_i = (size_t)(base + y * pitch + x);
                 const size_t p = PACKED ? px_i * (spp * spp) + sample : (size_t)sample * sb.n_px + px_i;
-                sb.gdot[p] = gdot;
-                sb.state[p] = state;
+                if constexpr (PACKED && sizeof(T) == 4) {
+                    reinterpret_cast<uint32_t *>(sb.gdot)[p] = sample_word(state, gdot);      // k_resolve_words
+                } else {
+                    sb.gdot[p] = gdot;
+                    sb.state[p] = state;
+                }
             }
         }
     }
@@ -654,6 +658,58 @@ __global__ __launch_bounds__(kBlockThreads) void k_resolve_samples(SampleBuf<T> 
         else if (st == kAmbient) g = add(g, AMBIENT);                                   // render.rs:196
         else if (st == kLit) { g = add(add(g, mulf(OBJECT, -gdot)), AMBIENT); alpha += T(1.0); }      // render.rs:209-210
         else g = add(add(g, BACKGROUND), mulf(AMBIENT, -gdot));                         // render.rs:212
+    }
+    g = mulf(g, total_recip);
+    alpha *= total_recip;
+    reinterpret_cast<unsigned *>(out)[out_index(tile, x, y, frame_w)] =
+        scale_u8(g.x) | (scale_u8(g.y) << 8) | (scale_u8(g.z) << 16) | (scale_u8(alpha) << 24);
+}
+
+// The same for the f32 sample-packed passes (kSkipPacked, k_render_skip2): one word per sample (sample_word, rt_kernels.hpp), a pixel's
+// NS samples contiguous -- a thread fetches them 16 bytes at a time and adds them in the reference's order.  Each sample adds
+// (g + A) + B: {BACKGROUND, 0}, {AMBIENT, 0}, {OBJECT * -n.light, AMBIENT} (render.rs:209), {BACKGROUND, AMBIENT * -n.light} (render.rs:212);
+// adding +0 to a non-negative sum changes no bit, so the single-term exits need no branch.
+template <unsigned NS>
+__global__ __launch_bounds__(kBlockThreads) void k_resolve_words(const uint4 *__restrict__ words, const TileDev *__restrict__ tiles, unsigned n_tiles,
+                                                                uint8_t *__restrict__ out, unsigned frame_w)
+{
+    typedef float T;
+    unsigned lo = 0, hi = n_tiles - 1;
+    while (lo < hi) {
+        unsigned mid = (lo + hi + 1) >> 1;
+        if (tiles[mid].blk_first <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const TileDev tile = tiles[lo];
+    const unsigned lb = blockIdx.x - tile.blk_first;
+    const unsigned x = tile.l + (lb % tile.blks_x) * kBlockW + (threadIdx.x & 15);
+    const unsigned y = tile.b + (lb / tile.blks_x) * kBlockH + (threadIdx.x >> 4);
+    if (!(x < tile.r && y < tile.t)) return;
+    const size_t p = out_index(tile, x, y, 0);                   // the samples are always stored tile-major
+    const V3<T> OBJECT = { T(0xae) / T(255.0), T(0x31) / T(255.0), T(0x31) / T(255.0) };
+    const V3<T> BACKGROUND = { T(0x22) / T(255.0), T(0x0a) / T(255.0), T(0x0a) / T(255.0) };
+    const V3<T> AMBIENT = { BACKGROUND.x * T(0.8), BACKGROUND.y * T(0.8), BACKGROUND.z * T(0.8) };
+    constexpr unsigned kSpp = NS == 4 ? 2u : NS == 16 ? 4u : 8u;
+    const T ssf = T(kSpp);
+    const T total_recip = T(1.0) / (ssf * ssf);
+    V3<T> g = { T(0.0), T(0.0), T(0.0) };
+    T alpha = T(0.0);
+    const uint4 *src = words + p * (NS / 4u);
+#pragma unroll 4
+    for (unsigned j = 0; j < NS / 4u; ++j) {
+        const uint4 q = src[j];
+        const uint32_t w4[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+        for (unsigned k = 0; k < 4; ++k) {
+            const uint32_t w = w4[k];
+            const bool miss = w == kSampleMiss, amb = w == kSampleAmbient, lit = !miss && !amb && (w & 0x80000000u) != 0u, sh = !miss && !amb && !lit;
+            const T m = __uint_as_float(w & 0x7fffffffu);           // -n.light of a lit / shadowed sample
+            const V3<T> A = { lit ? OBJECT.x * m : amb ? AMBIENT.x : BACKGROUND.x, lit ? OBJECT.y * m : amb ? AMBIENT.y : BACKGROUND.y,
+                              lit ? OBJECT.z * m : amb ? AMBIENT.z : BACKGROUND.z };
+            const V3<T> B = { lit ? AMBIENT.x : sh ? AMBIENT.x * m : T(0.0), lit ? AMBIENT.y : sh ? AMBIENT.y * m : T(0.0),
+                              lit ? AMBIENT.z : sh ? AMBIENT.z * m : T(0.0) };
+            g = add(add(g, A), B);
+            alpha += lit ? T(1.0) : T(0.0);
+        }
     }
     g = mulf(g, total_recip);
     alpha *= total_recip;

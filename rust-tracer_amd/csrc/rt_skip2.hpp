@@ -165,8 +165,7 @@ __global__ __launch_bounds__(kSkip2Threads) void k_render_skip2(SkipView<float> 
             if (PACKED) {
                 const size_t px_i = (size_t)(base + y * pitch + x[h]);
                 const size_t p = px_i * (spp * spp) + sample;
-                sb.gdot[p] = gdot[h];
-                sb.state[p] = state[h];
+                reinterpret_cast<uint32_t *>(sb.gdot)[p] = sample_word(state[h], gdot[h]);          // k_resolve_words
             } else {
                 // render.rs:233-252 for one sample: 0 + term, the mean over one sample and alpha * 1 are the identity bit for bit
                 V3<T> g = { T(0.0), T(0.0), T(0.0) };

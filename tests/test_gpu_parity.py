@@ -935,7 +935,8 @@ def test_scalar_fed_flat_scan_on_tiny_discriminants():
 def test_two_rays_per_lane_walk_on_the_default_scene(w, h, spp, level):
     # k_render_skip2 against k_render_skip, byte for byte, on the reference's pyramid: cost-ordered and narrowed descriptors
     # (1080p), the sample-packed modes, a ragged frame, a pass dealt out over workgroups (2048 x 2048 spp 4: 262,144 descriptors)
-    # and the library's own choice -- spp-1 frames of 3.5 M pixels and more take the two-ray kernel without being asked
+    # and the library's own choice -- spp-1 frames of 2.9 M pixels and more (2560 x 1664) and sample-packed frames of 6 M samples and
+    # more (`make image`, 2048 x 2048 spp 4) take the two-ray kernel without being asked
     s = rta.Scene.default(level)
     regs = bucket_list(w, h, spp)
     d = s.device()
@@ -950,6 +951,27 @@ def test_two_rays_per_lane_walk_on_the_default_scene(w, h, spp, level):
     if (w, h, spp, level) == (1920, 1080, 1, 8):
         case = next(c for c in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))["cases"] if c["name"] == "config3_1920x1080_f32")
         assert zlib.crc32(util.stitch((w, h), regs, two).tobytes()) & 0xFFFFFFFF == case["frame_crc32"]
+
+
+@pytest.mark.parametrize("percent", [0, 35, 70])
+def test_shadow_origins_the_bounds_do_not_cover_run_the_reference_arithmetic(percent):
+    # The filtered shadow walks cover ray origins within a radius Ro of the scene's centroid; an origin further out gets q1 = NaN, which
+    # passes every outer bound and fails every sure test, so the ray falls back to the reference's arithmetic at every node.  No origin
+    # of a real scene is out there -- RT_DEBUG_FILTER_RO_PERCENT shrinks Ro at scene creation so that all (0), most (35) or some (70 %)
+    # of them are: both kernels (one ray per lane: per-lane NaN; two: one uncovered ray turns its whole wave) must still render the
+    # unfiltered C++ loops' bytes, at spp 1 and in a sample-packed mode.
+    with rta.capi.debug(rta.capi.DEBUG_FILTER_RO_PERCENT, percent):
+        d = rta.Scene.default(6).device()
+    for (w, h, spp) in ((333, 217, 1), (160, 120, 4)):
+        regs = bucket_list(w, h, spp)
+        with rta.capi.debug(rta.capi.DEBUG_SKIP_VARIANT, 1):
+            ref, _ = d.render_tiles((w, h, spp), regs, SKIP, want_stats=True)      # also checks the bounds next to every test it makes
+            ref = ref.copy()
+        for rays in (1, 2):
+            with rta.capi.debug(rta.capi.DEBUG_SKIP_RAYS, rays):
+                got, _ = d.render_tiles((w, h, spp), regs, SKIP, want_stats=False)
+            assert np.array_equal(got, ref), (percent, w, h, spp, rays)
+    d.close()
 
 
 def test_only_memory_this_library_pinned_is_written_by_the_kernel():

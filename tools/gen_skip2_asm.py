@@ -554,9 +554,9 @@ def shadow_copy_filt(r, name):
     pk(m, "add", r.E[1].p, None, r.Q2.p, sx=fs(c, 1), neg_y=True)
     pk(m, "mul", r.E[0].p, r.E[0].p, r.E[0].p)
     pk_fma(m, r.P2.p, r.E[1].p, r.E[1].p, r.E[0].p)
-    outer_cmp(m, r, s_r2o(c))
-    m.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
-    m.op("s_cbranch_scc1 %s" % lab("hit"))
+    m.op("v_min_f32_e32 %s, %s, %s" % (r.E[0].h[0], r.P2.h[0], r.P2.h[1]))
+    m.op("v_cmp_ngt_f32_e64 vcc, %s, |%s|" % (r.E[0].h[0], s_r2o(c)), "some ray not beyond the outer bound?  (NaN: a wave with an uncovered ray passes)")
+    m.op("s_cbranch_vccnz %s" % lab("hit"))
     m.label(lab("skip"))
     m.op("s_add_u32 %s, %s, %d" % (NX, s_skip(c), STRIDE), "jump over the subtree")
     m.op("s_waitcnt lgkmcnt(0)")
@@ -566,6 +566,7 @@ def shadow_copy_filt(r, name):
     k.label(lab("hit"))
     for h in range(2):
         k.op("v_cmp_gt_u32_e64 %s, %s, %s" % (ACT[h], NX, r.RES.h[h]), "active = i >= resume  (NX = i + stride)" if h == 0 else None)
+    outer_cmp(k, r, s_r2o(c))
     for h in range(2):
         k.op("s_and_b64 %s, %s, %s" % (C[h], C[h], ACT[h]))
     k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
@@ -639,7 +640,6 @@ def shadow_filt():
         a.op("v_mov_b32_e32 %s, %%[oy%d]" % (r.DY.h[h], h))
         a.op("v_mov_b32_e32 %s, %%[oz%d]" % (r.DZ.h[h], h))
         a.op("v_mov_b32_e32 %s, %%[res%d]" % (r.RES.h[h], h))
-    a.op("v_mov_b32_e32 %s, 0x7fc00000" % r.E[4].h[0])
     a.op("s_mov_b64 %s, exec" % EX)
     a.op("s_waitcnt lgkmcnt(0)")
     # shadow_filter_origin (rt_skip.hpp) for both rays: q = ((o - m0) . e1, (o - m0) . e2), ol = (o - m0) . l, FMA chains in its order
@@ -654,10 +654,18 @@ def shadow_filt():
     pk(a, "mul", d2.p, x.p, x.p)
     pk_fma(a, d2.p, y.p, y.p, d2.p)
     pk_fma(a, d2.p, z.p, z.p, d2.p)
+    # An origin the constants do not cover (further than sqrt(ro2) from m0) must pass every outer bound and fail every sure test: q1 = NaN.
+    # The step's outer test looks at min(P2 of ray 0, P2 of ray 1), which would drop a single NaN -- so one uncovered shadow ray makes
+    # q1 NaN for the whole wave (none is on a scene the library built the constants for; such a wave runs the reference's arithmetic).
     for h in range(2):
-        a.op("v_cmp_nle_f32_e64 %s, %s, s%d" % (M, d2.h[h], FC + 15), "an origin the constants do not cover: q1 = NaN passes every outer bound and fails every sure test" if h == 0 else None)
-        a.op("s_nop 1")
-        a.op("v_cndmask_b32_e64 %s, %s, %s, %s" % (r.Q1.h[h], r.Q1.h[h], r.E[4].h[0], M))
+        a.op("v_cmp_nle_f32_e64 %s, %s, s%d" % (C[h], d2.h[h], FC + 15))
+        a.op("v_cmp_eq_u32_e64 %s, 0, %s" % (ACT[h], r.RES.h[h]), "only rays that have a shadow ray count")
+        a.op("s_and_b64 %s, %s, %s" % (C[h], C[h], ACT[h]))
+    a.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+    a.op("s_cbranch_scc0 .Lr2_covered_%=")
+    for h in range(2):
+        a.op("v_mov_b32_e32 %s, 0x7fc00000" % r.Q1.h[h])
+    a.label(".Lr2_covered_%=")
     for k in range(3):
         a.op("s_mov_b32 s%d, s%d" % (LIGHT + k, FC + 9 + k), "the shadow rays' direction, -light (render.rs:206)" if k == 0 else None)
     a.op("s_mov_b32 %s, s%d" % (A0, FC + 12))
