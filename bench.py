@@ -368,7 +368,7 @@ def main():
                                        "not from HBM, so it is not a fraction of the HBM peak (SURVEY.md H3)"},
                "note": note}
         pt = m["my_stats"].get("primary_tests")
-        if pt is not None and kernel == "k_render_skip":
+        if pt is not None and kernel in ("k_render_skip", "k_render_skip2"):
             ops = 8 * pt + 16 * (m["my_tests"] - pt)
             out["path_arithmetic"] = {"primary_tests": pt, "shadow_tests": m["my_tests"] - pt, "lane_ops": ops,
                                       "frac": round(ops / t / 1e12 / peak, 4),
@@ -386,7 +386,10 @@ def main():
 
     head_trav = rta.RT_TRAVERSAL_SKIP if args.traversal == "skip" else rta.RT_TRAVERSAL_FLAT
     multi = args.multi if (world > 1 or args.force_collective) else "tiles"
+    two_ray_before = rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_TWO_RAY_LAUNCHES)
     m = measure(args.workload, head_trav, args.steps, args.warmup, max(1, args.repeats), multi, min_region_s=args.min_timed_region)
+    # which kernel the library chose for this workload (rt_capi.hip skip2_by_default): large frames walk two rays per lane
+    skip_kernel = "k_render_skip2" if rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_TWO_RAY_LAUNCHES) > two_ray_before else "k_render_skip"
     flat = None
     if args.traversal == "skip" and not args.no_flat and world == 1:
         flat = measure(args.workload, rta.RT_TRAVERSAL_FLAT, max(2, min(5, args.steps)), 1, 3, multi)
@@ -451,7 +454,7 @@ def main():
             "frame_crc_source": "tests/golden/oracle_vectors.json:%s.frame_crc32 (frame buffers zeroed after the warm-up; read back after the timed loop)" % golden_name,
             "mprimary_per_s": round(m["primary"] / (ms_per_step * 1e-3) / 1e6, 3),
             "git_head": git_head(), "kernel_src_sha": src_sha,
-            "roofline": roofline(m, "k_render_skip" if args.traversal == "skip" else "k_flat_primary", FLOPS_PER_TEST if args.traversal == "skip" else 8,
+            "roofline": roofline(m, skip_kernel if args.traversal == "skip" else "k_flat_primary", FLOPS_PER_TEST if args.traversal == "skip" else 8,
                                  skip_note if args.traversal == "skip" else flat_note),
         }
         if flat is not None:

@@ -149,7 +149,7 @@ lib.rt_debug_wave_trace.argtypes = [C.c_char_p]
 lib.rt_debug_count.restype = C.c_longlong
 lib.rt_debug_count.argtypes = [C.c_int]
 (DEBUG_COUNT_REGION_CALLS, DEBUG_COUNT_REGION_PASSES, DEBUG_COUNT_FILTER_PASS, DEBUG_COUNT_FILTER_VIOLATIONS, DEBUG_COUNT_PRIMARY_TESTS,
- DEBUG_COUNT_FRAME_AHEAD_PASSES) = range(6)
+ DEBUG_COUNT_FRAME_AHEAD_PASSES, DEBUG_COUNT_TWO_RAY_LAUNCHES) = range(7)
 
 
 def debug_set(key, value=-1):

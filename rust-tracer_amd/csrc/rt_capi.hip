@@ -34,7 +34,7 @@ thread_local char g_err[512] = "";
 
 // Diagnostic controls (rt_debug.h): process-wide, -1 = default.  The library reads no environment variable.
 std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
-std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = { {0}, {0}, {0}, {0}, {0}, {0} };
+std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = { {0}, {0}, {0}, {0}, {0}, {0}, {0} };
 std::atomic<bool> g_trace_on{ false };
 std::mutex g_trace_mu;
 std::string g_trace_path;
@@ -939,6 +939,7 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     if (!use_split(spp)) {
         if constexpr (!COUNT && (VAR & 15) == 7 && sizeof(T) == 4) {
             if (two_rays) {
+                g_count[RT_DEBUG_COUNT_TWO_RAY_LAUNCHES].fetch_add(1, std::memory_order_relaxed);
                 hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipOne, (VAR & 16) != 0>), rgrid, b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt, d_out, sb, frame_w,
                                    order.d, order.wg_first);
                 return RT_OK;
@@ -963,6 +964,7 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     bool done2 = false;
     if constexpr (!COUNT && (VAR & 15) == 7 && sizeof(T) == 4) {
         if (two_rays) {
+            g_count[RT_DEBUG_COUNT_TWO_RAY_LAUNCHES].fetch_add(1, std::memory_order_relaxed);
             hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipPacked, (VAR & 16) != 0>), dim3(rgrid.x, (unsigned)ns), b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt,
                                d_out, sb, frame_w, order.d, order.wg_first);
             done2 = true;

@@ -57,7 +57,8 @@ typedef enum rt_debug_counter {
     RT_DEBUG_COUNT_PRIMARY_TESTS = 4,   /* hierarchy walk: of the LAST call that returned rt_stats, the tests (items + bounds) made for primary rays
                                            (the rest of sphere_tests + bound_tests were made for shadow rays); not cumulative */
     RT_DEBUG_COUNT_FRAME_AHEAD_PASSES = 5,  /* whole-grid passes rendered for rt_render_region's frame-ahead */
-    RT_DEBUG_COUNTERS = 6
+    RT_DEBUG_COUNT_TWO_RAY_LAUNCHES = 6,    /* hierarchy-walk passes that ran k_render_skip2 (two rays per lane) instead of k_render_skip */
+    RT_DEBUG_COUNTERS = 7
 } rt_debug_counter;
 long long rt_debug_count(int counter);
 
