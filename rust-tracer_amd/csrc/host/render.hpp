@@ -94,6 +94,7 @@ public:
         // (render.rs:373-401).  Here the frame is kept in the file's own pixel format: a bucket is converted once, when it
         // arrives (while the device is still rendering the next ones), and a write of the file is the header plus one write.
         encoded_.assign((size_t)x * y * (rgb_ ? 3 : 1), 0);
+        rows_with_data_ = 0;
     }
     void write_rgba_buffer(const RGBABuffer &buffer) override     // render.rs:422-433
     {
@@ -115,6 +116,8 @@ private:
     bool rgb_;
     std::optional<std::chrono::steady_clock::time_point> last_written_at_;
     bool buffer_dirty_ = false;
+    bool emptied_ = false;                                        // this writer has emptied the file once (render.rs:366 does it on every write)
+    uint32_t rows_with_data_ = 0;                                 // rows [0, n) of `encoded_` may hold pixels; the rest is still zero
 };
 
 // Device copies of a Scene on one GPU (replaces handing Arc<Scene> to the pool threads, render.rs:279).

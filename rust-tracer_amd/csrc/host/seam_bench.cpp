@@ -78,6 +78,7 @@ int main(int argc, char **argv)
         else if (a == "--level") level = atoi(argv[i + 1]);
         else if (a == "--dir") dir = argv[i + 1];
         else if (a == "--leaders") rt_debug_set(RT_DEBUG_COALESCE, atoi(argv[i + 1]));       // diagnostic: merged passes in flight (0: no merging)
+        else if (a == "--frame-ahead") rt_debug_set(RT_DEBUG_FRAME_AHEAD, atoi(argv[i + 1])); // diagnostic: 0 / 1 / 2 (rt_debug.h)
         else { fprintf(stderr, "seam_bench: unknown option %s\n", a.c_str()); return 2; }
     }
     frames = std::max(frames, 3); threads = std::max(threads, 1);
@@ -192,22 +193,44 @@ int main(int argc, char **argv)
         ThreadPool pool((size_t)nt);
         Series s;
         const int reps = std::max(3, frames / 3);
+        double part[5] = { 0, 0, 0, 0, 0 };                           // fopen | Renderer::render | the writer's Drop (second write of the file) | fclose | of render: inside the writer
+        struct TimedWriter : PPMStdoutRGBABufferWriter {              // how much of Renderer::render is the consumer's own work (conversion + the first write of the file)
+            using PPMStdoutRGBABufferWriter::PPMStdoutRGBABufferWriter;
+            double in_writer = 0;
+            void write_rgba_buffer(const RGBABuffer &b) override
+            {
+                const auto t = Clock::now();
+                PPMStdoutRGBABufferWriter::write_rgba_buffer(b);
+                in_writer += ms_since(t);
+            }
+        };
         for (int f = 0; f < reps + 1; ++f) {
             const auto t0 = Clock::now();
             FileOrAnyWriter sink;
             sink.f = fopen(path.c_str(), "wb");
             sink.is_file = true;
             if (!sink.f) { fprintf(stderr, "seam_bench: cannot write %s\n", path.c_str()); return 5; }
+            const double t_open = ms_since(t0);
+            double t_render = 0;
             {
-                PPMStdoutRGBABufferWriter writer(true, sink);
+                TimedWriter writer(true, sink);
                 Renderer::render(o, be, writer, pool);
+                t_render = ms_since(t0);
+                if (f >= 1) part[4] += writer.in_writer;
             }
+            const double t_drop = ms_since(t0);
             fclose(sink.f);
-            if (f >= 1) s.v.push_back(ms_since(t0));
+            const double t_all = ms_since(t0);
+            if (f >= 1) {
+                s.v.push_back(t_all);
+                part[0] += t_open; part[1] += t_render - t_open; part[2] += t_drop - t_render; part[3] += t_all - t_drop;
+            }
         }
         char name[64];
         snprintf(name, sizeof name, "end_to_end_scheduler_%s", nt == 1 ? "1_thread" : "T_threads");
-        stats_json(name, s, rays, nt == threads);
+        stats_json(name, s, rays);
+        printf("  \"%s_parts_ms\": {\"fopen_truncate\": %.3f, \"render_and_first_write\": %.3f, \"drop_second_write\": %.3f, \"fclose\": %.3f, \"of_render_inside_the_writer\": %.3f}%s\n", name,
+               part[0] / reps, part[1] / reps, part[2] / reps, part[3] / reps, part[4] / reps, nt == threads ? "" : ",");
         if (threads == 1) break;
     }
     unlink(path.c_str());

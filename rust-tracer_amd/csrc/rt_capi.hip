@@ -140,8 +140,12 @@ struct rt_scene {
     // scheduler's grid renders the WHOLE grid in one pass into pinned staging, and the following requests of that frame are a 16 KB
     // copy each.  A bucket is handed out once per rendered frame: asking for one again means the caller has started its next frame,
     // and the grid is rendered again -- every byte a caller receives was rendered for the frame it belongs to.
-    struct FrameAhead { rt_options o{}; rt_traversal trav = RT_TRAVERSAL_SKIP; uint8_t *h = nullptr; size_t cap = 0; std::vector<size_t> off;
-                        std::vector<rt_region> grid; std::vector<uint8_t> served; bool valid = false; std::mutex mu; } ahead;
+    // While the caller copies frame k's buckets out the device is idle: the pass for frame k + 1 is started right away into a second
+    // staging buffer (a Scene is immutable, so its bytes are those a pass started later would produce) and is simply waited for when
+    // the caller comes back for its next frame.  One pass too many is rendered when the caller stops (RT_DEBUG_FRAME_AHEAD = 1: off).
+    struct FrameAhead { rt_options o{}; rt_traversal trav = RT_TRAVERSAL_SKIP; uint8_t *h = nullptr, *h_next = nullptr; size_t cap = 0; std::vector<size_t> off;
+                        std::vector<rt_region> grid; std::vector<uint8_t> served; bool valid = false, next_inflight = false;
+                        hipStream_t stream = nullptr; hipEvent_t ev = nullptr; std::mutex mu; } ahead;
     std::mutex comb_mu;
     std::vector<RegionReq *> comb_pending;
     int comb_leaders = 0;              // passes being led right now (<= kMaxRegionLeaders)
@@ -1324,6 +1328,7 @@ rt_status rt_scene_destroy(rt_scene *s)
 {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->device);
+    if (s->ahead.stream) { (void)hipStreamSynchronize(s->ahead.stream); (void)hipStreamDestroy(s->ahead.stream); }      // a pass rendered ahead may still be running
     s->pool.clear();
     for (auto &t : s->tables) { (void)hipFree(t.dev); if (t.dev_order) (void)hipFree(t.dev_order); if (t.dev_wg) (void)hipFree(t.dev_wg); }
     if (s->d_items) (void)hipFree(s->d_items);
@@ -1332,7 +1337,9 @@ rt_status rt_scene_destroy(rt_scene *s)
     if (s->d_cprim) (void)hipFree(s->d_cprim);
     if (s->d_cshad) (void)hipFree(s->d_cshad);
     for (void *p : { s->d_xprim, s->d_xshad, s->d_xcprim, s->d_xcshad, s->d_xown, s->d_fc }) if (p) (void)hipFree(p);
+    if (s->ahead.ev) (void)hipEventDestroy(s->ahead.ev);
     if (s->ahead.h) (void)rt_host_free(s->ahead.h);
+    if (s->ahead.h_next) (void)rt_host_free(s->ahead.h_next);
     if (s->d_fprim) (void)hipFree(s->d_fprim);
     if (s->d_fprim_rr) (void)hipFree(s->d_fprim_rr);
     if (s->d_fshad) (void)hipFree(s->d_fshad);
@@ -1831,8 +1838,11 @@ static bool region_from_frame_ahead(rt_scene *s, const rt_options *o, rt_travers
     rt_scene::FrameAhead &a = s->ahead;
     std::lock_guard<std::mutex> lk(a.mu);
     const bool same = a.valid && a.trav == trav && a.o.width == o->width && a.o.height == o->height && a.o.samples_per_pixel == o->samples_per_pixel;
+    auto drain_next = [&] { if (a.next_inflight) { (void)hipEventSynchronize(a.ev); (void)hipGetLastError(); a.next_inflight = false; } };
     if (!same || a.served[idx]) {
+        bool have = false;
         if (!same) {
+            drain_next();                                   // a pass for other options may still be writing h_next
             a.valid = false;
             a.grid.clear(); a.off.clear();
             size_t off = 0;
@@ -1845,19 +1855,40 @@ static bool region_from_frame_ahead(rt_scene *s, const rt_options *o, rt_travers
                 }
             if (a.cap < frame_bytes) {
                 if (a.h) (void)rt_host_free(a.h);
-                a.h = nullptr; a.cap = 0;
-                void *p = nullptr;
+                if (a.h_next) (void)rt_host_free(a.h_next);
+                a.h = a.h_next = nullptr; a.cap = 0;
+                void *p = nullptr, *q = nullptr;
                 if ((*st = rt_host_alloc(frame_bytes, &p)) != RT_OK) return true;
-                a.h = static_cast<uint8_t *>(p); a.cap = frame_bytes;
+                if ((*st = rt_host_alloc(frame_bytes, &q)) != RT_OK) { (void)rt_host_free(p); return true; }
+                a.h = static_cast<uint8_t *>(p); a.h_next = static_cast<uint8_t *>(q); a.cap = frame_bytes;
             }
             a.o = *o; a.trav = trav;
+        } else if (a.next_inflight) {
+            // the pass that was started when the previous frame was first asked for
+            const hipError_t e = hipEventSynchronize(a.ev);
+            a.next_inflight = false;
+            if (e == hipSuccess) { std::swap(a.h, a.h_next); have = true; } else (void)hipGetLastError();
         }
-        // the whole grid in one pass, the kernel storing into the pinned staging (rt_host_alloc'd memory is recognised by address)
-        *st = render_tiles_host(s, o, trav, a.grid.data(), (uint32_t)a.grid.size(), a.h, nullptr, nullptr, true);
-        if (*st != RT_OK) { a.valid = false; return true; }
+        if (!have) {
+            // the whole grid in one pass, the kernel storing into the pinned staging (rt_host_alloc'd memory is recognised by address)
+            *st = render_tiles_host(s, o, trav, a.grid.data(), (uint32_t)a.grid.size(), a.h, nullptr, nullptr, true);
+            if (*st != RT_OK) { a.valid = false; return true; }
+        }
         a.served.assign(a.grid.size(), 0);
         a.valid = true;
         g_count[RT_DEBUG_COUNT_FRAME_AHEAD_PASSES].fetch_add(1, std::memory_order_relaxed);
+        if (knob(RT_DEBUG_FRAME_AHEAD) != 1) {
+            // the next frame's pass, asynchronously, on a stream of its own; whatever fails here only costs the overlap
+            hipError_t e = hipSuccess;
+            if (!a.stream) e = hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking);
+            if (e == hipSuccess && !a.ev) e = hipEventCreateWithFlags(&a.ev, hipEventDisableTiming);
+            const HostDest next = classify_host_pointer(a.h_next);
+            if (e == hipSuccess && next.pinned && next.dev_alias && next.room >= frame_bytes &&
+                rt_render_tiles_device(s, o, trav, a.grid.data(), (uint32_t)a.grid.size(), next.dev_alias, a.stream, nullptr) == RT_OK &&
+                hipEventRecord(a.ev, a.stream) == hipSuccess)
+                a.next_inflight = true;
+            else if (a.stream) { (void)hipStreamSynchronize(a.stream); (void)hipGetLastError(); }
+        }
     }
     memcpy(out, a.h + a.off[idx], (size_t)(region->r - region->l) * (region->t - region->b) * 4);
     a.served[idx] = 1;

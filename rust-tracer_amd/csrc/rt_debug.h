@@ -38,7 +38,8 @@ typedef enum rt_debug_key {
                                     packed math, rt_skip2.hpp) wherever it exists (spp 1, 2, 4, 8; launches that do not count tests);
                                     default: the library's choice per workload (large spp-1 frames, large scenes) */
     RT_DEBUG_FRAME_AHEAD = 13,   /* 0: rt_render_region never serves a bucket from a whole-grid pass rendered ahead (every call its own device pass,
-                                    or merged with concurrent ones: RT_DEBUG_COALESCE).  Default 1 */
+                                    or merged with concurrent ones: RT_DEBUG_COALESCE); 1: whole-grid passes, each rendered when its frame is first
+                                    asked for; default (2): the pass for the next frame is started as soon as the current one is being handed out */
     RT_DEBUG_FILTER_RO_PERCENT = 14, /* read by rt_scene_create: the radius around the scene's centroid in which the filtered loops' bounds cover
                                     shadow-ray origins, in percent of the library's own value.  A small value leaves real origins
                                     uncovered -- they must then fall back to the reference's arithmetic at every node (tests).  Default 100 */

@@ -70,12 +70,16 @@ def test_render_region_frame_ahead_serves_a_frame_from_one_pass():
     regs = bucket_list(w, h)
     ref, _, _ = o.render(w, h, 1, nthreads=os.cpu_count() or 1)
     count = lambda: rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_FRAME_AHEAD_PASSES)
-    c0 = count()
-    for frame in range(3):
-        for (l, t, r, b) in regs:
-            got, _ = d.render_region((w, h, 1), (l, t, r, b), SKIP)
-            np.testing.assert_array_equal(got, ref[b:t, l:r])
-    assert count() - c0 == 3
+    # default: the pass for the next frame is started while this frame's buckets are handed out (frames 2 and 3 below come out of such
+    # passes); RT_DEBUG_FRAME_AHEAD = 1: every pass is rendered when its frame is first asked for.  One pass per frame either way.
+    for mode in (-1, 1):
+        with rta.capi.debug(rta.capi.DEBUG_FRAME_AHEAD, mode):
+            c0 = count()
+            for frame in range(3):
+                for (l, t, r, b) in regs:
+                    got, _ = d.render_region((w, h, 1), (l, t, r, b), SKIP)
+                    np.testing.assert_array_equal(got, ref[b:t, l:r])
+            assert count() - c0 == 3
     # other options: a new grid; a region that is not a bucket of the grid: its own pass; with stats: the counting path
     got, _ = d.render_region((w, h, 2), regs[7], SKIP)
     ref2, _ = o.render_region(w, h, 2, *regs[7])
