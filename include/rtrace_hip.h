@@ -169,9 +169,13 @@ rt_status rt_render_frame_device(rt_scene *scene, const rt_options *options, rt_
                                  void *frame_rgba_device, void *hip_stream, rt_stats *stats);
 
 /* Single bucket: the exact shape of the reference call (render.rs:283-294), made from up to RTRACEMAXPROCS pool threads
- * at once.  Concurrent calls on one scene are merged into shared device passes (whoever finds no pass running leads the
- * next one and renders every request waiting at that moment), so RTRACEMAXPROCS keeps its meaning: more scheduler threads,
- * more buckets per pass.  A lone caller gets one pass per call.  With stats != NULL the call runs on its own. */
+ * at once.  A request for a bucket of the scheduler's own grid (64 x 64, row-major from (0, 0), edge buckets clipped:
+ * render.rs:273-298) is served from a pass that renders the WHOLE grid once per frame into pinned staging -- the call is then a
+ * 16 KB copy.  A bucket is handed out once per pass (asking for it again starts the caller's next frame), and the pass for the next
+ * frame is started while the current one is being handed out: a scene is immutable, so its bytes are those of a pass started later;
+ * one pass too many is rendered when the caller stops.  Other requests: concurrent calls on one scene are merged into shared device
+ * passes (whoever finds no pass running leads the next one and renders every request waiting at that moment); a lone caller gets
+ * one pass per call.  With stats != NULL the call runs on its own. */
 rt_status rt_render_region(rt_scene *scene, const rt_options *options, rt_traversal traversal,
                            const rt_region *region, uint8_t *rgba_out, rt_stats *stats);
 
