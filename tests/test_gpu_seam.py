@@ -97,6 +97,28 @@ def test_render_region_frame_ahead_serves_a_frame_from_one_pass():
     assert count() == c1
 
 
+def test_render_region_pass_started_ahead_survives_destroy_and_option_changes():
+    # The pass for the next frame is started while the current one is handed out: a scene destroyed with that pass in flight must wait
+    # for it, and a caller that alternates between options (each change discards the pass that was started ahead) still gets the right
+    # bytes every time.
+    s, o = util.scene_pair_default()
+    for _ in range(8):
+        d = s.device()
+        got, _ = d.render_region((640, 448, 1), (0, 64, 64, 0), SKIP)          # one bucket only: the pass for frame 2 is in flight now
+        d.close()
+        s._device.clear()
+    d = s.device()
+    refs = {}
+    for k in range(12):
+        w, h, spp = ((256, 192, 1), (320, 256, 1), (256, 192, 2))[k % 3]
+        regs = bucket_list(w, h, spp)
+        i = (5 * k) % len(regs)
+        got, _ = d.render_region((w, h, spp), regs[i], SKIP)
+        if (w, h, spp, i) not in refs:
+            refs[(w, h, spp, i)], _ = o.render_region(w, h, spp, *regs[i])
+        np.testing.assert_array_equal(got, refs[(w, h, spp, i)])
+
+
 def test_render_region_frame_ahead_under_concurrent_callers():
     s, o = util.scene_pair_default()
     d = s.device()
