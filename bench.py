@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flat", action="store_true", help="skip the secondary flat-scan measurement")
     ap.add_argument("--no-seam", action="store_true", help="skip the host-boundary legs (seam_bench child process)")
-    ap.add_argument("--no-extras", action="store_true", help="N > 1: skip the weak_frames and config5_tiles side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (N > 1: weak_frames and config5_tiles; N = 1: frames_in_flight)")
     ap.add_argument("--traversal", choices=("skip", "flat"), default="skip", help="traversal of the headline measurement")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: take the shard -> RCCL gather -> blit path even at N = 1 (needs torch.distributed.run)")
@@ -307,6 +307,34 @@ def main():
                 "my_tests": st["sphere_tests"] + st["bound_tests"], "my_stats": st, "crc": crc, "crc_ok": crc_ok,
                 "timed_region_s": sum(r * steps for r in reps) / 1e3, "frames_per_step": world if (mode == "frames" and fs.collective) else 1}
 
+    def measure_in_flight(wl, steps, n_streams=2):
+        """N = 1 only, never `value`: the same `steps` launches dealt round-robin over n_streams HIP streams (each its own frame
+        buffer), so that frame k + 1's waves fill the SIMDs that frame k's last, longest waves leave idle.  What a caller of the
+        asynchronous entry points gets by keeping two frames in flight; the difference to `ms_per_step` is the share of a frame
+        that is its tail."""
+        w, h, k, lv, gname = WORKLOADS[wl]
+        dev = scene_of(lv).device(local)
+        regs = dev._regions([tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, k))])
+        streams = [torch.cuda.Stream() for _ in range(n_streams)]
+        outs = [torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda") for _ in range(n_streams)]
+        for i in range(2 * n_streams):
+            dev.render_frame_device((w, h, k), regs, outs[i % n_streams].data_ptr(), streams[i % n_streams].cuda_stream)
+        torch.cuda.synchronize()
+        for o in outs:
+            o.zero_()
+        reps = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                dev.render_frame_device((w, h, k), regs, outs[i % n_streams].data_ptr(), streams[i % n_streams].cuda_stream)
+            torch.cuda.synchronize()
+            reps.append((time.perf_counter() - t0) / steps * 1e3)
+        g = golden_case(gname)
+        crcs = [zlib.crc32(o.cpu().numpy().tobytes()) & 0xFFFFFFFF for o in outs]
+        return {"streams": n_streams, "ms_per_step": sorted(reps)[len(reps) // 2], "ms_reps": reps,
+                "crc_ok": (all(c == g["frame_crc32"] for c in crcs) if g else None)}
+
     probe = probe_cycles()
     src_sha = kernel_src_sha()
 
@@ -393,6 +421,9 @@ def main():
     flat = None
     if args.traversal == "skip" and not args.no_flat and world == 1:
         flat = measure(args.workload, rta.RT_TRAVERSAL_FLAT, max(2, min(5, args.steps)), 1, 3, multi)
+    in_flight = None
+    if world == 1 and not args.force_collective and not args.no_extras and args.traversal == "skip":
+        in_flight = measure_in_flight(args.workload, max(args.steps, 100))
     extras = {}
     if world > 1 and not args.no_extras and args.workload == "1080p" and args.traversal == "skip":
         other = "frames" if multi == "tiles" else "tiles"
@@ -487,11 +518,23 @@ def main():
         for k, e in extras.items():
             out[k] = summary(e, "config5" if k == "config5_tiles" else "1080p")
             out[k]["scaling"] = "weak" if k == "weak_frames" else "strong"
+        if in_flight is not None:
+            out["frames_in_flight"] = {
+                "streams": in_flight["streams"], "ms_per_step": round(in_flight["ms_per_step"], 4),
+                "value": round(rays / (in_flight["ms_per_step"] * 1e-3) / 1e6, 3), "unit": "Mrays/s",
+                "ms_per_step_each": [round(v, 4) for v in in_flight["ms_reps"]], "frame_crc_ok": in_flight["crc_ok"],
+                "note": "NOT `value`: the same launches dealt round-robin over two HIP streams through the asynchronous entry point (rt_render_frame_device), "
+                        "each stream its own frame buffer, host wall time over the steps.  `value` / `ms_per_step` time the launches in order on ONE stream, "
+                        "where a frame ends with its few longest waves on an otherwise idle chip; with a second frame in flight those SIMDs are busy, and a "
+                        "frame costs what its instructions cost (SQ_ACTIVE_INST_VALU x 4 cycles / 1,024 SIMDs).  The difference is the frame's tail."}
+            ok_in_flight = in_flight["crc_ok"] is not False
+        else:
+            ok_in_flight = True
         if seam is not None:
             out["seam"] = seam
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(width, height, spp, level)
-        ok = m["crc_ok"] is not False and (flat is None or flat["crc_ok"] is not False) and all(e["crc_ok"] is not False for e in extras.values())
+        ok = m["crc_ok"] is not False and (flat is None or flat["crc_ok"] is not False) and all(e["crc_ok"] is not False for e in extras.values()) and ok_in_flight
         os.write(json_fd, (json.dumps(out) + "\n").encode())
         if not ok:
             sys.stderr.write("bench.py: the frame left by the timed launches does not match the committed oracle vector\n")

@@ -5,7 +5,7 @@ TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-B="python3 bench.py --workload config5 --no-cpu-baseline --no-seam --no-flat --steps 2 --warmup 1 --repeats 1 --min-timed-region 0"
+B="python3 bench.py --workload config5 --no-cpu-baseline --no-seam --no-flat --no-extras --steps 2 --warmup 1 --repeats 1 --min-timed-region 0"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/c5sq1_$TAG -- $B > gpurun_out/c5sq1_$TAG.log 2>&1
 rocprofv3 --pmc SQ_INSTS_BRANCH SQ_INSTS_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_INST_CYCLES_SALU SQ_INST_LEVEL_SMEM SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/c5sq2_$TAG -- $B > gpurun_out/c5sq2_$TAG.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/c5kt_$TAG -- $B > gpurun_out/c5kt_$TAG.log 2>&1
