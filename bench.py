@@ -460,7 +460,8 @@ def main():
                       % (world, world, args.frames_per_gather))
         else:
             layout = ("%d GPUs, the buckets of ONE frame dealt round-robin (tile_id %% N), u8 shards gathered to rank 0 over "
-                      "RCCL and blitted into the frame there, pipelined across frames" % world)
+                      "RCCL (the shards of %d consecutive frames per collective) and blitted into the frame there, pipelined across frames: "
+                      "two render streams per rank, the gather of a batch under the render of the next" % (world, args.frames_per_gather))
         srt = sorted(m["ms_reps"])
         out = {
             "metric": "Mrays/sec + ms/frame, 1920x1080 20k-sphere scene" if args.workload == "1080p" else

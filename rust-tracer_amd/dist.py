@@ -104,9 +104,10 @@ class FrameSharder:
         if mode not in ("tiles", "frames"):
             raise ValueError("mode must be 'tiles' or 'frames'")
         self.mode = mode
-        # "frames" mode may batch: a rank renders `batch` consecutive frames into one buffer and ONE gather moves them all
-        # (fewer, larger collectives: the per-call host cost of a gather is paid once per batch, the wire time is the same)
-        self.batch = max(1, int(frames_per_gather)) if mode == "frames" else 1
+        # both modes may batch: a rank renders `batch` consecutive frames (their shards, in "tiles" mode) into one buffer and ONE gather
+        # moves them all (fewer, larger collectives: the per-call host cost of a gather -- some 30 us through torch.distributed, more
+        # than a 1080p shard takes to render -- is paid once per batch, the wire time is the same)
+        self.batch = max(1, int(frames_per_gather))
         self._counts, self._next, self._slot_count = [], 0, [self.batch, self.batch]
         # force_collective: take the shard -> gather -> blit path even for world == 1 (a one-rank RCCL gather); lets a
         # single-GPU test drive exactly the code the 8-GPU run executes
@@ -128,11 +129,21 @@ class FrameSharder:
         self.shard = self.shards[0]
         self.frame = None
         self.side = torch.cuda.Stream(device=tdev) if (rank == 0 and self.collective) else None   # rank 0's blits run here
+        # one render stream per shard buffer: frame k + 1 is rendered on the other stream while frame k's few longest waves are
+        # still finishing (a frame -- and a shard of it -- ends with its heaviest pixels' chains on an otherwise idle chip,
+        # DESIGN.md 4.1), and the gather of a slot is ordered behind that slot's stream only
+        self.render_streams = [torch.cuda.Stream(device=tdev) for _ in range(2)] if self.collective else None
         if rank == 0:
             self.frame = torch.zeros(self.options.height * self.options.width * 4, dtype=torch.uint8, device=tdev)
             regions, offsets, _ = gathered_tile_table(self.options, world if mode == "tiles" else 1)
             self.all_regions_c = self.dev._regions(regions)
             self.all_offsets = offsets
+            # "tiles" with a batch: the gathered buffer is [rank][frame of the batch][shard], so frame j's tiles of rank r start
+            # (r * batch + j) shards in instead of r
+            per_rank = shard_layout(self.options, world if mode == "tiles" else 1)[1]
+            rank_of = np.concatenate([np.full(len(idx), r, dtype=np.int64) for r, (idx, _, _) in enumerate(per_rank)])
+            self.batch_offsets = [(offsets.astype(np.int64) + (rank_of * (self.batch - 1) + j) * self.shard_px).astype(np.uint32)
+                                  for j in range(self.batch)]
             if self.collective:
                 # one buffer per in-flight frame for the blit; the gather lists are views of its rows
                 self.gathered_flat = [torch.zeros(world * self.batch * self.unit_bytes, dtype=torch.uint8, device=tdev) for _ in range(2)]
@@ -149,8 +160,8 @@ class FrameSharder:
             return self.dev.render_frame_device(tuple(self.options), self.my_regions_c,
                                                 self.shards[slot].data_ptr() + index * self.unit_bytes, self._stream(),
                                                 self.traversal, want_stats)
-        return self.dev.render_tiles_device(tuple(self.options), self.my_regions_c, self.shards[slot].data_ptr(), self._stream(),
-                                            self.traversal, want_stats)
+        return self.dev.render_tiles_device(tuple(self.options), self.my_regions_c, self.shards[slot].data_ptr() + index * self.unit_bytes,
+                                            self._stream(), self.traversal, want_stats)
 
     def render_frame(self, want_stats=False):
         """world == 1: the buckets straight into the row-major frame (rt_render_frame_device = render + blit fused)."""
@@ -167,13 +178,17 @@ class FrameSharder:
         return dist.gather(self.shards[slot][:nb], [g[:nb] for g in self.gathered[slot]] if self.rank == 0 else None, dst=0,
                            async_op=async_op)
 
-    def blit(self, slot=0):
+    def blit(self, slot=0, count=None):
         """Rank 0: gathered shards -> row-major frame (set_pixels_from_buffer on the device).  "frames" mode gathers finished
         frames (gathered[slot][r] is rank r's frame), there is nothing to assemble."""
         if self.rank == 0 and self.mode == "tiles":
-            src = self.gathered_flat[slot] if self.collective else self.shards[slot]
-            self.dev.blit_tiles_device(tuple(self.options), self.all_regions_c, src.data_ptr(), self.frame.data_ptr(),
-                                       self._stream(), self.all_offsets)
+            if not self.collective:
+                self.dev.blit_tiles_device(tuple(self.options), self.all_regions_c, self.shards[slot].data_ptr(), self.frame.data_ptr(),
+                                           self._stream(), self.all_offsets)
+                return
+            for j in range(count if count is not None else self.batch):      # every frame of the batch, in order, into the frame
+                self.dev.blit_tiles_device(tuple(self.options), self.all_regions_c, self.gathered_flat[slot].data_ptr(), self.frame.data_ptr(),
+                                           self._stream(), self.batch_offsets[j])
 
     def step(self):
         """One complete frame, nothing left in flight."""
@@ -181,19 +196,22 @@ class FrameSharder:
             self.render_frame()
         else:
             self.render_shard(slot=0)
-            self.gather(slot=0)
-            self.blit(slot=0)
+            self.gather(slot=0, count=1)
+            self.blit(slot=0, count=1)
 
     # ---- the operations run_pipeline() schedules (a CPU stand-in with the same five methods is used by the gloo tests) ----
     def op_render(self, slot):
         count = self._counts[self._next] if self._next < len(self._counts) else self.batch
         self._next += 1
         self._slot_count[slot] = count
-        for j in range(count):
-            self.render_shard(slot=slot, index=j)
+        with self.torch.cuda.stream(self.render_streams[slot]):
+            for j in range(count):
+                self.render_shard(slot=slot, index=j)
 
     def op_gather_async(self, slot):
-        return self.gather(slot=slot, async_op=True, count=self._slot_count[slot])
+        # issued under the slot's render stream: the collective waits for that stream's work (the render of this slot) only
+        with self.torch.cuda.stream(self.render_streams[slot]):
+            return self.gather(slot=slot, async_op=True, count=self._slot_count[slot])
 
     def op_blit_after(self, work, slot):
         """Frame in `slot` has been gathered once `work` is done: blit it.  Rank 0 does that on its side stream, so the blit
@@ -201,18 +219,24 @@ class FrameSharder:
         if self.side is not None:
             with self.torch.cuda.stream(self.side):
                 work.wait()
-                self.blit(slot=slot)
+                self.blit(slot=slot, count=self._slot_count[slot])
         else:
-            work.wait()
+            with self.torch.cuda.stream(self.render_streams[slot]):      # the slot's next render must not overwrite a shard still being sent
+                work.wait()
 
     def op_before_reuse(self, slot):
-        """gathered[slot] is about to be overwritten by the next gather: the blit that read it must be ordered before."""
+        """shards[slot] is about to be re-rendered and gathered[slot] overwritten by the next gather: the gather that read the
+        shard has been waited for on the side stream (op_blit_after) and the blit that read its gathered copy runs there -- the
+        slot's render stream is ordered behind both."""
         if self.side is not None:
-            self.torch.cuda.current_stream(self.device).wait_stream(self.side)
+            self.render_streams[slot].wait_stream(self.side)
 
     def op_drain(self):
+        main = self.torch.cuda.current_stream(self.device)                        # the caller synchronises the main stream only
         if self.side is not None:
-            self.torch.cuda.current_stream(self.device).wait_stream(self.side)    # the caller synchronises the main stream only
+            main.wait_stream(self.side)
+        for rs in self.render_streams:
+            main.wait_stream(rs)
 
     def run(self, steps):
         """`steps` complete frames.  world > 1: software-pipelined, gather(k) overlaps render(k+1); every frame has been
@@ -224,6 +248,11 @@ class FrameSharder:
         # `steps` frames in batches of self.batch (the last one may be partial); one pipeline step per batch
         self._counts = [self.batch] * (steps // self.batch) + ([steps % self.batch] if steps % self.batch else [])
         self._next = 0
+        main = self.torch.cuda.current_stream(self.device)
+        for rs in self.render_streams:                           # whatever the caller enqueued before (zeroed buffers, an earlier run)
+            rs.wait_stream(main)
+        if self.side is not None:
+            self.side.wait_stream(main)
         run_pipeline(len(self._counts), self)
 
     def frame_host(self, slot=0, of_rank=0, index=0):

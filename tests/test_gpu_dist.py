@@ -98,6 +98,32 @@ def test_frames_mode_batched_gather_delivers_every_frame(one_rank_rccl):
     assert int(fs2.frame_host(slot=0, index=1).min()) == 0xCD and int(fs2.frame_host(slot=0, index=3).max()) == 0xCD
 
 
+def test_tiles_mode_batched_gather_blits_every_frame_of_a_batch(one_rank_rccl):
+    # "tiles" (BASELINE config 4) with several frames' shards per collective, as bench.py runs it for N > 1: 7 frames in batches of
+    # 3 (3 + 3 + 1, the last one a partial gather), two render streams.  The frame on rank 0 must be the oracle's after the run, a
+    # single step() must work with the batched buffers too, and every gathered slot must hold valid shards where it was written.
+    import torch
+    s, o = util.scene_pair_default()
+    ref, _, _ = o.render(640, 360, 1, nthreads=os.cpu_count() or 1)
+    fs = FrameSharder(s, (640, 360, 1), 0, 1, 0, rta.RT_TRAVERSAL_SKIP, force_collective=True, mode="tiles", frames_per_gather=3)
+    for g in fs.gathered_flat:
+        g.fill_(0xCD)
+    fs.frame.fill_(0xEE)
+    fs.run(7)
+    np.testing.assert_array_equal(fs.frame_host(), ref)
+    flat = [g.cpu().numpy() for g in fs.gathered_flat]
+    unit = fs.unit_bytes
+    for j in range(3):                                            # slot 1: batch 2, three shards; slot 0: batch 1 then the partial batch 3
+        assert np.array_equal(flat[1][j * unit:(j + 1) * unit], flat[1][:unit])
+        assert np.array_equal(flat[0][j * unit:(j + 1) * unit], flat[1][:unit])
+    fs.frame.fill_(0xEE)
+    fs.step()
+    np.testing.assert_array_equal(fs.frame_host(), ref)
+    fs.frame.fill_(0xEE)
+    fs.run(2)                                                     # one partial batch
+    np.testing.assert_array_equal(fs.frame_host(), ref)
+
+
 @pytest.mark.parametrize("ndev", [1, 2])
 @pytest.mark.parametrize("size", [(1920, 1080, 1), (200, 130, 2)])
 def test_native_gang_rccl_gather_is_byte_identical(ndev, size):
