@@ -169,19 +169,21 @@ int main(int argc, char **argv)
         void *pinned = nullptr;
         die(rt_host_alloc((size_t)width * height * 4, &pinned), "rt_host_alloc");
         const rt_region whole{ 0, (uint16_t)height, (uint16_t)width, 0 };
-        std::vector<uint8_t> rgb((size_t)width * height * 3);
         Series s;
         for (int f = 0; f < frames + 2; ++f) {
             const auto t0 = Clock::now();
             die(rt_render_tiles(h, &opts, RT_TRAVERSAL_SKIP, &whole, 1, static_cast<uint8_t *>(pinned), nullptr), "rt_render_tiles");
-            const uint8_t *b = static_cast<const uint8_t *>(pinned);
-            uint8_t *w = rgb.data();
-            for (size_t i = 0, px = (size_t)width * height; i < px; ++i, b += 4, w += 3) { w[0] = b[0]; w[1] = b[1]; w[2] = b[2]; }
-            FILE *fp = fopen(path.c_str(), "wb");
-            if (!fp) { fprintf(stderr, "seam_bench: cannot write %s\n", path.c_str()); return 5; }
-            fprintf(fp, "P6\n%u %u\n255\n", width, height);
-            fwrite(rgb.data(), 1, rgb.size(), fp);
-            fclose(fp);
+            // the library's own writer, fed the whole frame as ONE RGBABuffer: one conversion, one write of the file
+            FileOrAnyWriter sink;
+            sink.f = fopen(path.c_str(), "wb");
+            sink.is_file = true;
+            if (!sink.f) { fprintf(stderr, "seam_bench: cannot write %s\n", path.c_str()); return 5; }
+            {
+                PPMStdoutRGBABufferWriter writer(true, sink);
+                writer.begin((uint16_t)width, (uint16_t)height);
+                writer.write_rgba_buffer(RGBABuffer(ImageRegion{ 0, (uint16_t)height, (uint16_t)width, 0 }, static_cast<const uint8_t *>(pinned), RGBABuffer::View{}));
+            }
+            fclose(sink.f);
             if (f >= 2) s.v.push_back(ms_since(t0));
         }
         stats_json("end_to_end_frame", s, rays);
