@@ -145,7 +145,7 @@ struct rt_scene {
     // the caller comes back for its next frame.  One pass too many is rendered when the caller stops (RT_DEBUG_FRAME_AHEAD = 1: off).
     struct FrameAhead { rt_options o{}; rt_traversal trav = RT_TRAVERSAL_SKIP; uint8_t *h = nullptr, *h_next = nullptr; size_t cap = 0; std::vector<size_t> off;
                         std::vector<rt_region> grid; std::vector<uint8_t> served; bool valid = false, next_inflight = false;
-                        hipStream_t stream = nullptr; hipEvent_t ev = nullptr; std::mutex mu; } ahead;
+                        hipStream_t stream = nullptr; hipEvent_t ev = nullptr; int readers = 0; std::mutex mu; std::condition_variable cv; } ahead;
     std::mutex comb_mu;
     std::vector<RegionReq *> comb_pending;
     int comb_leaders = 0;              // passes being led right now (<= kMaxRegionLeaders)
@@ -1836,10 +1836,15 @@ static bool region_from_frame_ahead(rt_scene *s, const rt_options *o, rt_travers
     if (frame_bytes > kFrameAheadMaxBytes || check_traversal(s, trav) != RT_OK) return false;
     const unsigned nbx = (w + kBucket - 1) / kBucket, idx = (region->b / kBucket) * nbx + region->l / kBucket;
     rt_scene::FrameAhead &a = s->ahead;
-    std::lock_guard<std::mutex> lk(a.mu);
-    const bool same = a.valid && a.trav == trav && a.o.width == o->width && a.o.height == o->height && a.o.samples_per_pixel == o->samples_per_pixel;
+    std::unique_lock<std::mutex> lk(a.mu);
     auto drain_next = [&] { if (a.next_inflight) { (void)hipEventSynchronize(a.ev); (void)hipGetLastError(); a.next_inflight = false; } };
-    if (!same || a.served[idx]) {
+    // The copies out of the staging run OUTSIDE the lock (the reference's pool threads call this concurrently, render.rs:283-294), so
+    // a new pass -- which replaces the staging the readers copy from -- waits until the last of them is done, and whoever was waiting
+    // looks again afterwards: another caller may have brought the new pass in meanwhile.
+    for (;;) {
+        const bool same = a.valid && a.trav == trav && a.o.width == o->width && a.o.height == o->height && a.o.samples_per_pixel == o->samples_per_pixel;
+        if (same && !a.served[idx]) break;
+        if (a.readers != 0) { a.cv.wait(lk); continue; }
         bool have = false;
         if (!same) {
             drain_next();                                   // a pass for other options may still be writing h_next
@@ -1889,9 +1894,15 @@ static bool region_from_frame_ahead(rt_scene *s, const rt_options *o, rt_travers
                 a.next_inflight = true;
             else if (a.stream) { (void)hipStreamSynchronize(a.stream); (void)hipGetLastError(); }
         }
+        break;
     }
-    memcpy(out, a.h + a.off[idx], (size_t)(region->r - region->l) * (region->t - region->b) * 4);
+    const uint8_t *src = a.h + a.off[idx];
     a.served[idx] = 1;
+    ++a.readers;
+    lk.unlock();
+    memcpy(out, src, (size_t)(region->r - region->l) * (region->t - region->b) * 4);
+    lk.lock();
+    if (--a.readers == 0) a.cv.notify_all();
     *st = RT_OK;
     return true;
 }
