@@ -423,7 +423,10 @@ def main():
         flat = measure(args.workload, rta.RT_TRAVERSAL_FLAT, max(2, min(5, args.steps)), 1, 3, multi)
     in_flight = None
     if world == 1 and not args.force_collective and not args.no_extras and args.traversal == "skip":
-        in_flight = measure_in_flight(args.workload, max(args.steps, 100))
+        try:
+            in_flight = measure_in_flight(args.workload, max(args.steps, 100))
+        except Exception as e:                       # a side measurement must not take the headline down with it
+            sys.stderr.write("bench.py: frames_in_flight skipped: %r\n" % (e,))
     extras = {}
     if world > 1 and not args.no_extras and args.workload == "1080p" and args.traversal == "skip":
         other = "frames" if multi == "tiles" else "tiles"
