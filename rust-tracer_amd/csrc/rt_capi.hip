@@ -9,6 +9,7 @@
 #include "rt_flat.hpp"
 #include "rt_flat_wf.hpp"
 #include "rt_flat_sc.hpp"
+#include "rt_flat_f64.hpp"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>       // types and prototypes only: librccl.so is loaded with dlopen when the first gang is created
@@ -115,6 +116,8 @@ struct rt_scene {
     bool fused = false;            // every BOUND is followed by an ITEM with the same centre (rt_skip.hpp, Node)
     void *d_fprim = nullptr, *d_fprim_rr = nullptr, *d_fshad = nullptr;   // pre-formed per-item terms (RT_TRAVERSAL_FLAT)
     uint32_t n_padded = 0;
+    void *d_f64_pf = nullptr, *d_f64_sf = nullptr, *d_f64_sg = nullptr;        // f64, the filtered LDS scan (rt_flat_f64.hpp)
+    double flat_centre64[3] = { 0, 0, 0 };
     void *d_pf = nullptr, *d_pe = nullptr, *d_sg = nullptr, *d_se = nullptr;   // f32, the scalar-fed scan (rt_flat_sc.hpp): filter groups of four
                                                                                // items and exact records, primary / shadow
     uint32_t flat_filter_bytes = 0, flat_shadow_bytes = 0;                     // 128 x number of primary / shadow filter group pairs
@@ -302,8 +305,36 @@ rt_status upload_flat(rt_scene *s, const void *host_items)
                            static_cast<rt::FExact *>(s->d_pe), static_cast<rt::FGroup *>(s->d_sg), static_cast<rt::FExactShadow *>(s->d_se));
         HIP_TRY(hipGetLastError());
     }
+    if constexpr (sizeof(T) == 8) {
+        // the filtered f64 scan (rt_flat_f64.hpp): per-item bound terms next to the exact arrays
+        double m0[3] = { 0, 0, 0 };
+        for (unsigned i = 0; i < s->n_items; ++i)
+            for (int k = 0; k < 3; ++k) m0[k] += (double)it[4 * i + k];
+        for (int k = 0; k < 3; ++k) s->flat_centre64[k] = m0[k] / (double)s->n_items;
+        const size_t n_alloc = (size_t)s->n_padded + rt::kFlatF64Tail;
+        HIP_TRY(hipMalloc(&s->d_f64_pf, sizeof(rt::Quad<double>) * n_alloc));
+        HIP_TRY(hipMalloc(&s->d_f64_sf, sizeof(rt::Quad<double>) * n_alloc));
+        HIP_TRY(hipMalloc(&s->d_f64_sg, sizeof(double) * n_alloc));
+        hipLaunchKernelGGL(rt::k_build_flat_f64, dim3((unsigned)((n_alloc + 255) / 256)), dim3(256), 0, nullptr,
+                           static_cast<const rt::Item<double> *>(s->d_items), d_order, s->n_items, s->n_padded,
+                           rt::V3<double>{ s->eye[0], s->eye[1], s->eye[2] },
+                           rt::V3<double>{ s->flat_centre64[0], s->flat_centre64[1], s->flat_centre64[2] },
+                           rt::V3<double>{ -s->light[0], -s->light[1], -s->light[2] }, static_cast<rt::Quad<double> *>(s->d_f64_pf),
+                           static_cast<rt::Quad<double> *>(s->d_f64_sf), static_cast<double *>(s->d_f64_sg));
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipDeviceSynchronize());
     return RT_OK;
+}
+
+rt::FlatF64View flat_f64_view_of(const rt_scene *s)
+{
+    rt::FlatF64View v;
+    v.pf = static_cast<const rt::Quad<double> *>(s->d_f64_pf);
+    v.sf = static_cast<const rt::Quad<double> *>(s->d_f64_sf);
+    v.sg = static_cast<const double *>(s->d_f64_sg);
+    v.centre = { s->flat_centre64[0], s->flat_centre64[1], s->flat_centre64[2] };
+    return v;
 }
 
 rt::FlatScView flat_sc_view_of(const rt_scene *s)
@@ -887,6 +918,23 @@ rt_status launch_flat_wavefront(const rt_scene *s, Context *c, hipStream_t strea
     }
     c->flat_first_pass_items = (unsigned)CHUNK;
     const rt::FlatView<T> view = flat_view_of<T>(s);
+    if constexpr (sizeof(T) == 8) {
+        if (knob(RT_DEBUG_FLAT_KERNELS) != 0) {
+            // f64: the same pipeline with the conservative bound in front of the exact test (rt_flat_f64.hpp)
+            const rt::FlatF64View fx = flat_f64_view_of(s);
+            hipLaunchKernelGGL((rt::k_flat_primary_f64<CHUNK>), dim3(blocks32, (unsigned)ns), b, 0, stream, view, fx, w, h, spp, d_tab32, nt, sb, q1, c->d_queues, cnt);
+            HIP_TRY(hipGetLastError());
+            const unsigned rays_per_wg = rt::kBlockThreads * rt::kFlatR;
+            const dim3 gsh((unsigned)((samples + rays_per_wg - 1) / rays_per_wg));
+            hipLaunchKernelGGL((rt::k_flat_shadow_f64<CHUNK>), gsh, b, 0, stream, view, fx, 0u, (unsigned)CHUNK, q1, &c->d_queues->n1, q2, &c->d_queues->n2, sb, cnt);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL((rt::k_flat_shadow_f64<CHUNK>), gsh, b, 0, stream, view, fx, (unsigned)CHUNK, 0xFFFFFFFFu, q2, &c->d_queues->n2,
+                               (rt::Quad<T> *)nullptr, (unsigned *)nullptr, sb, cnt);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL((rt::k_resolve_samples<T>), dim3(blocks16), b, 0, stream, sb, spp, d_tab16, nt, d_out, frame_w, false);
+            return RT_OK;
+        }
+    }
     hipLaunchKernelGGL((rt::k_flat_primary<T, CHUNK>), dim3(blocks32, (unsigned)ns), b, 0, stream, view, w, h, spp, d_tab32, nt, sb, q1, c->d_queues, cnt);
     HIP_TRY(hipGetLastError());
     const unsigned rays_per_block = rt::kBlockThreads * rt::kFlatR;
@@ -1183,13 +1231,21 @@ long long rt_debug_count(int counter)
 // ray of a width x height x spp frame and every item.  counts: {disc >= 0, bound >= 0, disc >= 0 && bound < 0} primary, then shadow.
 rt_status rt_debug_flat_filter_check(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp, unsigned long long counts[6])
 {
-    if (!s || !counts || s->precision != RT_F32 || !s->d_pf || !width || !height || !spp) return RT_ERR_INVALID_ARGUMENT;
+    if (!s || !counts || !width || !height || !spp || (s->precision == RT_F32 ? !s->d_pf : !s->d_f64_pf)) return RT_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(s->device));
     unsigned long long *d = nullptr;
     HIP_TRY(hipMalloc(&d, 6 * sizeof(unsigned long long)));
     struct Free { unsigned long long *p; ~Free() { (void)hipFree(p); } } fr{ d };
     HIP_TRY(hipMemset(d, 0, 6 * sizeof(unsigned long long)));
     const uint64_t px = (uint64_t)width * height;
+    if (s->precision != RT_F32) {
+        hipLaunchKernelGGL(rt::k_flat_filter_check_f64, dim3((unsigned)((px + rt::kBlockThreads - 1) / rt::kBlockThreads), spp * spp), dim3(rt::kBlockThreads), 0,
+                           nullptr, flat_view_of<double>(s), flat_f64_view_of(s), (const unsigned *)nullptr, width, height, spp, d);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(counts, d, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        return RT_OK;
+    }
     hipLaunchKernelGGL(rt::k_flat_filter_check, dim3((unsigned)((px + rt::kBlockThreads - 1) / rt::kBlockThreads), spp * spp), dim3(rt::kBlockThreads), 0,
                        nullptr, flat_sc_view_of(s), width, height, spp, d);
     HIP_TRY(hipGetLastError());
@@ -1343,6 +1399,7 @@ rt_status rt_scene_destroy(rt_scene *s)
     if (s->d_fprim) (void)hipFree(s->d_fprim);
     if (s->d_fprim_rr) (void)hipFree(s->d_fprim_rr);
     if (s->d_fshad) (void)hipFree(s->d_fshad);
+    for (void *p : { s->d_f64_pf, s->d_f64_sf, s->d_f64_sg }) if (p) (void)hipFree(p);
     if (s->d_pf) (void)hipFree(s->d_pf);
     if (s->d_pe) (void)hipFree(s->d_pe);
     if (s->d_sg) (void)hipFree(s->d_sg);

@@ -910,6 +910,50 @@ def test_flat_scan_filter_never_rejects_a_candidate(scale):
         assert util.ray_stats(st) == util.ray_stats(rst)
 
 
+@pytest.mark.parametrize("scale", [1.0, 1e-20, 5e13])
+def test_f64_flat_scan_filter_never_rejects_a_candidate_and_matches_the_unfiltered_kernels(scale):
+    # The f64 flat scan (rt_flat_f64.hpp) puts the same kind of conservative bound in front of its exact test (eps = 2^-53).
+    # rt_debug_flat_filter_check on the f64 arrays: no ray x item pair with disc >= 0 and a negative bound, on the default scene at
+    # 1080p and on nested scenes scaled to both ends of the validated range and moved far from the origin; and the filtered kernels
+    # render the bytes and counters of round 1's unfiltered LDS kernels (RT_DEBUG_FLAT_KERNELS = 0), which the other f64 tests hold
+    # against the oracle.
+    scenes = []
+    if scale == 1.0:
+        s = rta.Scene.default(8, rta.RT_F64)
+        c = rta.capi.flat_filter_check(s.device()._h, 1920, 1080, 1)
+        assert c[0] > 5_000_000 and c[3] > 1_000_000
+        assert c[1] < 2 * c[0] and c[4] < 2 * c[3]
+        assert c[2] == 0 and c[5] == 0
+        scenes.append((rta.Scene.default(6, rta.RT_F64), (333, 217, 1)))
+    for seed in (31, 32, 33):
+        items, bounds, ranges = util.random_nested_scene(seed, depth=3, fan=3, leaf_items=2, concentric=seed == 32)
+        sc = lambda a: np.asarray(a, dtype=np.float64) * scale
+        eye = tuple(float(v) for v in sc((0.07, -0.12, -3.1)))
+        s, _ = util.scene_pair_ranges(sc(items), sc(bounds), ranges, rta.RT_F64, eye=eye)
+        c = rta.capi.flat_filter_check(s.device()._h, 320, 240, 2)
+        assert c[0] > 50_000 and c[3] > 10_000, c
+        assert c[2] == 0 and c[5] == 0, c
+        scenes.append((s, (160, 120, 2)))
+    if scale == 1.0:
+        items, bounds, ranges = util.random_nested_scene(34, depth=3, fan=3, leaf_items=2)
+        shift = np.array([3000.0, -2000.0, 5000.0])
+        mv = lambda a: np.concatenate([np.asarray(a, dtype=np.float64)[:, :3] + shift, np.asarray(a, dtype=np.float64)[:, 3:]], axis=1)
+        eye = tuple(float(v) for v in (np.array([0.07, -0.12, -3.1]) + shift))
+        s, _ = util.scene_pair_ranges(mv(items), mv(bounds), ranges, rta.RT_F64, eye=eye)
+        c = rta.capi.flat_filter_check(s.device()._h, 320, 240, 2)
+        assert c[0] > 30_000 and c[3] > 10_000 and c[2] == 0 and c[5] == 0, c
+        assert c[1] < 2 * c[0] and c[4] < 2 * c[3], c
+        scenes.append((s, (160, 120, 2)))
+    for s, (w, h, spp) in scenes:
+        regs = bucket_list(w, h, spp)
+        new, st_new = s.device().render_tiles((w, h, spp), regs, FLAT)
+        new = new.copy()
+        with rta.capi.debug(rta.capi.DEBUG_FLAT_KERNELS, 0):
+            old, st_old = s.device().render_tiles((w, h, spp), regs, FLAT)
+        assert np.array_equal(new, old)
+        assert util.ray_stats(st_new) == util.ray_stats(st_old)
+
+
 def test_scalar_fed_flat_scan_on_tiny_discriminants():
     # the exact path of the flat scan's assembly (root of a denormal / zero discriminant: the scaled `tiny` branch) on a scene
     # scaled by 1e-20, and the default scene at 1080p against the golden frame CRC

@@ -81,10 +81,12 @@ while time.time() < t_end:
             with rta.capi.debug(rta.capi.DEBUG_SKIP_RAYS, 2):
                 got, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
             assert np.array_equal(got, ref), "seed %d: two rays per lane differ" % seed
-        flat, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_FLAT, want_stats=False)
-        with rta.capi.debug(rta.capi.DEBUG_FLAT_KERNELS, 0):
-            lds, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_FLAT, want_stats=False)
-        assert np.array_equal(flat, lds), "seed %d: filtered flat scan differs from the LDS kernels" % seed
+    # both precisions: the filtered flat scan (f32: scalar-fed, two rays per lane; f64: rt_flat_f64.hpp) against round 1's unfiltered LDS kernels
+    flat, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_FLAT, want_stats=False)
+    flat = flat.copy()
+    with rta.capi.debug(rta.capi.DEBUG_FLAT_KERNELS, 0):
+        lds, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_FLAT, want_stats=False)
+    assert np.array_equal(flat, lds), "seed %d: filtered flat scan differs from the LDS kernels" % seed
     dv.close()
     checked += 1
     seed += 1
