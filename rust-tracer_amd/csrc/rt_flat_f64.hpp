@@ -19,6 +19,14 @@ namespace rt {
 
 constexpr unsigned kFlatF64Tail = 4;       // pad records behind n_padded: a group's successor is fetched before the group is evaluated
 
+// The high word of a bound, kept apart from its low word (left alone the compiler ANDs whole 64-bit values: twice the instructions).
+__device__ __forceinline__ int bound_sign_word(double bound)
+{
+    int hi = __double2hiint(bound);
+    asm("" : "+v"(hi));
+    return hi;
+}
+
 struct FlatF64View {
     const Quad<double> *pf;     // primary filter: {vx, vy, vz, K} per item, DFS order, padded like FlatView (pad: K = -inf)
     const Quad<double> *sf;     // shadow filter: {cx', cy', cz', CL} per item of the shadow array (radius descending)
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_flat_primary_f64(FlatView<dou
 #pragma unroll
             for (int r = 0; r < kFlatR; ++r) {
                 const T bp = __builtin_fma(f.z, dir[r].z, __builtin_fma(f.y, dir[r].y, f.x * dir[r].x));
-                all_negative &= __double2hiint(__builtin_fma(bp, bp, f.w));
+                all_negative &= bound_sign_word(__builtin_fma(bp, bp, f.w));
             }
         }
         if (__builtin_expect(all_negative >= 0, 0)) {                       // rare: the bound cannot rule out one of the 4 items for some lane
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_flat_shadow_f64(FlatView<doub
                 for (int r = 0; r < kFlatR; ++r) {
                     const T u = __builtin_fma(f.z, o2[r].z, __builtin_fma(f.y, o2[r].y, __builtin_fma(f.x, o2[r].x, npm[r])));
                     const T bp = f.w - ol[r];
-                    all_negative &= __double2hiint(__builtin_fma(bp, bp, u) + g);
+                    all_negative &= bound_sign_word(__builtin_fma(bp, bp, u) + g);
                 }
             }
             const bool candidate = all_negative >= 0;
