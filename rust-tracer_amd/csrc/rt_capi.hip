@@ -34,8 +34,12 @@ namespace {
 thread_local char g_err[512] = "";
 
 // Diagnostic controls (rt_debug.h): process-wide, -1 = default.  The library reads no environment variable.
-std::atomic<long long> g_knob[RT_DEBUG_KEYS] = { {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1} };
-std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = { {0}, {0}, {0}, {0}, {0}, {0}, {0} };
+struct KnobArray {
+    std::atomic<long long> v[RT_DEBUG_KEYS];
+    KnobArray() { for (auto &k : v) k.store(-1, std::memory_order_relaxed); }
+    std::atomic<long long> &operator[](int i) { return v[i]; }
+} g_knob;
+std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = {};
 std::atomic<bool> g_trace_on{ false };
 std::mutex g_trace_mu;
 std::string g_trace_path;
@@ -114,6 +118,9 @@ struct rt_scene {
     void *d_fc = nullptr;          // device copy of fc
     uint32_t n_nodes = 0, n_fnodes = 0;
     bool fused = false;            // every BOUND is followed by an ITEM with the same centre (rt_skip.hpp, Node)
+    // f32: the hierarchy once more in sibling-contiguous order for the lane-cooperative walk (rt_coop.hpp); coop.fanout == 0: none
+    void *d_coop_prim = nullptr, *d_coop_shad = nullptr;
+    rt::CoopView coop{};
     void *d_fprim = nullptr, *d_fprim_rr = nullptr, *d_fshad = nullptr;   // pre-formed per-item terms (RT_TRAVERSAL_FLAT)
     uint32_t n_padded = 0;
     void *d_f64_pf = nullptr, *d_f64_sf = nullptr, *d_f64_sg = nullptr;        // f64, the filtered LDS scan (rt_flat_f64.hpp)
@@ -128,8 +135,14 @@ struct rt_scene {
     // Immutable device copies of recently used tile tables (a scheduler re-submits the same bucket list every
     // frame): a hit means a pass enqueues nothing but its kernel.
     // dev_order: one descriptor per 16x16 block of the pass, most expensive first (block_order below), or NULL.
-    struct CachedTable { std::vector<rt::TileDev> host; unsigned w = 0, h = 0, passes = 0; rt::TileDev *dev = nullptr; rt::BlockDesc *dev_order = nullptr; uint32_t n_order = 0;
-                         uint32_t *dev_wg = nullptr; uint32_t n_wg = 0; };
+    // One dispatch order of a tile list: descriptors (+ optional workgroup offsets, + the holes of a cooperative pass, rt_kernels.hpp BlockList).
+    // A list whose pass could use the lane-cooperative walk gets several (none / a few cooperative thresholds) and the library TRIES them: the
+    // first launches take turns, timed with a pair of events each, and the fastest is kept -- whether the cooperative walk pays depends on
+    // how much of the pass is tail, which no estimate made here predicted as well as three measurements do.
+    struct Order { rt::BlockDesc *dev_order = nullptr; uint32_t n_order = 0; uint32_t *dev_wg = nullptr; uint32_t n_wg = 0; uint64_t *dev_holes = nullptr; uint32_t n_holes = 0;
+                   hipEvent_t e0 = nullptr, e1 = nullptr; bool pending = false; float best_ms = 1e30f; int samples = 0; };
+    struct CachedTable { std::vector<rt::TileDev> host; unsigned w = 0, h = 0, passes = 0; rt::TileDev *dev = nullptr; std::vector<Order> orders; int chosen = 0; unsigned turn = 0;
+                         long long coop_key = 0; };
     std::vector<CachedTable> tables;
     // Tests per primary ray (its shadow ray included) on a kCostRes x kCostRes grid over the camera's field of view,
     // rendered once per scene with the counting kernel.  It only ever decides the ORDER in which blocks are dispatched.
@@ -505,6 +518,8 @@ rt_status derive_streams(const rt_scene *s, const std::vector<rt::RawNode<T>> &r
     return RT_OK;
 }
 
+rt_status upload_coop(rt_scene *s, const std::vector<rt::RawNode<float>> &raw);
+
 template <typename T>
 rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, const rt_range *ranges)
 {
@@ -556,7 +571,56 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
         HIP_TRY(hipMemcpy(s->d_fc, &s->fc, sizeof(rt::FilterConsts), hipMemcpyHostToDevice));
         if ((st = derive_fstreams(s, s->d_prim, s->d_shad, s->n_nodes, false, &s->d_xprim, &s->d_xshad, nullptr)) != RT_OK) return st;
         if (fused && (st = derive_fstreams(s, s->d_cprim, s->d_cshad, s->n_fnodes, true, &s->d_xcprim, &s->d_xcshad, &s->d_xown)) != RT_OK) return st;
+        if ((st = upload_coop(s, raw)) != RT_OK) return st;
     }
+    return RT_OK;
+}
+
+// The lane-cooperative walk's copy of the hierarchy (rt_coop.hpp): the nodes of the plain stream in breadth-first order, so that the
+// children of a group are consecutive records.  Scenes whose largest child count (or number of top-level nodes) exceeds what a
+// work-list word holds simply get none: the cooperative walk is an optimisation of the skip-pointer walk, never a requirement.
+rt_status upload_coop(rt_scene *s, const std::vector<rt::RawNode<float>> &raw)
+{
+    const uint32_t n = (uint32_t)raw.size();
+    if (n == 0 || n >= rt::kCoopMaxNodes) return RT_OK;
+    auto next_sibling = [&](uint32_t i) { return raw[i].skip ? raw[i].skip : i + 1u; };
+    std::vector<uint32_t> perm;                       // breadth-first position -> stream index
+    perm.reserve(n);
+    for (uint32_t i = 0; i < n; i = next_sibling(i)) perm.push_back(i);
+    const uint32_t n_roots = (uint32_t)perm.size();
+    uint32_t fanout = n_roots;
+    std::vector<uint2> link(n);
+    for (uint32_t j = 0; j < perm.size(); ++j) {
+        const uint32_t i = perm[j];
+        if (raw[i].skip == 0u) { link[j] = make_uint2(raw[i].item, 0u); continue; }
+        const uint32_t first = (uint32_t)perm.size();
+        for (uint32_t c = i + 1u; c < raw[i].skip; c = next_sibling(c)) perm.push_back(c);
+        const uint32_t count = (uint32_t)perm.size() - first;
+        if (count == 0u) return RT_OK;                // cannot happen (groups without items are dropped); no copy rather than a wrong one
+        link[j] = make_uint2(first, count);
+        fanout = std::max(fanout, count);
+    }
+    if (perm.size() != n || fanout > rt::kCoopMaxFanout) return RT_OK;
+    uint32_t *d_perm = nullptr; uint2 *d_link = nullptr;
+    hipError_t e = hipMalloc(&d_perm, sizeof(uint32_t) * n);
+    if (e == hipSuccess) e = hipMalloc(&d_link, sizeof(uint2) * n);
+    if (e == hipSuccess) e = hipMemcpy(d_perm, perm.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_link, link.data(), sizeof(uint2) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&s->d_coop_prim, sizeof(rt::CNode) * n);
+    if (e == hipSuccess) e = hipMalloc(&s->d_coop_shad, sizeof(rt::CNode) * n);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rt::k_build_coop, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->d_prim, s->d_shad, (unsigned)sizeof(rt::Node<float>), d_perm, d_link, n,
+                           static_cast<rt::CNode *>(s->d_coop_prim), static_cast<rt::CNode *>(s->d_coop_shad));
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    if (d_perm) (void)hipFree(d_perm);
+    if (d_link) (void)hipFree(d_link);
+    if (e != hipSuccess) return hip_fail(e, "upload_coop", __LINE__);
+    s->coop.prim = static_cast<const rt::CNode *>(s->d_coop_prim);
+    s->coop.shad = static_cast<const rt::CNode *>(s->d_coop_shad);
+    s->coop.n_roots = n_roots;
+    s->coop.fanout = fanout;
     return RT_OK;
 }
 
@@ -673,18 +737,37 @@ constexpr size_t kNarrowMax = 64;
 constexpr uint64_t kNarrowPercent = 60;
 constexpr size_t kNarrowPassBlocks = 16384;
 constexpr size_t kNarrowLevel2Blocks = 4096;
+// the cooperative walk (rt_coop.hpp): blocks whose estimate reaches kCoopPercent of the pass's largest (and kCoopMinCost tests), at most
+// 1 / kCoopMaxShare of the pass
+constexpr uint64_t kCoopPercent = 40, kCoopMinCost = 96;
+constexpr size_t kCoopMaxShare = 8, kCoopPassBlocks = 4096;
+constexpr unsigned kCoopLevel = 2;
+constexpr unsigned kCoopRestLevel = 0;      // what is left of a block with holes: 0 = one descriptor (8x8 pixels per wave), 1 = four (4x4 per wave)
 
 // `passes`: how many times the render kernel walks the list in one launch (one per sample in the sample-parallel path).
 // Workgroups a launch keeps resident at once: 8 waves per SIMD, 4 waves per workgroup, 256 CUs.
 constexpr size_t kResidentWorkgroups = 2048;
 
+// coop (optional): the scene's cooperative copy; holes (with coop): one 64-bit word per descriptor [0, holes->size()) of the list -- the
+// 2x2-pixel quads of that 16x16 block (bit (y >> 1) * 8 + (x >> 1)) which cooperative descriptors further down the list render instead.
 void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev> &tab, unsigned w, unsigned h, unsigned passes,
-                 std::vector<rt::BlockDesc> &descs, std::vector<uint32_t> &wg_first)
+                 std::vector<rt::BlockDesc> &descs, std::vector<uint32_t> &wg_first, const rt::CoopView *coop = nullptr, std::vector<uint64_t> *holes = nullptr,
+                 int coop_percent = -1)            // 0: no cooperative quads; > 0: from that share of the pass's largest estimate; -1: as rt_debug.h says (default share)
 {
     wg_first.clear();
+    if (holes) holes->clear();
     constexpr int R = (int)kCostRes;
     std::vector<uint32_t> cost;
     std::vector<rt::BlockDesc> raster;
+    auto map_col = [&](unsigned x) { return std::clamp((int)((uint64_t)x * R / w), 0, R - 1); };
+    auto map_row = [&](unsigned y) { return std::clamp((int)std::floor(((double)y - h / 2.0) * R / w + R / 2.0), 0, R - 1); };
+    // the largest map value under the pixels [x0, x1] x [y0, y1], grown by `grow` cells on every side
+    auto map_max = [&](unsigned x0, unsigned y0, unsigned x1, unsigned y1, int grow) {
+        uint32_t m = 0;
+        for (int Y = std::max(0, map_row(y0) - grow); Y <= std::min(R - 1, map_row(y1) + grow); ++Y)
+            for (int X = std::max(0, map_col(x0) - grow); X <= std::min(R - 1, map_col(x1) + grow); ++X) m = std::max(m, (*map)[(size_t)Y * R + X]);
+        return m;
+    };
     for (const rt::TileDev &t : tab) {
         const unsigned bys = ((unsigned)(t.t - t.b) + rt::kBlockH - 1) / rt::kBlockH;
         const uint32_t pitch = (uint32_t)t.r - t.l;
@@ -693,13 +776,7 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
                 const unsigned x0 = t.l + bx * rt::kBlockW, y0 = t.b + by * rt::kBlockH;
                 raster.push_back(rt::BlockDesc{ (uint16_t)x0, (uint16_t)y0, t.r, t.t, pitch, t.out_px - t.b * pitch - t.l });
                 uint32_t m = 0;
-                if (map) {
-                    const unsigned x1 = std::min<unsigned>(x0 + rt::kBlockW, t.r) - 1, y1 = std::min<unsigned>(y0 + rt::kBlockH, t.t) - 1;
-                    auto col = [&](unsigned x) { return std::clamp((int)((uint64_t)x * R / w), 0, R - 1); };
-                    auto row = [&](unsigned y) { return std::clamp((int)std::floor(((double)y - h / 2.0) * R / w + R / 2.0), 0, R - 1); };
-                    for (int Y = row(y0); Y <= row(y1); ++Y)
-                        for (int X = col(x0); X <= col(x1); ++X) m = std::max(m, (*map)[(size_t)Y * R + X]);
-                }
+                if (map) m = map_max(x0, y0, std::min<unsigned>(x0 + rt::kBlockW, t.r) - 1, std::min<unsigned>(y0 + rt::kBlockH, t.t) - 1, 0);
                 cost.push_back(m);
             }
     }
@@ -715,26 +792,105 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
         for (size_t i = 0; i < order.size(); i = i < 64 ? i + 4 : i * 2) fprintf(stderr, " #%zu=%u", i, cost[order[i]]);
         fprintf(stderr, "\n");
     }
+    // The quads whose rays meet the most nodes are walked COOPERATIVELY (rt_coop.hpp; single-pass f32 launches of scenes that have the
+    // cooperative copy, blocks not dealt to workgroups on the host).  A block that holds such quads -- 2x2 pixels whose estimate (the map
+    // cells under them) reaches the threshold -- goes out as its
+    // ordinary descriptor plus a 64-bit word of HOLES, the quads its own waves leave out, and one cooperative descriptor per 4x4-pixel
+    // region that has holes (level 2: a 2x2 quad = 4 rays per wave; rt_debug.h can ask for 16 rays or one): the waves of those trace
+    // the holes and nothing else.  RT_DEBUG_COOP: 0 never, 2 every quad of every block (tests).
+    size_t n_coop = 0;
+    uint64_t coop_thr = 0;
+    const long long coop_knob = knob(RT_DEBUG_COOP);
+    const bool coop_all = coop_knob == 2;
+    if (coop && holes && coop->fanout != 0u && passes == 1 && knob(RT_DEBUG_WG_POLICY) <= 0 && coop_knob != 0 && coop_percent != 0 && !cost.empty() && (map || coop_all)) {
+        if (coop_all) n_coop = order.size();
+        else {
+            const uint64_t top = cost[order[0]];
+            const long long t = knob(RT_DEBUG_COOP_THR), m = knob(RT_DEBUG_COOP_MAX);
+            coop_thr = t >= 0 ? (uint64_t)t : std::max<uint64_t>(kCoopMinCost, top * (uint64_t)(coop_percent > 0 ? coop_percent : (int)kCoopPercent) / 100);
+            // (a pass of more blocks is throughput-bound from its first to its last wave -- 1080p: DESIGN.md 4.1 -- and a cooperative test costs
+            // four to five times the vector instructions of a test of the skip-pointer walk: it only pays where waves wait for a few chains)
+            const size_t cap = m >= 0 ? (size_t)m : order.size() > kCoopPassBlocks ? 0 : order.size() / kCoopMaxShare;
+            while (n_coop < order.size() && n_coop < cap && cost[order[n_coop]] >= coop_thr) ++n_coop;
+        }
+    }
     if (map && !cost.empty()) {
         const long long e = knob(RT_DEBUG_NARROW_MAX);
         // a pass of more blocks than kNarrowPassBlocks is throughput-bound: narrowing only adds work there (3840x2160 + 2 %)
         // (and only in single-pass launches: the packed sample-parallel mapping has its own, finer ray packets)
-        const size_t cap = passes > 1 ? 0 : e >= 0 ? (size_t)e : order.size() > kNarrowPassBlocks ? 0 : std::min<size_t>(kNarrowMax, order.size() / 128);
-        const uint64_t top = cost[order[0]];
-        while (n_narrow < order.size() && n_narrow < cap && cost[order[n_narrow]] > 0 && (uint64_t)cost[order[n_narrow]] * 100 >= top * kNarrowPercent)
+        // (behind a cooperative tier the next blocks are narrowed more generously: tools/coop_sweep.py, 800x600 28.4 -> 26.4 us)
+        const size_t cap = passes > 1 ? 0 : e >= 0 ? (size_t)e : order.size() > kNarrowPassBlocks ? 0 : std::min<size_t>(kNarrowMax, order.size() / (n_coop && !coop_all ? 32 : 128));
+        // (with the heaviest blocks walked cooperatively, "expensive" is measured against the cooperative threshold)
+        const uint64_t top = n_coop && !coop_all ? coop_thr : cost[order[0]];
+        while (n_coop + n_narrow < order.size() && n_narrow < cap && cost[order[n_coop + n_narrow]] > 0 &&
+               (uint64_t)cost[order[n_coop + n_narrow]] * 100 >= top * kNarrowPercent)
             ++n_narrow;
     }
     descs.clear();
-    descs.reserve(order.size() + 15 * n_narrow);
+    descs.reserve(order.size() + 15 * n_narrow + 63 * n_coop);
     std::vector<uint32_t> dcost;                          // cost estimate of every descriptor, descending
-    dcost.reserve(order.size() + 15 * n_narrow);
-    for (size_t i = 0; i < order.size(); ++i) {
+    dcost.reserve(order.size() + 15 * n_narrow + 63 * n_coop);
+    if (n_coop) {
+        // level 1: workgroups of 8x8 pixels (a 4x4 quad = 16 rays per wave); 2: 4x4 (2x2 = 4 rays per wave); 3: 2x2 (one ray per wave)
+        const long long lk = knob(RT_DEBUG_COOP_LEVEL);
+        const unsigned level = lk >= 1 && lk <= 3 ? (unsigned)lk : kCoopLevel, step = 16u >> level, cnt = 1u << level, quad = step / 2u;
+        const unsigned grain = std::max(2u, quad);           // a hole is decided for `grain` x `grain` pixels at once: whole cooperative quads
+        // the chains follow silhouettes thinner than a map cell: where cells are small (a few pixels) their neighbours count too
+        const int grow = (w + R - 1) / R <= 4 ? 1 : 0;
+        const unsigned rest_level = knob(RT_DEBUG_COOP_REST) >= 0 ? (unsigned)std::min(1ll, knob(RT_DEBUG_COOP_REST)) : kCoopRestLevel;
+        std::vector<rt::BlockDesc> cdescs;
+        std::vector<uint32_t> ccost;
+        for (size_t i = 0; i < n_coop; ++i) {
+            const rt::BlockDesc &d = raster[order[i]];
+            uint64_t hole = 0;
+            for (unsigned gy = 0; gy < 16u; gy += grain)
+                for (unsigned gx = 0; gx < 16u; gx += grain) {
+                    const unsigned px0 = d.x0 + gx, py0 = d.y0 + gy;
+                    if (!(px0 < d.r && py0 < d.t)) continue;                    // outside a clipped edge tile
+                    if (!(coop_all || map_max(px0, py0, std::min<unsigned>(px0 + grain, d.r) - 1, std::min<unsigned>(py0 + grain, d.t) - 1, grow) >= coop_thr)) continue;
+                    for (unsigned sy = 0; sy < grain; sy += 2)
+                        for (unsigned sx = 0; sx < grain; sx += 2) hole |= 1ull << (((gy + sy) >> 1) * 8u + ((gx + sx) >> 1));
+                }
+            if (rest_level == 0u || !hole) { descs.push_back(d); dcost.push_back(cost[order[i]]); holes->push_back(hole); }
+            else
+                for (unsigned qy = 0; qy < 2; ++qy)             // what is left of the block as four quarters (a 4x4 patch per wave), each with its 4x4 holes
+                    for (unsigned qx = 0; qx < 2; ++qx) {
+                        rt::BlockDesc n = d;
+                        n.x0 = (uint16_t)(d.x0 + qx * 8u); n.y0 = (uint16_t)(d.y0 + qy * 8u);
+                        if (!(n.x0 < d.r && n.y0 < d.t)) continue;
+                        uint64_t sub = 0;
+                        for (unsigned sy = 0; sy < 4; ++sy)
+                            for (unsigned sx = 0; sx < 4; ++sx)
+                                if ((hole >> ((qy * 4u + sy) * 8u + qx * 4u + sx)) & 1ull) sub |= 1ull << (sy * 4u + sx);
+                        if (sub == 0xFFFFull) continue;          // nothing left of this quarter
+                        n.pitch |= 1u << rt::kBlockNarrowShift;
+                        descs.push_back(n); dcost.push_back(cost[order[i]]); holes->push_back(sub);
+                    }
+            if (!hole) continue;
+            for (unsigned qy = 0; qy < cnt; ++qy)
+                for (unsigned qx = 0; qx < cnt; ++qx) {
+                    rt::BlockDesc n = d;
+                    n.x0 = (uint16_t)(d.x0 + qx * step); n.y0 = (uint16_t)(d.y0 + qy * step);
+                    uint32_t mask = 0;
+                    for (unsigned wv = 0; wv < 4; ++wv) {
+                        const unsigned lx = qx * step + (wv & 1u) * quad, ly = qy * step + (wv >> 1) * quad;      // the wave's quad, inside the block
+                        if ((hole >> ((ly >> 1) * 8u + (lx >> 1))) & 1ull) mask |= 1u << wv;
+                    }
+                    if (!mask) continue;
+                    n.pitch |= (level << rt::kBlockNarrowShift) | (mask << rt::kBlockCoopShift);
+                    cdescs.push_back(n); ccost.push_back(cost[order[i]]);
+                }
+        }
+        descs.insert(descs.end(), cdescs.begin(), cdescs.end());
+        dcost.insert(dcost.end(), ccost.begin(), ccost.end());
+    }
+    for (size_t i = n_coop; i < order.size(); ++i) {
         const rt::BlockDesc &d = raster[order[i]];
-        if (i >= n_narrow) { descs.push_back(d); dcost.push_back(cost[order[i]]); continue; }
+        if (i >= n_coop + n_narrow) { descs.push_back(d); dcost.push_back(cost[order[i]]); continue; }
         // 4x4 pixels per wave; 2x2 in a pass so small that its waves all start at once anyway (800x600: 63 -> 52 us; at 1080p the
         // sixteen-fold wave count of 2x2 costs more throughput than the shorter chains buy)
         const long long l2 = knob(RT_DEBUG_NARROW_L2);
-        const unsigned level = (l2 >= 0 ? (long long)i < l2 : order.size() <= kNarrowLevel2Blocks) ? 2u : 1u, step = 16u >> level, cnt = 1u << level;
+        const unsigned level = (l2 >= 0 ? (long long)(i - n_coop) < l2 : (order.size() <= kNarrowLevel2Blocks && n_coop == 0)) ? 2u : 1u, step = 16u >> level, cnt = 1u << level;
         for (unsigned qy = 0; qy < cnt; ++qy)
             for (unsigned qx = 0; qx < cnt; ++qx) {
                 rt::BlockDesc n = d;
@@ -755,7 +911,7 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
     size_t n_wg = 0;
     if (policy > 0) n_wg = kResidentWorkgroups * (size_t)policy / std::max(1u, passes);
     else if (policy < 0 && total_wg > 32768) n_wg = std::clamp<size_t>(total_wg / 8, 8192, 65536) / std::max(1u, passes);
-    if (map && n_wg >= 64 && descs.size() > n_wg) {
+    if (map && n_wg >= 64 && descs.size() > n_wg && n_coop == 0) {        // (the holes of a cooperative pass are indexed by descriptor position)
         std::vector<std::vector<uint32_t>> lists(n_wg);
         std::vector<std::pair<uint64_t, uint32_t>> heap;                      // (load, workgroup), min-heap
         heap.reserve(n_wg);
@@ -783,6 +939,61 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
 
 bool block_order_enabled() { return knob(RT_DEBUG_BLOCK_ORDER) != 0; }     // read per call: A/B timing interleaves both
 
+void release_order(rt_scene::Order &od)
+{
+    if (od.dev_order) (void)hipFree(od.dev_order);
+    if (od.dev_wg) (void)hipFree(od.dev_wg);
+    if (od.dev_holes) (void)hipFree(od.dev_holes);
+    if (od.e0) (void)hipEventDestroy(od.e0);
+    if (od.e1) (void)hipEventDestroy(od.e1);
+    od = rt_scene::Order{};
+}
+
+// The dispatch order a launch of this table uses (called under the scene's lock).  While a table with several candidates is undecided, its
+// launches take turns: a candidate that is not being timed right now is handed out with its pair of events (the caller records them around
+// the launch); results are collected here as they complete, and once every candidate has kOrderTrialSamples the fastest stays.
+constexpr int kOrderTrialSamples = 3;
+rt::BlockList pick_order(rt_scene::CachedTable &t)
+{
+    if (t.orders.empty()) return rt::BlockList{};
+    // (orders[0] never has holes: what a launch that cannot walk cooperatively -- counters, f64, two rays per lane -- falls back to)
+    auto list_of = [&t](const rt_scene::Order &od) {
+        rt::BlockList l{ od.dev_order, od.n_order, od.dev_wg, od.n_wg, od.dev_holes, od.n_holes };
+        l.plain_d = t.orders[0].dev_order; l.plain_n = t.orders[0].n_order; l.plain_wg_first = t.orders[0].dev_wg; l.plain_n_wg = t.orders[0].n_wg;
+        return l;
+    };
+    if (t.chosen >= 0) return list_of(t.orders[(size_t)t.chosen]);
+    bool all_done = true;
+    for (auto &od : t.orders) {
+        if (od.pending && hipEventQuery(od.e1) == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, od.e0, od.e1) == hipSuccess && ms > 0.f) { od.best_ms = std::min(od.best_ms, ms); ++od.samples; }
+            od.pending = false;
+        }
+        (void)hipGetLastError();                         // hipErrorNotReady is not an error here
+        all_done = all_done && od.samples >= kOrderTrialSamples;
+    }
+    if (all_done) {
+        size_t best = 0;
+        for (size_t i = 1; i < t.orders.size(); ++i) if (t.orders[i].best_ms < t.orders[best].best_ms) best = i;
+        t.chosen = (int)best;
+        return list_of(t.orders[best]);
+    }
+    for (size_t k = 0; k < t.orders.size(); ++k) {
+        rt_scene::Order &od = t.orders[(t.turn + k) % t.orders.size()];
+        if (od.pending || od.samples >= kOrderTrialSamples) continue;
+        t.turn = (unsigned)((t.turn + k + 1) % t.orders.size());
+        od.pending = true;
+        rt::BlockList l = list_of(od);
+        l.ev0 = od.e0; l.ev1 = od.e1;
+        return l;
+    }
+    // every candidate that still needs samples is in flight: the best known so far, untimed
+    size_t best = 0;
+    for (size_t i = 1; i < t.orders.size(); ++i) if (t.orders[i].best_ms < t.orders[best].best_ms) best = i;
+    return list_of(t.orders[best]);
+}
+
 rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, const rt::TileDev **out, int slot,
                        const rt_options *o, rt::BlockList *order_out, bool cacheable)
 {
@@ -791,12 +1002,18 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
     const unsigned passes = (o && use_split(o->samples_per_pixel)) ? (unsigned)o->samples_per_pixel * o->samples_per_pixel : 1u;
     if (order_out) *order_out = rt::BlockList{};
     const std::vector<uint32_t> *map = (o && order_out && cacheable) ? cost_map_of(s) : nullptr;     // before taking the lock: it renders
+    // the cooperative walk's controls (rt_debug.h) are part of a dispatch table's identity: tests render one tile list with and without
+    long long coop_key = 0;
+    if (o && order_out)
+        for (int k : { RT_DEBUG_COOP, RT_DEBUG_COOP_THR, RT_DEBUG_COOP_MAX, RT_DEBUG_COOP_LEVEL, RT_DEBUG_COOP_REST, RT_DEBUG_NARROW_MAX, RT_DEBUG_NARROW_L2 })
+            coop_key = coop_key * 1000003ll + (knob(k) + 2);
     if (cacheable) {
         std::lock_guard<std::mutex> lk(s->mu);
         for (auto &t : s->tables)
-            if ((!o || (t.w == w && t.h == h && t.passes == passes)) && t.host.size() == tab.size() && memcmp(t.host.data(), tab.data(), bytes) == 0) {
+            if ((!o || (t.w == w && t.h == h && t.passes == passes && (!order_out || t.coop_key == coop_key))) && t.host.size() == tab.size() &&
+                memcmp(t.host.data(), tab.data(), bytes) == 0) {
                 *out = t.dev;
-                if (order_out && block_order_enabled()) *order_out = rt::BlockList{ t.dev_order, t.n_order, t.dev_wg, t.n_wg };
+                if (order_out && block_order_enabled()) *order_out = pick_order(t);
                 return RT_OK;
             }
         if (s->tables.size() < kMaxCachedTables) {
@@ -804,34 +1021,61 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
             HIP_TRY(hipMalloc(&t.dev, bytes));
             hipError_t e = hipMemcpy(t.dev, tab.data(), bytes, hipMemcpyHostToDevice);    // blocking, once per table
             if (e != hipSuccess) { (void)hipFree(t.dev); return hip_fail(e, "hipMemcpy(tile table)", __LINE__); }
+            auto drop = [&t] { (void)hipFree(t.dev); for (auto &od : t.orders) release_order(od); };
             if (o && order_out) {
-                std::vector<rt::BlockDesc> order;
-                std::vector<uint32_t> wg_first;
-                block_order(map, tab, w, h, passes, order, wg_first);
-                e = hipMalloc(&t.dev_order, order.size() * sizeof(rt::BlockDesc));
-                if (e == hipSuccess) e = hipMemcpy(t.dev_order, order.data(), order.size() * sizeof(rt::BlockDesc), hipMemcpyHostToDevice);
-                if (e == hipSuccess && !wg_first.empty()) {
-                    e = hipMalloc(&t.dev_wg, wg_first.size() * sizeof(uint32_t));
-                    if (e == hipSuccess) e = hipMemcpy(t.dev_wg, wg_first.data(), wg_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-                    t.n_wg = (uint32_t)wg_first.size() - 1;
+                const bool coop_pass = s->precision == RT_F32 && s->coop.fanout != 0u && passes == 1;
+                // candidates: the plain dispatch first; where the cooperative walk could serve the pass and nothing was asked for explicitly
+                // (rt_debug.h), a few thresholds in percent of the pass's largest estimate -- pick_order tries them
+                uint64_t total_px = 0;
+                for (const rt::TileDev &td : tab) total_px += (uint64_t)(td.r - td.l) * (td.t - td.b);
+                const long long rays = knob(RT_DEBUG_SKIP_RAYS);
+                const bool two_rays = s->fused && (rays < 0 ? skip2_by_default(total_px, 1, s->n_fnodes) : rays == 2);      // k_render_skip2 knows no cooperative quads
+                std::vector<int> percents;
+                if (coop_pass && map && !two_rays && knob(RT_DEBUG_COOP) < 0 && knob(RT_DEBUG_COOP_THR) < 0) percents = { 0, 30, 40, 55 };
+                else if (coop_pass && (knob(RT_DEBUG_COOP) > 0 || knob(RT_DEBUG_COOP_THR) >= 0)) percents = { 0, -1 };       // as asked, behind the plain one
+                else percents = { -1 };
+                for (int pc : percents) {
+                    std::vector<rt::BlockDesc> order;
+                    std::vector<uint32_t> wg_first;
+                    std::vector<uint64_t> holes;
+                    block_order(map, tab, w, h, passes, order, wg_first, coop_pass ? &s->coop : nullptr, &holes, pc);
+                    const bool any_hole = std::any_of(holes.begin(), holes.end(), [](uint64_t v) { return v != 0; });
+                    if (pc != percents[0] && !any_hole) continue;       // the same dispatch as the plain one
+                    rt_scene::Order od;
+                    e = hipMalloc(&od.dev_order, order.size() * sizeof(rt::BlockDesc));
+                    if (e == hipSuccess) e = hipMemcpy(od.dev_order, order.data(), order.size() * sizeof(rt::BlockDesc), hipMemcpyHostToDevice);
+                    if (e == hipSuccess && any_hole) {
+                        e = hipMalloc(&od.dev_holes, holes.size() * sizeof(uint64_t));
+                        if (e == hipSuccess) e = hipMemcpy(od.dev_holes, holes.data(), holes.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+                        od.n_holes = (uint32_t)holes.size();
+                    }
+                    if (e == hipSuccess && !wg_first.empty()) {
+                        e = hipMalloc(&od.dev_wg, wg_first.size() * sizeof(uint32_t));
+                        if (e == hipSuccess) e = hipMemcpy(od.dev_wg, wg_first.data(), wg_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+                        od.n_wg = (uint32_t)wg_first.size() - 1;
+                    }
+                    od.n_order = (uint32_t)order.size();
+                    t.orders.push_back(od);
+                    if (e != hipSuccess) { drop(); return hip_fail(e, "block order", __LINE__); }
                 }
-                if (e != hipSuccess) {
-                    (void)hipFree(t.dev); if (t.dev_order) (void)hipFree(t.dev_order); if (t.dev_wg) (void)hipFree(t.dev_wg);
-                    return hip_fail(e, "block order", __LINE__);
+                if (t.orders.size() > 1 && percents.size() == 2) t.chosen = 1;      // asked for explicitly
+                else if (t.orders.size() > 1) {
+                    t.chosen = -1;                                      // to be decided by measurement
+                    for (auto &od : t.orders) {
+                        e = hipEventCreate(&od.e0);
+                        if (e == hipSuccess) e = hipEventCreate(&od.e1);
+                        if (e != hipSuccess) { drop(); return hip_fail(e, "hipEventCreate(order trial)", __LINE__); }
+                    }
                 }
-                t.n_order = (uint32_t)order.size();
             }
             // The copies above are blocking for the host, but the render kernel runs on another (non-blocking) stream: make sure
             // the tables have landed in device memory before anything can be launched against them (once per tile list).
             e = hipDeviceSynchronize();
-            if (e != hipSuccess) {
-                (void)hipFree(t.dev); if (t.dev_order) (void)hipFree(t.dev_order); if (t.dev_wg) (void)hipFree(t.dev_wg);
-                return hip_fail(e, "hipDeviceSynchronize(tile tables)", __LINE__);
-            }
-            t.host = tab; t.w = w; t.h = h; t.passes = passes;
+            if (e != hipSuccess) { drop(); return hip_fail(e, "hipDeviceSynchronize(tile tables)", __LINE__); }
+            t.host = tab; t.w = w; t.h = h; t.passes = passes; t.coop_key = coop_key;
             *out = t.dev;
-            if (order_out && block_order_enabled()) *order_out = rt::BlockList{ t.dev_order, t.n_order, t.dev_wg, t.n_wg };
             s->tables.push_back(std::move(t));
+            if (order_out && block_order_enabled()) *order_out = pick_order(s->tables.back());
             return RT_OK;
         }
     }
@@ -953,6 +1197,19 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
                           const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt, unsigned frame_w,
                           rt::BlockList order)
 {
+    // two rays per lane (rt_skip2.hpp): f32, fused assembly loops, launches that neither count nor trace
+    bool two_rays = false;
+    if constexpr (!COUNT && (VAR & 15) == 7 && sizeof(T) == 4) {
+        const long long k = knob(RT_DEBUG_SKIP_RAYS);
+        two_rays = k < 0 ? skip2_by_default(total_px, spp, s->n_fnodes) : k == 2;
+        two_rays = two_rays && (spp == 1 || (use_split(spp) && packed_samples(spp)));
+    }
+    // an order with cooperative quads needs the COOP flavour of k_render_skip: everything else renders the plain order of the same list
+    constexpr bool kCoopFlavour = !COUNT && sizeof(T) == 4 && (VAR == 19 || VAR == 23 || VAR == 31);
+    if (order.holes && !(kCoopFlavour && spp == 1 && !two_rays && !order.wg_first)) {
+        order.d = order.plain_d; order.n = order.plain_n; order.wg_first = order.plain_wg_first; order.n_wg = order.plain_n_wg;
+        order.holes = nullptr; order.n_holes = 0;
+    }
     const dim3 b(rt::kBlockThreads);
     const unsigned lds = (unsigned)std::max(0ll, knob(RT_DEBUG_LDS_BYTES));
     uint32_t *no_cost = nullptr;
@@ -980,13 +1237,6 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
         no_cost = tr.d;
     }
     rt::SampleBuf<T> sb{ nullptr, nullptr, (unsigned)total_px };
-    // two rays per lane (rt_skip2.hpp): f32, fused assembly loops, launches that neither count nor trace
-    bool two_rays = false;
-    if constexpr (!COUNT && (VAR & 15) == 7 && sizeof(T) == 4) {
-        const long long k = knob(RT_DEBUG_SKIP_RAYS);
-        two_rays = k < 0 ? skip2_by_default(total_px, spp, s->n_fnodes) : k == 2;
-        two_rays = two_rays && (spp == 1 || (use_split(spp) && packed_samples(spp)));
-    }
     const dim3 b2(rt::kSkip2Threads);
     if (!use_split(spp)) {
         if constexpr (!COUNT && (VAR & 15) == 7 && sizeof(T) == 4) {
@@ -994,6 +1244,14 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
                 g_count[RT_DEBUG_COUNT_TWO_RAY_LAUNCHES].fetch_add(1, std::memory_order_relaxed);
                 hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipOne, (VAR & 16) != 0>), rgrid, b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt, d_out, sb, frame_w,
                                    order.d, order.wg_first);
+                return RT_OK;
+            }
+        }
+        if constexpr (!COUNT && sizeof(T) == 4 && (VAR == 19 || VAR == 23 || VAR == 31)) {
+            if (spp == 1 && order.d && order.holes && !order.wg_first) {        // some quads of the pass are walked cooperatively (rt_coop.hpp)
+                g_count[RT_DEBUG_COUNT_COOP_LAUNCHES].fetch_add(1, std::memory_order_relaxed);
+                hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipOne, true>), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
+                                   frame_w, order.d, no_cost, order.wg_first, s->coop, order.holes, order.n_holes);
                 return RT_OK;
             }
         }
@@ -1102,6 +1360,10 @@ rt_status launch_render(rt_scene *s, Context *c, const rt_options *o, rt_travers
 {
     const dim3 grid(total_blocks);
     const unsigned w = o->width, h = o->height, spp = o->samples_per_pixel;
+    // a dispatch order that is being timed against others (pick_order); never a counting launch: its loops are different ones
+    const bool timed = order.ev0 && order.ev1 && !cnt && trav == RT_TRAVERSAL_SKIP;
+    if (timed) HIP_TRY(hipEventRecord(order.ev0, stream));
+    struct Stop { hipEvent_t e; hipStream_t s; ~Stop() { if (e) (void)hipEventRecord(e, s); } } stop{ timed ? order.ev1 : nullptr, stream };
     if (trav == RT_TRAVERSAL_FLAT && d_tab16) {                     // wavefront pipeline (needs a context and the 16x16 table)
         rt_status fst = s->precision == RT_F32
             ? launch_flat_wavefront<float, 1024>(s, c, stream, w, h, spp, d_tab, nt, total_blocks, d_tab16, blocks16, total_px, d_out, cnt, frame_w)
@@ -1386,13 +1648,13 @@ rt_status rt_scene_destroy(rt_scene *s)
     (void)hipSetDevice(s->device);
     if (s->ahead.stream) { (void)hipStreamSynchronize(s->ahead.stream); (void)hipStreamDestroy(s->ahead.stream); }      // a pass rendered ahead may still be running
     s->pool.clear();
-    for (auto &t : s->tables) { (void)hipFree(t.dev); if (t.dev_order) (void)hipFree(t.dev_order); if (t.dev_wg) (void)hipFree(t.dev_wg); }
+    for (auto &t : s->tables) { (void)hipFree(t.dev); for (auto &od : t.orders) release_order(od); }
     if (s->d_items) (void)hipFree(s->d_items);
     if (s->d_prim) (void)hipFree(s->d_prim);
     if (s->d_shad) (void)hipFree(s->d_shad);
     if (s->d_cprim) (void)hipFree(s->d_cprim);
     if (s->d_cshad) (void)hipFree(s->d_cshad);
-    for (void *p : { s->d_xprim, s->d_xshad, s->d_xcprim, s->d_xcshad, s->d_xown, s->d_fc }) if (p) (void)hipFree(p);
+    for (void *p : { s->d_xprim, s->d_xshad, s->d_xcprim, s->d_xcshad, s->d_xown, s->d_fc, s->d_coop_prim, s->d_coop_shad }) if (p) (void)hipFree(p);
     if (s->ahead.ev) (void)hipEventDestroy(s->ahead.ev);
     if (s->ahead.h) (void)rt_host_free(s->ahead.h);
     if (s->ahead.h_next) (void)rt_host_free(s->ahead.h_next);

@@ -1,0 +1,240 @@
+// rt_coop.hpp -- the lane-cooperative walk of k_render_skip's heaviest pixels (f32).
+//
+// The skip-pointer walk (rt_skip.hpp) gives every lane a ray and moves the whole wave through the node stream one node at a time:
+// a pixel whose ray meets 400-500 nodes is a chain of that many DEPENDENT scalar loads, each an L2 round trip (a node is touched once
+// per wave), and a frame waits for the few waves that hold such pixels while the rest of the chip is idle.  Here the lanes of a wave
+// carry NODES instead: a wave owns a 4x4-pixel quad (16 rays) and keeps a work list of (ray, group) pairs in LDS; every round the
+// lanes take the children of the pairs on top of the list -- one (ray, child) test per lane, the node records fetched by independent
+// vector loads --, run the reference's own test on them (primitive.rs:55-72, operation for operation) and put every group whose bound
+// returns a finite distance back on the list: a gather of the ray's CLOSURE, the nodes all of whose ancestors have a finite bound
+// distance.  About eight dependent rounds of loads on the reference's pyramid instead of several hundred.
+//
+// Why the result is the reference's (TypedGroup::intersect, group.rs:72-83: `if bound.distance_from_ray(ray) >= hit.distance return`,
+// Sphere::intersect, primitive.rs:77-84: strict `<`, so the first item in traversal order keeps a tie):
+//   * The reference only descends into a group whose bound distance d is < hit.distance <= INF, so every node it visits is in the
+//     closure; it visits a subset of it, in DFS order.
+//   * Shadow rays (render.rs:202-208 only asks has_missed()): hit.distance stays INF until the first item hit, so the reference
+//     visits exactly the closure until then -- the ray is occluded iff some item of the closure returns a finite distance.  No check.
+//   * Primary rays: let F be the smallest distance over the closure's items and t the first item in DFS order (= smallest DFS item
+//     index) that attains it.  If every ancestor bound a of t has d_a <= F, the reference's result is (F, t): when the DFS reaches a,
+//     hit.distance is the minimum over items visited before a -- all of them closure items before t, hence > F >= d_a -- so a is
+//     entered; t is reached with hit.distance > F and takes it; no later item has a smaller distance, and equal ones do not replace
+//     it.  Each work-list pair carries the largest bound distance on its path (`anc`), the winner's is kept beside the minimum, and a
+//     ray whose winner fails `anc <= F` (a ray that starts INSIDE a bound: the reference then compares the far intersection, SURVEY
+//     H2) is handed back to the skip-pointer walk, as is every ray of a wave whose work list overflows.  Exact on every scene.
+//   * Every distance compared is the reference's individually rounded one; distances are >= +0 (t2 is never -0: disc is never -0 and
+//     b + root of opposite signs sums to +0), so their bit patterns order like the values and (distance bits << 32 | DFS item index)
+//     is the key of one LDS ds_min_u64 per item hit.
+//
+// The node records live in a second copy of the hierarchy in SIBLING-CONTIGUOUS (breadth-first) order, so the children of a group
+// are `count` consecutive records from `first` -- a pair on the work list is one 8-byte word pair {first | count << 24 | ray << 28, anc}.
+#pragma once
+#include "rt_kernels.hpp"
+
+namespace rt {
+
+// One node of the cooperative copy.  Primary array: a = {vx, vy, vz, vv}, a4 = rr (v = centre - eye: the same pre-formed terms as
+// Node<float>, rt_skip.hpp, copied from that stream bit for bit); shadow array: a = {cx, cy, cz, rr}, a4 unused.
+// count == 0: an ITEM, `first` is its DFS item index.  count > 0: a BOUND whose children are records [first, first + count).
+struct alignas(32) CNode {
+    float a0, a1, a2, a3;
+    float a4;
+    uint32_t first, count, pad;
+};
+static_assert(sizeof(CNode) == 32, "two 16-byte vector loads");
+
+constexpr unsigned kCoopRays = 16;            // a wave's quad: at most 4x4 pixels (level-1 descriptors; level 2: 2x2, level 3: one)
+constexpr unsigned kCoopStack = 448;          // work-list capacity per wave (pairs)
+constexpr unsigned kCoopMaxFanout = 15;       // `count` has four bits in a work-list word
+constexpr uint32_t kCoopMaxNodes = 1u << 24;  // `first` has 24
+
+struct CoopView {
+    const CNode *prim = nullptr, *shad = nullptr;
+    uint32_t n_roots = 0;       // the top-level nodes are records [0, n_roots)
+    uint32_t fanout = 0;        // the largest child count of the scene (and n_roots): lanes are dealt to (pair, child) by it; 0: no cooperative copy
+};
+
+struct CoopLds {
+    float ray[kCoopRays][4];                    // primary: direction; shadow: origin
+    unsigned long long best[kCoopRays];         // (distance bits << 32) | item, ~0 = no hit
+    float best_anc[kCoopRays];                  // largest ancestor bound distance of the item that holds `best`
+    uint32_t occluded;                          // shadow: bit per ray
+    uint32_t pad;
+    uint2 stack[kCoopStack];
+};
+static_assert(sizeof(CoopLds) <= 4096, "four waves and eight workgroups per CU: 160 KB of LDS");
+
+__device__ __forceinline__ unsigned coop_lane_rank(unsigned long long mask)      // set bits of mask below this lane
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// Sphere::distance_from_ray with the ray-independent terms pre-formed (primitive.rs:55-72), as the C++ loop of k_render_skip forms it.
+__device__ __forceinline__ float coop_primary_distance(const float4 g, float rr, float dx, float dy, float dz)
+{
+    const float b = (g.x * dx + g.y * dy) + g.z * dz;
+    const float disc = (b * b - g.w) + rr;
+    float d = inf<float>();
+    if (!(disc < 0.0f)) {
+        const float s = sqrt_rn_lean(disc);
+        const float t2 = b + s;
+        if (!(t2 < 0.0f)) {
+            const float t1 = b - s;
+            d = t1 > 0.0f ? t1 : t2;
+        }
+    }
+    return d;
+}
+
+// ... for a ray with its own origin: does the shadow ray hit the sphere (finite distance)?  primitive.rs:55-68
+__device__ __forceinline__ bool coop_shadow_hit(const float4 g, float ox, float oy, float oz, V3<float> sdir)
+{
+    const V3<float> v = { g.x - ox, g.y - oy, g.z - oz };
+    const float b = dot(v, sdir);
+    const float disc = (b * b - dot(v, v)) + g.w;
+    bool hit = false;
+    if (!(disc < 0.0f)) hit = !((b + sqrt_rn_lean(disc)) < 0.0f);
+    return hit;
+}
+
+// The pairs a round takes from the top of the work list, dealt to the lanes: lane (e, k) gets child k of the e-th pair from the top.
+struct CoopSlot { unsigned e, k, per; };
+__device__ __forceinline__ CoopSlot coop_slot(unsigned fan)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    CoopSlot s;
+    s.per = 64u / fan;
+    s.e = lane / fan;
+    s.k = lane - s.e * fan;
+    return s;
+}
+__device__ __forceinline__ unsigned coop_uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+
+// The primary rays of a quad: lanes [0, n_rays) hold them (dir; `want`: the lane has a ray; n_rays = 16, 4 or 1).  Returns, in those lanes,
+// hit.distance / the DFS index of the nearest item, and `failed` = the ray has to be walked by the skip-pointer loops instead (its winner is
+// nearer than one of its ancestor bounds, or the wave's work list overflowed).  Wave-uniform control flow; `lds` is this wave's.
+__device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, unsigned n_rays, float dx, float dy, float dz, bool want, float &best_out,
+                                             unsigned &item_out, bool &failed_out)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const CoopSlot sl = coop_slot(cv.fanout);
+    const bool mine = want && lane < n_rays;
+    if (lane < n_rays) {
+        lds.ray[lane][0] = dx; lds.ray[lane][1] = dy; lds.ray[lane][2] = dz;
+        lds.best[lane] = ~0ull;
+        lds.best_anc[lane] = 0.0f;
+    }
+    // one pair per ray: (ray, the top level)
+    const unsigned long long wm = __ballot(mine);
+    if (mine) lds.stack[coop_lane_rank(wm)] = make_uint2(0u | (cv.n_roots << 24) | (lane << 28), 0u);
+    unsigned top = coop_uniform((unsigned)__popcll(wm));
+    bool overflow = false;
+    // (Keeping a second round's records in flight -- fetched while the first is evaluated -- takes the kernel from 59 to 76 vector registers
+    // and every wave of the launch from 8 to 6 per SIMD: measured and dropped)
+    while (top > 0u) {
+        const unsigned n_e = min(sl.per, top);
+        const bool have = sl.e < n_e;
+        const uint2 e = lds.stack[have ? top - 1u - sl.e : 0u];
+        top -= n_e;
+        const unsigned cnt = (e.x >> 24) & 15u, ray = e.x >> 28;
+        const bool valid = have && sl.k < cnt;
+        const unsigned node = valid ? (e.x & 0xFFFFFFu) + sl.k : 0u;
+        const float4 g = *reinterpret_cast<const float4 *>(&cv.prim[node].a0);
+        const float4 h = *reinterpret_cast<const float4 *>(&cv.prim[node].a4);       // {rr, first, count, -}
+        const float rx = lds.ray[ray][0], ry = lds.ray[ray][1], rz = lds.ray[ray][2];
+        const float d = coop_primary_distance(g, h.x, rx, ry, rz);
+        const bool finite = valid && d < inf<float>();
+        const unsigned link_first = __float_as_uint(h.y), link_count = __float_as_uint(h.z);
+        const float anc = __uint_as_float(e.y);
+        // ITEM: keep the nearest by (distance, DFS index), and beside it the largest bound distance on its path
+        const bool item_hit = finite && link_count == 0u;
+        if (__ballot(item_hit) != 0ull) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | link_first;
+            if (item_hit) atomicMin(&lds.best[ray], key);
+            if (item_hit && lds.best[ray] == key) lds.best_anc[ray] = anc;
+        }
+        // BOUND with a finite distance: its children are wanted
+        const bool push = finite && link_count != 0u;
+        const unsigned long long pm = __ballot(push);
+        const unsigned n_push = (unsigned)__popcll(pm);
+        if (top + n_push > kCoopStack) { overflow = true; break; }
+        if (push) lds.stack[top + coop_lane_rank(pm)] = make_uint2(link_first | (link_count << 24) | (ray << 28), __float_as_uint(fmaxf(anc, d)));
+        top = coop_uniform(top + n_push);
+    }
+    float best = inf<float>();
+    unsigned item = 0u;
+    bool failed = false;
+    if (mine) {
+        const unsigned long long k = lds.best[lane];
+        if (k != ~0ull) {
+            best = __uint_as_float((unsigned)(k >> 32));
+            item = (unsigned)k;
+            failed = lds.best_anc[lane] > best;            // an ancestor bound is farther than the winner: the reference may have culled it
+        }
+        failed = failed || overflow;
+    }
+    best_out = best; item_out = item; failed_out = failed;
+}
+
+// The shadow rays of a quad (any hit, render.rs:202-208): lanes [0, n_rays), origin (ox, oy, oz), `want`: the lane casts one.  Returns
+// `occluded` in those lanes and `failed` (work list overflow: the skip-pointer loops decide).
+__device__ __forceinline__ void coop_shadow(const CoopView &cv, CoopLds &lds, unsigned n_rays, float ox, float oy, float oz, V3<float> sdir, bool want,
+                                            bool &occluded_out, bool &failed_out)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const CoopSlot sl = coop_slot(cv.fanout);
+    const bool mine = want && lane < n_rays;
+    if (lane < n_rays) { lds.ray[lane][0] = ox; lds.ray[lane][1] = oy; lds.ray[lane][2] = oz; }
+    if (lane == 0u) lds.occluded = 0u;
+    const unsigned long long wm = __ballot(mine);
+    if (mine) lds.stack[coop_lane_rank(wm)] = make_uint2(0u | (cv.n_roots << 24) | (lane << 28), 0u);
+    unsigned top = coop_uniform((unsigned)__popcll(wm));
+    bool overflow = false;
+    while (top > 0u) {
+        const unsigned n_e = min(sl.per, top);
+        const bool have = sl.e < n_e;
+        const uint2 e = lds.stack[have ? top - 1u - sl.e : 0u];
+        const unsigned occ = lds.occluded;
+        top -= n_e;
+        const unsigned cnt = (e.x >> 24) & 15u, ray = e.x >> 28;
+        const bool valid = have && sl.k < cnt && ((occ >> ray) & 1u) == 0u;       // a ray that is occluded wants nothing more
+        const unsigned node = valid ? (e.x & 0xFFFFFFu) + sl.k : 0u;
+        const float4 g = *reinterpret_cast<const float4 *>(&cv.shad[node].a0);
+        const uint2 link = *reinterpret_cast<const uint2 *>(&cv.shad[node].first);
+        const float rx = lds.ray[ray][0], ry = lds.ray[ray][1], rz = lds.ray[ray][2];
+        const bool hit = valid && coop_shadow_hit(g, rx, ry, rz, sdir);
+        const bool item_hit = hit && link.y == 0u;
+        if (__ballot(item_hit) != 0ull) {
+            if (item_hit) atomicOr(&lds.occluded, 1u << ray);
+        }
+        const bool push = hit && link.y != 0u;
+        const unsigned long long pm = __ballot(push);
+        const unsigned n_push = (unsigned)__popcll(pm);
+        if (top + n_push > kCoopStack) { overflow = true; break; }
+        if (push) lds.stack[top + coop_lane_rank(pm)] = make_uint2(link.x | (link.y << 24) | (ray << 28), 0u);
+        top = coop_uniform(top + n_push);
+    }
+    const unsigned occ = lds.occluded;
+    occluded_out = mine && ((occ >> (lane & 15u)) & 1u) != 0u;
+    // an occluded ray is settled whatever happened to the list afterwards: some item of its closure is hit
+    failed_out = mine && overflow && !occluded_out;
+}
+
+// Device half of the cooperative copy: record j of the breadth-first arrays is node perm[j] of the (plain) skip streams, whose terms are
+// copied bit for bit; link[j] = {first, count}.
+__global__ void k_build_coop(const void *prim_stream, const void *shad_stream, unsigned node_stride, const uint32_t *__restrict__ perm,
+                             const uint2 *__restrict__ link, unsigned n, CNode *__restrict__ cprim, CNode *__restrict__ cshad)
+{
+    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float *p = reinterpret_cast<const float *>(static_cast<const char *>(prim_stream) + (size_t)perm[j] * node_stride);
+    const float *s = reinterpret_cast<const float *>(static_cast<const char *>(shad_stream) + (size_t)perm[j] * node_stride);
+    CNode a, b;
+    a.a0 = p[0]; a.a1 = p[1]; a.a2 = p[2]; a.a3 = p[3]; a.a4 = p[4];
+    b.a0 = s[0]; b.a1 = s[1]; b.a2 = s[2]; b.a3 = s[3]; b.a4 = 0.0f;
+    a.first = b.first = link[j].x; a.count = b.count = link[j].y; a.pad = b.pad = 0u;
+    cprim[j] = a;
+    cshad[j] = b;
+}
+
+}  // namespace rt

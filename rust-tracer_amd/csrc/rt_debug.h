@@ -43,7 +43,13 @@ typedef enum rt_debug_key {
     RT_DEBUG_FILTER_RO_PERCENT = 14, /* read by rt_scene_create: the radius around the scene's centroid in which the filtered loops' bounds cover
                                     shadow-ray origins, in percent of the library's own value.  A small value leaves real origins
                                     uncovered -- they must then fall back to the reference's arithmetic at every node (tests).  Default 100 */
-    RT_DEBUG_KEYS = 15
+    RT_DEBUG_COOP = 15,          /* the lane-cooperative walk of the heaviest quads (rt_coop.hpp; read when a tile list is first seen): 0 never,
+                                    2 every quad of every block (parity tests); default: the library's choice by the scene's cost map */
+    RT_DEBUG_COOP_THR = 16,      /* ... the cost-map value (tests per pixel) from which a quad is walked cooperatively; default: 30 % of the pass's largest */
+    RT_DEBUG_COOP_MAX = 17,      /* ... cap on the number of 16x16 blocks that are split for it; default: an eighth of the pass */
+    RT_DEBUG_COOP_LEVEL = 18,    /* ... rays per cooperative wave: 1 = 16 (4x4 pixels), 2 = 4 (2x2), 3 = one; default 2 */
+    RT_DEBUG_COOP_REST = 19,     /* ... what is left of a block with cooperative quads: 0 = one descriptor (8x8 pixels per wave), 1 = four (4x4 per wave) */
+    RT_DEBUG_KEYS = 20
 } rt_debug_key;
 
 /* value < 0 restores the default. */
@@ -59,7 +65,8 @@ typedef enum rt_debug_counter {
                                            (the rest of sphere_tests + bound_tests were made for shadow rays); not cumulative */
     RT_DEBUG_COUNT_FRAME_AHEAD_PASSES = 5,  /* whole-grid passes rendered for rt_render_region's frame-ahead */
     RT_DEBUG_COUNT_TWO_RAY_LAUNCHES = 6,    /* hierarchy-walk passes that ran k_render_skip2 (two rays per lane) instead of k_render_skip */
-    RT_DEBUG_COUNTERS = 7
+    RT_DEBUG_COUNT_COOP_LAUNCHES = 7,       /* hierarchy-walk passes whose launch carried cooperative quads (k_render_skip<..., COOP>) */
+    RT_DEBUG_COUNTERS = 8
 } rt_debug_counter;
 long long rt_debug_count(int counter);
 

@@ -33,9 +33,18 @@ static_assert(sizeof(BlockDesc) == 16, "one s_load_dwordx4");
 // nodes and the pass is as long as its longest wave, so the few most expensive blocks are dealt out as four such workgroups
 // each: their chains get ~17 % shorter (1080p: 74 -> 66 us with the ~30 heaviest blocks narrowed; narrowing hundreds costs
 // throughput).  Level 2 (2x2 patches, sixteen workgroups per block) is used in passes too small to fill the chip.
-constexpr uint32_t kBlockNarrowShift = 16;       // pitch >> 16: 0 full, 1: 4x4 pixels per wave, 2: 2x2
+constexpr uint32_t kBlockNarrowShift = 16;       // (pitch >> 16) & 3: 0 full, 1: 4x4 pixels per wave, 2: 2x2
+// A narrow descriptor with a mask in bits 20..23 is COOPERATIVE (rt_coop.hpp): wave w of its workgroup traces its quad cooperatively when
+// bit 20 + w is set and has nothing to do otherwise (those pixels belong to the block's ordinary descriptor).
+constexpr uint32_t kBlockCoopShift = 20;
 // wg_first (optional): n_wg + 1 offsets into d -- workgroup w renders the descriptors [wg_first[w], wg_first[w + 1]).
-struct BlockList { const BlockDesc *d = nullptr; uint32_t n = 0; const uint32_t *wg_first = nullptr; uint32_t n_wg = 0; };
+// holes (optional): descriptors [0, n_holes) are 16x16 blocks some of whose 2x2-pixel quads (one bit each, row-major 8x8) are rendered by
+// cooperative descriptors further down the list (the launch then needs the COOP flavour of k_render_skip and its LDS).
+// ev0 / ev1 (optional): the library is timing this order against others (rt_capi.hip pick_order): record them around the launch.
+struct BlockList { const BlockDesc *d = nullptr; uint32_t n = 0; const uint32_t *wg_first = nullptr; uint32_t n_wg = 0; const uint64_t *holes = nullptr; uint32_t n_holes = 0;
+                   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+                   // the same list without cooperative quads (for launches that cannot walk them)
+                   const BlockDesc *plain_d = nullptr; uint32_t plain_n = 0; const uint32_t *plain_wg_first = nullptr; uint32_t plain_n_wg = 0; };
 
 // Outcome of one sample, stored by the sample-parallel paths and consumed by k_resolve_samples in the reference's
 // accumulation order: the four exits of Renderer::raytrace (render.rs:190-213) and n.light where it is needed.

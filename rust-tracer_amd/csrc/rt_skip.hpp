@@ -15,6 +15,7 @@
 #pragma once
 #include "rt_kernels.hpp"
 #include "rt_skip_rot.hpp"
+#include "rt_coop.hpp"
 
 namespace rt {
 
@@ -291,15 +292,23 @@ __device__ __forceinline__ int shadow_filter_verdict(const FNodeS &f, const Filt
 //   of their walk than 64 rays spread over 64 pixels (`make image`: 0.39 -> see DESIGN.md); samples are stored
 //   [pixel][sample], so a wave's stores are one contiguous run.
 enum { kSkipLoop = 0, kSkipSplit = 1, kSkipOne = 2, kSkipPacked = 3 };
-template <typename T, bool COUNT, int VAR, int MODE>
+// COOP (f32, spp 1, the assembly loops): some quads of the pass are traced by the lane-cooperative walk (rt_coop.hpp):
+//   a narrow descriptor (level 1: 8x8 pixels, a 4x4 quad per wave; level 2: 4x4, 2x2 per wave; level 3: 2x2, one pixel per wave) with a
+//   4-bit mask in pitch bits 20..23 is cooperative -- wave w of the workgroup traces its quad cooperatively when bit w is set and leaves
+//   otherwise; the rays the cooperative walk hands back (rt_coop.hpp: `failed`) are walked by the loops.  The 16x16 block those quads
+//   belong to is descriptor di < n_holes of the same list (or its four quarters, level 1), and holes[di] tells its own waves which 2x2-pixel quads to leave out.
+template <typename T, bool COUNT, int VAR, int MODE, bool COOP = false>
 __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, unsigned width, unsigned height, unsigned spp_arg,
                                                               const TileDev *__restrict__ tiles, unsigned n_tiles,
                                                               uint8_t *__restrict__ out, Counters *__restrict__ counters,
                                                               SampleBuf<T> sb, unsigned frame_w,
                                                               const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost,
-                                                              const uint32_t *__restrict__ wg_first)
+                                                              const uint32_t *__restrict__ wg_first, CoopView cv = CoopView{},
+                                                              const uint64_t *__restrict__ holes = nullptr, unsigned n_holes = 0)
 {
     constexpr bool PACKED = MODE == kSkipPacked, SPLIT = MODE == kSkipSplit || PACKED, ONE = MODE == kSkipOne;
+    static_assert(!COOP || (sizeof(T) == 4 && !COUNT && ONE && (VAR & 2) != 0), "the cooperative walk serves f32 spp-1 passes of the assembly loops");
+    [[maybe_unused]] __shared__ CoopLds coop_lds[COOP ? kBlockThreads / 64 : 1];
     const unsigned spp = ONE ? 1u : spp_arg;
     // `order` (optional): block descriptors in dispatch order, most expensive block first -- a pass is as long as its last
     // wave, so the long chains must not be the ones dispatched last (rt_capi.hip, block_order).  Without it the workgroup
@@ -310,11 +319,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     if (order && wg_first) { d_first = wg_first[blockIdx.x]; d_last = wg_first[blockIdx.x + 1]; }
     for (unsigned di = d_first; di < d_last; ++di) {
     unsigned bx0, by0, tile_r, tile_t, pitch, base;
-    unsigned level = 0;             // 0: 8x8 pixels per wave; 1: 4x4 (16 live lanes); 2: 2x2 (4 live lanes)
+    unsigned level = 0;             // 0: 8x8 pixels per wave; 1: 4x4 (16 live lanes); 2: 2x2 (4 live lanes); 3: one pixel
+    [[maybe_unused]] unsigned coop_mask = 0;
     if (order) {
         const BlockDesc bd = order[di];
         bx0 = bd.x0; by0 = bd.y0; tile_r = bd.r; tile_t = bd.t; pitch = bd.pitch & 0xFFFFu; base = bd.base;
-        level = bd.pitch >> kBlockNarrowShift;
+        level = (bd.pitch >> kBlockNarrowShift) & 3u;
+        if constexpr (COOP) coop_mask = (bd.pitch >> kBlockCoopShift) & 15u;
     } else {
         unsigned lo = 0, hi = n_tiles - 1;
         while (lo < hi) {
@@ -330,6 +341,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
     }
     const unsigned gblock = di;
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    [[maybe_unused]] const bool coop_wave = COOP && __builtin_amdgcn_readfirstlane((int)((coop_mask >> wave) & 1u)) != 0;        // wave-uniform
+    [[maybe_unused]] const unsigned coop_rays = (8u >> level) * (8u >> level);
     unsigned x, y, sample = 0;
     bool inside;
     if (PACKED) {
@@ -348,6 +361,14 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
         y = by0 + (wave >> 1) * pw + ((lane >> pbits) & (pw - 1));
         inside = x < tile_r && y < tile_t && lane < pw * pw;
         sample = blockIdx.y;
+        if constexpr (COOP) {
+            // a cooperative descriptor's other waves have nothing to do; an ordinary block leaves its holes to the cooperative descriptors
+            if (coop_mask != 0u) inside = inside && coop_wave;
+            else if (di < n_holes) {          // level 0: a 16x16 block, 8x8 quads; level 1: one of its 8x8 quarters, 4x4 quads
+                const unsigned long long hole = holes[di];
+                inside = inside && ((hole >> (((y - by0) >> 1) * (8u >> level) + ((x - bx0) >> 1))) & 1ull) == 0ull;
+            }
+        }
     }
     if (__ballot(inside) == 0) continue;        // waves are independent here: no LDS, no barrier
 
@@ -396,15 +417,27 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             constexpr unsigned kStride = (unsigned)sizeof(Node<T>);
             const unsigned nb = ((VAR & 4) ? sc.n_fnodes : sc.n_nodes) * kStride;
             if constexpr ((VAR & 2) && !COUNT) {
+                // lanes whose ray the loops walk: all of them, or what the cooperative walk of this quad hands back
+                bool walk = inside;
+                [[maybe_unused]] T cbest = inf<T>();
+                [[maybe_unused]] unsigned citem = 0;
+                if constexpr (COOP) {
+                    if (coop_wave) coop_primary(cv, coop_lds[wave], coop_rays, dir.x, dir.y, dir.z, inside, cbest, citem, walk);
+                }
+                if (!coop_wave || __ballot(walk) != 0) {
                 if constexpr ((VAR & 16) != 0 && sizeof(T) == 4) {
                     if constexpr ((VAR & 4) != 0) {
-                        skip_primary_rot_filt_fused(sc.xfprim, nb, dir.x, dir.y, dir.z, inside ? 0u : nb, best, best_item);
+                        skip_primary_rot_filt_fused(sc.xfprim, nb, dir.x, dir.y, dir.z, walk ? 0u : nb, best, best_item);
                         // a group's own sphere won: the walk recorded the offset behind its BOUND node
                         if (best_item != 0u && !(best_item & kNodeItem)) best_item = sc.xown[best_item / kStride - 1u];
-                    } else skip_primary_rot_filt(sc.xprim, nb, dir.x, dir.y, dir.z, inside ? 0u : nb, best, best_item);
-                } else if constexpr ((VAR & 4) != 0) skip_primary_rot_fused(sc.fprim, nb, dir.x, dir.y, dir.z, inside ? 0u : nb, best, best_item);
-                else skip_primary_rot(sc.prim, nb, dir.x, dir.y, dir.z, inside ? 0u : nb, best, best_item);
+                    } else skip_primary_rot_filt(sc.xprim, nb, dir.x, dir.y, dir.z, walk ? 0u : nb, best, best_item);
+                } else if constexpr ((VAR & 4) != 0) skip_primary_rot_fused(sc.fprim, nb, dir.x, dir.y, dir.z, walk ? 0u : nb, best, best_item);
+                else skip_primary_rot(sc.prim, nb, dir.x, dir.y, dir.z, walk ? 0u : nb, best, best_item);
                 best_item &= kNodeIndexMask;
+                }
+                if constexpr (COOP) {
+                    if (coop_wave && !walk) { best = cbest; best_item = citem; }
+                }
             } else {
             Node<T> nd = sc.prim[0];                                    // wave-uniform record -> SGPRs
             for (;;) {
@@ -483,8 +516,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
             resume = need_shadow ? 0u : kNever;
             i = 0;
             if constexpr ((VAR & 2) && !COUNT) {
-                if (__ballot(need_shadow) != 0) {
-                    resume = need_shadow ? 0u : nb;                 // lanes without a shadow ray sleep until END
+                bool walk_s = need_shadow;
+                if constexpr (COOP) {
+                    if (coop_wave && __ballot(need_shadow) != 0) coop_shadow(cv, coop_lds[wave], coop_rays, sp.x, sp.y, sp.z, sdir, need_shadow, occluded, walk_s);
+                }
+                if (__ballot(walk_s) != 0) {
+                    resume = walk_s ? 0u : nb;                      // lanes without a shadow ray sleep until END
                     [[maybe_unused]] float q1 = 0.0f, q2 = 0.0f, fol = 0.0f, fa0 = 0.0f, fk1 = 0.0f, fkc = 0.0f;
                     if constexpr ((VAR & 16) != 0 && sizeof(T) == 4) {
                         const FilterConsts fc = *sc.fc;
@@ -596,7 +633,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
         rec[0] = (uint32_t)r_start;
         rec[1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
         rec[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16);  // HW_ID | XCC_ID << 16
-        rec[3] = gblock;
+        rec[3] = gblock | (coop_wave ? 0x80000000u : 0u);
     }
     if (COUNT) {
         Counters *const stripe = counters + (gblock + blockIdx.y) % kCounterStripes;

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kSkip2Threads) void k_render_skip2(SkipView<float> 
         if (order) {
             const BlockDesc bd = order[di];
             bx0 = bd.x0; by0 = bd.y0; tile_r = bd.r; tile_t = bd.t; pitch = bd.pitch & 0xFFFFu; base = bd.base;
-            level = bd.pitch >> kBlockNarrowShift;
+            level = (bd.pitch >> kBlockNarrowShift) & 3u;         // (a cooperative mask in the bits above is ignored: those quads are walked like any other)
         } else {
             unsigned lo = 0, hi = n_tiles - 1;
             while (lo < hi) {

@@ -52,6 +52,12 @@ def _check_both_launch_flavours(request, monkeypatch):
         if want_stats:
             plain, _ = orig(self, options, regions, traversal, False)
             assert np.array_equal(plain, data), "the launch without counters renders different bytes"
+            if options[2] == 1 and traversal in (None, rta.RT_TRAVERSAL_SKIP):
+                # ... and once more with EVERY quad walked by the lane-cooperative gather (csrc/rt_coop.hpp; f32 scenes that have the
+                # cooperative copy -- for the others the control changes nothing)
+                with rta.capi.debug(rta.capi.DEBUG_COOP, 2):
+                    coop, _ = orig(self, options, regions, traversal, False)
+                assert np.array_equal(coop, data), "the lane-cooperative walk renders different bytes"
         return data, st
 
     monkeypatch.setattr(rta.DeviceScene, "render_tiles", both)

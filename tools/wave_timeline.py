@@ -2,7 +2,7 @@
 """Diagnostic: per-wave timeline of one k_render_skip launch (rt_debug_wave_trace, csrc/rt_debug.h).  Every wave records its start and
 end on the 100 MHz clock plus HW_ID / XCC_ID; this prints how the launch's time is made up: when the last wave was
 dispatched, how long the longest waves ran, how busy the SIMDs were over time.
-usage: wave_timeline.py [w h spp level]      """
+usage: wave_timeline.py [w h spp level [coop_thr [coop_level [narrow_max [narrow_l2]]]]]      """
 import os
 import sys
 
@@ -15,6 +15,14 @@ import rust_tracer_amd as rta
 
 def main():
     w, h, spp, level = (int(a) for a in sys.argv[1:5]) if len(sys.argv) > 4 else (1920, 1080, 1, 8)
+    if len(sys.argv) > 5:
+        rta.capi.debug_set(rta.capi.DEBUG_COOP_THR, int(sys.argv[5]))
+    if len(sys.argv) > 6:
+        rta.capi.debug_set(rta.capi.DEBUG_COOP_LEVEL, int(sys.argv[6]))
+    if len(sys.argv) > 7:
+        rta.capi.debug_set(rta.capi.DEBUG_NARROW_MAX, int(sys.argv[7]))
+    if len(sys.argv) > 8:
+        rta.capi.debug_set(rta.capi.DEBUG_NARROW_L2, int(sys.argv[8]))
     path = os.path.join(ROOT, "gpurun_out", "wave_trace.bin")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     scene = rta.Scene.default(level)
@@ -41,11 +49,17 @@ def main():
     print("wave duration us: median %.2f  p90 %.2f  p99 %.2f  max %.2f ; sum %.0f us = %.1f us x 1024 SIMDs" % (
         np.median(dur) / 1e3, np.percentile(dur, 90) / 1e3, np.percentile(dur, 99) / 1e3, dur.max() / 1e3, dur.sum() / 1e3, dur.sum() / 1e3 / 1024))
     print("last wave dispatched at %.1f us; first wave ends at %.1f us" % (start.max() / 1e3, end.min() / 1e3))
-    order = np.argsort(-dur)[:10]
-    print("10 longest waves: (start, end, dur us, dispatch index)")
+    coop = (r[:, 3] >> 31) != 0
+    for name, sel in (("cooperative (rt_coop.hpp)", coop), ("skip-pointer walk", ~coop)):
+        if sel.any():
+            d = dur[sel]
+            print("  %-26s %6d waves: median %.2f  p90 %.2f  p99 %.2f  max %.2f us; sum %.0f us; last end %.1f us" % (
+                name, int(sel.sum()), np.median(d) / 1e3, np.percentile(d, 90) / 1e3, np.percentile(d, 99) / 1e3, d.max() / 1e3, d.sum() / 1e3, end[sel].max() / 1e3))
+    order = np.argsort(-dur)[:16]
+    print("16 longest waves: (start, end, dur us, dispatch index)")
     idx = np.nonzero(ran)[0]
     for k in order:
-        print("   %.1f  %.1f  %.1f   #%d" % (start[k] / 1e3, end[k] / 1e3, dur[k] / 1e3, idx[k]))
+        print("   %.1f  %.1f  %.1f   #%d%s" % (start[k] / 1e3, end[k] / 1e3, dur[k] / 1e3, idx[k], " coop" if coop[k] else ""))
     # waves in flight over time
     T = int(end.max() // 1000) + 1
     print("time(us)  waves in flight   started so far")
