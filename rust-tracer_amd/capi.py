@@ -205,5 +205,20 @@ def shard_costs(scene_handle, options, regions, n_devices):
     return cost
 
 
+lib.rt_debug_rccl_library.argtypes = [C.c_char_p]
+FAKE_RCCL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "c", "libfake_rccl.so")
+
+
+@contextlib.contextmanager
+def rccl_stand_in(path=FAKE_RCCL):
+    """TESTS ONLY: gangs created inside bind the stand-in library (tests/c/fake_rccl.cpp) instead of librccl.so and may put several ranks
+    on one device -- the N > 1 code of rt_gang_* on a one-GPU box."""
+    check(lib.rt_debug_rccl_library(path.encode()), "rt_debug_rccl_library")
+    try:
+        yield
+    finally:
+        check(lib.rt_debug_rccl_library(None), "rt_debug_rccl_library")
+
+
 def wave_trace(path):
     check(lib.rt_debug_wave_trace(path.encode() if path else None), "rt_debug_wave_trace")

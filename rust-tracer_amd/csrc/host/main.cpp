@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "render.hpp"
+#include "../rt_debug.h"
 
 using namespace rtrace;
 
@@ -103,7 +104,7 @@ int main(int argc, char **argv)
     }
 
     std::string width = "1024", height = "1024", ssp = "1", numcores = "1", output;
-    std::string device = "0", devices = "1", traversal = "skip", level = "8", gather = "", scene_file = "";
+    std::string device = "0", devices = "1", traversal = "skip", level = "8", gather = "", scene_file = "", rccl_stand_in = "";
     bool have_output = false, stats = false, strict64 = false;
     auto take = [&](int &i, const std::string &arg, const char *name, std::string &dst) -> bool {
         const std::string flag = std::string("--") + name;
@@ -123,7 +124,8 @@ int main(int argc, char **argv)
         if (a == "--strict-64") { strict64 = true; continue; }
         if (take(i, a, "width", width) || take(i, a, "height", height) || take(i, a, "samples-per-pixel", ssp) ||
             take(i, a, "num-cores", numcores) || take(i, a, "device", device) || take(i, a, "devices", devices) ||
-            take(i, a, "traversal", traversal) || take(i, a, "level", level) || take(i, a, "gather", gather) || take(i, a, "scene", scene_file))
+            take(i, a, "traversal", traversal) || take(i, a, "level", level) || take(i, a, "gather", gather) || take(i, a, "scene", scene_file) ||
+            take(i, a, "rccl-stand-in", rccl_stand_in))
             continue;
         if (a.size() > 1 && a[0] == '-' && a != "-") {
             fprintf(stderr, "error: Found argument '%s' which wasn't expected, or isn't valid in this context\n\nFor more information try --help\n", a.c_str());
@@ -179,8 +181,12 @@ int main(int argc, char **argv)
         // more than one GPU: the native gather (rt_gang: ncclCommInitAll + one ncclGather per frame); `--gather rccl` takes
         // that path with a single GPU too (a one-rank communicator), `--gather host` keeps the per-device host copies
         if (gather == "rccl" || (gather.empty() && ndev > 1)) {
+            // (not in the help text: --rccl-stand-in <library> is test infrastructure -- the gather goes through that library instead of
+            // librccl.so and all N ranks sit on --device, so that the N > 1 path runs on a one-GPU box; tests/c/fake_rccl.cpp)
+            if (!rccl_stand_in.empty() && rt_debug_rccl_library(rccl_stand_in.c_str()) != RT_OK)
+                throw std::runtime_error(std::string("--rccl-stand-in: ") + rt_last_error_message());
             std::vector<int> ids;
-            for (int d = 0; d < ndev; ++d) ids.push_back(dev0 + d);
+            for (int d = 0; d < ndev; ++d) ids.push_back(rccl_stand_in.empty() ? dev0 + d : dev0);
             rt_status gst = RT_OK;
             be.gang = DeviceGang::try_create(scene, ids, &gst);
             if (!be.gang && gst == RT_ERR_UNSUPPORTED && gather.empty()) {

@@ -2294,32 +2294,48 @@ struct Rccl {
     std::string error;
 };
 
+static void load_rccl(Rccl &r, std::initializer_list<const char *> names)
+{
+    for (const char *name : names) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) { r.error = std::string("dlopen(") + *names.begin() + "): " + (dlerror() ? dlerror() : "not found"); return; }
+    auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); if (!p) r.error = std::string(*names.begin()) + " lacks " + n; return p; };
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.Gather = reinterpret_cast<decltype(r.Gather)>(sym("ncclGather"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
+}
+
 // librccl.so is ~0.5 GB: it is loaded on first use, never for single-GPU renders.
-static Rccl *rccl()
+static Rccl *real_rccl()
 {
     static Rccl r;
     static std::once_flag once;
-    std::call_once(once, [] {
-        for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (r.lib) break;
-        }
-        if (!r.lib) { r.error = std::string("dlopen(librccl.so): ") + (dlerror() ? dlerror() : "not found"); return; }
-        auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); if (!p) r.error = std::string("librccl.so lacks ") + n; return p; };
-        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
-        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
-        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
-        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
-        r.Gather = reinterpret_cast<decltype(r.Gather)>(sym("ncclGather"));
-        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
-    });
+    std::call_once(once, [] { load_rccl(r, { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }); });
     return &r;
 }
 
+// Test infrastructure (rt_debug.h rt_debug_rccl_library): a stand-in library given by path takes the place of librccl.so for the gangs
+// created while it is set, and such gangs may put several ranks on ONE device -- how the N > 1 code is executed on a one-GPU box.
+static std::mutex g_standin_mu;
+static std::shared_ptr<Rccl> g_standin;
+
+static std::shared_ptr<Rccl> current_standin()
+{
+    std::lock_guard<std::mutex> lk(g_standin_mu);
+    return g_standin;
+}
+
+static thread_local const Rccl *g_err_rccl = nullptr;       // whose error strings rccl_fail prints
+
 static rt_status rccl_fail(ncclResult_t e, const char *what, int line)
 {
-    snprintf(g_err, sizeof g_err, "%s failed at rt_capi.hip:%d: %s", what, line, rccl()->GetErrorString ? rccl()->GetErrorString(e) : "RCCL error");
+    snprintf(g_err, sizeof g_err, "%s failed at rt_capi.hip:%d: %s", what, line, g_err_rccl && g_err_rccl->GetErrorString ? g_err_rccl->GetErrorString(e) : "RCCL error");
     return RT_ERR_HIP;
 }
 
@@ -2367,6 +2383,8 @@ static void gang_layout(const rt_region *tiles, uint32_t n, size_t nd, GangLayou
 }
 
 struct rt_gang {
+    std::shared_ptr<Rccl> standin;            // set: this gang talks to a stand-in library (tests), else to librccl.so
+    const Rccl *nccl = nullptr;
     std::vector<int> devices;
     std::vector<rt_scene *> scenes;
     std::vector<ncclComm_t> comms;
@@ -2395,13 +2413,17 @@ rt_status rt_gang_create(const int *devices, int n_devices, rt_precision precisi
         snprintf(g_err, sizeof g_err, "rt_gang_create: NULL argument or n_devices outside 1..64");
         return RT_ERR_INVALID_ARGUMENT;
     }
-    for (int a = 0; a < n_devices; ++a)
-        for (int b = a + 1; b < n_devices; ++b)
-            if (devices[a] == devices[b]) { snprintf(g_err, sizeof g_err, "rt_gang_create: device %d listed twice", devices[a]); return RT_ERR_INVALID_ARGUMENT; }
-    Rccl *r = rccl();
+    const std::shared_ptr<Rccl> standin = current_standin();
+    if (!standin)                                       // RCCL wants one GPU per rank; only a stand-in library (tests) takes several ranks on one
+        for (int a = 0; a < n_devices; ++a)
+            for (int b = a + 1; b < n_devices; ++b)
+                if (devices[a] == devices[b]) { snprintf(g_err, sizeof g_err, "rt_gang_create: device %d listed twice", devices[a]); return RT_ERR_INVALID_ARGUMENT; }
+    const Rccl *r = standin ? standin.get() : real_rccl();
+    g_err_rccl = r;
     if (!r->error.empty() || !r->Gather) { snprintf(g_err, sizeof g_err, "rt_gang_create: %s", r->error.c_str()); return RT_ERR_UNSUPPORTED; }
     std::unique_ptr<rt_gang> g(new (std::nothrow) rt_gang());
     if (!g) return RT_ERR_OUT_OF_MEMORY;
+    g->standin = standin; g->nccl = r;
     auto fail = [&](rt_status st) { rt_gang_destroy(g.release()); return st; };
     g->devices.assign(devices, devices + n_devices);
     for (int d = 0; d < n_devices; ++d) {
@@ -2437,7 +2459,7 @@ rt_status rt_gang_destroy(rt_gang *g)
 {
     if (!g) return RT_OK;
     for (ncclComm_t c : g->comms)
-        if (c) (void)rccl()->CommDestroy(c);
+        if (c && g->nccl) (void)g->nccl->CommDestroy(c);
     for (size_t d = 0; d < g->devices.size(); ++d) {
         (void)hipSetDevice(g->devices[d]);
         for (int p = 0; p < 2; ++p) {
@@ -2481,7 +2503,8 @@ static rt_status gang_sync_all(rt_gang *g)
 static rt_status gang_render(rt_gang *g, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n, uint8_t *const *frames_host,
                              uint32_t k, rt_stats *stats)
 {
-    Rccl *r = rccl();
+    const Rccl *r = g->nccl;
+    g_err_rccl = r;
     const size_t nd = g->devices.size();
     // the layout of this tile list (cached: a scheduler submits the same list every frame)
     bool new_list = false;
@@ -2619,6 +2642,20 @@ rt_status rt_gang_render_frames(rt_gang *g, const rt_options *o, rt_traversal tr
     if (rt_tiles_rgba_bytes(tiles, n) == 0) { snprintf(g_err, sizeof g_err, "rt_gang_render_frames: empty region in the tile list"); return RT_ERR_INVALID_REGION; }
     std::lock_guard<std::mutex> lk(g->mu);
     return gang_render(g, o, trav, tiles, n, frames_rgba_host, n_frames, stats);
+}
+
+// Test infrastructure (rt_debug.h): a stand-in for librccl.so, by path; NULL: the real library again.  Gangs keep the one they were made with.
+rt_status rt_debug_rccl_library(const char *path)
+{
+    std::shared_ptr<Rccl> r;
+    if (path && *path) {
+        r = std::make_shared<Rccl>();
+        load_rccl(*r, { path });
+        if (!r->error.empty() || !r->Gather) { snprintf(g_err, sizeof g_err, "rt_debug_rccl_library: %s", r->error.c_str()); return RT_ERR_INVALID_ARGUMENT; }
+    }
+    std::lock_guard<std::mutex> lk(g_standin_mu);
+    g_standin = r;
+    return RT_OK;
 }
 
 // Test infrastructure (rt_debug.h): the gang's sharding arithmetic without a device.

@@ -86,6 +86,10 @@ rt_status rt_debug_flat_filter_check(rt_scene *scene, uint32_t width, uint32_t h
  * (sum of tests per pixel under each device's buckets): cost[n_devices]. */
 rt_status rt_debug_gang_layout(const rt_region *tiles, uint32_t n_tiles, uint32_t n_devices, uint32_t *device_of, uint32_t *px_offset,
                                uint64_t *shard_px, uint64_t *padded_px);
+/* A stand-in for librccl.so (tests/c/fake_rccl.cpp), by path: gangs created while it is set bind ITS ncclCommInitAll / ncclGroupStart / ncclGather /
+ * ... instead of librccl.so's and may list one device several times (several ranks on one GPU) -- how the N > 1 code of rt_gang_* is
+ * executed on a one-GPU box.  NULL: librccl.so again.  A gang keeps the library it was created with. */
+rt_status rt_debug_rccl_library(const char *path);
 rt_status rt_debug_shard_costs(rt_scene *scene, const rt_options *options, const rt_region *tiles, uint32_t n_tiles, uint32_t n_devices, double *cost);
 
 #ifdef __cplusplus

@@ -124,28 +124,47 @@ def test_tiles_mode_batched_gather_blits_every_frame_of_a_batch(one_rank_rccl):
     np.testing.assert_array_equal(fs.frame_host(), ref)
 
 
-@pytest.mark.parametrize("ndev", [1, 2])
+@pytest.mark.parametrize("ndev", [1, 2, 4])
 @pytest.mark.parametrize("size", [(1920, 1080, 1), (200, 130, 2)])
 def test_native_gang_rccl_gather_is_byte_identical(ndev, size):
-    # rt_gang_*: one process, N GPUs, bucket i -> GPU i % N, one ncclGather to the root, blit, frame to the host.  Byte-identical
-    # to the oracle for N in {1, 2} (N = 2 skips below two devices), counters summed over the devices equal the CPU path's.
+    # rt_gang_*: one process, N ranks, bucket i -> rank i % N, one ncclGather to the root, blit, frame to the host.  Byte-identical
+    # to the oracle for N in {1, 2, 4}, counters summed over the ranks equal the CPU path's.  With fewer GPUs than ranks the ranks share
+    # GPU 0 and the gather goes through the stand-in for librccl.so (tests/c/fake_rccl.cpp, rt_debug_rccl_library): the N > 1 code --
+    # sharding, equal-length padded shards, the grouped gather, the blit of the device-major gathered buffer -- runs either way.
+    import contextlib
     import oracle
-    if rta.device_count() < ndev:
-        pytest.skip("needs %d GPUs" % ndev)
     w, h, spp = size
     s = rta.Scene.default(8 if w > 1000 else 6)
     o = oracle.Scene.default(level=8 if w > 1000 else 6)
-    g = rta.Gang(s, list(range(ndev)))
+    shared = rta.device_count() < ndev
+    with (rta.capi.rccl_stand_in() if shared else contextlib.nullcontext()):
+        g = rta.Gang(s, [0] * ndev if shared else list(range(ndev)))
     assert g.size() == ndev
     regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
     ref, rst, _ = o.render(w, h, spp, os.cpu_count() or 1, oracle.MODE_HIERARCHY | oracle.MODE_ANYHIT_EXIT)
-    frame, st = g.render_frame((w, h, spp), regs, want_stats=True)
+    # poison: every byte the caller gets must have been rendered, gathered and blitted by this call
+    out = np.full(w * h * 4, 0xAB, dtype=np.uint8)
+    frame, st = g.render_frame((w, h, spp), regs, want_stats=True, out=out)
     np.testing.assert_array_equal(frame, ref)
     for k in ("primary", "hits", "shadow", "occluded", "sphere_tests", "bound_tests"):
         assert st[k] == rst[k], k
     frame2, _ = g.render_frame((w, h, spp), regs[::-1])          # the deal follows the list order; the frame does not care
     np.testing.assert_array_equal(frame2, ref)
+    if ndev > 1:
+        # an odd number of buckets: the shards differ in length and the short ones travel padded
+        odd = regs[:len(regs) - (1 if len(regs) % ndev == 0 else 0)]
+        part, _ = g.render_frame((w, h, spp), odd)
+        for (l, t, r, b) in odd:
+            np.testing.assert_array_equal(part[b:t, l:r], ref[b:t, l:r])
     g.close()
+
+
+def test_the_stand_in_library_is_only_for_gangs_created_under_it():
+    # outside rt_debug_rccl_library a device may not be listed twice (RCCL wants one GPU per rank)
+    s = rta.Scene.default(5)
+    with pytest.raises(rta.RtError) as e:
+        rta.Gang(s, [0, 0])
+    assert e.value.status == rta.capi.RT_ERR_INVALID_ARGUMENT
 
 
 @pytest.mark.parametrize("multi", ["tiles", "frames"])

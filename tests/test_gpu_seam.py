@@ -184,13 +184,20 @@ import rust_tracer_amd as rta
 from tests import util
 
 s, o = util.scene_pair_default()
+ranks = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 try:
-    g = rta.Gang(s, [0])
+    if ranks > 1:
+        # several ranks on this one GPU through the stand-in for librccl.so (tests/c/fake_rccl.cpp, rt_debug_rccl_library)
+        with rta.capi.rccl_stand_in():
+            g = rta.Gang(s, [0] * ranks)
+    else:
+        g = rta.Gang(s, [0])
 except rta.RtError as e:
     if e.status == rta.capi.RT_ERR_UNSUPPORTED:
         print("SKIP no RCCL")
         sys.exit(0)
     raise
+assert g.size() == ranks
 w, h = 800, 600
 regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, 1))]
 ref, rst, _ = o.render(w, h, 1, nthreads=os.cpu_count() or 1)
@@ -208,6 +215,19 @@ assert not part[64:].any() and np.array_equal(part[0:64, 0:448], ref[0:64, 0:448
 g.close()
 print("OK")
 """
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_gang_pipelined_frames_several_ranks_on_one_gpu(tmp_path, ranks):
+    # the same with 2 and 4 ranks: rt_gang_render_frames' N > 1 code (ncclGroupStart / one ncclGather per rank / ncclGroupEnd, shards double-
+    # buffered, gather(f) under render(f + 1), blit on the root) EXECUTED on this box's one GPU -- every rank a communicator of the
+    # stand-in library on device 0 (tests/c/fake_rccl.cpp; /root/reference/src/rust/render.rs:271,293,301 is what the gather replaces)
+    import sys
+    script = tmp_path / "gang_frames.py"
+    script.write_text(_GANG_SCRIPT)
+    r = subprocess.run([sys.executable, str(script), ROOT, str(ranks)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "OK" in r.stdout and "SKIP" not in r.stdout
 
 
 def test_gang_pipelined_frames_one_rank(tmp_path):

@@ -278,3 +278,18 @@ def test_native_and_python_hierarchy_builders_agree_bit_for_bit(tmp_path):
     bad = tmp_path / "bad.txt"
     bad.write_text("1 2 3\n")
     assert subprocess.run([exe, "--hierarchy", str(bad)], capture_output=True, text=True, timeout=60).returncode == 2
+
+
+def test_the_rccl_stand_in_exports_what_the_library_binds():
+    # tests/c/fake_rccl.cpp (test infrastructure: several ranks of rt_gang_* on one GPU) must offer every entry point rt_capi.hip binds
+    # from librccl.so, and the library must take it (and give it up again) through rt_debug_rccl_library without touching a device
+    import ctypes
+    import rust_tracer_amd as rta
+    fake = ctypes.CDLL(rta.capi.FAKE_RCCL)
+    for name in ("ncclCommInitAll", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclGather", "ncclGetErrorString", "ncclGetVersion"):
+        assert hasattr(fake, name), name
+    v = ctypes.c_int(-1)
+    assert fake.ncclGetVersion(ctypes.byref(v)) == 0 and v.value == 0          # 0: not a real RCCL
+    with rta.capi.rccl_stand_in():
+        pass
+    assert rta.capi.lib.rt_debug_rccl_library(b"/nonexistent/librccl.so") == rta.capi.RT_ERR_INVALID_ARGUMENT
