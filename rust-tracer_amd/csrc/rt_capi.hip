@@ -2300,7 +2300,11 @@ static void load_rccl(Rccl &r, std::initializer_list<const char *> names)
         r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (r.lib) break;
     }
-    if (!r.lib) { r.error = std::string("dlopen(") + *names.begin() + "): " + (dlerror() ? dlerror() : "not found"); return; }
+    if (!r.lib) {
+        const char *why = dlerror();                          // (a second call returns NULL: the message is handed out once)
+        r.error = std::string("dlopen(") + *names.begin() + "): " + (why ? why : "not found");
+        return;
+    }
     auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); if (!p) r.error = std::string(*names.begin()) + " lacks " + n; return p; };
     r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
