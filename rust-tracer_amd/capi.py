@@ -110,8 +110,9 @@ class HostBuffer:
     """rt_host_alloc'd bytes as a numpy uint8 array (`.array`): RGBABuffer storage the render kernel writes directly.
 
     The allocation lives as long as ANY array derived from `.array` (views, slices, what render_tiles returns): the array's base is
-    a ctypes block whose finalizer calls rt_host_free, so `render_tiles(..., out=capi.HostBuffer(n).array)` is safe.  close() only
-    drops this object's own reference."""
+    a ctypes block whose finalizer calls rt_host_free, so `render_tiles(..., out=capi.HostBuffer(n).array)` is safe.  close() drops
+    this object's own reference; close(force=True) frees the pinned block NOW (a benchmark or a long-running service that must not
+    accumulate frame-sized pinned buffers) -- every array still derived from it is invalid from then on."""
 
     def __init__(self, nbytes):
         import weakref
@@ -119,11 +120,14 @@ class HostBuffer:
         p = C.c_void_p()
         check(lib.rt_host_alloc(nbytes, C.byref(p)), "rt_host_alloc")
         block = (C.c_uint8 * nbytes).from_address(p.value)
-        weakref.finalize(block, lib.rt_host_free, C.c_void_p(p.value))      # runs when the last array over the block is gone
+        self._finalizer = weakref.finalize(block, lib.rt_host_free, C.c_void_p(p.value))      # runs when the last array over the block is gone
+        self._finalizer.atexit = False                                       # not during interpreter shutdown: the GPU runtime may be gone by then
         self.array = np.ctypeslib.as_array(block)                            # .base chain keeps `block` alive
 
-    def close(self):
+    def close(self, force=False):
         self.array = None
+        if force:
+            self._finalizer()                                                # rt_host_free now (a no-op if it already ran)
 
 
 def selftest_sqrt(device=0):

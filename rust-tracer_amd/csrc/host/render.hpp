@@ -95,6 +95,8 @@ public:
         // arrives (while the device is still rendering the next ones), and a write of the file is the header plus one write.
         encoded_.assign((size_t)x * y * (rgb_ ? 3 : 1), 0);
         rows_with_data_ = 0;
+        emptied_ = false;                                         // a second frame through the same writer: its first write empties the file again,
+                                                                  // so rows it has not reached read as zeros, never as the previous frame's (render.rs:366)
     }
     void write_rgba_buffer(const RGBABuffer &buffer) override     // render.rs:422-433
     {

@@ -161,6 +161,7 @@ struct rt_scene {
     // the caller comes back for its next frame.  One pass too many is rendered when the caller stops (RT_DEBUG_FRAME_AHEAD = 1: off).
     struct FrameAhead { rt_options o{}; rt_traversal trav = RT_TRAVERSAL_SKIP; uint8_t *h = nullptr, *h_next = nullptr; size_t cap = 0; std::vector<size_t> off;
                         std::vector<rt_region> grid; std::vector<uint8_t> served; bool valid = false, next_inflight = false;
+                        rt_options seen_o{}; rt_traversal seen_trav = RT_TRAVERSAL_SKIP; int seen_idx = -1;      // the last lone request (frame-ahead engages with the second bucket)
                         hipStream_t stream = nullptr; hipEvent_t ev = nullptr; int readers = 0; std::mutex mu; std::condition_variable cv; } ahead;
     std::mutex comb_mu;
     std::vector<RegionReq *> comb_pending;
@@ -2145,6 +2146,7 @@ static void run_region_batch(rt_scene *s, const std::vector<rt_scene::RegionReq 
 // grid (render.rs:273-298: 64x64, edge buckets clipped) or the frame is too large to keep -- the caller renders it on its own.
 constexpr unsigned kBucket = 64;
 constexpr size_t kFrameAheadMaxBytes = (size_t)1 << 28;
+constexpr uint64_t kFrameAheadMaxSampleBytes = 1ull << 30;
 static bool region_from_frame_ahead(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *region, uint8_t *out, rt_status *st)
 {
     const unsigned w = o->width, h = o->height;
@@ -2152,7 +2154,11 @@ static bool region_from_frame_ahead(rt_scene *s, const rt_options *o, rt_travers
         region->t != std::min<unsigned>(region->b + kBucket, h) || region->l >= w || region->b >= h)
         return false;
     const size_t frame_bytes = (size_t)w * h * 4;
-    if (frame_bytes > kFrameAheadMaxBytes || check_traversal(s, trav) != RT_OK) return false;
+    // a whole-grid pass of a sample-parallel frame also needs its per-sample buffers (spp >= 2: a word or more per sample), twice with the
+    // pass rendered ahead: the bucket on its own needs a few MB -- leave large frames to the per-bucket path
+    const uint64_t ns = (uint64_t)o->samples_per_pixel * o->samples_per_pixel;
+    const uint64_t sample_bytes = use_split(o->samples_per_pixel) ? (uint64_t)w * h * ns * (s->precision == RT_F32 ? 5u : 9u) : 0u;
+    if (frame_bytes > kFrameAheadMaxBytes || sample_bytes > kFrameAheadMaxSampleBytes || check_traversal(s, trav) != RT_OK) return false;
     const unsigned nbx = (w + kBucket - 1) / kBucket, idx = (region->b / kBucket) * nbx + region->l / kBucket;
     rt_scene::FrameAhead &a = s->ahead;
     std::unique_lock<std::mutex> lk(a.mu);
@@ -2163,6 +2169,13 @@ static bool region_from_frame_ahead(rt_scene *s, const rt_options *o, rt_travers
     for (;;) {
         const bool same = a.valid && a.trav == trav && a.o.width == o->width && a.o.height == o->height && a.o.samples_per_pixel == o->samples_per_pixel;
         if (same && !a.served[idx]) break;
+        if (!same) {
+            // Whole-grid passes are for a caller that walks the grid (the scheduler, render.rs:273-298).  A lone request -- a partial redraw,
+            // a tool, a test -- is rendered on its own: the frame-ahead engages with the SECOND distinct bucket asked for with the same options.
+            const bool seen = a.seen_idx >= 0 && a.seen_trav == trav && a.seen_o.width == o->width && a.seen_o.height == o->height &&
+                              a.seen_o.samples_per_pixel == o->samples_per_pixel;
+            if (!seen || a.seen_idx == (int)idx) { a.seen_o = *o; a.seen_trav = trav; a.seen_idx = (int)idx; return false; }
+        }
         if (a.readers != 0) { a.cv.wait(lk); continue; }
         bool have = false;
         if (!same) {
@@ -2182,8 +2195,9 @@ static bool region_from_frame_ahead(rt_scene *s, const rt_options *o, rt_travers
                 if (a.h_next) (void)rt_host_free(a.h_next);
                 a.h = a.h_next = nullptr; a.cap = 0;
                 void *p = nullptr, *q = nullptr;
-                if ((*st = rt_host_alloc(frame_bytes, &p)) != RT_OK) return true;
-                if ((*st = rt_host_alloc(frame_bytes, &q)) != RT_OK) { (void)rt_host_free(p); return true; }
+                // whatever fails in here: the caller renders its bucket on its own (the per-bucket path needs a few MB, not two pinned frames)
+                if (rt_host_alloc(frame_bytes, &p) != RT_OK) { a.valid = false; return false; }
+                if (rt_host_alloc(frame_bytes, &q) != RT_OK) { (void)rt_host_free(p); a.valid = false; return false; }
                 a.h = static_cast<uint8_t *>(p); a.h_next = static_cast<uint8_t *>(q); a.cap = frame_bytes;
             }
             a.o = *o; a.trav = trav;
@@ -2195,13 +2209,15 @@ static bool region_from_frame_ahead(rt_scene *s, const rt_options *o, rt_travers
         }
         if (!have) {
             // the whole grid in one pass, the kernel storing into the pinned staging (rt_host_alloc'd memory is recognised by address)
-            *st = render_tiles_host(s, o, trav, a.grid.data(), (uint32_t)a.grid.size(), a.h, nullptr, nullptr, true);
-            if (*st != RT_OK) { a.valid = false; return true; }
+            if (render_tiles_host(s, o, trav, a.grid.data(), (uint32_t)a.grid.size(), a.h, nullptr, nullptr, true) != RT_OK) {
+                a.valid = false; a.seen_idx = -1;          // e.g. out of memory for the whole grid: the bucket alone may still fit
+                return false;
+            }
         }
         a.served.assign(a.grid.size(), 0);
         a.valid = true;
         g_count[RT_DEBUG_COUNT_FRAME_AHEAD_PASSES].fetch_add(1, std::memory_order_relaxed);
-        if (knob(RT_DEBUG_FRAME_AHEAD) != 1) {
+        if (knob(RT_DEBUG_FRAME_AHEAD) != 1 && sample_bytes <= kFrameAheadMaxSampleBytes / 4) {
             // the next frame's pass, asynchronously, on a stream of its own; whatever fails here only costs the overlap
             hipError_t e = hipSuccess;
             if (!a.stream) e = hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking);
@@ -2231,6 +2247,10 @@ rt_status rt_render_region(rt_scene *s, const rt_options *o, rt_traversal trav, 
 {
     if (!check_common(s, o, region, 1, rgba_out)) return RT_ERR_INVALID_ARGUMENT;
     if (!stats && knob(RT_DEBUG_FRAME_AHEAD) != 0) {
+        if (classify_host_pointer(rgba_out).bad) {              // the frame-ahead path copies with the CPU: same answer as rt_render_tiles gives
+            snprintf(g_err, sizeof g_err, "rt_render_region: rgba_out is device memory; use rt_render_tiles_device");
+            return RT_ERR_INVALID_ARGUMENT;
+        }
         rt_status fst = RT_OK;
         if (region_from_frame_ahead(s, o, trav, region, rgba_out, &fst)) return fst;
     }

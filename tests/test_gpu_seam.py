@@ -97,6 +97,34 @@ def test_render_region_frame_ahead_serves_a_frame_from_one_pass():
     assert count() == c1
 
 
+def test_render_region_lone_requests_stay_cheap_and_device_pointers_are_refused():
+    # a lone request for a grid bucket (a partial redraw, a tool) is rendered on its own -- no whole-grid pass, nothing
+    # started ahead; the frame-ahead engages with the second distinct bucket of the same frame.  A device pointer is refused by
+    # rt_render_region exactly as rt_render_tiles refuses it, whatever path would have served the call.
+    import ctypes as C
+    import torch
+    s, o = util.scene_pair_default()
+    d = s.device()
+    w, h = 1024, 768
+    regs = bucket_list(w, h)
+    count = lambda: rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_FRAME_AHEAD_PASSES)
+    c0 = count()
+    for _ in range(3):                                           # the same bucket again and again: never a whole-grid pass
+        got, _ = d.render_region((w, h, 1), regs[17], SKIP)
+    ref17, _ = o.render_region(w, h, 1, *regs[17])
+    np.testing.assert_array_equal(got, ref17)
+    assert count() == c0
+    got, _ = d.render_region((w, h, 1), regs[18], SKIP)          # a second bucket of that frame: now the grid is rendered
+    ref18, _ = o.render_region(w, h, 1, *regs[18])
+    np.testing.assert_array_equal(got, ref18)
+    assert count() == c0 + 1
+    dev = torch.zeros(64 * 64 * 4, dtype=torch.uint8, device="cuda")
+    opts = rta.capi.Options(w, h, 1)
+    reg = rta.capi.Region(*regs[3])
+    rc = rta.capi.lib.rt_render_region(d._h, C.byref(opts), SKIP, C.byref(reg), C.c_void_p(dev.data_ptr()), None)
+    assert rc == rta.capi.RT_ERR_INVALID_ARGUMENT and b"device memory" in rta.capi.lib.rt_last_error_message()
+
+
 def test_render_region_pass_started_ahead_survives_destroy_and_option_changes():
     # The pass for the next frame is started while the current one is handed out: a scene destroyed with that pass in flight must wait
     # for it, and a caller that alternates between options (each change discards the pass that was started ahead) still gets the right
