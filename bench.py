@@ -30,6 +30,13 @@ Figures that need rocprofv3 counters (instruction issue, HBM traffic) are quoted
 the kernel sources they were collected on, and dropped when that stamp is not the sources' of this run.
 The timed region is at least 0.2 s: when --steps x --repeats frames take less, more repetitions are run (a step stays one frame).
 
+`configs` (N = 1): BASELINE's neighbouring configurations (config 2 = 800x600, `make image`, config 5) in one short repetition each after
+the headline -- ms per frame, the same 17-flop fraction of the nominal peak, the kernel the library chose, the frame CRC against the
+committed oracle vector; never `value`.  `first_frame_ms`: a fresh Scene's first 1080p frame (dispatch tables, cost map and all).
+N > 1 adds `frame_latency_ms` (ONE frame, render -> gather -> blit, nothing batched, nothing pipelined) beside the batched, pipelined
+`ms_per_step`, `frames_per_gather`, the host cost of one collective call measured in this run, and the builder's expectation of a
+rank's shard render time from one GPU (`expected_shard_render_us`).
+
 `seam` (N = 1): the boundary the reference binds, timed from native threads by rust-tracer_amd/seam_bench (child process):
 host_tiles / host_region / end_to_end (render + D2H + PPM write).  `flat`: the north-star linear scan, same run.
 `cpu_baseline`: the oracle on this host's cores.
@@ -174,6 +181,7 @@ def main():
     ap.add_argument("--no-flat", action="store_true", help="skip the secondary flat-scan measurement")
     ap.add_argument("--no-seam", action="store_true", help="skip the host-boundary legs (seam_bench child process)")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (N > 1: weak_frames and config5_tiles; N = 1: frames_in_flight)")
+    ap.add_argument("--no-configs", action="store_true", help="N = 1: skip BASELINE's neighbouring configurations (`configs`) and `first_frame_ms`")
     ap.add_argument("--traversal", choices=("skip", "flat"), default="skip", help="traversal of the headline measurement")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: take the shard -> RCCL gather -> blit path even at N = 1 (needs torch.distributed.run)")
@@ -181,7 +189,7 @@ def main():
                     help="N > 1 headline layout: 'tiles' = BASELINE config 4, the buckets of ONE frame dealt over the GPUs (strong scaling); "
                          "'frames' = every GPU renders whole frames, N per step (weak scaling)")
     ap.add_argument("--frames-per-gather", type=int, default=4,
-                    help="'frames' layout: frames a rank renders per RCCL gather (fewer, larger collectives)")
+                    help="N > 1: frames (or, 'tiles' layout, shards) a rank renders per RCCL gather (fewer, larger collectives)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1080p",
                     help="1080p = the headline workload; the others are BASELINE's neighbouring configs")
     args = ap.parse_args()
@@ -365,6 +373,8 @@ def main():
                     ("vop2", "v_mul_f32 (SGPR x VGPR, independent)"), ("vop2_new_sgpr_operand", "v_mul_f32 (a DIFFERENT SGPR x VGPR each instruction, independent)"),
                     ("vop3_cmp_e64", "v_cmp_lt_f32_e64 -> SGPR pair"), ("packed", "v_pk_fma_f32 (VGPR pairs, independent)"),
                     ("step_mix_10_valu_12_salu", "traversal-step mix: 10 VALU + 12 SALU per 22"))}
+                if v.get("valu_active_quad_cycles"):
+                    out["valu_busy_frac"] = round(v["valu_active_quad_cycles"] * 4 / (N_SIMD * CLOCK_HZ * t), 4)     # SQ_ACTIVE_INST_VALU x 4 / (1,024 SIMDs x 2.4 GHz x t)
                 if insts:
                     out["instruction_issue"] = {
                         "wave_instructions_per_launch": insts, "valu": v.get("valu_insts"), "salu": v.get("salu_insts"), "smem": v.get("smem_insts"),
@@ -407,6 +417,8 @@ def main():
         out["from_profiles"] = fp
         if "hbm_traffic" in fp:
             out["traffic"] = fp["hbm_traffic"]["bytes_per_launch"]
+        if "valu_busy_frac" in fp:
+            out["valu_busy_frac"] = fp["valu_busy_frac"]
         valu = (fp.get("instruction_issue") or {}).get("valu")
         if valu and "path_arithmetic" in out:
             out["valu_lane_utilisation"] = round(out["path_arithmetic"]["lane_ops"] / (valu * LANES), 4)
@@ -427,6 +439,78 @@ def main():
             in_flight = measure_in_flight(args.workload, max(args.steps, 100))
         except Exception as e:                       # a side measurement must not take the headline down with it
             sys.stderr.write("bench.py: frames_in_flight skipped: %r\n" % (e,))
+    peak_nominal = N_SIMD * LANES * CLOCK_HZ / 2.0 / 1e12
+    configs, first_frame = None, None
+    if world == 1 and not args.force_collective and not args.no_configs and args.workload == "1080p" and args.traversal == "skip":
+        # BASELINE's neighbouring configurations, one short leg each (never `value`): what the driver's record otherwise never sees
+        configs = {}
+        for wl, steps_c, warm_c in (("config2", 200, 60), ("make_image", 50, 10), ("config5", 4, 2)):
+            try:
+                before2 = rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_TWO_RAY_LAUNCHES)
+                before_c = rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_COOP_LAUNCHES)
+                e = measure(wl, head_trav, steps_c, warm_c, 3, "tiles")
+                kern = "k_render_skip2" if rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_TWO_RAY_LAUNCHES) > before2 else "k_render_skip"
+                if rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_COOP_LAUNCHES) > before_c:
+                    kern += " (+ lane-cooperative quads, rt_coop.hpp)"
+                w_c, h_c, k_c, lv_c, _ = WORKLOADS[wl]
+                if k_c > 1:
+                    kern += " + k_resolve_words"
+                t_c = e["kern_ms"] * 1e-3
+                configs[wl] = {"workload": "%dx%d spp %d L%d" % (w_c, h_c, k_c, lv_c), "ms": round(e["ms_per_step"], 4), "kernel_ms": round(e["kern_ms"], 4),
+                               "frac": round(e["my_tests"] * FLOPS_PER_TEST / t_c / 1e12 / peak_nominal, 4), "kernel": kern,
+                               "value": round((e["primary"] + e["shadow"]) / (e["ms_per_step"] * 1e-3) / 1e6, 1), "unit": "Mrays/s",
+                               "frame_crc_ok": e["crc_ok"]}
+            except Exception as ex:                  # a side leg must not take the headline down with it
+                configs[wl] = {"error": repr(ex)}
+        scenes.clear()                               # (config 5's per-sample buffers)
+        try:
+            # a fresh Scene's first frame: everything a one-shot caller (`make image`) pays that the steady state does not
+            fresh = rta.Scene.default(8, rta.RT_F32)
+            t0 = time.perf_counter()
+            dev = fresh.device(local)
+            torch.cuda.synchronize()
+            t_create = time.perf_counter() - t0
+            regs_f = dev._regions([tuple(r) for r in rta.buckets(rta.RenderOptions(1920, 1080, 1))])
+            buf = torch.zeros(1920 * 1080 * 4, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dev.render_frame_device((1920, 1080, 1), regs_f, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            t_first = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            dev.render_frame_device((1920, 1080, 1), regs_f, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            t_second = time.perf_counter() - t0
+            g = golden_case("config3_1920x1080_f32")
+            first_frame = {"first_frame_ms": round(t_first * 1e3, 4), "second_frame_ms": round(t_second * 1e3, 4), "scene_create_ms": round(t_create * 1e3, 3),
+                           "frame_crc_ok": ((zlib.crc32(buf.cpu().numpy().tobytes()) & 0xFFFFFFFF) == g["frame_crc32"]) if g else None,
+                           "note": "host wall time, call to completion, of a fresh Scene's first 1920x1080 frame (tile table, dispatch orders and the "
+                                   "scene's cost map are made here) and of the one after it; never `value`"}
+        except Exception as ex:
+            first_frame = {"error": repr(ex)}
+    latency = None
+    if (world > 1 or args.force_collective) and args.workload == "1080p" and args.traversal == "skip":
+        # ONE frame end to end, nothing batched, nothing pipelined: render -> gather -> blit, synchronised -- what a caller who wants
+        # THIS frame waits for.  And the host cost of a collective call (what batching several frames per gather amortises).
+        fs1 = FrameSharder(scene_of(8), rta.RenderOptions(1920, 1080, 1), rank, world, local, head_trav, force_collective=args.force_collective, mode="tiles",
+                           frames_per_gather=1)
+        for _ in range(5):
+            fs1.step()
+        barrier()
+        lat, host = [], []
+        for _ in range(20):
+            barrier()
+            t0 = time.perf_counter()
+            fs1.render_shard(slot=0)
+            h0 = time.perf_counter()
+            fs1.gather(slot=0, count=1)
+            host.append(time.perf_counter() - h0)
+            fs1.blit(slot=0, count=1)
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            lat.append(float(tt.item()) * 1e3)
+        latency = {"frame_latency_ms": round(sorted(lat)[len(lat) // 2], 4), "collective_call_host_ms": round(sorted(host)[len(host) // 2] * 1e3, 4)}
     extras = {}
     if world > 1 and not args.no_extras and args.workload == "1080p" and args.traversal == "skip":
         other = "frames" if multi == "tiles" else "tiles"
@@ -534,11 +618,30 @@ def main():
             ok_in_flight = in_flight["crc_ok"] is not False
         else:
             ok_in_flight = True
+        if configs is not None:
+            out["configs"] = configs
+        if first_frame is not None:
+            out["first_frame"] = first_frame
+            if "first_frame_ms" in first_frame:
+                out["first_frame_ms"] = first_frame["first_frame_ms"]
+        if latency is not None:
+            out.update(latency)
+            out["frames_per_gather"] = args.frames_per_gather
+            out["n_gt_1_note"] = ("ms_per_step / value are a THROUGHPUT figure for N > 1: consecutive frames are software-pipelined (two render streams per rank, the "
+                                  "gather of a batch under the render of the next) and %d frames share one collective.  frame_latency_ms is ONE frame, render -> "
+                                  "gather -> blit, nothing batched or pipelined (max over ranks, median of 20); collective_call_host_ms is what one "
+                                  "torch.distributed gather call costs this rank's host thread." % args.frames_per_gather)
+            try:
+                exp = json.load(open(os.path.join(ROOT, "profiles", "expected_shard_render.json")))
+                out["expected_shard_render_us"] = {"n_%d" % world: (exp.get("1080p") or {}).get(str(world)), "source": exp.get("source")}
+            except Exception:
+                pass
         if seam is not None:
             out["seam"] = seam
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(width, height, spp, level)
         ok = m["crc_ok"] is not False and (flat is None or flat["crc_ok"] is not False) and all(e["crc_ok"] is not False for e in extras.values()) and ok_in_flight
+        ok = ok and all(c.get("frame_crc_ok") is not False for c in (configs or {}).values()) and (first_frame or {}).get("frame_crc_ok") is not False
         os.write(json_fd, (json.dumps(out) + "\n").encode())
         if not ok:
             sys.stderr.write("bench.py: the frame left by the timed launches does not match the committed oracle vector\n")

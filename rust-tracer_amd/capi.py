@@ -147,7 +147,7 @@ def selftest_rcp(device=0):
 # ---- csrc/rt_debug.h: diagnostic controls (not part of the drop-in ABI; the library reads no environment variable) ----
 (DEBUG_SKIP_VARIANT, DEBUG_BLOCK_ORDER, DEBUG_NARROW_MAX, DEBUG_PACKED_SAMPLES, DEBUG_PRINT_STEPS, DEBUG_PRINT_COSTS,
  DEBUG_HOST_COPY, DEBUG_COALESCE, DEBUG_LDS_BYTES, DEBUG_WG_POLICY, DEBUG_NARROW_L2, DEBUG_FLAT_KERNELS, DEBUG_SKIP_RAYS,
- DEBUG_FRAME_AHEAD, DEBUG_FILTER_RO_PERCENT, DEBUG_COOP, DEBUG_COOP_THR, DEBUG_COOP_MAX, DEBUG_COOP_LEVEL, DEBUG_COOP_REST) = range(20)
+ DEBUG_FRAME_AHEAD, DEBUG_FILTER_RO_PERCENT, DEBUG_COOP, DEBUG_COOP_THR, DEBUG_COOP_MAX, DEBUG_COOP_LEVEL, DEBUG_COOP_REST, DEBUG_ASYNC_ORDERS) = range(21)
 lib.rt_debug_set.argtypes = [C.c_int, C.c_longlong]
 lib.rt_debug_wave_trace.argtypes = [C.c_char_p]
 lib.rt_debug_count.restype = C.c_longlong

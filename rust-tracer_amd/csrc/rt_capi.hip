@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -27,6 +28,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -141,9 +143,10 @@ struct rt_scene {
     // how much of the pass is tail, which no estimate made here predicted as well as three measurements do.
     struct Order { rt::BlockDesc *dev_order = nullptr; uint32_t n_order = 0; uint32_t *dev_wg = nullptr; uint32_t n_wg = 0; uint64_t *dev_holes = nullptr; uint32_t n_holes = 0;
                    hipEvent_t e0 = nullptr, e1 = nullptr; bool pending = false; float best_ms = 1e30f; int samples = 0; };
-    struct CachedTable { std::vector<rt::TileDev> host; unsigned w = 0, h = 0, passes = 0; rt::TileDev *dev = nullptr; std::vector<Order> orders; int chosen = 0; unsigned turn = 0;
+    struct CachedTable { std::vector<rt::TileDev> host; unsigned w = 0, h = 0, passes = 0; rt::TileDev *dev = nullptr; std::vector<Order> orders; int chosen = 0; unsigned turn = 0; bool building = false;
                          long long coop_key = 0; };
     std::vector<CachedTable> tables;
+    std::vector<std::thread> builders;           // dispatch orders being made in the background (build_orders_async); joined by rt_scene_destroy
     // Tests per primary ray (its shadow ray included) on a kCostRes x kCostRes grid over the camera's field of view,
     // rendered once per scene with the counting kernel.  It only ever decides the ORDER in which blocks are dispatched.
     std::once_flag cost_once;
@@ -940,6 +943,18 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
 
 bool block_order_enabled() { return knob(RT_DEBUG_BLOCK_ORDER) != 0; }     // read per call: A/B timing interleaves both
 
+// RT_DEBUG_PRINT_COSTS: where the first use of a tile list spends its host time
+struct StageClock {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (knob(RT_DEBUG_PRINT_COSTS) <= 0) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rtrace_hip] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(n - t).count());
+        t = n;
+    }
+};
+
 void release_order(rt_scene::Order &od)
 {
     if (od.dev_order) (void)hipFree(od.dev_order);
@@ -995,6 +1010,90 @@ rt::BlockList pick_order(rt_scene::CachedTable &t)
     return list_of(t.orders[best]);
 }
 
+// Something about the dispatch was asked for explicitly (rt_debug.h: tests, A/B tools): then a tile list's orders are made at once, by the
+// caller, so that its very first launch already runs what was asked for.
+bool order_knobs_set()
+{
+    for (int k : { RT_DEBUG_COOP, RT_DEBUG_COOP_THR, RT_DEBUG_COOP_MAX, RT_DEBUG_COOP_LEVEL, RT_DEBUG_COOP_REST, RT_DEBUG_NARROW_MAX, RT_DEBUG_NARROW_L2, RT_DEBUG_WG_POLICY,
+                   RT_DEBUG_PRINT_COSTS })
+        if (knob(k) >= 0) return true;
+    return knob(RT_DEBUG_ASYNC_ORDERS) == 0;
+}
+
+// The candidate dispatch orders of one tile list: the plain one first; where the cooperative walk could serve the pass and nothing was
+// asked for explicitly, a few thresholds in percent of the pass's largest estimate (pick_order tries them: chosen = -1).
+rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std::vector<rt::TileDev> &tab, unsigned w, unsigned h, unsigned passes,
+                       std::vector<rt_scene::Order> &orders, int &chosen)
+{
+    const bool coop_pass = s->precision == RT_F32 && s->coop.fanout != 0u && passes == 1;
+    uint64_t total_px = 0, total_blocks = 0;
+    for (const rt::TileDev &td : tab) {
+        total_px += (uint64_t)(td.r - td.l) * (td.t - td.b);
+        total_blocks += (uint64_t)td.blks_x * (((unsigned)(td.t - td.b) + rt::kBlockH - 1) / rt::kBlockH);
+    }
+    const long long rays = knob(RT_DEBUG_SKIP_RAYS);
+    const bool two_rays = s->fused && (rays < 0 ? skip2_by_default(total_px, 1, s->n_fnodes) : rays == 2);      // k_render_skip2 knows no cooperative quads
+    std::vector<int> percents;
+    if (coop_pass && map && !two_rays && total_blocks <= kCoopPassBlocks && knob(RT_DEBUG_COOP) < 0 && knob(RT_DEBUG_COOP_THR) < 0) percents = { 0, 30, 40, 55 };
+    else if (coop_pass && (knob(RT_DEBUG_COOP) > 0 || knob(RT_DEBUG_COOP_THR) >= 0)) percents = { 0, -1 };       // as asked, behind the plain one
+    else percents = { -1 };
+    auto fail = [&](hipError_t e) { for (auto &od : orders) release_order(od); orders.clear(); return hip_fail(e, "dispatch orders", __LINE__); };
+    for (int pc : percents) {
+        std::vector<rt::BlockDesc> order;
+        std::vector<uint32_t> wg_first;
+        std::vector<uint64_t> holes;
+        block_order(map, tab, w, h, passes, order, wg_first, coop_pass ? &s->coop : nullptr, &holes, pc);
+        const bool any_hole = std::any_of(holes.begin(), holes.end(), [](uint64_t v) { return v != 0; });
+        if (pc != percents[0] && !any_hole) continue;       // the same dispatch as the plain one
+        rt_scene::Order od;
+        hipError_t e = hipMalloc(&od.dev_order, order.size() * sizeof(rt::BlockDesc));
+        if (e == hipSuccess) e = hipMemcpy(od.dev_order, order.data(), order.size() * sizeof(rt::BlockDesc), hipMemcpyHostToDevice);
+        if (e == hipSuccess && any_hole) {
+            e = hipMalloc(&od.dev_holes, holes.size() * sizeof(uint64_t));
+            if (e == hipSuccess) e = hipMemcpy(od.dev_holes, holes.data(), holes.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+            od.n_holes = (uint32_t)holes.size();
+        }
+        if (e == hipSuccess && !wg_first.empty()) {
+            e = hipMalloc(&od.dev_wg, wg_first.size() * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemcpy(od.dev_wg, wg_first.data(), wg_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            od.n_wg = (uint32_t)wg_first.size() - 1;
+        }
+        od.n_order = (uint32_t)order.size();
+        orders.push_back(od);
+        if (e != hipSuccess) return fail(e);
+    }
+    chosen = 0;
+    if (orders.size() > 1 && percents.size() == 2) chosen = 1;      // asked for explicitly
+    else if (orders.size() > 1) {
+        chosen = -1;                                                // to be decided by measurement
+        for (auto &od : orders) {
+            hipError_t e = hipEventCreate(&od.e0);
+            if (e == hipSuccess) e = hipEventCreate(&od.e1);
+            if (e != hipSuccess) return fail(e);
+        }
+    }
+    return RT_OK;
+}
+
+// The same from a thread of its own (see device_table): cost map, orders, uploads -- then the finished orders are handed to table `index`
+// under the scene's lock.  Whatever fails here only costs the ordering: the table keeps rendering through the tile table.
+void build_orders_async(rt_scene *s, size_t index, std::vector<rt::TileDev> tab, unsigned w, unsigned h, unsigned passes)
+{
+    std::vector<rt_scene::Order> orders;
+    int chosen = 0;
+    bool ok = hipSetDevice(s->device) == hipSuccess;
+    if (ok) {
+        const std::vector<uint32_t> *map = cost_map_of(s);
+        ok = build_orders(s, map, tab, w, h, passes, orders, chosen) == RT_OK && hipDeviceSynchronize() == hipSuccess;       // (uploads landed)
+    }
+    (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(s->mu);
+    rt_scene::CachedTable &t = s->tables[index];
+    if (ok) { t.orders = std::move(orders); t.chosen = chosen; }
+    else for (auto &od : orders) release_order(od);
+    t.building = false;
+}
+
 rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, const rt::TileDev **out, int slot,
                        const rt_options *o, rt::BlockList *order_out, bool cacheable)
 {
@@ -1002,7 +1101,7 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
     const unsigned w = o ? o->width : 0u, h = o ? o->height : 0u;
     const unsigned passes = (o && use_split(o->samples_per_pixel)) ? (unsigned)o->samples_per_pixel * o->samples_per_pixel : 1u;
     if (order_out) *order_out = rt::BlockList{};
-    const std::vector<uint32_t> *map = (o && order_out && cacheable) ? cost_map_of(s) : nullptr;     // before taking the lock: it renders
+    StageClock clk;
     // the cooperative walk's controls (rt_debug.h) are part of a dispatch table's identity: tests render one tile list with and without
     long long coop_key = 0;
     if (o && order_out)
@@ -1021,61 +1120,34 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
             rt_scene::CachedTable t;
             HIP_TRY(hipMalloc(&t.dev, bytes));
             hipError_t e = hipMemcpy(t.dev, tab.data(), bytes, hipMemcpyHostToDevice);    // blocking, once per table
+            clk.lap("tile table upload");
             if (e != hipSuccess) { (void)hipFree(t.dev); return hip_fail(e, "hipMemcpy(tile table)", __LINE__); }
             auto drop = [&t] { (void)hipFree(t.dev); for (auto &od : t.orders) release_order(od); };
-            if (o && order_out) {
-                const bool coop_pass = s->precision == RT_F32 && s->coop.fanout != 0u && passes == 1;
-                // candidates: the plain dispatch first; where the cooperative walk could serve the pass and nothing was asked for explicitly
-                // (rt_debug.h), a few thresholds in percent of the pass's largest estimate -- pick_order tries them
-                uint64_t total_px = 0;
-                for (const rt::TileDev &td : tab) total_px += (uint64_t)(td.r - td.l) * (td.t - td.b);
-                const long long rays = knob(RT_DEBUG_SKIP_RAYS);
-                const bool two_rays = s->fused && (rays < 0 ? skip2_by_default(total_px, 1, s->n_fnodes) : rays == 2);      // k_render_skip2 knows no cooperative quads
-                std::vector<int> percents;
-                if (coop_pass && map && !two_rays && knob(RT_DEBUG_COOP) < 0 && knob(RT_DEBUG_COOP_THR) < 0) percents = { 0, 30, 40, 55 };
-                else if (coop_pass && (knob(RT_DEBUG_COOP) > 0 || knob(RT_DEBUG_COOP_THR) >= 0)) percents = { 0, -1 };       // as asked, behind the plain one
-                else percents = { -1 };
-                for (int pc : percents) {
-                    std::vector<rt::BlockDesc> order;
-                    std::vector<uint32_t> wg_first;
-                    std::vector<uint64_t> holes;
-                    block_order(map, tab, w, h, passes, order, wg_first, coop_pass ? &s->coop : nullptr, &holes, pc);
-                    const bool any_hole = std::any_of(holes.begin(), holes.end(), [](uint64_t v) { return v != 0; });
-                    if (pc != percents[0] && !any_hole) continue;       // the same dispatch as the plain one
-                    rt_scene::Order od;
-                    e = hipMalloc(&od.dev_order, order.size() * sizeof(rt::BlockDesc));
-                    if (e == hipSuccess) e = hipMemcpy(od.dev_order, order.data(), order.size() * sizeof(rt::BlockDesc), hipMemcpyHostToDevice);
-                    if (e == hipSuccess && any_hole) {
-                        e = hipMalloc(&od.dev_holes, holes.size() * sizeof(uint64_t));
-                        if (e == hipSuccess) e = hipMemcpy(od.dev_holes, holes.data(), holes.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
-                        od.n_holes = (uint32_t)holes.size();
-                    }
-                    if (e == hipSuccess && !wg_first.empty()) {
-                        e = hipMalloc(&od.dev_wg, wg_first.size() * sizeof(uint32_t));
-                        if (e == hipSuccess) e = hipMemcpy(od.dev_wg, wg_first.data(), wg_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-                        od.n_wg = (uint32_t)wg_first.size() - 1;
-                    }
-                    od.n_order = (uint32_t)order.size();
-                    t.orders.push_back(od);
-                    if (e != hipSuccess) { drop(); return hip_fail(e, "block order", __LINE__); }
-                }
-                if (t.orders.size() > 1 && percents.size() == 2) t.chosen = 1;      // asked for explicitly
-                else if (t.orders.size() > 1) {
-                    t.chosen = -1;                                      // to be decided by measurement
-                    for (auto &od : t.orders) {
-                        e = hipEventCreate(&od.e0);
-                        if (e == hipSuccess) e = hipEventCreate(&od.e1);
-                        if (e != hipSuccess) { drop(); return hip_fail(e, "hipEventCreate(order trial)", __LINE__); }
-                    }
-                }
+            // The dispatch orders (and the scene's cost map they are made from) cost the host a few milliseconds: unless something was asked
+            // for explicitly (rt_debug.h), they are made by a thread of their own while this and the next launches find their blocks through
+            // the tile table -- a one-shot caller (`make image`) never waits for them, a scheduler gets them a few frames in.
+            const bool want_orders = o && order_out;
+            const bool in_background = want_orders && !order_knobs_set();
+            if (want_orders && !in_background) {
+                const std::vector<uint32_t> *map = cost_map_of(s);
+                clk.lap("cost map (cached after 1st)");
+                rt_status bst = build_orders(s, map, tab, w, h, passes, t.orders, t.chosen);
+                clk.lap("dispatch orders");
+                if (bst != RT_OK) { drop(); return bst; }
             }
             // The copies above are blocking for the host, but the render kernel runs on another (non-blocking) stream: make sure
             // the tables have landed in device memory before anything can be launched against them (once per tile list).
             e = hipDeviceSynchronize();
             if (e != hipSuccess) { drop(); return hip_fail(e, "hipDeviceSynchronize(tile tables)", __LINE__); }
+            clk.lap("device sync");
+            t.building = in_background;
             t.host = tab; t.w = w; t.h = h; t.passes = passes; t.coop_key = coop_key;
             *out = t.dev;
             s->tables.push_back(std::move(t));
+            if (in_background) {
+                const size_t index = s->tables.size() - 1;
+                s->builders.emplace_back([s, index, tab, w, h, passes] { build_orders_async(s, index, tab, w, h, passes); });
+            }
             if (order_out && block_order_enabled()) *order_out = pick_order(s->tables.back());
             return RT_OK;
         }
@@ -1647,6 +1719,7 @@ rt_status rt_scene_destroy(rt_scene *s)
 {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->device);
+    for (std::thread &b : s->builders) if (b.joinable()) b.join();          // dispatch orders still being made in the background
     if (s->ahead.stream) { (void)hipStreamSynchronize(s->ahead.stream); (void)hipStreamDestroy(s->ahead.stream); }      // a pass rendered ahead may still be running
     s->pool.clear();
     for (auto &t : s->tables) { (void)hipFree(t.dev); for (auto &od : t.orders) release_order(od); }

@@ -49,7 +49,10 @@ typedef enum rt_debug_key {
     RT_DEBUG_COOP_MAX = 17,      /* ... cap on the number of 16x16 blocks that are split for it; default: an eighth of the pass */
     RT_DEBUG_COOP_LEVEL = 18,    /* ... rays per cooperative wave: 1 = 16 (4x4 pixels), 2 = 4 (2x2), 3 = one; default 2 */
     RT_DEBUG_COOP_REST = 19,     /* ... what is left of a block with cooperative quads: 0 = one descriptor (8x8 pixels per wave), 1 = four (4x4 per wave) */
-    RT_DEBUG_KEYS = 20
+    RT_DEBUG_ASYNC_ORDERS = 20,  /* 0: the dispatch orders of a tile list (and the scene's cost map) are made by the first call that uses the list, as they are
+                                    whenever another dispatch control here is set; default: by a background thread, the first launches finding their blocks
+                                    through the tile table */
+    RT_DEBUG_KEYS = 21
 } rt_debug_key;
 
 /* value < 0 restores the default. */

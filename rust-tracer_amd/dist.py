@@ -6,12 +6,14 @@ its shard tile-major into device memory and a single RCCL gather of the u8 shard
 rank 0, which blits them into the row-major frame on the device.  No other collective touches the data path.
 
 Two ways to use N GPUs, both with the gather as the only collective:
-  * mode "frames" (bench.py's default for N > 1, weak scaling): every GPU renders whole frames -- all 510 buckets of its
-    own frame per step, N frames per step in total -- and the finished u8 frames are gathered to rank 0, where the writer
-    lives.  Per-GPU work is fixed as N grows.
-  * mode "tiles" (BASELINE config 4, strong scaling): the buckets of ONE frame are dealt round-robin over the ranks,
-    the tile-major shards are gathered and blitted into the frame on rank 0.  Byte-identical for every N, but a
-    1080p frame takes ~0.11 ms and is bounded by its heaviest wave, so sharding it cannot make it faster.
+  * mode "tiles" (BASELINE config 4, strong scaling; bench.py's headline for N > 1): the buckets of ONE frame are dealt round-robin
+    over the ranks, the tile-major shards are gathered and blitted into the frame on rank 0.  Byte-identical for every N.  A 1080p
+    frame takes ~0.046 ms on one GPU and a rank's shard of it is still a few tens of microseconds (profiles/: 24 us at N = 8 with
+    the lane-cooperative walk of its heaviest quads), less than one torch.distributed gather call costs the host (~0.03 ms) -- so
+    `frames_per_gather` shards share a collective and consecutive frames are pipelined; bench.py also prints the un-batched,
+    un-pipelined latency of one frame.
+  * mode "frames" (weak scaling, rides along as `weak_frames`): every GPU renders whole frames -- all 510 buckets of its own frame
+    per step, N frames per step in total -- and the finished u8 frames are gathered to rank 0, where the writer lives.
 
 The sharding arithmetic is plain Python (testable on CPU with gloo); only `FrameSharder.step` touches the GPU.
 

@@ -46,6 +46,9 @@ def _check_both_launch_flavours(request, monkeypatch):
     import numpy as np
     import rust_tracer_amd as rta
     orig = rta.DeviceScene.render_tiles
+    # the dispatch orders of a tile list are normally made by a background thread while the first launches walk the tile table
+    # (rt_capi.hip build_orders_async); the tests want the ordered / narrowed / cooperative dispatch in the very launch they look at
+    rta.capi.debug_set(rta.capi.DEBUG_ASYNC_ORDERS, 0)
 
     def both(self, options, regions, traversal=None, want_stats=True, out=None):
         data, st = orig(self, options, regions, traversal, want_stats, out)

@@ -74,6 +74,31 @@ def test_the_library_tries_its_dispatch_orders_and_every_one_renders_the_frame()
         assert st[k] == case["stats"][k], k
 
 
+def test_dispatch_orders_made_in_the_background_arrive_and_change_no_byte():
+    # the default, outside the test suite: a new tile list's first launches find their blocks through the tile table while a thread of
+    # the library renders the scene's cost map and builds the candidate orders; a few frames in the ordered (here: partly cooperative)
+    # dispatch takes over.  Every frame on the way is the oracle's.
+    import time
+    case = next(c for c in _vector_cases() if c["name"] == "config2_800x600")
+    w, h = case["width"], case["height"]
+    regs = bucket_list(w, h)
+    with rta.capi.debug(rta.capi.DEBUG_ASYNC_ORDERS, -1):
+        s = rta.Scene.default()
+        d = s.device()
+        before, t0, frames = coop_launches(), time.time(), 0
+        data, _ = d.render_tiles((w, h, 1), regs, SKIP, want_stats=False)
+        assert tile_crcs(data, regs) == case["tile_crc32"]                      # the very first launch: no order yet
+        while coop_launches() == before and time.time() - t0 < 20.0:
+            data, _ = d.render_tiles((w, h, 1), regs, SKIP, want_stats=False)
+            frames += 1
+            assert tile_crcs(data, regs) == case["tile_crc32"]
+        assert coop_launches() > before, "no cooperative candidate after %d frames" % frames
+        for _ in range(20):
+            data, _ = d.render_tiles((w, h, 1), regs, SKIP, want_stats=False)
+            assert tile_crcs(data, regs) == case["tile_crc32"]
+        d.close()                                                                # joins the builder
+
+
 def test_level9_pyramid_and_ragged_tiles():
     # 87,381 spheres (BASELINE config 5's scene) on ragged 50x50 tiles whose last block row / column is clipped to 2 pixels
     s, o = rta.Scene.default(9), oracle.Scene.default(level=9)

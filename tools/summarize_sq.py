@@ -44,7 +44,8 @@ def main():
         if k != "_stamp" and "SQ_INSTS_VALU" in d:
             quote[k + "_n1"] = {"valu_insts": d["SQ_INSTS_VALU"], "salu_insts": d.get("SQ_INSTS_SALU"), "smem_insts": d.get("SQ_INSTS_SMEM"),
                                 "branch_insts": d.get("SQ_INSTS_BRANCH"), "other_insts": (d.get("SQ_INSTS_SENDMSG") or 0) + (d.get("SQ_INSTS_VMEM") or 0) +
-                                (d.get("SQ_INSTS_LDS") or 0), "waves": d.get("SQ_WAVES")}
+                                (d.get("SQ_INSTS_LDS") or 0), "waves": d.get("SQ_WAVES"),
+                                "valu_active_quad_cycles": d.get("SQ_ACTIVE_INST_VALU")}
     a, b = quote.get("k_flat_primary_sc_n1"), quote.get("k_flat_shadow_sc_n1")
     if a and b:                     # one flat frame = the primary pass + two shadow passes (the counters are per-launch averages)
         quote["k_flat_pipeline_n1"] = {k: (a.get(k) or 0) + 2 * (b.get(k) or 0) for k in a}
