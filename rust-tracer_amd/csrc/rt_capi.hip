@@ -144,12 +144,16 @@ struct rt_scene {
     struct Order { rt::BlockDesc *dev_order = nullptr; uint32_t n_order = 0; uint32_t *dev_wg = nullptr; uint32_t n_wg = 0; uint64_t *dev_holes = nullptr; uint32_t n_holes = 0;
                    hipEvent_t e0 = nullptr, e1 = nullptr; bool pending = false; float best_ms = 1e30f; int samples = 0; };
     struct CachedTable { std::vector<rt::TileDev> host; unsigned w = 0, h = 0, passes = 0; rt::TileDev *dev = nullptr; std::vector<Order> orders; int chosen = 0; unsigned turn = 0; bool building = false;
+                         void *order_arena = nullptr;      // ONE device allocation holds every order's arrays (allocation calls wait for a busy device)
                          long long coop_key = 0; };
     std::vector<CachedTable> tables;
     std::vector<std::thread> builders;           // dispatch orders being made in the background (build_orders_async); joined by rt_scene_destroy
     // Tests per primary ray (its shadow ray included) on a kCostRes x kCostRes grid over the camera's field of view,
     // rendered once per scene with the counting kernel.  It only ever decides the ORDER in which blocks are dispatched.
     std::once_flag cost_once;
+    hipStream_t cost_stream = nullptr;
+    void *d_cost_arena = nullptr, *h_cost = nullptr;
+    bool cost_started = false;
     std::vector<uint32_t> cost_map;
     // Concurrent rt_render_region callers (the reference's pool threads, render.rs:283-294) are merged into shared passes:
     // whoever finds no pass running becomes its leader and renders every request that is waiting at that moment.
@@ -688,36 +692,33 @@ constexpr unsigned kCostRes = 256;
 
 // The scene's cost map: one counting render of a kCostRes^2 image (same camera: x spans the same field of view at every
 // width), each lane storing the number of tests its pixel took.
+// Enqueues the counting render of the cost map on the scene's own stream (rt_scene_create does this right away: by the time a tile list
+// wants the map it has usually been rendered); cost_map_of waits for it.
 template <typename T>
-rt_status render_cost_map(rt_scene *s, std::vector<uint32_t> &map)
+rt_status start_cost_map(rt_scene *s)
 {
     constexpr unsigned R = kCostRes;
     const rt::TileDev tile{ 0, (uint16_t)R, (uint16_t)R, 0, 0u, 0u, R / rt::kBlockW };
-    rt::TileDev *d_tile = nullptr; uint8_t *d_out = nullptr; uint32_t *d_cost = nullptr; rt::Counters *d_cnt = nullptr;
-    hipStream_t stream = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(&d_tile, sizeof tile);
-    if (e == hipSuccess) e = hipMalloc(&d_out, (size_t)R * R * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_cost, (size_t)R * R * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_cnt, sizeof(rt::Counters) * rt::kCounterStripes);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_tile, &tile, sizeof tile, hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, sizeof(rt::Counters) * rt::kCounterStripes, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_cost, 0, (size_t)R * R * 4, stream);
-    if (e == hipSuccess) {
-        rt::SampleBuf<T> sb{ nullptr, nullptr, R * R };
-        hipLaunchKernelGGL((rt::k_render_skip<T, true, 1, rt::kSkipLoop>), dim3((R / rt::kBlockW) * (R / rt::kBlockH)), dim3(rt::kBlockThreads), 0, stream,
-                           skip_view_of<T>(s), R, R, 1u, d_tile, 1u, d_out, d_cnt, sb, 0u, (const rt::BlockDesc *)nullptr, d_cost, (const uint32_t *)nullptr);
-        e = hipGetLastError();
-    }
-    map.assign((size_t)R * R, 0u);
-    if (e == hipSuccess) e = hipMemcpyAsync(map.data(), d_cost, (size_t)R * R * 4, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (d_tile) (void)hipFree(d_tile);
-    if (d_out) (void)hipFree(d_out);
-    if (d_cost) (void)hipFree(d_cost);
-    if (d_cnt) (void)hipFree(d_cnt);
-    if (stream) (void)hipStreamDestroy(stream);
-    if (e != hipSuccess) { map.clear(); return hip_fail(e, "render_cost_map", __LINE__); }
+    // ONE device allocation, kept until the scene goes (hipMalloc / hipFree wait for a busy device): tile | frame | costs | counters
+    constexpr size_t kTileBytes = 256, kPx = (size_t)R * R * 4, kCnt = sizeof(rt::Counters) * rt::kCounterStripes;
+    HIP_TRY(hipStreamCreateWithFlags(&s->cost_stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&s->d_cost_arena, kTileBytes + 2 * kPx + kCnt));
+    HIP_TRY(hipHostMalloc(&s->h_cost, kPx + kTileBytes, hipHostMallocDefault));
+    hipStream_t stream = s->cost_stream;
+    char *base = static_cast<char *>(s->d_cost_arena);
+    rt::TileDev *d_tile = reinterpret_cast<rt::TileDev *>(base);
+    uint8_t *d_out = reinterpret_cast<uint8_t *>(base + kTileBytes);
+    uint32_t *d_cost = reinterpret_cast<uint32_t *>(base + kTileBytes + kPx);
+    rt::Counters *d_cnt = reinterpret_cast<rt::Counters *>(base + kTileBytes + 2 * kPx);
+    memcpy(static_cast<char *>(s->h_cost) + kPx, &tile, sizeof tile);                 // (pinned: the copy below is truly asynchronous)
+    HIP_TRY(hipMemcpyAsync(d_tile, static_cast<char *>(s->h_cost) + kPx, sizeof tile, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(d_cost, 0, kPx + kCnt, stream));
+    rt::SampleBuf<T> sb{ nullptr, nullptr, R * R };
+    hipLaunchKernelGGL((rt::k_render_skip<T, true, 1, rt::kSkipLoop>), dim3((R / rt::kBlockW) * (R / rt::kBlockH)), dim3(rt::kBlockThreads), 0, stream,
+                       skip_view_of<T>(s), R, R, 1u, d_tile, 1u, d_out, d_cnt, sb, 0u, (const rt::BlockDesc *)nullptr, d_cost, (const uint32_t *)nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(s->h_cost, d_cost, kPx, hipMemcpyDeviceToHost, stream));
+    s->cost_started = true;
     return RT_OK;
 }
 
@@ -725,9 +726,10 @@ rt_status render_cost_map(rt_scene *s, std::vector<uint32_t> &map)
 const std::vector<uint32_t> *cost_map_of(rt_scene *s)
 {
     std::call_once(s->cost_once, [s] {
-        if (s->n_nodes == 0) return;
-        rt_status st = s->precision == RT_F32 ? render_cost_map<float>(s, s->cost_map) : render_cost_map<double>(s, s->cost_map);
-        if (st != RT_OK) s->cost_map.clear();
+        if (s->n_nodes == 0 || !s->cost_started) return;
+        if (hipStreamSynchronize(s->cost_stream) != hipSuccess) { (void)hipGetLastError(); return; }
+        const uint32_t *h = static_cast<const uint32_t *>(s->h_cost);
+        s->cost_map.assign(h, h + (size_t)kCostRes * kCostRes);
     });
     return s->cost_map.empty() ? nullptr : &s->cost_map;
 }
@@ -955,11 +957,8 @@ struct StageClock {
     }
 };
 
-void release_order(rt_scene::Order &od)
+void release_order(rt_scene::Order &od)           // (its arrays live in the table's arena)
 {
-    if (od.dev_order) (void)hipFree(od.dev_order);
-    if (od.dev_wg) (void)hipFree(od.dev_wg);
-    if (od.dev_holes) (void)hipFree(od.dev_holes);
     if (od.e0) (void)hipEventDestroy(od.e0);
     if (od.e1) (void)hipEventDestroy(od.e1);
     od = rt_scene::Order{};
@@ -993,6 +992,11 @@ rt::BlockList pick_order(rt_scene::CachedTable &t)
         size_t best = 0;
         for (size_t i = 1; i < t.orders.size(); ++i) if (t.orders[i].best_ms < t.orders[best].best_ms) best = i;
         t.chosen = (int)best;
+        if (knob(RT_DEBUG_PRINT_STEPS) > 0) {
+            fprintf(stderr, "[rtrace_hip] dispatch orders of a %zu-tile list, ms:", t.host.size());
+            for (const auto &od : t.orders) fprintf(stderr, " %.4f%s", od.best_ms, od.dev_holes ? "c" : "");
+            fprintf(stderr, " -> #%zu\n", best);
+        }
         return list_of(t.orders[best]);
     }
     for (size_t k = 0; k < t.orders.size(); ++k) {
@@ -1023,7 +1027,7 @@ bool order_knobs_set()
 // The candidate dispatch orders of one tile list: the plain one first; where the cooperative walk could serve the pass and nothing was
 // asked for explicitly, a few thresholds in percent of the pass's largest estimate (pick_order tries them: chosen = -1).
 rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std::vector<rt::TileDev> &tab, unsigned w, unsigned h, unsigned passes,
-                       std::vector<rt_scene::Order> &orders, int &chosen)
+                       std::vector<rt_scene::Order> &orders, int &chosen, void **arena_out)
 {
     const bool coop_pass = s->precision == RT_F32 && s->coop.fanout != 0u && passes == 1;
     uint64_t total_px = 0, total_blocks = 0;
@@ -1037,41 +1041,54 @@ rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std:
     if (coop_pass && map && !two_rays && total_blocks <= kCoopPassBlocks && knob(RT_DEBUG_COOP) < 0 && knob(RT_DEBUG_COOP_THR) < 0) percents = { 0, 30, 40, 55 };
     else if (coop_pass && (knob(RT_DEBUG_COOP) > 0 || knob(RT_DEBUG_COOP_THR) >= 0)) percents = { 0, -1 };       // as asked, behind the plain one
     else percents = { -1 };
-    auto fail = [&](hipError_t e) { for (auto &od : orders) release_order(od); orders.clear(); return hip_fail(e, "dispatch orders", __LINE__); };
+    // every candidate on the host first, then ONE device allocation for all their arrays: hipMalloc / hipFree wait for a busy device,
+    // and this may run in the background of a caller who keeps it busy
+    struct Host { std::vector<rt::BlockDesc> order; std::vector<uint32_t> wg_first; std::vector<uint64_t> holes; bool any_hole = false; };
+    std::vector<Host> cand;
     for (int pc : percents) {
-        std::vector<rt::BlockDesc> order;
-        std::vector<uint32_t> wg_first;
-        std::vector<uint64_t> holes;
-        block_order(map, tab, w, h, passes, order, wg_first, coop_pass ? &s->coop : nullptr, &holes, pc);
-        const bool any_hole = std::any_of(holes.begin(), holes.end(), [](uint64_t v) { return v != 0; });
-        if (pc != percents[0] && !any_hole) continue;       // the same dispatch as the plain one
+        Host c;
+        block_order(map, tab, w, h, passes, c.order, c.wg_first, coop_pass ? &s->coop : nullptr, &c.holes, pc);
+        c.any_hole = std::any_of(c.holes.begin(), c.holes.end(), [](uint64_t v) { return v != 0; });
+        if (pc != percents[0] && !c.any_hole) continue;     // the same dispatch as the plain one
+        cand.push_back(std::move(c));
+    }
+    auto up = [](size_t n) { return (n + 255) & ~(size_t)255; };
+    size_t bytes = 0;
+    for (const Host &c : cand)
+        bytes += up(c.order.size() * sizeof(rt::BlockDesc)) + (c.any_hole ? up(c.holes.size() * sizeof(uint64_t)) : 0) + (c.wg_first.empty() ? 0 : up(c.wg_first.size() * sizeof(uint32_t)));
+    char *arena = nullptr;
+    hipError_t e = hipMalloc(&arena, std::max<size_t>(bytes, 256));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(dispatch orders)", __LINE__);
+    auto fail = [&](hipError_t err) { for (auto &od : orders) release_order(od); orders.clear(); (void)hipFree(arena); return hip_fail(err, "dispatch orders", __LINE__); };
+    size_t off = 0;
+    for (const Host &c : cand) {
         rt_scene::Order od;
-        hipError_t e = hipMalloc(&od.dev_order, order.size() * sizeof(rt::BlockDesc));
-        if (e == hipSuccess) e = hipMemcpy(od.dev_order, order.data(), order.size() * sizeof(rt::BlockDesc), hipMemcpyHostToDevice);
-        if (e == hipSuccess && any_hole) {
-            e = hipMalloc(&od.dev_holes, holes.size() * sizeof(uint64_t));
-            if (e == hipSuccess) e = hipMemcpy(od.dev_holes, holes.data(), holes.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
-            od.n_holes = (uint32_t)holes.size();
+        od.dev_order = reinterpret_cast<rt::BlockDesc *>(arena + off); od.n_order = (uint32_t)c.order.size();
+        if ((e = hipMemcpy(od.dev_order, c.order.data(), c.order.size() * sizeof(rt::BlockDesc), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+        off += up(c.order.size() * sizeof(rt::BlockDesc));
+        if (c.any_hole) {
+            od.dev_holes = reinterpret_cast<uint64_t *>(arena + off); od.n_holes = (uint32_t)c.holes.size();
+            if ((e = hipMemcpy(od.dev_holes, c.holes.data(), c.holes.size() * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+            off += up(c.holes.size() * sizeof(uint64_t));
         }
-        if (e == hipSuccess && !wg_first.empty()) {
-            e = hipMalloc(&od.dev_wg, wg_first.size() * sizeof(uint32_t));
-            if (e == hipSuccess) e = hipMemcpy(od.dev_wg, wg_first.data(), wg_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-            od.n_wg = (uint32_t)wg_first.size() - 1;
+        if (!c.wg_first.empty()) {
+            od.dev_wg = reinterpret_cast<uint32_t *>(arena + off); od.n_wg = (uint32_t)c.wg_first.size() - 1;
+            if ((e = hipMemcpy(od.dev_wg, c.wg_first.data(), c.wg_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+            off += up(c.wg_first.size() * sizeof(uint32_t));
         }
-        od.n_order = (uint32_t)order.size();
         orders.push_back(od);
-        if (e != hipSuccess) return fail(e);
     }
     chosen = 0;
     if (orders.size() > 1 && percents.size() == 2) chosen = 1;      // asked for explicitly
     else if (orders.size() > 1) {
         chosen = -1;                                                // to be decided by measurement
         for (auto &od : orders) {
-            hipError_t e = hipEventCreate(&od.e0);
+            e = hipEventCreate(&od.e0);
             if (e == hipSuccess) e = hipEventCreate(&od.e1);
             if (e != hipSuccess) return fail(e);
         }
     }
+    *arena_out = arena;
     return RT_OK;
 }
 
@@ -1081,16 +1098,18 @@ void build_orders_async(rt_scene *s, size_t index, std::vector<rt::TileDev> tab,
 {
     std::vector<rt_scene::Order> orders;
     int chosen = 0;
+    void *arena = nullptr;
     bool ok = hipSetDevice(s->device) == hipSuccess;
     if (ok) {
         const std::vector<uint32_t> *map = cost_map_of(s);
-        ok = build_orders(s, map, tab, w, h, passes, orders, chosen) == RT_OK && hipDeviceSynchronize() == hipSuccess;       // (uploads landed)
+        // (the uploads are blocking copies: the data is in device memory when they return.  No device-wide synchronise here -- the caller's
+        // own launches keep the device busy and it would wait for all of them)
+        ok = build_orders(s, map, tab, w, h, passes, orders, chosen, &arena) == RT_OK;
     }
     (void)hipGetLastError();
     std::lock_guard<std::mutex> lk(s->mu);
     rt_scene::CachedTable &t = s->tables[index];
-    if (ok) { t.orders = std::move(orders); t.chosen = chosen; }
-    else for (auto &od : orders) release_order(od);
+    if (ok) { t.orders = std::move(orders); t.chosen = chosen; t.order_arena = arena; }
     t.building = false;
 }
 
@@ -1122,7 +1141,7 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
             hipError_t e = hipMemcpy(t.dev, tab.data(), bytes, hipMemcpyHostToDevice);    // blocking, once per table
             clk.lap("tile table upload");
             if (e != hipSuccess) { (void)hipFree(t.dev); return hip_fail(e, "hipMemcpy(tile table)", __LINE__); }
-            auto drop = [&t] { (void)hipFree(t.dev); for (auto &od : t.orders) release_order(od); };
+            auto drop = [&t] { (void)hipFree(t.dev); for (auto &od : t.orders) release_order(od); if (t.order_arena) (void)hipFree(t.order_arena); };
             // The dispatch orders (and the scene's cost map they are made from) cost the host a few milliseconds: unless something was asked
             // for explicitly (rt_debug.h), they are made by a thread of their own while this and the next launches find their blocks through
             // the tile table -- a one-shot caller (`make image`) never waits for them, a scheduler gets them a few frames in.
@@ -1131,7 +1150,7 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
             if (want_orders && !in_background) {
                 const std::vector<uint32_t> *map = cost_map_of(s);
                 clk.lap("cost map (cached after 1st)");
-                rt_status bst = build_orders(s, map, tab, w, h, passes, t.orders, t.chosen);
+                rt_status bst = build_orders(s, map, tab, w, h, passes, t.orders, t.chosen, &t.order_arena);
                 clk.lap("dispatch orders");
                 if (bst != RT_OK) { drop(); return bst; }
             }
@@ -1265,6 +1284,14 @@ rt_status launch_flat_wavefront(const rt_scene *s, Context *c, hipStream_t strea
     return RT_OK;
 }
 
+// The render kernel of a hierarchy-walk launch: f32 launches that do not count run the build held to 8 waves per SIMD (rt_skip.hpp).
+template <typename T, bool COUNT, int VAR, int MODE, bool COOP = false>
+constexpr auto skip_kernel()
+{
+    if constexpr (sizeof(T) == 4 && !COUNT) return &rt::k_render_skip_f32<COUNT, VAR, MODE, COOP>;
+    else return &rt::k_render_skip<T, COUNT, VAR, MODE, COOP>;
+}
+
 template <typename T, bool COUNT, int VAR>
 rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t stream, unsigned w, unsigned h, unsigned spp,
                           const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt, unsigned frame_w,
@@ -1323,17 +1350,17 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
         if constexpr (!COUNT && sizeof(T) == 4 && (VAR == 19 || VAR == 23 || VAR == 31)) {
             if (spp == 1 && order.d && order.holes && !order.wg_first) {        // some quads of the pass are walked cooperatively (rt_coop.hpp)
                 g_count[RT_DEBUG_COUNT_COOP_LAUNCHES].fetch_add(1, std::memory_order_relaxed);
-                hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipOne, true>), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
+                hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipOne, true>()), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
                                    frame_w, order.d, no_cost, order.wg_first, s->coop, order.holes, order.n_holes);
                 return RT_OK;
             }
         }
         if (spp == 1)
-            hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipOne>), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
-                               frame_w, order.d, no_cost, order.wg_first);
+            hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipOne>()), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
+                               frame_w, order.d, no_cost, order.wg_first, rt::CoopView{}, (const uint64_t *)nullptr, 0u);
         else
-            hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipLoop>), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
-                               frame_w, order.d, no_cost, order.wg_first);
+            hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipLoop>()), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
+                               frame_w, order.d, no_cost, order.wg_first, rt::CoopView{}, (const uint64_t *)nullptr, 0u);
         return RT_OK;
     }
     const size_t ns = (size_t)spp * spp;
@@ -1355,11 +1382,11 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     }
     if (done2) {
     } else if (packed)
-        hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipPacked>), dim3(rgrid.x, (unsigned)ns), b, lds, stream, skip_view_of<T>(s), w, h, spp,
-                           d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost, order.wg_first);
+        hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipPacked>()), dim3(rgrid.x, (unsigned)ns), b, lds, stream, skip_view_of<T>(s), w, h, spp,
+                           d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost, order.wg_first, rt::CoopView{}, (const uint64_t *)nullptr, 0u);
     else
-        hipLaunchKernelGGL((rt::k_render_skip<T, COUNT, VAR, rt::kSkipSplit>), dim3(rgrid.x, (unsigned)ns), b, lds, stream, skip_view_of<T>(s), w, h, spp,
-                           d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost, order.wg_first);
+        hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipSplit>()), dim3(rgrid.x, (unsigned)ns), b, lds, stream, skip_view_of<T>(s), w, h, spp,
+                           d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost, order.wg_first, rt::CoopView{}, (const uint64_t *)nullptr, 0u);
     HIP_TRY(hipGetLastError());
     if constexpr (sizeof(T) == 4) {
         if (packed) {        // one word per sample, [pixel][sample] (rt_kernels.hpp sample_word)
@@ -1710,6 +1737,9 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
     if (n_bounds) {
         rt_status sst = f32 ? upload_streams<float>(s.get(), dfs_items, bounds, ranges) : upload_streams<double>(s.get(), dfs_items, bounds, ranges);
         if (sst != RT_OK) return fail(sst);
+        // the cost map the dispatch orders are made from: enqueued now, on a stream of its own, collected when a tile list first wants it
+        // (failing to start it only costs the ordering)
+        if ((f32 ? start_cost_map<float>(s.get()) : start_cost_map<double>(s.get())) != RT_OK) { s->cost_started = false; (void)hipGetLastError(); }
     }
     *out = s.release();
     return RT_OK;
@@ -1722,13 +1752,15 @@ rt_status rt_scene_destroy(rt_scene *s)
     for (std::thread &b : s->builders) if (b.joinable()) b.join();          // dispatch orders still being made in the background
     if (s->ahead.stream) { (void)hipStreamSynchronize(s->ahead.stream); (void)hipStreamDestroy(s->ahead.stream); }      // a pass rendered ahead may still be running
     s->pool.clear();
-    for (auto &t : s->tables) { (void)hipFree(t.dev); for (auto &od : t.orders) release_order(od); }
+    for (auto &t : s->tables) { (void)hipFree(t.dev); for (auto &od : t.orders) release_order(od); if (t.order_arena) (void)hipFree(t.order_arena); }
     if (s->d_items) (void)hipFree(s->d_items);
     if (s->d_prim) (void)hipFree(s->d_prim);
     if (s->d_shad) (void)hipFree(s->d_shad);
     if (s->d_cprim) (void)hipFree(s->d_cprim);
     if (s->d_cshad) (void)hipFree(s->d_cshad);
-    for (void *p : { s->d_xprim, s->d_xshad, s->d_xcprim, s->d_xcshad, s->d_xown, s->d_fc, s->d_coop_prim, s->d_coop_shad }) if (p) (void)hipFree(p);
+    for (void *p : { s->d_xprim, s->d_xshad, s->d_xcprim, s->d_xcshad, s->d_xown, s->d_fc, s->d_coop_prim, s->d_coop_shad, s->d_cost_arena }) if (p) (void)hipFree(p);
+    if (s->cost_stream) { (void)hipStreamSynchronize(s->cost_stream); (void)hipStreamDestroy(s->cost_stream); }
+    if (s->h_cost) (void)hipHostFree(s->h_cost);
     if (s->ahead.ev) (void)hipEventDestroy(s->ahead.ev);
     if (s->ahead.h) (void)rt_host_free(s->ahead.h);
     if (s->ahead.h_next) (void)rt_host_free(s->ahead.h_next);

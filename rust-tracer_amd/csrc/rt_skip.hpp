@@ -297,14 +297,13 @@ enum { kSkipLoop = 0, kSkipSplit = 1, kSkipOne = 2, kSkipPacked = 3 };
 //   4-bit mask in pitch bits 20..23 is cooperative -- wave w of the workgroup traces its quad cooperatively when bit w is set and leaves
 //   otherwise; the rays the cooperative walk hands back (rt_coop.hpp: `failed`) are walked by the loops.  The 16x16 block those quads
 //   belong to is descriptor di < n_holes of the same list (or its four quarters, level 1), and holes[di] tells its own waves which 2x2-pixel quads to leave out.
-template <typename T, bool COUNT, int VAR, int MODE, bool COOP = false>
-__global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, unsigned width, unsigned height, unsigned spp_arg,
-                                                              const TileDev *__restrict__ tiles, unsigned n_tiles,
-                                                              uint8_t *__restrict__ out, Counters *__restrict__ counters,
-                                                              SampleBuf<T> sb, unsigned frame_w,
-                                                              const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost,
-                                                              const uint32_t *__restrict__ wg_first, CoopView cv = CoopView{},
-                                                              const uint64_t *__restrict__ holes = nullptr, unsigned n_holes = 0)
+template <typename T, bool COUNT, int VAR, int MODE, bool COOP>
+__device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width, unsigned height, unsigned spp_arg,
+                                                 const TileDev *__restrict__ tiles, unsigned n_tiles,
+                                                 uint8_t *__restrict__ out, Counters *__restrict__ counters,
+                                                 SampleBuf<T> sb, unsigned frame_w,
+                                                 const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost,
+                                                 const uint32_t *__restrict__ wg_first, CoopView cv, const uint64_t *__restrict__ holes, unsigned n_holes)
 {
     constexpr bool PACKED = MODE == kSkipPacked, SPLIT = MODE == kSkipSplit || PACKED, ONE = MODE == kSkipOne;
     static_assert(!COOP || (sizeof(T) == 4 && !COUNT && ONE && (VAR & 2) != 0), "the cooperative walk serves f32 spp-1 passes of the assembly loops");
@@ -659,6 +658,31 @@ __global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, u
         }
     }
     }       // descriptors of this workgroup
+}
+
+template <typename T, bool COUNT, int VAR, int MODE, bool COOP = false>
+__global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, unsigned width, unsigned height, unsigned spp_arg,
+                                                              const TileDev *__restrict__ tiles, unsigned n_tiles,
+                                                              uint8_t *__restrict__ out, Counters *__restrict__ counters,
+                                                              SampleBuf<T> sb, unsigned frame_w,
+                                                              const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost,
+                                                              const uint32_t *__restrict__ wg_first, CoopView cv = CoopView{},
+                                                              const uint64_t *__restrict__ holes = nullptr, unsigned n_holes = 0)
+{
+    render_skip_body<T, COUNT, VAR, MODE, COOP>(sc, width, height, spp_arg, tiles, n_tiles, out, counters, sb, frame_w, order, lane_cost, wg_first, cv, holes, n_holes);
+}
+
+// The same kernel for f32 launches that do not count, held to 94 scalar registers (100 with the hardware's six): 8 waves per SIMD instead
+// of the 7 that the 106 of the unconstrained build allow -- the compiler parks eight values in vector-register lanes (v_writelane /
+// v_readlane outside the loops) and the 1080p frame goes from 46.9 to 44.3 us (tools/ab_libs.sh, same box, interleaved).  The f64 loops own
+// s[36:97] and cannot live under that limit, hence a kernel of its own rather than an attribute on the template.
+template <bool COUNT, int VAR, int MODE, bool COOP = false>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(94))) void k_render_skip_f32(
+    SkipView<float> sc, unsigned width, unsigned height, unsigned spp_arg, const TileDev *__restrict__ tiles, unsigned n_tiles, uint8_t *__restrict__ out,
+    Counters *__restrict__ counters, SampleBuf<float> sb, unsigned frame_w, const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost,
+    const uint32_t *__restrict__ wg_first, CoopView cv = CoopView{}, const uint64_t *__restrict__ holes = nullptr, unsigned n_holes = 0)
+{
+    render_skip_body<float, COUNT, VAR, MODE, COOP>(sc, width, height, spp_arg, tiles, n_tiles, out, counters, sb, frame_w, order, lane_cost, wg_first, cv, holes, n_holes);
 }
 
 // Second pass of the SPLIT path: render.rs:233-252 for one pixel -- its samples' contributions accumulated strictly
