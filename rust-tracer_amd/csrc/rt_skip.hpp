@@ -145,7 +145,9 @@ __device__ __forceinline__ float next_f32_below(float f)      // finite f
 __device__ __forceinline__ float primary_filter_threshold(float vv_f, float rr_f)
 {
     const double eps = 0x1p-24, vv = vv_f, rr = rr_f;
-    if (!(vv >= 1e-30) || !(vv - rr >= 64.0 * eps * (vv + rr))) return -__builtin_huge_valf();
+    // (vv >= 1e-14: |v| >= 1e-7, so that b >= sqrt(60 eps vv) keeps the squares of the BOUND step's root-free decision -- differences of
+    // values of b's magnitude -- in the normal range: bound_shortcut_verdict)
+    if (!(vv >= 1e-14) || !(vv - rr >= 64.0 * eps * (vv + rr))) return -__builtin_huge_valf();
     const double m0 = vv - rr * (1.0 + 2.0 * eps) - 1e-44;
     const double t = __builtin_sqrt(m0 * (1.0 - 2.0 * eps)) - 8.0 * eps * __builtin_sqrt(vv);
     float tf = (float)t;
@@ -258,6 +260,17 @@ __device__ __forceinline__ bool primary_filter_pass(const FNode &f, float dx, fl
 {
     return f.f5 <= __builtin_fmaf(f.a2, dz, __builtin_fmaf(f.a1, dy, f.a0 * dx));
 }
+// The root-free decision of a primary BOUND step, as the filtered loops evaluate it (tools/gen_skip_asm.py bound_shortcut): for a
+// node the eye is clearly outside of (FNode::f5 > -inf) and a lane with disc >= 0 -- 0: the lane does not enter, 2: it enters, 1: the root decides.
+__device__ __forceinline__ int bound_shortcut_verdict(float b, float disc, float best)
+{
+    if (!(0.0f < b)) return 0;                          // behind the eye: t2 < 0
+    const float w = b - best;
+    if (w < 0.0f) return 2;                             // RN(b - s) <= b < hit.distance
+    const float k = 0x1.00001p+0f;                      // 1 + 2^-20
+    return disc * k <= w * w ? 0 : 1;                   // s <= sqrt(disc)(1 + 2^-24) <= b - hit.distance
+}
+
 // 0: the bounds say MISS, 1: they cannot tell, 2: they say HIT
 __device__ __forceinline__ int shadow_filter_verdict(const FNodeS &f, const FilterConsts &fc, float q1, float q2, float ol)
 {
@@ -458,9 +471,15 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
                     }
                     if constexpr (COUNT && sizeof(T) == 4) {
                         if (sc.xprim && active) {
-                            const bool pass = primary_filter_pass(sc.xprim[i], dir.x, dir.y, dir.z);
+                            const FNode fn = sc.xprim[i];
+                            const bool pass = primary_filter_pass(fn, dir.x, dir.y, dir.z);
                             c_fpass += pass ? 1u : 0u;
                             c_fviol += (!pass && d < inf<T>()) ? 1u : 0u;
+                            // the BOUND step's root-free decision (rt_skip_rot.hpp, bound_shortcut), held against the reference's own `d >= hit.distance`
+                            if (nd.is_bound() && pos && fn.f5 > -inf<float>()) {
+                                const int v = bound_shortcut_verdict((float)b, (float)disc, (float)best);
+                                c_fviol += ((v == 2 && !(d < best)) || (v == 0 && d < best)) ? 1u : 0u;
+                            }
                         }
                     }
                     if (nd.is_bound()) {                                // BOUND  group.rs:73

@@ -388,6 +388,30 @@ class F32F(F32):
         a.op("s_bitcmp1_b32 %s, 31" % self.item(c), "an ITEM or the END node?  (flag bits of the tag word)")
         a.op("s_cbranch_scc1 %s" % lab("flagged"))
 
+    def bound_shortcut(self, a, c, lab):
+        """Primary BOUND step, vcc = live lanes with disc >= 0: decide `d < hit.distance` (group.rs:73) WITHOUT the root where the reference's
+        own values already settle it ("the BOUND step without its root").  Only for a node the eye is clearly outside of
+        (T > -inf: then a finite distance needs b > 0 and is t1 = RN(b - s) with 0 <= s = RN(sqrt(disc)) < b):
+            b <= 0                         -> the sphere is behind the eye: t2 < 0, the test returns INF          (no)
+            b <  hit.distance              -> RN(b - s) <= b < hit.distance                                        (yes)
+            disc * K <= RN(w)^2, w = RN(b - hit.distance) >= 0, K = 1 + 2^-20
+                                           -> s <= sqrt(disc) (1 + 2^-24) <= b - hit.distance, so RN(b - s) >= hit.distance   (no)
+        A lane none of these settles sends the whole step through the root (lab bexact); otherwise vcc = the lanes that enter (lab bdecided)."""
+        a.op("s_cmp_eq_u32 %s, 0xff800000" % self.thr(c), "T = -inf: the eye is not clearly outside this sphere -- the reference's arithmetic decides")
+        a.op("s_cbranch_scc1 %s" % lab("bexact"))
+        a.op("v_cmp_lt_f32_e64 %s, 0, %%[b]" % self.M54, "b > 0")
+        a.op("v_sub_f32_e32 %[t3], %[b], %[best]", "w = b - hit.distance  (-inf while nothing was hit)")
+        a.op("v_cmp_gt_f32_e64 %s, 0, %%[t3]" % self.M56, "b < hit.distance: enters")
+        a.op("v_mul_f32_e32 %[t4], %[t3], %[t3]", "w^2")
+        a.op("v_mul_f32_e32 %[t5], 0x3f800008, %[disc]", "disc (1 + 2^-20)")
+        a.op("v_cmp_le_f32_e64 %s, %%[t5], %%[t4]" % self.M58, "the root cannot reach down to b - hit.distance: culled")
+        a.op("s_and_b64 vcc, vcc, %s" % self.M54, "candidates in front of the eye")
+        a.op("s_or_b64 %s, %s, %s" % (self.M58, self.M58, self.M56), "settled lanes")
+        a.op("s_andn2_b64 %s, vcc, %s" % (self.M58, self.M58), "candidates nothing above settles")
+        a.op("s_cbranch_scc1 %s" % lab("bexact"), "(vcc lost only lanes with b <= 0, which the root path rejects as well)")
+        a.op("s_and_b64 vcc, vcc, %s" % self.M56, "go")
+        a.op("s_branch %s" % lab("bdecided"))
+
     def own_item_update(self, a, c):
         # the fused BOUND's tag is its own sphere's rr: the hit records WHERE it happened (NX = this node's offset + stride, bit 31
         # clear) and the kernel looks the item up in the stream's own_item table afterwards
@@ -478,8 +502,13 @@ def primary_copy(P, name, fused):
     exact_after_filter(k, P, c, lab, P.primary_terms)
     kind_test(k, P, c, lab)
     # BOUND (group.rs:73)
+    if P.filt:
+        P.bound_shortcut(k, c, lab)
+        k.label(lab("bexact"))
     P.root(k, "vcc", lab("brooted"), lab("btiny"))
     P.primary_distance(k)
+    if P.filt:
+        k.label(lab("bdecided"))
     k.op("s_cbranch_vccz %s" % lab("skip"), "nobody enters (the lanes that culled it are awake again at `skip`)")
     enter_group(k, P, c, n)
     sleep_culled(k, P, c)

@@ -25,14 +25,16 @@ def main():
         rta.capi.debug_set(rta.capi.DEBUG_NARROW_L2, int(sys.argv[8]))
     path = os.path.join(ROOT, "gpurun_out", "wave_trace.bin")
     os.makedirs(os.path.dirname(path), exist_ok=True)
+    rta.capi.debug_set(rta.capi.DEBUG_ASYNC_ORDERS, 0)        # the dispatch orders at once, not from the background
     scene = rta.Scene.default(level)
     dev = scene.device(0)
     opts = (w, h, spp)
     regs_c = dev._regions([tuple(r) for r in rta.buckets(rta.RenderOptions(*opts))])
     out = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    for _ in range(5):
+    for _ in range(60):         # (the library times its candidate dispatch orders over the first launches of a tile list: let it settle)
         dev.render_frame_device(opts, regs_c, out.data_ptr(), stream)
+        torch.cuda.synchronize()
     torch.cuda.synchronize()
     rta.capi.wave_trace(path)
     dev.render_frame_device(opts, regs_c, out.data_ptr(), stream)
