@@ -573,6 +573,23 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
         s->n_fnodes = (uint32_t)compact.size();
         if ((st = derive_streams<T>(s, compact, true, &s->d_cprim, &s->d_cshad)) != RT_OK) return st;
     }
+    if constexpr (sizeof(T) == 8) {
+        // f64: FNode copies of the primary streams for the filtered primary walk (rt_skip.hpp k_build_fstream64)
+        auto derive64 = [&](const void *d_prim, size_t n_nodes, bool compacted, void **d_x, void **d_own) -> rt_status {
+            const size_t total = n_nodes + rt::kNodePad;
+            HIP_TRY(hipMalloc(d_x, sizeof(rt::FNode) * total));
+            if (d_own) HIP_TRY(hipMalloc(d_own, sizeof(uint32_t) * total));
+            hipLaunchKernelGGL(rt::k_build_fstream64, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, static_cast<const rt::Node<double> *>(d_prim),
+                               (unsigned)total, compacted, static_cast<rt::FNode *>(*d_x), d_own ? static_cast<uint32_t *>(*d_own) : nullptr);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+            return RT_OK;
+        };
+        if ((uint64_t)(s->n_nodes + rt::kNodePad) * sizeof(rt::Node<T>) <= 0xFFFFFFFFull) {
+            if ((st = derive64(s->d_prim, s->n_nodes, false, &s->d_xprim, nullptr)) != RT_OK) return st;
+            if (fused && (st = derive64(s->d_cprim, s->n_fnodes, true, &s->d_xcprim, &s->d_xown)) != RT_OK) return st;
+        }
+    }
     if constexpr (sizeof(T) == 4) {
         filter_constants<T>(s, raw, static_cast<const T *>(items));
         HIP_TRY(hipMalloc(&s->d_fc, sizeof(rt::FilterConsts)));
@@ -1184,7 +1201,7 @@ int skip_variant(const rt_scene *s)
     if (const long long o = knob(RT_DEBUG_SKIP_VARIANT); o >= 0) v = (int)o & 23;
     if (v & 2) v |= 1;                                  // the assembly loops imply the lean sqrt in what C++ remains
     if (!s->fused || !(v & 2)) v &= ~4;
-    if (s->precision != RT_F32 || !s->d_xprim || !(v & 2)) v &= ~16;      // the filtered loops exist in f32
+    if (!s->d_xprim || !(v & 2)) v &= ~16;      // the filtered loops (f32: both walks; f64: the primary walk) need their streams
     if ((v & 3) == 3 && g_trace_on.load(std::memory_order_relaxed)) v |= 8;      // diagnostic build of the assembly variants
     return v;
 }
@@ -1416,8 +1433,8 @@ rt_status launch_skip_var(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
         case 0: return launch_skip_one<T, false, 0>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
         case 3: return launch_skip_one<T, false, 3>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
         case 7: return launch_skip_one<T, false, 7>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
-        case 19: if constexpr (sizeof(T) == 4) return launch_skip_one<T, false, 19>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order); else break;
-        case 23: if constexpr (sizeof(T) == 4) return launch_skip_one<T, false, 23>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order); else break;
+        case 19: return launch_skip_one<T, false, 19>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+        case 23: return launch_skip_one<T, false, 23>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
         case 27: if constexpr (sizeof(T) == 4) return launch_skip_one<T, false, 27>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order); else break;
         case 31: if constexpr (sizeof(T) == 4) return launch_skip_one<T, false, 31>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order); else break;
         case 11: return launch_skip_one<T, false, 11>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);

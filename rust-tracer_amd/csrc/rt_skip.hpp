@@ -125,7 +125,7 @@ template <typename T> struct SkipView {
     const Item<T> *items;   // DFS items (centre of the winning item for the normal)
     uint32_t n_nodes, n_fnodes;
     V3<T> light, eye;
-    // f32 only (else NULL): filtered copies of the four streams and the compacted stream's own_item table
+    // filtered copies of the streams and the compacted stream's own_item table (f32: all four; f64: the two primary ones; else NULL)
     const FNode *xprim, *xfprim;
     const FNodeS *xshad, *xfshad;
     const uint32_t *xown;
@@ -153,6 +153,40 @@ __device__ __forceinline__ float primary_filter_threshold(float vv_f, float rr_f
     float tf = (float)t;
     if ((double)tf > t) tf = next_f32_below(tf);
     return next_f32_below(tf);
+}
+
+// The same threshold for an f64 scene's PRIMARY walk (rt_skip_rot.hpp, the double overloads of skip_primary_rot_filt*): the f64 test
+// returns a finite distance only if b >= sqrt(vv - rr) (1 - 1e-15) (disc >= 0 and, the eye clearly outside, b > 0); the filter's
+// b' = fma(vz, dz, fma(vy, dy, vx*dx)) is formed in f32 from f32 roundings of v and of the ray direction (relative error 2^-24 each) with
+// three more roundings: | b' - b | <= 5.3 * 2^-24 * |v| (|d| <= 1 + 2^-23).  T = sqrt(vv - rr) - 6 * 2^-24 * sqrt(vv), rounded down twice.
+__device__ __forceinline__ float primary_filter_threshold64(double vv, double rr)
+{
+    const double eps = 0x1p-24;
+    if (!(vv >= 1e-30) || !(vv < 1e300) || !(vv - rr >= 64.0 * eps * (vv + rr))) return -__builtin_huge_valf();
+    const double t = __builtin_sqrt(vv - rr) * (1.0 - 1e-14) - 6.0 * eps * __builtin_sqrt(vv);
+    float tf = (float)t;
+    if ((double)tf > t) tf = next_f32_below(tf);
+    return next_f32_below(tf);
+}
+
+// FNode copy of an f64 scene's primary stream (plain or compacted; END nodes included) for the filtered f64 primary walk: f32 roundings of
+// v, the threshold above, skip_off in FNode units (half the Node<double> offset), the tag as in the f32 streams (a compacted BOUND's is 0:
+// its own sphere's rr is read from the exact record).
+__global__ void k_build_fstream64(const Node<double> *__restrict__ prim, unsigned n_total, bool compacted, FNode *__restrict__ xprim, uint32_t *__restrict__ own_item)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    const Node<double> p = prim[i];
+    const bool end = (p.item & kNodeEnd) != 0u, item = (p.item & kNodeItem) != 0u;
+    FNode fp;
+    fp.a0 = (float)p.a0; fp.a1 = (float)p.a1; fp.a2 = (float)p.a2; fp.a3 = 0.0f; fp.a4 = 0.0f;
+    fp.f5 = end ? -__builtin_huge_valf() : primary_filter_threshold64(p.a3, p.a4);
+    // an f32 rounding that overflowed (|v| > 3.4e38 cannot happen: coordinates are <= 1e15) or lost everything (|v| < 1e-45) says nothing
+    if (!end && !(__builtin_fabsf(fp.a0) < 3e38f && __builtin_fabsf(fp.a1) < 3e38f && __builtin_fabsf(fp.a2) < 3e38f)) fp.f5 = -__builtin_huge_valf();
+    fp.skip_off = p.skip_off / 2u;
+    fp.tag = end ? (kNodeItem | kNodeEnd) : item ? (kNodeItem | (p.item & kNodeIndexMask)) : 0u;
+    xprim[i] = fp;
+    if (own_item) own_item[i] = (compacted && !end && !item) ? p.item : 0u;
 }
 
 // Filtered copies of a pair of Node<float> streams (plain or compacted; END nodes included).
@@ -437,7 +471,16 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
                     if (coop_wave) coop_primary(cv, coop_lds[wave], coop_rays, dir.x, dir.y, dir.z, inside, cbest, citem, walk);
                 }
                 if (!coop_wave || __ballot(walk) != 0) {
-                if constexpr ((VAR & 16) != 0 && sizeof(T) == 4) {
+                if constexpr ((VAR & 16) != 0 && sizeof(T) == 8) {
+                    // f64: the walk reads the scene's FNode stream (f32 filter terms; positions in ITS units) and fetches a node's own
+                    // Node<double> record only when the filter lets some live lane through
+                    constexpr unsigned kFStride = (unsigned)sizeof(FNode);
+                    const unsigned nbf = ((VAR & 4) ? sc.n_fnodes : sc.n_nodes) * kFStride;
+                    if constexpr ((VAR & 4) != 0) {
+                        skip_primary_rot_filt_fused(sc.xfprim, nbf, dir.x, dir.y, dir.z, walk ? 0u : nbf, best, best_item, (float)dir.x, (float)dir.y, (float)dir.z, sc.fprim);
+                        if (best_item != 0u && !(best_item & kNodeItem)) best_item = sc.xown[best_item / kFStride - 1u];
+                    } else skip_primary_rot_filt(sc.xprim, nbf, dir.x, dir.y, dir.z, walk ? 0u : nbf, best, best_item, (float)dir.x, (float)dir.y, (float)dir.z, sc.prim);
+                } else if constexpr ((VAR & 16) != 0 && sizeof(T) == 4) {
                     if constexpr ((VAR & 4) != 0) {
                         skip_primary_rot_filt_fused(sc.xfprim, nb, dir.x, dir.y, dir.z, walk ? 0u : nb, best, best_item);
                         // a group's own sphere won: the walk recorded the offset behind its BOUND node
@@ -467,6 +510,13 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
                         if (!(t2 < T(0.0))) {
                             const T t1 = b - s;
                             d = t1 > T(0.0) ? t1 : t2;
+                        }
+                    }
+                    if constexpr (COUNT && sizeof(T) == 8) {
+                        if (sc.xprim && active) {              // the f64 primary walk's f32 filter: never in the way of a finite distance
+                            const bool pass = primary_filter_pass(sc.xprim[i], (float)dir.x, (float)dir.y, (float)dir.z);
+                            c_fpass += pass ? 1u : 0u;
+                            c_fviol += (!pass && d < inf<T>()) ? 1u : 0u;
                         }
                     }
                     if constexpr (COUNT && sizeof(T) == 4) {

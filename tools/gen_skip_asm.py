@@ -79,6 +79,10 @@ def sp(first, n=2):
 class Prec:
     """Register plan and the precision-dependent instruction sequences."""
     filt = False
+    shortcut = False                 # the primary BOUND step's root-free decision (F32F.bound_shortcut)
+    primary_extra_args = ""
+    primary_extra_in = ""
+    primary_only = False
     shadow_extra_in = ""
     shadow_extra_out = ""
     shadow_extra_decl = ""
@@ -344,6 +348,7 @@ class F32F(F32):
     does it form the reference's own discriminant, operation for operation, exactly as the unfiltered loops do."""
     name = "f32"
     filt = True
+    shortcut = True
 
     def item(self, b):
         return "s%d" % (self.bank(b) + 7)            # the tag word: an ITEM's index | bit 31
@@ -425,6 +430,72 @@ class F32F(F32):
     shadow_extra_decl = "\n    float p2, av, inn;"
 
 
+class F64F(F64):
+    """f64 PRIMARY walk behind the f32 filter (round 4; the shadow walk of f64 scenes stays the plain F64 loop).  The walk reads the scene's
+    FNode stream -- f32 roundings of {vx, vy, vz}, a threshold T for the f32 fma-chain b' on an f32 rounding of the ray direction, skip_off
+    and tag as in F32F -- one 32-byte record per step; only when some live lane has b' >= T is the node's own 64-byte Node<double> record
+    fetched (same index, twice the offset) and the reference's f64 test run, instruction for instruction as in F64.  Positions (NX, resume,
+    skip_off) are byte offsets into the FNODE stream.  T: rt_skip.hpp primary_filter_threshold64 -- a finite f64 distance needs
+    b >= sqrt(vv - rr) (1 - 1e-15), and b' is within 5.3 eps32 sqrt(vv) of b (two f32 roundings of the operands, three of the chain)."""
+    name = "f64"
+    filt = True
+    primary_only = True
+    stride = 32
+    fbank_first = (36, 44, 52)                       # three filter banks of 8; the exact record lives in s[60:75]
+    EXACT = 60
+    load_op = "s_load_dwordx8"
+
+    def fbank(self, b):
+        return self.fbank_first[b]
+
+    def load(self, a, b, off, comment=None):
+        a.op("s_load_dwordx8 %s, %%[base], %s" % (sp(self.fbank(b), 8), off), comment)
+
+    def fld(self, b, k):                             # geometry terms: always the exact record of the CURRENT node
+        return sp(self.EXACT + 2 * k)
+
+    def own(self, b):
+        return sp(self.EXACT + 12)
+
+    def item(self, b):
+        return "s%d" % (self.fbank(b) + 7)           # tag word of the filter record
+
+    def skip(self, b):
+        return "s%d" % (self.fbank(b) + 6)
+
+    def thr(self, b):
+        return "s%d" % (self.fbank(b) + 5)
+
+    def primary_filter(self, a, c):
+        a.op("v_mul_f32_e32 %%[tf0], s%d, %%[dxf]" % (self.fbank(c) + 0), "filter (f32): b' = fma(vz, dz, fma(vy, dy, vx*dx)) >= T ?")
+        a.op("v_fma_f32 %%[tf1], s%d, %%[dyf], %%[tf0]" % (self.fbank(c) + 1))
+        a.op("v_fma_f32 %%[tf1], s%d, %%[dzf], %%[tf1]" % (self.fbank(c) + 2))
+        a.op("v_cmp_le_f32_e32 vcc, %s, %%[tf1]" % self.thr(c))
+
+    def primary_terms_after_filter(self, a, c):
+        tmp = "s76"                                  # (free: the filter banks end at s59, the exact record at s75, NX and the masks start at s85)
+        a.op("s_sub_u32 %s, %s, %d" % (tmp, self.NX, self.stride), "this node's offset in the filter stream ...")
+        a.op("s_lshl_b32 %s, %s, 1" % (tmp, tmp), "... and in the Node<double> stream")
+        a.op("s_load_dwordx16 %s, %%[base2], %s" % (sp(self.EXACT, 16), tmp), "its exact record")
+        a.op("s_waitcnt lgkmcnt(0)")
+        self.primary_terms(a, c)
+
+    def kind_test(self, a, c, lab):
+        a.op("s_bitcmp1_b32 %s, 31" % self.item(c), "an ITEM or the END node?  (flag bits of the tag word)")
+        a.op("s_cbranch_scc1 %s" % lab("flagged"))
+
+    def own_item_update(self, a, c):
+        a.op("s_mov_b64 exec, vcc", "primitive.rs:80-83")
+        a.op("v_mov_b64 %[best], %[t3]")
+        a.op("v_mov_b32_e32 %%[bitem], %s" % self.NX, "WHERE it happened: the kernel finds the item in the stream's own_item table")
+        a.op("s_mov_b64 exec, %s" % self.EX)
+
+    primary_decl = F64.primary_decl + "\n    float tf0, tf1;"
+    primary_out = F64.primary_out + ', [tf0] "=&v"(tf0), [tf1] "=&v"(tf1)'
+    primary_extra_args = ", float dxf, float dyf, float dzf, const void *exact"
+    primary_extra_in = ', [dxf] "v"(dxf), [dyf] "v"(dyf), [dzf] "v"(dzf), [base2] "s"(exact)'
+
+
 def top_of(name):
     return ".Lrt_%s_top_%%=" % name
 
@@ -502,12 +573,12 @@ def primary_copy(P, name, fused):
     exact_after_filter(k, P, c, lab, P.primary_terms)
     kind_test(k, P, c, lab)
     # BOUND (group.rs:73)
-    if P.filt:
+    if P.shortcut:
         P.bound_shortcut(k, c, lab)
         k.label(lab("bexact"))
     P.root(k, "vcc", lab("brooted"), lab("btiny"))
     P.primary_distance(k)
-    if P.filt:
+    if P.shortcut:
         k.label(lab("bdecided"))
     k.op("s_cbranch_vccz %s" % lab("skip"), "nobody enters (the lanes that culled it are awake again at `skip`)")
     enter_group(k, P, c, n)
@@ -754,7 +825,7 @@ PRIMARY_FN = """// Primary-ray traversal: s.group.intersect(&mut h, r) for all 6
 // n_bytes = n * %(stride)d.  resume: 0 for lanes with a ray, n_bytes for lanes without (they sleep until END).  Returns
 // hit.distance / item word per lane (mask the item with kNodeIndexMask).
 __device__ __forceinline__ void %(name)s(const void *nodes, unsigned n_bytes, %(ctype)s dx, %(ctype)s dy, %(ctype)s dz, unsigned resume,
-                                                 %(ctype)s &best_out, unsigned &item_out)
+                                                 %(ctype)s &best_out, unsigned &item_out%(primary_extra_args)s)
 {
     %(ctype)s best = %(inf)s;
     unsigned bitem = 0;
@@ -763,7 +834,7 @@ __device__ __forceinline__ void %(name)s(const void *nodes, unsigned n_bytes, %(
     asm volatile(
 %(body)s
         : [best] "+v"(best), [bitem] "+v"(bitem), [resume] "+v"(resume), %(out)s
-        : [base] "s"(nodes), [n] "s"(n_bytes), [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz)%(extra_in)s
+        : [base] "s"(nodes), [n] "s"(n_bytes), [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz)%(extra_in)s%(primary_extra_in)s
         : %(clobbers)s);
     best_out = best;
     item_out = bitem;
@@ -849,14 +920,16 @@ def shadow(P, fused):
 
 def main():
     text = HEADER
-    for P in (F32(), F64(), F32F()):
+    for P in (F32(), F64(), F32F(), F64F()):
         for fused in (False, True):
             sfx = ("_filt" if P.filt else "") + ("_fused" if fused else "")
             common = {"ctype": P.ctype, "stride": P.stride, "inf": P.inf, "extra_in": P.extra_in, "clobbers": clobbers(P),
                       "shadow_extra_in": P.shadow_extra_in, "shadow_extra_out": P.shadow_extra_out, "shadow_extra_decl": P.shadow_extra_decl,
-                      "shadow_extra_args": ", float q1, float q2, float ol, float a0, float k1, float kc, const void *exact" if P.filt else ""}
+                      "shadow_extra_args": ", float q1, float q2, float ol, float a0, float k1, float kc, const void *exact" if (P.filt and not P.primary_only) else "",
+                      "primary_extra_args": P.primary_extra_args, "primary_extra_in": P.primary_extra_in}
             text += PRIMARY_FN % dict(common, name="skip_primary_rot" + sfx, body=primary(P, fused), decl=P.primary_decl, out=P.primary_out)
-            text += SHADOW_FN % dict(common, name="skip_shadow_rot" + sfx, body=shadow(P, fused), decl=P.shadow_decl, out=P.shadow_out)
+            if not P.primary_only:
+                text += SHADOW_FN % dict(common, name="skip_shadow_rot" + sfx, body=shadow(P, fused), decl=P.shadow_decl, out=P.shadow_out)
     text += "}  // namespace rt\n"
     with open(OUT, "w") as f:
         f.write(text)
