@@ -22,7 +22,9 @@ stream = torch.cuda.current_stream().cuda_stream
 s = rta.Scene.default()
 d = s.device()
 t_phase = time.time()
-for (w, h, spp, trav, share, batch) in ((1920, 1080, 1, rta.RT_TRAVERSAL_SKIP, 0.20, 200), (1024, 768, 4, rta.RT_TRAVERSAL_SKIP, 0.10, 200),
+for (w, h, spp, trav, share, batch) in ((1920, 1080, 1, rta.RT_TRAVERSAL_SKIP, 0.15, 200), (1024, 768, 4, rta.RT_TRAVERSAL_SKIP, 0.10, 200),
+                                       (800, 600, 1, rta.RT_TRAVERSAL_SKIP, 0.10, 200),            # round 4: partly lane-cooperative once the library's orders are in
+                                       (640, 480, 1, rta.RT_TRAVERSAL_SKIP, 0.05, 200),
                                        (3840, 2160, 1, rta.RT_TRAVERSAL_SKIP, 0.05, 50),           # k_render_skip2 by default
                                        (1920, 1080, 1, rta.RT_TRAVERSAL_FLAT, 0.10, 10)):
     regs = d._regions([tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))])
@@ -44,6 +46,7 @@ for (w, h, spp, trav, share, batch) in ((1920, 1080, 1, rta.RT_TRAVERSAL_SKIP, 0
 seed = 1000
 checked = 0
 filter_tests = 0
+coop_scenes = 0
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
     depth, fan, leaf = int(rng.integers(2, 6)), int(rng.integers(2, 5)), int(rng.integers(1, 4))
@@ -65,12 +68,19 @@ while time.time() < t_end:
     regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
     rta.capi.debug_set(rta.capi.DEBUG_SKIP_VARIANT, 1)
     ref, st = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=True)
-    flavours = (0, 3, 7) if prec == rta.RT_F64 else (0, 3, 7, 19, 23)
+    flavours = (0, 3, 7, 19, 23)             # (f64: 19 / 23 put the f32 filter in front of the primary walk)
     for v in flavours:
         rta.capi.debug_set(rta.capi.DEBUG_SKIP_VARIANT, v)
         got, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
         assert np.array_equal(got, ref), "seed %d: flavour %d differs" % (seed, v)
-    if prec == rta.RT_F32:
+    if prec == rta.RT_F32 and spp == 1:
+        # round 4: every quad through the lane-cooperative gather (rt_coop.hpp) -- rays whose winner is nearer than an ancestor bound go back to the loops
+        rta.capi.debug_set(rta.capi.DEBUG_SKIP_VARIANT, -1)
+        with rta.capi.debug(rta.capi.DEBUG_COOP, 2):
+            got, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
+        assert np.array_equal(got, ref), "seed %d: the cooperative walk differs" % seed
+        coop_scenes += 1
+    if True:
         # the counting launch evaluated the filtered loops' bounds NEXT TO the reference's arithmetic for every test it made and
         # counts a violation whenever a bound rules out what the arithmetic finds (rt_skip.hpp, COUNT mode)
         assert rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_FILTER_VIOLATIONS) == 0, "seed %d: a bound ruled out a hit" % seed
@@ -93,4 +103,4 @@ while time.time() < t_end:
     if checked % 2000 == 0:
         print("fuzz: %d scenes so far" % checked, flush=True)        # a long run must not look hung
 print("fuzz: %d random scenes, all flavours identical (hierarchy: C++ / assembly / fused / filtered / two rays; flat: filtered scan / LDS kernels); "
-      "0 filter violations in %d counted tests" % (checked, filter_tests))
+      "the lane-cooperative walk on %d of them; 0 filter violations in %d counted tests" % (checked, coop_scenes, filter_tests))
