@@ -421,7 +421,9 @@ void filter_constants(rt_scene *s, const std::vector<rt::RawNode<T>> &raw, const
     if (const long long pc = g_knob[RT_DEBUG_FILTER_RO_PERCENT].load(std::memory_order_relaxed); pc >= 0) ro *= (double)pc / 100.0;   // tests only
     const double eps = 0x1p-24;
     // plane perpendicular to the shadow direction l = -light (f32 components)
-    const double l[3] = { -(double)(float)s->light[0], -(double)(float)s->light[1], -(double)(float)s->light[2] };
+    // plane perpendicular to the shadow direction l = -light: the f32 components an f32 scene's reference uses, the f64 ones for an f64 scene
+    const bool f64 = sizeof(T) == 8;
+    const double l[3] = { f64 ? -s->light[0] : -(double)(float)s->light[0], f64 ? -s->light[1] : -(double)(float)s->light[1], f64 ? -s->light[2] : -(double)(float)s->light[2] };
     const double l2 = l[0] * l[0] + l[1] * l[1] + l[2] * l[2], ln = std::sqrt(l2);
     const double lh[3] = { l[0] / ln, l[1] / ln, l[2] / ln };
     int ax = 0;
@@ -575,19 +577,24 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
     }
     if constexpr (sizeof(T) == 8) {
         // f64: FNode copies of the primary streams for the filtered primary walk (rt_skip.hpp k_build_fstream64)
-        auto derive64 = [&](const void *d_prim, size_t n_nodes, bool compacted, void **d_x, void **d_own) -> rt_status {
+        filter_constants<T>(s, raw, static_cast<const T *>(items));
+        HIP_TRY(hipMalloc(&s->d_fc, sizeof(rt::FilterConsts)));
+        HIP_TRY(hipMemcpy(s->d_fc, &s->fc, sizeof(rt::FilterConsts), hipMemcpyHostToDevice));
+        auto derive64 = [&](const void *d_prim, const void *d_shad, size_t n_nodes, bool compacted, void **d_x, void **d_xs, void **d_own) -> rt_status {
             const size_t total = n_nodes + rt::kNodePad;
             HIP_TRY(hipMalloc(d_x, sizeof(rt::FNode) * total));
+            HIP_TRY(hipMalloc(d_xs, sizeof(rt::FNodeS) * total));
             if (d_own) HIP_TRY(hipMalloc(d_own, sizeof(uint32_t) * total));
             hipLaunchKernelGGL(rt::k_build_fstream64, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, static_cast<const rt::Node<double> *>(d_prim),
-                               (unsigned)total, compacted, static_cast<rt::FNode *>(*d_x), d_own ? static_cast<uint32_t *>(*d_own) : nullptr);
+                               static_cast<const rt::Node<double> *>(d_shad), (unsigned)total, compacted, s->fc, static_cast<rt::FNode *>(*d_x),
+                               static_cast<rt::FNodeS *>(*d_xs), d_own ? static_cast<uint32_t *>(*d_own) : nullptr);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipDeviceSynchronize());
             return RT_OK;
         };
         if ((uint64_t)(s->n_nodes + rt::kNodePad) * sizeof(rt::Node<T>) <= 0xFFFFFFFFull) {
-            if ((st = derive64(s->d_prim, s->n_nodes, false, &s->d_xprim, nullptr)) != RT_OK) return st;
-            if (fused && (st = derive64(s->d_cprim, s->n_fnodes, true, &s->d_xcprim, &s->d_xown)) != RT_OK) return st;
+            if ((st = derive64(s->d_prim, s->d_shad, s->n_nodes, false, &s->d_xprim, &s->d_xshad, nullptr)) != RT_OK) return st;
+            if (fused && (st = derive64(s->d_cprim, s->d_cshad, s->n_fnodes, true, &s->d_xcprim, &s->d_xcshad, &s->d_xown)) != RT_OK) return st;
         }
     }
     if constexpr (sizeof(T) == 4) {

@@ -172,11 +172,33 @@ __device__ __forceinline__ float primary_filter_threshold64(double vv, double rr
 // FNode copy of an f64 scene's primary stream (plain or compacted; END nodes included) for the filtered f64 primary walk: f32 roundings of
 // v, the threshold above, skip_off in FNode units (half the Node<double> offset), the tag as in the f32 streams (a compacted BOUND's is 0:
 // its own sphere's rr is read from the exact record).
-__global__ void k_build_fstream64(const Node<double> *__restrict__ prim, unsigned n_total, bool compacted, FNode *__restrict__ xprim, uint32_t *__restrict__ own_item)
+__global__ void k_build_fstream64(const Node<double> *__restrict__ prim, const Node<double> *__restrict__ shad, unsigned n_total, bool compacted, FilterConsts fc,
+                                  FNode *__restrict__ xprim, FNodeS *__restrict__ xshad, uint32_t *__restrict__ own_item)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_total) return;
     const Node<double> p = prim[i];
+    {
+        // shadow walk: the f32 OUTER bound only (rt_skip_rot.hpp F64FS) -- the centre in the plane perpendicular to the light (formed in
+        // double, rounded once) and R2o from the f32 walk's formula with rr rounded UP (its margins cover an f32 reference's roundings, a
+        // superset of what the f64 reference needs)
+        const Node<double> sn = shad[i];
+        const bool s_end = (sn.item & kNodeEnd) != 0u, s_item = (sn.item & kNodeItem) != 0u;
+        const double cx = sn.a0 - (double)fc.m0[0], cy = sn.a1 - (double)fc.m0[1], cz = sn.a2 - (double)fc.m0[2];
+        FNodeS fs;
+        fs.w1 = s_end ? 0.0f : (float)((cx * (double)fc.e1[0] + cy * (double)fc.e1[1]) + cz * (double)fc.e1[2]);
+        fs.w2 = s_end ? 0.0f : (float)((cx * (double)fc.e2[0] + cy * (double)fc.e2[1]) + cz * (double)fc.e2[2]);
+        fs.cl = 0.0f;
+        float rr_up = (float)sn.a3;
+        if ((double)rr_up < sn.a3) rr_up = next_f32_above(rr_up);
+        float r2i_unused;
+        shadow_filter_bounds(fc, s_end ? __builtin_huge_valf() : rr_up, fs.r2o, r2i_unused);
+        if (!(__builtin_fabsf(fs.w1) < 3e38f && __builtin_fabsf(fs.w2) < 3e38f)) fs.r2o = __builtin_huge_valf();      // nothing known: never "beyond"
+        if (s_end || s_item) fs.r2o = -fs.r2o;
+        fs.r2i = -1.0f; fs.r2o_own = s_end ? -0.0f : 0.0f; fs.r2i_own = -1.0f;
+        fs.skip_off = sn.skip_off / 2u;
+        xshad[i] = fs;
+    }
     const bool end = (p.item & kNodeEnd) != 0u, item = (p.item & kNodeItem) != 0u;
     FNode fp;
     fp.a0 = (float)p.a0; fp.a1 = (float)p.a1; fp.a2 = (float)p.a2; fp.a3 = 0.0f; fp.a4 = 0.0f;
@@ -286,6 +308,15 @@ __device__ __forceinline__ void shadow_filter_origin(const FilterConsts &fc, flo
     q1 = __builtin_fmaf(z, fc.e1[2], __builtin_fmaf(y, fc.e1[1], x * fc.e1[0]));
     q2 = __builtin_fmaf(z, fc.e2[2], __builtin_fmaf(y, fc.e2[1], x * fc.e2[0]));
     ol = __builtin_fmaf(z, fc.l[2], __builtin_fmaf(y, fc.l[1], x * fc.l[0]));
+    const float d2 = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+    if (!(d2 <= fc.ro2)) q1 = __builtin_nanf("");
+}
+// ... of an f64 scene's shadow ray: the origin relative to m0 formed in double and rounded once, then the same f32 chains.
+__device__ __forceinline__ void shadow_filter_origin64(const FilterConsts &fc, double ox, double oy, double oz, float &q1, float &q2)
+{
+    const float x = (float)(ox - (double)fc.m0[0]), y = (float)(oy - (double)fc.m0[1]), z = (float)(oz - (double)fc.m0[2]);
+    q1 = __builtin_fmaf(z, fc.e1[2], __builtin_fmaf(y, fc.e1[1], x * fc.e1[0]));
+    q2 = __builtin_fmaf(z, fc.e2[2], __builtin_fmaf(y, fc.e2[1], x * fc.e2[0]));
     const float d2 = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
     if (!(d2 <= fc.ro2)) q1 = __builtin_nanf("");
 }
@@ -514,9 +545,17 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
                     }
                     if constexpr (COUNT && sizeof(T) == 8) {
                         if (sc.xprim && active) {              // the f64 primary walk's f32 filter: never in the way of a finite distance
-                            const bool pass = primary_filter_pass(sc.xprim[i], (float)dir.x, (float)dir.y, (float)dir.z);
+                            const FNode fn = sc.xprim[i];
+                            const bool pass = primary_filter_pass(fn, (float)dir.x, (float)dir.y, (float)dir.z);
                             c_fpass += pass ? 1u : 0u;
                             c_fviol += (!pass && d < inf<T>()) ? 1u : 0u;
+                            if (nd.is_bound() && pos && fn.f5 > -inf<float>()) {      // ... and the BOUND step's root-free decision, in f64
+                                int v = 1;
+                                if (!(0.0 < b)) v = 0;
+                                else if (b - best < 0.0) v = 2;
+                                else if (disc * 0x1.00001p+0 <= (b - best) * (b - best)) v = 0;
+                                c_fviol += ((v == 2 && !(d < best)) || (v == 0 && d < best)) ? 1u : 0u;
+                            }
                         }
                     }
                     if constexpr (COUNT && sizeof(T) == 4) {
@@ -596,6 +635,25 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
                         shadow_filter_origin(fc, sp.x, sp.y, sp.z, q1, q2, fol);
                         fa0 = fc.a0; fk1 = fc.k1; fkc = fc.kc;
                     }
+                    if constexpr ((VAR & 16) != 0 && sizeof(T) == 8) {
+                        // f64: the walk reads the FNodeS stream (positions in ITS units) and fetches a node's Node<double> record only when some live
+                        // lane is inside the node's outer bound
+                        constexpr unsigned kFStride = (unsigned)sizeof(FNodeS);
+                        const unsigned nbf = ((VAR & 4) ? sc.n_fnodes : sc.n_nodes) * kFStride;
+                        const FilterConsts fc = *sc.fc;
+                        float fq1, fq2;
+                        shadow_filter_origin64(fc, sp.x, sp.y, sp.z, fq1, fq2);
+                        resume = walk_s ? 0u : nbf;
+                        while (i < nbf) {
+                            unsigned fin;
+                            if constexpr ((VAR & 4) != 0) i = skip_shadow_rot_filt_fused(sc.xfshad, nbf, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, fq1, fq2, sc.fshad);
+                            else i = skip_shadow_rot_filt(sc.xshad, nbf, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, fq1, fq2, sc.shad);
+                            if (i >= nbf) break;
+                            if (fin) { occluded = true; resume = nbf; }
+                            i = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_min_u32(resume >= nbf ? nbf : (resume > i ? resume : i + kFStride)));
+                        }
+                        i = nb;                          // (the plain loop below has nothing left to do)
+                    }
                     while (i < nb) {
                         unsigned fin;
                         if constexpr ((VAR & 16) != 0 && sizeof(T) == 4) {
@@ -615,6 +673,7 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
                 [[maybe_unused]] float fq1 = 0.0f, fq2 = 0.0f, fql = 0.0f;
                 [[maybe_unused]] FilterConsts cfc{};
                 if constexpr (COUNT && sizeof(T) == 4) { if (sc.xshad) { cfc = *sc.fc; shadow_filter_origin(cfc, sp.x, sp.y, sp.z, fq1, fq2, fql); } }
+                if constexpr (COUNT && sizeof(T) == 8) { if (sc.xshad) { cfc = *sc.fc; shadow_filter_origin64(cfc, sp.x, sp.y, sp.z, fq1, fq2); } }
                 Node<T> nd = sc.shad[0];
                 for (;;) {
                     const bool active = i >= resume;
@@ -625,6 +684,15 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
                     {
                         const bool pos = !(disc < T(0.0));
                         if (pos) hit = !((b + ((VAR & 1) ? sqrt_rn_lean(disc) : rsqrt_exact(disc))) < T(0.0));
+                    }
+                    if constexpr (COUNT && sizeof(T) == 8) {
+                        if (sc.xshad && active) {              // the f64 shadow walk's f32 outer bound: "beyond it" must mean miss
+                            const FNodeS fsn = sc.xshad[i];
+                            const float t0 = fsn.w1 - fq1, t1 = fsn.w2 - fq2;
+                            const bool beyond = __builtin_fmaf(t1, t1, t0 * t0) > __builtin_fabsf(fsn.r2o);
+                            c_fpass += beyond ? 0u : 1u;
+                            c_fviol += (beyond && hit) ? 1u : 0u;
+                        }
                     }
                     if constexpr (COUNT && sizeof(T) == 4) {
                         if (sc.xshad && active) {

@@ -484,16 +484,76 @@ class F64F(F64):
         a.op("s_bitcmp1_b32 %s, 31" % self.item(c), "an ITEM or the END node?  (flag bits of the tag word)")
         a.op("s_cbranch_scc1 %s" % lab("flagged"))
 
+    shortcut = True
+
+    def bound_shortcut(self, a, c, lab):
+        """F32F.bound_shortcut in f64 (same three facts; K = 1 + 2^-20 again -- far more than f64 needs, but a literal an f64 instruction can
+        carry: its high word): saves the 17-instruction f64 root and the distance on the steps it settles."""
+        a.op("s_cmp_eq_u32 %s, 0xff800000" % self.thr(c), "T = -inf: the eye is not clearly outside this sphere -- the reference's arithmetic decides")
+        a.op("s_cbranch_scc1 %s" % lab("bexact"))
+        a.op("v_cmp_lt_f64_e64 %s, 0, %%[b]" % self.M54, "b > 0")
+        a.op("v_add_f64 %[t3], %[b], -%[best]", "w = b - hit.distance  (-inf while nothing was hit)")
+        a.op("v_cmp_gt_f64_e64 %s, 0, %%[t3]" % self.M56, "b < hit.distance: enters")
+        a.op("v_mul_f64 %[t4], %[t3], %[t3]", "w^2")
+        a.op("v_mul_f64 %[t0], %[kk], %[disc]", "disc (1 + 2^-20)")
+        a.op("v_cmp_le_f64_e64 %s, %%[t0], %%[t4]" % self.M58, "the root cannot reach down to b - hit.distance: culled")
+        a.op("s_and_b64 vcc, vcc, %s" % self.M54, "candidates in front of the eye")
+        a.op("s_or_b64 %s, %s, %s" % (self.M58, self.M58, self.M56), "settled lanes")
+        a.op("s_andn2_b64 %s, vcc, %s" % (self.M58, self.M58), "candidates nothing above settles")
+        a.op("s_cbranch_scc1 %s" % lab("bexact"), "(vcc lost only lanes with b <= 0, which the root path rejects as well)")
+        a.op("s_and_b64 vcc, vcc, %s" % self.M56, "go")
+        a.op("s_branch %s" % lab("bdecided"))
+
     def own_item_update(self, a, c):
         a.op("s_mov_b64 exec, vcc", "primitive.rs:80-83")
         a.op("v_mov_b64 %[best], %[t3]")
         a.op("v_mov_b32_e32 %%[bitem], %s" % self.NX, "WHERE it happened: the kernel finds the item in the stream's own_item table")
         a.op("s_mov_b64 exec, %s" % self.EX)
 
-    primary_decl = F64.primary_decl + "\n    float tf0, tf1;"
+    primary_decl = F64.primary_decl + "\n    float tf0, tf1;\n    const double kk = 0x1.00001p+0;      // 1 + 2^-20 (bound_shortcut)"
     primary_out = F64.primary_out + ', [tf0] "=&v"(tf0), [tf1] "=&v"(tf1)'
     primary_extra_args = ", float dxf, float dyf, float dzf, const void *exact"
-    primary_extra_in = ', [dxf] "v"(dxf), [dyf] "v"(dyf), [dzf] "v"(dzf), [base2] "s"(exact)'
+    primary_extra_in = ', [dxf] "v"(dxf), [dyf] "v"(dyf), [dzf] "v"(dzf), [base2] "s"(exact), [kk] "s"(kk)'
+
+
+class F64FS(F64F):
+    """The SHADOW walk of f64 scenes behind the f32 OUTER bound (round 4): the walk reads FNodeS records {w1, w2, -, R2o | ITEM / END
+    flag, -, -, -, skip_off} -- the centre's coordinates in the plane perpendicular to the light and the squared distance beyond which the
+    reference's test says miss, exactly the quantities of the f32 walk (their margins cover f32 reference roundings, a superset of what
+    an f64 reference needs) -- and fetches the node's Node<double> record for the reference's own sixteen operations only when some
+    live lane is inside that bound.  No inner bound: a hit is always established by the f64 arithmetic."""
+    primary_only = False
+
+    def item(self, b):
+        return "s%d" % (self.EXACT + 10)             # the exact record's item word
+
+    def skip(self, b):
+        return "s%d" % (self.fbank(b) + 7)           # FNodeS::skip_off
+
+    def s_skip(self, b):
+        return self.skip(b)
+
+    def kind_test(self, a, c, lab):
+        F64.kind_test(self, a, c, lab)
+
+    def shadow_filter(self, a, c):
+        a.op("v_sub_f32_e32 %%[tf0], s%d, %%[q1]" % (self.fbank(c) + 0), "P2 = |w - q|^2 in the plane perpendicular to the light (f32)")
+        a.op("v_sub_f32_e32 %%[tf1], s%d, %%[q2]" % (self.fbank(c) + 1))
+        a.op("v_mul_f32_e32 %[tf0], %[tf0], %[tf0]")
+        a.op("v_fma_f32 %[tf1], %[tf1], %[tf1], %[tf0]")
+        a.op("v_cmp_ngt_f32_e64 vcc, %%[tf1], |s%d|" % (self.fbank(c) + 3), "not beyond the outer bound (a NaN -- a ray the bounds do not cover -- passes)")
+
+    def shadow_terms(self, a, c):
+        tmp = "s76"
+        a.op("s_sub_u32 %s, %s, %d" % (tmp, self.NX, self.stride), "this node's offset in the filter stream ...")
+        a.op("s_lshl_b32 %s, %s, 1" % (tmp, tmp), "... and in the Node<double> stream")
+        a.op("s_load_dwordx16 %s, %%[base2], %s" % (sp(self.EXACT, 16), tmp), "its exact record")
+        a.op("s_waitcnt lgkmcnt(0)")
+        F64.shadow_terms(self, a, c)
+
+    shadow_decl = F64.shadow_decl + "\n    float tf0, tf1;"
+    shadow_out = F64.shadow_out + ', [tf0] "=&v"(tf0), [tf1] "=&v"(tf1)'
+    shadow_extra_in = ', [q1] "v"(q1), [q2] "v"(q2), [base2] "s"(exact)'
 
 
 def top_of(name):
@@ -906,7 +966,7 @@ def shadow(P, fused):
     a.op("s_mov_b64 %s, exec" % P.EX)
     P.load(a, 0, "%[start]")
     a.op("s_waitcnt lgkmcnt(0)")
-    assemble(a, P, shadow_copy_filt if P.filt else shadow_copy, fused)
+    assemble(a, P, shadow_copy_filt if (P.filt and not isinstance(P, F64FS)) else shadow_copy, fused)
     a.label(".Lrt_fin_%=")
     a.op("v_cndmask_b32_e64 %[fin], 0, 1, vcc", "the lanes whose ray hit the ITEM (or the group's own sphere) of the current node")
     a.op("s_sub_u32 %%[stop], %s, %d" % (P.NX, P.stride), "its position")
@@ -930,6 +990,11 @@ def main():
             text += PRIMARY_FN % dict(common, name="skip_primary_rot" + sfx, body=primary(P, fused), decl=P.primary_decl, out=P.primary_out)
             if not P.primary_only:
                 text += SHADOW_FN % dict(common, name="skip_shadow_rot" + sfx, body=shadow(P, fused), decl=P.shadow_decl, out=P.shadow_out)
+            elif isinstance(P, F64F):
+                S = F64FS()
+                sc = dict(common, shadow_extra_in=S.shadow_extra_in, shadow_extra_out="", shadow_extra_decl="",
+                          shadow_extra_args=", float q1, float q2, const void *exact")
+                text += SHADOW_FN % dict(sc, name="skip_shadow_rot" + sfx, body=shadow(S, fused), decl=S.shadow_decl, out=S.shadow_out)
     text += "}  // namespace rt\n"
     with open(OUT, "w") as f:
         f.write(text)
