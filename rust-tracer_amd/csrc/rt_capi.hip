@@ -1116,6 +1116,34 @@ rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std:
     return RT_OK;
 }
 
+// Builder threads must not outlive the HIP runtime: a process that exits without destroying its scenes (a Python interpreter does not run
+// every finalizer) still has them joined, by an exit handler registered when the first one is started -- later than the runtime's own
+// teardown was registered, hence run before it.
+std::mutex g_live_mu;
+std::vector<rt_scene *> g_live_scenes;           // scenes that ever started a builder and are not destroyed yet
+
+void join_builders_at_exit()
+{
+    std::vector<rt_scene *> live;
+    { std::lock_guard<std::mutex> lk(g_live_mu); live.swap(g_live_scenes); }
+    for (rt_scene *sc : live)
+        for (std::thread &b : sc->builders) if (b.joinable()) b.join();
+}
+
+void note_builder(rt_scene *s)
+{
+    static std::once_flag once;
+    std::call_once(once, [] { std::atexit(join_builders_at_exit); });
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    if (std::find(g_live_scenes.begin(), g_live_scenes.end(), s) == g_live_scenes.end()) g_live_scenes.push_back(s);
+}
+
+void forget_scene(rt_scene *s)
+{
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live_scenes.erase(std::remove(g_live_scenes.begin(), g_live_scenes.end(), s), g_live_scenes.end());
+}
+
 // The same from a thread of its own (see device_table): cost map, orders, uploads -- then the finished orders are handed to table `index`
 // under the scene's lock.  Whatever fails here only costs the ordering: the table keeps rendering through the tile table.
 void build_orders_async(rt_scene *s, size_t index, std::vector<rt::TileDev> tab, unsigned w, unsigned h, unsigned passes)
@@ -1189,6 +1217,7 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
             s->tables.push_back(std::move(t));
             if (in_background) {
                 const size_t index = s->tables.size() - 1;
+                note_builder(s);
                 s->builders.emplace_back([s, index, tab, w, h, passes] { build_orders_async(s, index, tab, w, h, passes); });
             }
             if (order_out && block_order_enabled()) *order_out = pick_order(s->tables.back());
@@ -1774,6 +1803,7 @@ rt_status rt_scene_destroy(rt_scene *s)
     if (!s) return RT_OK;
     (void)hipSetDevice(s->device);
     for (std::thread &b : s->builders) if (b.joinable()) b.join();          // dispatch orders still being made in the background
+    forget_scene(s);
     if (s->ahead.stream) { (void)hipStreamSynchronize(s->ahead.stream); (void)hipStreamDestroy(s->ahead.stream); }      // a pass rendered ahead may still be running
     s->pool.clear();
     for (auto &t : s->tables) { (void)hipFree(t.dev); for (auto &od : t.orders) release_order(od); if (t.order_arena) (void)hipFree(t.order_arena); }
