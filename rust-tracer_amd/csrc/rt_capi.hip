@@ -45,7 +45,9 @@ std::atomic<long long> g_count[RT_DEBUG_COUNTERS] = {};
 std::atomic<bool> g_trace_on{ false };
 std::mutex g_trace_mu;
 std::string g_trace_path;
-inline long long knob(int key) { return g_knob[key].load(std::memory_order_relaxed); }
+// (a background builder of dispatch orders works for a caller that had no control set: it must not see one that is set meanwhile)
+thread_local bool g_knobs_at_default = false;
+inline long long knob(int key) { return g_knobs_at_default ? -1 : g_knob[key].load(std::memory_order_relaxed); }
 
 rt_status hip_fail(hipError_t e, const char *what, int line)
 {
@@ -142,7 +144,8 @@ struct rt_scene {
     // first launches take turns, timed with a pair of events each, and the fastest is kept -- whether the cooperative walk pays depends on
     // how much of the pass is tail, which no estimate made here predicted as well as three measurements do.
     struct Order { rt::BlockDesc *dev_order = nullptr; uint32_t n_order = 0; uint32_t *dev_wg = nullptr; uint32_t n_wg = 0; uint64_t *dev_holes = nullptr; uint32_t n_holes = 0;
-                   hipEvent_t e0 = nullptr, e1 = nullptr; bool pending = false; float best_ms = 1e30f; int samples = 0; };
+                   // the trial: kOrderTrialSamples timed launches, each with an event pair of its own (they may all be in flight at once)
+                   hipEvent_t e0[3] = { nullptr, nullptr, nullptr }, e1[3] = { nullptr, nullptr, nullptr }; int issued = 0, harvested = 0; float best_ms = 1e30f; };
     struct CachedTable { std::vector<rt::TileDev> host; unsigned w = 0, h = 0, passes = 0; rt::TileDev *dev = nullptr; std::vector<Order> orders; int chosen = 0; unsigned turn = 0; bool building = false;
                          void *order_arena = nullptr;      // ONE device allocation holds every order's arrays (allocation calls wait for a busy device)
                          long long coop_key = 0; };
@@ -983,14 +986,15 @@ struct StageClock {
 
 void release_order(rt_scene::Order &od)           // (its arrays live in the table's arena)
 {
-    if (od.e0) (void)hipEventDestroy(od.e0);
-    if (od.e1) (void)hipEventDestroy(od.e1);
+    for (hipEvent_t e : od.e0) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : od.e1) if (e) (void)hipEventDestroy(e);
     od = rt_scene::Order{};
 }
 
 // The dispatch order a launch of this table uses (called under the scene's lock).  While a table with several candidates is undecided, its
-// launches take turns: a candidate that is not being timed right now is handed out with its pair of events (the caller records them around
-// the launch); results are collected here as they complete, and once every candidate has kOrderTrialSamples the fastest stays.
+// launches take turns: every candidate is handed out kOrderTrialSamples times with a pair of events (the caller records them around the
+// launch; all of them may be in flight at once -- a caller that enqueues far ahead of the device is not waited for); results are collected
+// here as they complete, and once every sample is in, the candidate with the smallest one stays.
 constexpr int kOrderTrialSamples = 3;
 rt::BlockList pick_order(rt_scene::CachedTable &t)
 {
@@ -1004,17 +1008,21 @@ rt::BlockList pick_order(rt_scene::CachedTable &t)
     if (t.chosen >= 0) return list_of(t.orders[(size_t)t.chosen]);
     bool all_done = true;
     for (auto &od : t.orders) {
-        if (od.pending && hipEventQuery(od.e1) == hipSuccess) {
+        while (od.harvested < od.issued && hipEventQuery(od.e1[od.harvested]) == hipSuccess) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, od.e0, od.e1) == hipSuccess && ms > 0.f) { od.best_ms = std::min(od.best_ms, ms); ++od.samples; }
-            od.pending = false;
+            if (hipEventElapsedTime(&ms, od.e0[od.harvested], od.e1[od.harvested]) == hipSuccess && ms > 0.f) od.best_ms = std::min(od.best_ms, ms);
+            ++od.harvested;
         }
         (void)hipGetLastError();                         // hipErrorNotReady is not an error here
-        all_done = all_done && od.samples >= kOrderTrialSamples;
+        all_done = all_done && od.harvested >= kOrderTrialSamples;
     }
-    if (all_done) {
+    auto best_known = [&t] {
         size_t best = 0;
         for (size_t i = 1; i < t.orders.size(); ++i) if (t.orders[i].best_ms < t.orders[best].best_ms) best = i;
+        return best;
+    };
+    if (all_done) {
+        const size_t best = best_known();
         t.chosen = (int)best;
         if (knob(RT_DEBUG_PRINT_STEPS) > 0) {
             fprintf(stderr, "[rtrace_hip] dispatch orders of a %zu-tile list, ms:", t.host.size());
@@ -1025,17 +1033,14 @@ rt::BlockList pick_order(rt_scene::CachedTable &t)
     }
     for (size_t k = 0; k < t.orders.size(); ++k) {
         rt_scene::Order &od = t.orders[(t.turn + k) % t.orders.size()];
-        if (od.pending || od.samples >= kOrderTrialSamples) continue;
+        if (od.issued >= kOrderTrialSamples) continue;
         t.turn = (unsigned)((t.turn + k + 1) % t.orders.size());
-        od.pending = true;
         rt::BlockList l = list_of(od);
-        l.ev0 = od.e0; l.ev1 = od.e1;
+        l.ev0 = od.e0[od.issued]; l.ev1 = od.e1[od.issued];
+        ++od.issued;
         return l;
     }
-    // every candidate that still needs samples is in flight: the best known so far, untimed
-    size_t best = 0;
-    for (size_t i = 1; i < t.orders.size(); ++i) if (t.orders[i].best_ms < t.orders[best].best_ms) best = i;
-    return list_of(t.orders[best]);
+    return list_of(t.orders[best_known()]);              // every sample is in flight: the best known so far, untimed
 }
 
 // Something about the dispatch was asked for explicitly (rt_debug.h: tests, A/B tools): then a tile list's orders are made at once, by the
@@ -1062,7 +1067,7 @@ rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std:
     const long long rays = knob(RT_DEBUG_SKIP_RAYS);
     const bool two_rays = s->fused && (rays < 0 ? skip2_by_default(total_px, 1, s->n_fnodes) : rays == 2);      // k_render_skip2 knows no cooperative quads
     std::vector<int> percents;
-    if (coop_pass && map && !two_rays && total_blocks <= kCoopPassBlocks && knob(RT_DEBUG_COOP) < 0 && knob(RT_DEBUG_COOP_THR) < 0) percents = { 0, 30, 40, 55 };
+    if (coop_pass && map && !two_rays && total_blocks <= kCoopPassBlocks && knob(RT_DEBUG_COOP) < 0 && knob(RT_DEBUG_COOP_THR) < 0) percents = { 0, 28, 34, 40, 48, 58 };
     else if (coop_pass && (knob(RT_DEBUG_COOP) > 0 || knob(RT_DEBUG_COOP_THR) >= 0)) percents = { 0, -1 };       // as asked, behind the plain one
     else percents = { -1 };
     // every candidate on the host first, then ONE device allocation for all their arrays: hipMalloc / hipFree wait for a busy device,
@@ -1106,11 +1111,12 @@ rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std:
     if (orders.size() > 1 && percents.size() == 2) chosen = 1;      // asked for explicitly
     else if (orders.size() > 1) {
         chosen = -1;                                                // to be decided by measurement
-        for (auto &od : orders) {
-            e = hipEventCreate(&od.e0);
-            if (e == hipSuccess) e = hipEventCreate(&od.e1);
-            if (e != hipSuccess) return fail(e);
-        }
+        for (auto &od : orders)
+            for (int k = 0; k < kOrderTrialSamples; ++k) {
+                e = hipEventCreate(&od.e0[k]);
+                if (e == hipSuccess) e = hipEventCreate(&od.e1[k]);
+                if (e != hipSuccess) return fail(e);
+            }
     }
     *arena_out = arena;
     return RT_OK;
@@ -1148,6 +1154,7 @@ void forget_scene(rt_scene *s)
 // under the scene's lock.  Whatever fails here only costs the ordering: the table keeps rendering through the tile table.
 void build_orders_async(rt_scene *s, size_t index, std::vector<rt::TileDev> tab, unsigned w, unsigned h, unsigned passes)
 {
+    g_knobs_at_default = true;                    // this thread only exists because no dispatch control was set when the list was first seen
     std::vector<rt_scene::Order> orders;
     int chosen = 0;
     void *arena = nullptr;

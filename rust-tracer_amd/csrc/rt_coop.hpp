@@ -69,6 +69,17 @@ __device__ __forceinline__ unsigned coop_lane_rank(unsigned long long mask)     
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
+// sqrt_rn_lean (rt_math.hpp) for an operand that is known to be finite and >= 0 here (disc of a scene rt_scene_create accepted: no
+// intermediate overflows): one range test instead of two.
+__device__ __forceinline__ float coop_sqrt(float x)
+{
+    if (__builtin_expect(!(x >= 0x1p-96f), 0)) return __builtin_sqrtf(x);
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y, h = 0.5f * y;
+    const float r = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(r, h, g);
+}
+
 // Sphere::distance_from_ray with the ray-independent terms pre-formed (primitive.rs:55-72), as the C++ loop of k_render_skip forms it.
 __device__ __forceinline__ float coop_primary_distance(const float4 g, float rr, float dx, float dy, float dz)
 {
@@ -76,7 +87,7 @@ __device__ __forceinline__ float coop_primary_distance(const float4 g, float rr,
     const float disc = (b * b - g.w) + rr;
     float d = inf<float>();
     if (!(disc < 0.0f)) {
-        const float s = sqrt_rn_lean(disc);
+        const float s = coop_sqrt(disc);
         const float t2 = b + s;
         if (!(t2 < 0.0f)) {
             const float t1 = b - s;
@@ -93,7 +104,7 @@ __device__ __forceinline__ bool coop_shadow_hit(const float4 g, float ox, float 
     const float b = dot(v, sdir);
     const float disc = (b * b - dot(v, v)) + g.w;
     bool hit = false;
-    if (!(disc < 0.0f)) hit = !((b + sqrt_rn_lean(disc)) < 0.0f);
+    if (!(disc < 0.0f)) hit = !((b + coop_sqrt(disc)) < 0.0f);
     return hit;
 }
 
@@ -139,8 +150,9 @@ __device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, u
         const unsigned cnt = (e.x >> 24) & 15u, ray = e.x >> 28;
         const bool valid = have && sl.k < cnt;
         const unsigned node = valid ? (e.x & 0xFFFFFFu) + sl.k : 0u;
-        const float4 g = *reinterpret_cast<const float4 *>(&cv.prim[node].a0);
-        const float4 h = *reinterpret_cast<const float4 *>(&cv.prim[node].a4);       // {rr, first, count, -}
+        const char *rec = reinterpret_cast<const char *>(cv.prim) + node * (unsigned)sizeof(CNode);        // (a 32-bit offset: fewer than 2^24 nodes)
+        const float4 g = *reinterpret_cast<const float4 *>(rec);
+        const float4 h = *reinterpret_cast<const float4 *>(rec + 16);                // {rr, first, count, -}
         const float rx = lds.ray[ray][0], ry = lds.ray[ray][1], rz = lds.ray[ray][2];
         const float d = coop_primary_distance(g, h.x, rx, ry, rz);
         const bool finite = valid && d < inf<float>();
@@ -158,7 +170,7 @@ __device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, u
         const unsigned long long pm = __ballot(push);
         const unsigned n_push = (unsigned)__popcll(pm);
         if (top + n_push > kCoopStack) { overflow = true; break; }
-        if (push) lds.stack[top + coop_lane_rank(pm)] = make_uint2(link_first | (link_count << 24) | (ray << 28), __float_as_uint(fmaxf(anc, d)));
+        if (push) lds.stack[top + coop_lane_rank(pm)] = make_uint2(link_first | (link_count << 24) | (ray << 28), max(e.y, __float_as_uint(d)));      // (both >= +0: the bit patterns order like the values)
         top = coop_uniform(top + n_push);
     }
     float best = inf<float>();
@@ -199,8 +211,9 @@ __device__ __forceinline__ void coop_shadow(const CoopView &cv, CoopLds &lds, un
         const unsigned cnt = (e.x >> 24) & 15u, ray = e.x >> 28;
         const bool valid = have && sl.k < cnt && ((occ >> ray) & 1u) == 0u;       // a ray that is occluded wants nothing more
         const unsigned node = valid ? (e.x & 0xFFFFFFu) + sl.k : 0u;
-        const float4 g = *reinterpret_cast<const float4 *>(&cv.shad[node].a0);
-        const uint2 link = *reinterpret_cast<const uint2 *>(&cv.shad[node].first);
+        const char *rec = reinterpret_cast<const char *>(cv.shad) + node * (unsigned)sizeof(CNode);
+        const float4 g = *reinterpret_cast<const float4 *>(rec);
+        const uint2 link = *reinterpret_cast<const uint2 *>(rec + 20);
         const float rx = lds.ray[ray][0], ry = lds.ray[ray][1], rz = lds.ray[ray][2];
         const bool hit = valid && coop_shadow_hit(g, rx, ry, rz, sdir);
         const bool item_hit = hit && link.y == 0u;
