@@ -22,14 +22,14 @@ def shard_us(w, h, spp, level, n, launches, rounds=6):
     out = torch.zeros(sum((r - l) * (t - b) for (l, t, r, b) in regs) * 4, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     times = []
-    for r in range(rounds + 3):
+    for r in range(rounds + 12):                # (the library tries its dispatch orders over a list's first ~150 launches: measure after that)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(launches):
             dev.render_tiles_device((w, h, spp), regs_c, out.data_ptr(), stream, rta.RT_TRAVERSAL_SKIP)
         e1.record()
         torch.cuda.synchronize()
-        if r >= 3:
+        if r >= 12:
             times.append(e0.elapsed_time(e1) / launches * 1e3)
     return round(float(np.median(times)), 1)
 
