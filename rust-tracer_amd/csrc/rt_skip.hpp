@@ -336,11 +336,22 @@ __device__ __forceinline__ int bound_shortcut_verdict(float b, float disc, float
     return disc * k <= w * w ? 0 : 1;                   // s <= sqrt(disc)(1 + 2^-24) <= b - hit.distance
 }
 
+// The squared in-plane distance as the shadow loops form it.  SUM: the one-ray loops (tools/gen_skip_asm.py packed_p2 -- both differences and
+// both squares are one packed instruction each, then the sum: three roundings); otherwise the two-ray loops (rt_skip2_rot.hpp: the second
+// square is fused into the sum).  Either is within a factor (1 +- 2.01 eps) of the exact value for the rounded differences, which is what
+// the bounds' margins assume (NOTES.md, "Shadow rays, two-sided").
+template <bool SUM>
+__device__ __forceinline__ float shadow_p2(float w1, float w2, float q1, float q2)
+{
+    const float t0 = w1 - q1, t1 = w2 - q2;
+    if constexpr (SUM) return t0 * t0 + t1 * t1;                     // -ffp-contract=off: never fused
+    else return __builtin_fmaf(t1, t1, t0 * t0);
+}
 // 0: the bounds say MISS, 1: they cannot tell, 2: they say HIT
+template <bool SUM>
 __device__ __forceinline__ int shadow_filter_verdict(const FNodeS &f, const FilterConsts &fc, float q1, float q2, float ol)
 {
-    const float t0 = f.w1 - q1, t1 = f.w2 - q2;
-    const float p2 = __builtin_fmaf(t1, t1, t0 * t0);
+    const float p2 = shadow_p2<SUM>(f.w1, f.w2, q1, q2);
     if (p2 > __builtin_fabsf(f.r2o)) return 0;
     const float av = f.cl - ol, inn = __builtin_fmaf(av, av, p2);
     if (__builtin_fmaf(inn, fc.k1, p2) <= f.r2i && (fc.a0 <= av || inn <= f.r2i)) return 2;
@@ -688,17 +699,18 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
                     if constexpr (COUNT && sizeof(T) == 8) {
                         if (sc.xshad && active) {              // the f64 shadow walk's f32 outer bound: "beyond it" must mean miss
                             const FNodeS fsn = sc.xshad[i];
-                            const float t0 = fsn.w1 - fq1, t1 = fsn.w2 - fq2;
-                            const bool beyond = __builtin_fmaf(t1, t1, t0 * t0) > __builtin_fabsf(fsn.r2o);
+                            const bool beyond = shadow_p2<true>(fsn.w1, fsn.w2, fq1, fq2) > __builtin_fabsf(fsn.r2o);
                             c_fpass += beyond ? 0u : 1u;
                             c_fviol += (beyond && hit) ? 1u : 0u;
                         }
                     }
                     if constexpr (COUNT && sizeof(T) == 4) {
                         if (sc.xshad && active) {
-                            const int verdict = shadow_filter_verdict(sc.xshad[i], cfc, fq1, fq2, fql);
+                            const int verdict = shadow_filter_verdict<true>(sc.xshad[i], cfc, fq1, fq2, fql);
+                            const int verdict2 = shadow_filter_verdict<false>(sc.xshad[i], cfc, fq1, fq2, fql);    // the two-ray loops' rounding
                             c_fpass += verdict == 1 ? 1u : 0u;              // tests the bounds leave to the reference's arithmetic
                             c_fviol += ((verdict == 0 && hit) || (verdict == 2 && !hit)) ? 1u : 0u;
+                            c_fviol += ((verdict2 == 0 && hit) || (verdict2 == 2 && !hit)) ? 1u : 0u;
                         }
                     }
                     unsigned ni;

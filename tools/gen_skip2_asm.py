@@ -333,6 +333,34 @@ def primary_update(a, r, h, c, done, own=False):
     a.label(done)
 
 
+KK = 82                         # s82: 1 + 2^-20 (bound_shortcut), the low half of the pair a packed instruction reads it through
+G = (sp(78), sp(80))            # primary loop, per half: the rays the root-free decision lets enter (the shadow loops keep the light there)
+SGPR_LAST_PRIMARY = 83
+
+
+def bound_shortcut(a, r, c, lab):
+    """Primary BOUND step, C[h] = awake rays of half h with disc >= 0: decide `d < hit.distance` (group.rs:73) WITHOUT the root wherever the
+    reference's own b and disc already settle it -- tools/gen_skip_asm.py F32F.bound_shortcut (NOTES.md A.1), here for both rays
+    of a lane: w = b - hit.distance, w^2 and disc (1 + 2^-20) are one packed instruction each.  A ray nothing settles sends the whole step
+    through the root (lab bexact: C[h] lost only rays with b <= 0, which that path rejects as well)."""
+    a.op("s_cmp_eq_u32 %s, 0xff800000" % thr(c), "T = -inf: the eye is not clearly outside this sphere -- the reference's arithmetic decides")
+    a.op("s_cbranch_scc1 %s" % lab("bexact"))
+    pk(a, "add", r.T1.p, r.B.p, r.BEST.p, neg_y=True, comment="w = b - hit.distance  (-inf while nothing was hit)")
+    pk(a, "mul", r.T0.p, r.DISC.p, None, sy=KK, comment="disc (1 + 2^-20)")
+    pk(a, "mul", r.T2.p, r.T1.p, r.T1.p, comment="w^2")
+    for h in range(2):
+        a.op("v_cmp_lt_f32_e64 %s, 0, %s" % (M, r.B.h[h]), "b > 0" if h == 0 else None)
+        a.op("s_and_b64 %s, %s, %s" % (C[h], C[h], M), "candidates in front of the eye" if h == 0 else None)
+        a.op("v_cmp_gt_f32_e64 %s, 0, %s" % (G[h], r.T1.h[h]), "b < hit.distance: enters" if h == 0 else None)
+        a.op("v_cmp_le_f32_e64 %s, %s, %s" % (M2, r.T0.h[h], r.T2.h[h]), "the root cannot reach down to b - hit.distance: culled" if h == 0 else None)
+        a.op("s_or_b64 %s, %s, %s" % (M2, M2, G[h]), "settled rays" if h == 0 else None)
+        a.op("s_andn2_b64 %s, %s, %s" % (M2, C[h], M2), "candidates nothing above settles" if h == 0 else None)
+        a.op("s_cbranch_scc1 %s" % lab("bexact"))
+    for h in range(2):
+        a.op("s_and_b64 %s, %s, %s" % (C[h], C[h], G[h]), "go" if h == 0 else None)
+    a.op("s_branch %s" % lab("bdecided"))
+
+
 def primary_copy(r, name):
     c, n, s = COPIES[name]
     lab = lambda x: ".Lr2_%s_%s_%%=" % (name, x)
@@ -350,8 +378,11 @@ def primary_copy(r, name):
     k.op("s_bitcmp1_b32 %s, 31" % tag(c), "an ITEM or the END node?  (flag bits of the tag word)")
     k.op("s_cbranch_scc1 %s" % lab("flagged"))
     # BOUND (group.rs:73)
+    bound_shortcut(k, r, c, lab)
+    k.label(lab("bexact"))
     for h in range(2):
         k.label(primary_go(k, r, h, "b", lab, tinies))
+    k.label(lab("bdecided"))
     k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
     k.op("s_cbranch_scc0 %s" % lab("skip"), "nobody enters (the rays that culled it are awake again at `skip`)")
     load(k, n, NX, "somebody enters: fetch the group's first child")
@@ -733,6 +764,7 @@ def primary():
         a.op("v_mov_b32_e32 %s, 0" % r.BITEM.h[h])
     a.op("s_mov_b32 %s, %d" % (NX, STRIDE))
     a.op("s_mov_b64 %s, exec" % EX)
+    a.op("s_mov_b32 s%d, %%[kk]" % KK, "1 + 2^-20 where a packed instruction can read it")
     load(a, 0, "0x0")
     a.op("s_waitcnt lgkmcnt(0)")
     assemble(a, r, primary_copy)
@@ -786,7 +818,8 @@ HEADER = """// rt_skip2_rot.hpp -- GENERATED by tools/gen_skip2_asm.py; edit the
 // for operation, and the same walk as the one-ray loops (tools/gen_skip_asm.py documents it).
 //
 // The loops own v[32:63] and s[36:81] (clobbers): s[36:59] three node banks, s60 NX, s[62:65] awake masks, s[66:69] candidate /
-// go masks, s[70:77] scratch masks and EXEC at entry, s[78:80] the shadow rays' direction.
+// go masks, s[70:77] scratch masks and EXEC at entry, s[78:80] the shadow rays' direction (primary loop: s[78:81] the masks of the
+// root-free BOUND decision, s82 its constant).
 #pragma once
 #include "rt_kernels.hpp"
 
@@ -802,12 +835,12 @@ PRIMARY_FN = """// Primary-ray traversal: s.group.intersect(&mut h, r) for the w
 __device__ __forceinline__ void skip2_primary_rot_fused(const void *nodes, const float (&dx)[2], const float (&dy)[2], const float (&dz)[2],
                                                         const unsigned (&resume)[2], float (&best_out)[2], unsigned (&item_out)[2])
 {
-    const float tiny = 0x1p-96f;
+    const float tiny = 0x1p-96f, kk = 0x1.00001p+0f;       // kk = 1 + 2^-20 (bound_shortcut)
     asm volatile(
 %(body)s
         : [best0] "=v"(best_out[0]), [best1] "=v"(best_out[1]), [item0] "=v"(item_out[0]), [item1] "=v"(item_out[1])
         : [base] "s"(nodes), [dx0] "v"(dx[0]), [dx1] "v"(dx[1]), [dy0] "v"(dy[0]), [dy1] "v"(dy[1]), [dz0] "v"(dz[0]), [dz1] "v"(dz[1]),
-          [res0] "v"(resume[0]), [res1] "v"(resume[1]), [tiny] "s"(tiny)
+          [res0] "v"(resume[0]), [res1] "v"(resume[1]), [tiny] "s"(tiny), [kk] "s"(kk)
         : %(clobbers)s);
 }
 
@@ -873,7 +906,7 @@ def clobbers(last=SGPR_LAST):
 
 def main():
     text = HEADER
-    text += PRIMARY_FN % {"body": primary(), "clobbers": clobbers()}
+    text += PRIMARY_FN % {"body": primary(), "clobbers": clobbers(SGPR_LAST_PRIMARY)}
     text += SHADOW_FN % {"body": shadow(), "clobbers": clobbers()}
     text += SHADOW_FN_FILT % {"body": shadow_filt(), "clobbers": clobbers(SGPR_LAST_FILT)}
     text += "}  // namespace rt\n"

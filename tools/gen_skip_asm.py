@@ -76,6 +76,26 @@ def sp(first, n=2):
     return "s[%d:%d]" % (first, first + n - 1)
 
 
+# The shadow bound's in-plane distance on packed math: the lane's (q1, q2) sit in an aligned register pair, the node's (w1, w2) are the first
+# two words of its FNodeS record -- both differences, then both squares, are ONE v_pk_*_f32 each (a packed instruction issues in the 4 cycles
+# of a plain one, profiles/r02_valu_issue_probe.json).  The pairs are physical registers because inline assembly cannot name the halves of
+# a 64-bit operand: QQ is an input ("{v[40:41]}"), TT a clobber.
+QQ, TT = (30, 31), (32, 33)
+PACKED_CLOBBERS = ['"v%d"' % r for r in TT]
+QQ_IN = '[qq] "{v[%d:%d]}"(qq)' % QQ
+QQ_DECL = "\n    const rt_v2f qq = { q1, q2 };"
+
+
+def packed_p2(a, bank, dst):
+    """dst = RN(RN((w1 - q1)^2) + RN((w2 - q2)^2)) -- shadow_p2() in rt_skip.hpp, which the counting launches evaluate."""
+    assert bank % 2 == 0
+    tt = "v[%d:%d]" % TT
+    a.op("v_pk_add_f32 %s, s[%d:%d], v[%d:%d] neg_lo:[0,1] neg_hi:[0,1]" % ((tt, bank, bank + 1) + QQ),
+         "P2 = |w - q|^2 in the plane perpendicular to the light: (w1 - q1, w2 - q2) ...")
+    a.op("v_pk_mul_f32 %s, %s, %s" % (tt, tt, tt), "... their squares ...")
+    a.op("v_add_f32_e32 %s, v%d, v%d" % ((dst,) + TT), "... and the sum")
+
+
 class Prec:
     """Register plan and the precision-dependent instruction sequences."""
     filt = False
@@ -86,6 +106,8 @@ class Prec:
     shadow_extra_in = ""
     shadow_extra_out = ""
     shadow_extra_decl = ""
+    shadow_vclobbers = []            # vector registers the shadow loops name directly (packed_p2)
+    shadow_subst = ()                # named operands that are such registers
 
     def kind_test(self, a, c, lab):
         a.op("s_cmp_gt_u32 %s, %s" % (self.item(c), FLAG_LIMIT), "an ITEM or the END node?  (flag bits of the item word)")
@@ -383,10 +405,7 @@ class F32F(F32):
     def s_skip(self, b): return "s%d" % (self.bank(b) + 7)
 
     def shadow_filter(self, a, c):
-        a.op("v_sub_f32_e32 %%[t0], %s, %%[q1]" % self.s_w1(c), "P2 = |w - q|^2 in the plane perpendicular to the light")
-        a.op("v_sub_f32_e32 %%[t1], %s, %%[q2]" % self.s_w2(c))
-        a.op("v_mul_f32_e32 %[t0], %[t0], %[t0]")
-        a.op("v_fma_f32 %[p2], %[t1], %[t1], %[t0]")
+        packed_p2(a, self.bank(c), "%[p2]")
         a.op("v_cmp_ngt_f32_e64 vcc, %%[p2], |%s|" % self.s_r2o(c), "not beyond the outer bound (a NaN -- a ray the bounds do not cover -- passes)")
 
     def kind_test(self, a, c, lab):
@@ -425,9 +444,16 @@ class F32F(F32):
         a.op("v_mov_b32_e32 %%[bitem], %s" % self.NX)
         a.op("s_mov_b64 exec, %s" % self.EX)
 
-    shadow_extra_in = ', [q1] "v"(q1), [q2] "v"(q2), [ol] "v"(ol), [a0] "s"(a0), [k1] "s"(k1), [kc] "v"(kc), [base2] "s"(exact)'
+    shadow_extra_in = ', ' + QQ_IN + ', [ol] "v"(ol), [a0] "s"(a0), [k1] "s"(k1), [kc] "v"(kc), [base2] "s"(exact)'
     shadow_extra_out = ', [p2] "=&v"(p2), [av] "=&v"(av), [inn] "=&v"(inn)'
-    shadow_extra_decl = "\n    float p2, av, inn;"
+    shadow_extra_decl = "\n    float p2, av, inn;" + QQ_DECL
+    shadow_vclobbers = PACKED_CLOBBERS
+    # the shadow loops' temporaries t0 / t1 ARE the halves of TT (two registers fewer at the statement: the lane-cooperative flavour of the
+    # kernel sits at the 64-register limit of 8 waves per SIMD)
+    # ... and b*b - vv / the discriminant of the reference's arithmetic (shadow_exact) take the registers of v.y / v.x, dead by then
+    shadow_decl = F32.shadow_decl.replace("float t0, t1, ", "float ").replace("b, q, disc, root", "b, root")
+    shadow_out = F32.shadow_out.replace('[t0] "=&v"(t0), [t1] "=&v"(t1), ', "").replace(' [q] "=&v"(q),\n          [disc] "=&v"(disc),', "")
+    shadow_subst = (("%[t0]", "v%d" % TT[0]), ("%[t1]", "v%d" % TT[1]), ("%[q]", "%[vy]"), ("%[disc]", "%[vx]"))
 
 
 class F64F(F64):
@@ -537,10 +563,7 @@ class F64FS(F64F):
         F64.kind_test(self, a, c, lab)
 
     def shadow_filter(self, a, c):
-        a.op("v_sub_f32_e32 %%[tf0], s%d, %%[q1]" % (self.fbank(c) + 0), "P2 = |w - q|^2 in the plane perpendicular to the light (f32)")
-        a.op("v_sub_f32_e32 %%[tf1], s%d, %%[q2]" % (self.fbank(c) + 1))
-        a.op("v_mul_f32_e32 %[tf0], %[tf0], %[tf0]")
-        a.op("v_fma_f32 %[tf1], %[tf1], %[tf1], %[tf0]")
+        packed_p2(a, self.fbank(c), "%[tf1]")
         a.op("v_cmp_ngt_f32_e64 vcc, %%[tf1], |s%d|" % (self.fbank(c) + 3), "not beyond the outer bound (a NaN -- a ray the bounds do not cover -- passes)")
 
     def shadow_terms(self, a, c):
@@ -551,9 +574,10 @@ class F64FS(F64F):
         a.op("s_waitcnt lgkmcnt(0)")
         F64.shadow_terms(self, a, c)
 
-    shadow_decl = F64.shadow_decl + "\n    float tf0, tf1;"
-    shadow_out = F64.shadow_out + ', [tf0] "=&v"(tf0), [tf1] "=&v"(tf1)'
-    shadow_extra_in = ', [q1] "v"(q1), [q2] "v"(q2), [base2] "s"(exact)'
+    shadow_decl = F64.shadow_decl + "\n    float tf1;" + QQ_DECL
+    shadow_out = F64.shadow_out + ', [tf1] "=&v"(tf1)'
+    shadow_extra_in = ', ' + QQ_IN + ', [base2] "s"(exact)'
+    shadow_vclobbers = PACKED_CLOBBERS
 
 
 def top_of(name):
@@ -589,6 +613,10 @@ def step_top(a, P, c, n, s, terms):
     a.op("v_cmp_gt_u32_e64 %s, %s, %%[resume]" % (P.ACT, P.NX), "active = i >= resume  (NX = i + stride)")
     if P.filt:
         (P.primary_filter if terms == P.primary_terms else P.shadow_filter)(a, c)
+        for _ in range(int(os.environ.get("RT_GEN_PAD_VALU", "0")) if P.ctype == "float" else 0):   # design-time probe: what one more instruction per step costs
+            a.op("v_max_f32_e32 %[t2], %[t2], %[t2]")
+        for _ in range(int(os.environ.get("RT_GEN_PAD_SALU", "0")) if P.ctype == "float" else 0):
+            a.op("s_mov_b32 %s, %s" % (P.TINY.split(":")[0].replace("s[", "s"), P.NX))
         a.op("s_and_b64 vcc, vcc, %s" % P.ACT, "live lanes the bound cannot rule out")
         return
     terms(a, c)
@@ -879,6 +907,8 @@ HEADER = """// rt_skip_rot.hpp -- GENERATED by tools/gen_skip_asm.py; edit the g
 
 namespace rt {
 
+typedef float rt_v2f __attribute__((ext_vector_type(2)));      // an aligned register pair (packed_p2 in the generator)
+
 """
 
 PRIMARY_FN = """// Primary-ray traversal: s.group.intersect(&mut h, r) for all 64 rays of the wave.  nodes: Node<%(ctype)s>[n + 3], END at [n];
@@ -925,8 +955,8 @@ __device__ __forceinline__ unsigned %(name)s(const void *nodes, unsigned n_bytes
 """
 
 
-def clobbers(P):
-    regs = ['"s%d"' % r for r in range(P.clobber_lo, P.clobber_hi + 1)]
+def clobbers(P, vregs=()):
+    regs = ['"s%d"' % r for r in range(P.clobber_lo, P.clobber_hi + 1)] + list(vregs)
     lines, cur = [], '"memory", "vcc", "scc"'
     for r in regs:
         if len(cur) + len(r) + 2 > 118:
@@ -975,7 +1005,10 @@ def shadow(P, fused):
     a.op("s_mov_b32 %[stop], %[n]", "stream finished")
     a.label(".Lrt_out_%=")
     a.op("s_waitcnt lgkmcnt(0)")
-    return a.render()
+    text = a.render()
+    for name, reg in P.shadow_subst:
+        text = text.replace(name, reg)
+    return text
 
 
 def main():
@@ -989,10 +1022,11 @@ def main():
                       "primary_extra_args": P.primary_extra_args, "primary_extra_in": P.primary_extra_in}
             text += PRIMARY_FN % dict(common, name="skip_primary_rot" + sfx, body=primary(P, fused), decl=P.primary_decl, out=P.primary_out)
             if not P.primary_only:
-                text += SHADOW_FN % dict(common, name="skip_shadow_rot" + sfx, body=shadow(P, fused), decl=P.shadow_decl, out=P.shadow_out)
+                text += SHADOW_FN % dict(common, name="skip_shadow_rot" + sfx, body=shadow(P, fused), decl=P.shadow_decl, out=P.shadow_out,
+                                         clobbers=clobbers(P, P.shadow_vclobbers))
             elif isinstance(P, F64F):
                 S = F64FS()
-                sc = dict(common, shadow_extra_in=S.shadow_extra_in, shadow_extra_out="", shadow_extra_decl="",
+                sc = dict(common, shadow_extra_in=S.shadow_extra_in, shadow_extra_out="", shadow_extra_decl="", clobbers=clobbers(S, S.shadow_vclobbers),
                           shadow_extra_args=", float q1, float q2, const void *exact")
                 text += SHADOW_FN % dict(sc, name="skip_shadow_rot" + sfx, body=shadow(S, fused), decl=S.shadow_decl, out=S.shadow_out)
     text += "}  // namespace rt\n"
