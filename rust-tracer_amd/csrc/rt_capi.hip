@@ -23,6 +23,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -148,9 +150,22 @@ struct rt_scene {
                    hipEvent_t e0[3] = { nullptr, nullptr, nullptr }, e1[3] = { nullptr, nullptr, nullptr }; int issued = 0, harvested = 0; float best_ms = 1e30f; };
     struct CachedTable { std::vector<rt::TileDev> host; unsigned w = 0, h = 0, passes = 0; rt::TileDev *dev = nullptr; std::vector<Order> orders; int chosen = 0; unsigned turn = 0; bool building = false;
                          void *order_arena = nullptr;      // ONE device allocation holds every order's arrays (allocation calls wait for a busy device)
-                         long long coop_key = 0; };
+                         long long coop_key = 0;
+                         // a table uploaded asynchronously on its first caller's stream (device_table): until `landed` has completed, launches on
+                         // OTHER streams wait for it
+                         hipEvent_t landed = nullptr; hipStream_t landed_on = nullptr; };
     std::vector<CachedTable> tables;
     std::vector<std::thread> builders;           // dispatch orders being made in the background (build_orders_async); joined by rt_scene_destroy
+    // The scene's own worker thread (started by rt_scene_create next to the cost map): it makes the dispatch orders of new tile lists --
+    // handing it a list costs the first frame a few microseconds, starting a thread cost it 75-115 us (`builders` is the fallback)
+    std::thread worker;
+    std::mutex wmu;
+    std::condition_variable wcv;
+    std::deque<std::function<void()>> wjobs;
+    bool wstop = false;
+    // pinned staging for the tile tables of new lists (bump-allocated, never reused: a copy may still be queued behind the caller's kernels)
+    char *h_tab_stage = nullptr;
+    size_t tab_stage_used = 0;
     // Tests per primary ray (its shadow ray included) on a kCostRes x kCostRes grid over the camera's field of view,
     // rendered once per scene with the counting kernel.  It only ever decides the ORDER in which blocks are dispatched.
     std::once_flag cost_once;
@@ -716,6 +731,7 @@ rt_status upload_tiles(Context *c, const std::vector<rt::TileDev> &tab, hipStrea
 }
 
 constexpr unsigned kCostRes = 256;
+constexpr size_t kTableStageBytes = 256 * 1024;       // pinned staging for the tile tables of new lists (a 1080p list of 64x64 buckets: 10 KB)
 
 // The scene's cost map: one counting render of a kCostRes^2 image (same camera: x spans the same field of view at every
 // width), each lane storing the number of tests its pixel took.
@@ -730,7 +746,8 @@ rt_status start_cost_map(rt_scene *s)
     constexpr size_t kTileBytes = 256, kPx = (size_t)R * R * 4, kCnt = sizeof(rt::Counters) * rt::kCounterStripes;
     HIP_TRY(hipStreamCreateWithFlags(&s->cost_stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&s->d_cost_arena, kTileBytes + 2 * kPx + kCnt));
-    HIP_TRY(hipHostMalloc(&s->h_cost, kPx + kTileBytes, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&s->h_cost, kPx + kTileBytes + kTableStageBytes, hipHostMallocDefault));
+    s->h_tab_stage = static_cast<char *>(s->h_cost) + kPx + kTileBytes;
     hipStream_t stream = s->cost_stream;
     char *base = static_cast<char *>(s->d_cost_arena);
     rt::TileDev *d_tile = reinterpret_cast<rt::TileDev *>(base);
@@ -1125,6 +1142,7 @@ rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std:
 // Builder threads must not outlive the HIP runtime: a process that exits without destroying its scenes (a Python interpreter does not run
 // every finalizer) still has them joined, by an exit handler registered when the first one is started -- later than the runtime's own
 // teardown was registered, hence run before it.
+void stop_worker(rt_scene *s);
 std::mutex g_live_mu;
 std::vector<rt_scene *> g_live_scenes;           // scenes that ever started a builder and are not destroyed yet
 
@@ -1132,8 +1150,10 @@ void join_builders_at_exit()
 {
     std::vector<rt_scene *> live;
     { std::lock_guard<std::mutex> lk(g_live_mu); live.swap(g_live_scenes); }
-    for (rt_scene *sc : live)
+    for (rt_scene *sc : live) {
         for (std::thread &b : sc->builders) if (b.joinable()) b.join();
+        stop_worker(sc);
+    }
 }
 
 void note_builder(rt_scene *s)
@@ -1148,6 +1168,36 @@ void forget_scene(rt_scene *s)
 {
     std::lock_guard<std::mutex> lk(g_live_mu);
     g_live_scenes.erase(std::remove(g_live_scenes.begin(), g_live_scenes.end(), s), g_live_scenes.end());
+}
+
+// The scene's worker: runs the jobs handed to it one after the other; on stop, the ones still queued as well (they are finite and somebody
+// may be waiting for `building` to clear).
+void worker_main(rt_scene *s)
+{
+    g_knobs_at_default = true;                    // it only ever serves lists that were first seen with no dispatch control set
+    (void)hipSetDevice(s->device);
+    for (;;) {
+        std::function<void()> job;
+        {
+            std::unique_lock<std::mutex> lk(s->wmu);
+            s->wcv.wait(lk, [s] { return s->wstop || !s->wjobs.empty(); });
+            if (s->wjobs.empty()) return;
+            job = std::move(s->wjobs.front());
+            s->wjobs.pop_front();
+        }
+        // let the caller's first launch (and whoever waits for it) have the runtime to itself: the orders' allocations and blocking copies
+        // took 20-50 us out of a one-shot caller's first frame when they started at once, and nobody misses them for another 0.3 ms
+        if (!s->wstop) std::this_thread::sleep_for(std::chrono::microseconds(300));
+        job();
+    }
+}
+
+void stop_worker(rt_scene *s)
+{
+    if (!s->worker.joinable()) return;
+    { std::lock_guard<std::mutex> lk(s->wmu); s->wstop = true; }
+    s->wcv.notify_all();
+    s->worker.join();
 }
 
 // The same from a thread of its own (see device_table): cost map, orders, uploads -- then the finished orders are handed to table `index`
@@ -1191,21 +1241,44 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
             if ((!o || (t.w == w && t.h == h && t.passes == passes && (!order_out || t.coop_key == coop_key))) && t.host.size() == tab.size() &&
                 memcmp(t.host.data(), tab.data(), bytes) == 0) {
                 *out = t.dev;
+                if (t.landed) {                      // uploaded on its first caller's stream: has it arrived?
+                    if (hipEventQuery(t.landed) == hipSuccess) { (void)hipEventDestroy(t.landed); t.landed = nullptr; }
+                    else {
+                        (void)hipGetLastError();
+                        if (stream != t.landed_on) HIP_TRY(hipStreamWaitEvent(stream, t.landed, 0));
+                    }
+                }
                 if (order_out && block_order_enabled()) *order_out = pick_order(t);
                 return RT_OK;
             }
         if (s->tables.size() < kMaxCachedTables) {
             rt_scene::CachedTable t;
-            HIP_TRY(hipMalloc(&t.dev, bytes));
-            hipError_t e = hipMemcpy(t.dev, tab.data(), bytes, hipMemcpyHostToDevice);    // blocking, once per table
-            clk.lap("tile table upload");
-            if (e != hipSuccess) { (void)hipFree(t.dev); return hip_fail(e, "hipMemcpy(tile table)", __LINE__); }
-            auto drop = [&t] { (void)hipFree(t.dev); for (auto &od : t.orders) release_order(od); if (t.order_arena) (void)hipFree(t.order_arena); };
             // The dispatch orders (and the scene's cost map they are made from) cost the host a few milliseconds: unless something was asked
-            // for explicitly (rt_debug.h), they are made by a thread of their own while this and the next launches find their blocks through
+            // for explicitly (rt_debug.h), they are made by the scene's worker thread while this and the next launches find their blocks through
             // the tile table -- a one-shot caller (`make image`) never waits for them, a scheduler gets them a few frames in.
             const bool want_orders = o && order_out;
             const bool in_background = want_orders && !order_knobs_set();
+            HIP_TRY(hipMalloc(&t.dev, bytes));
+            auto drop = [&t] { (void)hipFree(t.dev); for (auto &od : t.orders) release_order(od); if (t.order_arena) (void)hipFree(t.order_arena);
+                               if (t.landed) (void)hipEventDestroy(t.landed); };
+            // The table itself: through the scene's pinned staging on the caller's own stream when the list is new to a caller in a hurry
+            // (the launch that follows is behind it on that stream; launches on other streams wait for `landed`) -- a blocking copy and the
+            // device-wide synchronise it needs cost the first frame 50 us.
+            const size_t staged = (bytes + 255) & ~(size_t)255;
+            bool async_copy = false;
+            if (in_background && s->h_tab_stage && s->tab_stage_used + staged <= kTableStageBytes &&
+                hipEventCreateWithFlags(&t.landed, hipEventDisableTiming) == hipSuccess) {
+                char *h = s->h_tab_stage + s->tab_stage_used;
+                memcpy(h, tab.data(), bytes);
+                if (hipMemcpyAsync(t.dev, h, bytes, hipMemcpyHostToDevice, stream) == hipSuccess && hipEventRecord(t.landed, stream) == hipSuccess) {
+                    s->tab_stage_used += staged;
+                    t.landed_on = stream;
+                    async_copy = true;
+                } else { (void)hipGetLastError(); (void)hipEventDestroy(t.landed); t.landed = nullptr; }
+            } else (void)hipGetLastError();
+            hipError_t e = async_copy ? hipSuccess : hipMemcpy(t.dev, tab.data(), bytes, hipMemcpyHostToDevice);    // blocking, once per table
+            clk.lap("tile table upload");
+            if (e != hipSuccess) { drop(); return hip_fail(e, "hipMemcpy(tile table)", __LINE__); }
             if (want_orders && !in_background) {
                 const std::vector<uint32_t> *map = cost_map_of(s);
                 clk.lap("cost map (cached after 1st)");
@@ -1215,8 +1288,10 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
             }
             // The copies above are blocking for the host, but the render kernel runs on another (non-blocking) stream: make sure
             // the tables have landed in device memory before anything can be launched against them (once per tile list).
-            e = hipDeviceSynchronize();
-            if (e != hipSuccess) { drop(); return hip_fail(e, "hipDeviceSynchronize(tile tables)", __LINE__); }
+            if (!async_copy) {
+                e = hipDeviceSynchronize();
+                if (e != hipSuccess) { drop(); return hip_fail(e, "hipDeviceSynchronize(tile tables)", __LINE__); }
+            }
             clk.lap("device sync");
             t.building = in_background;
             t.host = tab; t.w = w; t.h = h; t.passes = passes; t.coop_key = coop_key;
@@ -1225,7 +1300,10 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
             if (in_background) {
                 const size_t index = s->tables.size() - 1;
                 note_builder(s);
-                s->builders.emplace_back([s, index, tab, w, h, passes] { build_orders_async(s, index, tab, w, h, passes); });
+                if (s->worker.joinable()) {
+                    { std::lock_guard<std::mutex> wl(s->wmu); s->wjobs.emplace_back([s, index, tab, w, h, passes] { build_orders_async(s, index, tab, w, h, passes); }); }
+                    s->wcv.notify_one();
+                } else s->builders.emplace_back([s, index, tab, w, h, passes] { g_knobs_at_default = true; build_orders_async(s, index, tab, w, h, passes); });
             }
             if (order_out && block_order_enabled()) *order_out = pick_order(s->tables.back());
             return RT_OK;
@@ -1800,6 +1878,9 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
         // the cost map the dispatch orders are made from: enqueued now, on a stream of its own, collected when a tile list first wants it
         // (failing to start it only costs the ordering)
         if ((f32 ? start_cost_map<float>(s.get()) : start_cost_map<double>(s.get())) != RT_OK) { s->cost_started = false; (void)hipGetLastError(); }
+        else {
+            try { s->worker = std::thread(worker_main, s.get()); note_builder(s.get()); } catch (...) {}      // (without it a new list starts a thread of its own)
+        }
     }
     *out = s.release();
     return RT_OK;
@@ -1810,10 +1891,11 @@ rt_status rt_scene_destroy(rt_scene *s)
     if (!s) return RT_OK;
     (void)hipSetDevice(s->device);
     for (std::thread &b : s->builders) if (b.joinable()) b.join();          // dispatch orders still being made in the background
+    stop_worker(s);
     forget_scene(s);
     if (s->ahead.stream) { (void)hipStreamSynchronize(s->ahead.stream); (void)hipStreamDestroy(s->ahead.stream); }      // a pass rendered ahead may still be running
     s->pool.clear();
-    for (auto &t : s->tables) { (void)hipFree(t.dev); for (auto &od : t.orders) release_order(od); if (t.order_arena) (void)hipFree(t.order_arena); }
+    for (auto &t : s->tables) { (void)hipFree(t.dev); for (auto &od : t.orders) release_order(od); if (t.order_arena) (void)hipFree(t.order_arena); if (t.landed) (void)hipEventDestroy(t.landed); }
     if (s->d_items) (void)hipFree(s->d_items);
     if (s->d_prim) (void)hipFree(s->d_prim);
     if (s->d_shad) (void)hipFree(s->d_shad);

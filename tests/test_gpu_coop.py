@@ -99,6 +99,33 @@ def test_dispatch_orders_made_in_the_background_arrive_and_change_no_byte():
         d.close()                                                                # joins the builder
 
 
+def test_a_new_tile_list_is_uploaded_behind_its_first_callers_kernels_and_other_streams_wait_for_it():
+    # the default outside the test suite: a new list's tile table goes to the device through pinned staging on the FIRST caller's stream (no
+    # blocking copy, no device-wide synchronise in a one-shot caller's first frame).  A caller on another stream may use the cached table
+    # before that copy has run -- here it is queued behind 50 ms of somebody else's work -- and has to wait for it, not read an empty table.
+    import torch
+    case = next(c for c in _vector_cases() if c["name"] == "config2_800x600")
+    w, h = case["width"], case["height"]
+    regs = bucket_list(w, h)
+    n = sum((r - l) * (t - b) for (l, t, r, b) in regs) * 4
+    with rta.capi.debug(rta.capi.DEBUG_ASYNC_ORDERS, -1):
+        s = rta.Scene.default()
+        d = s.device()
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        outa, outb = torch.zeros(n, dtype=torch.uint8, device="cuda"), torch.zeros(n, dtype=torch.uint8, device="cuda")
+        big = torch.randn(8192, 8192, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(sa):
+            for _ in range(40):
+                big = big @ big * 1e-4                                           # keeps stream A busy while the calls below return
+        d.render_tiles_device((w, h, 1), regs, outa.data_ptr(), sa.cuda_stream, SKIP)       # first sight of the list: the table's copy is queued on A
+        d.render_tiles_device((w, h, 1), regs, outb.data_ptr(), sb.cuda_stream, SKIP)       # B finds the list cached
+        torch.cuda.synchronize()
+        assert tile_crcs(outb.cpu().numpy(), regs) == case["tile_crc32"]
+        assert tile_crcs(outa.cpu().numpy(), regs) == case["tile_crc32"]
+        d.close()
+
+
 def test_level9_pyramid_and_ragged_tiles():
     # 87,381 spheres (BASELINE config 5's scene) on ragged 50x50 tiles whose last block row / column is clipped to 2 pixels
     s, o = rta.Scene.default(9), oracle.Scene.default(level=9)
