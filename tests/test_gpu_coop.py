@@ -126,6 +126,38 @@ def test_a_new_tile_list_is_uploaded_behind_its_first_callers_kernels_and_other_
         d.close()
 
 
+def _native_threads():
+    with open("/proc/self/status") as f:
+        return int(next(line for line in f if line.startswith("Threads:")).split()[1])
+
+
+def test_scenes_come_and_go_with_their_worker_threads():
+    # every scene starts a worker thread (it makes the dispatch orders of new tile lists) and hands it work in its first frame: scenes
+    # destroyed at once, after one frame (the job may not have started), after the orders arrived, several lists queued behind each other
+    # -- no frame differs, nothing hangs, no thread is left behind
+    case = next(c for c in _vector_cases() if c["name"] == "config2_800x600")
+    w, h = case["width"], case["height"]
+    regs = bucket_list(w, h)
+    with rta.capi.debug(rta.capi.DEBUG_ASYNC_ORDERS, -1):
+        warm = rta.Scene.default(5).device()
+        warm.render_tiles((64, 64, 1), bucket_list(64, 64), SKIP, want_stats=False)
+        warm.close()
+        before = _native_threads()
+        for k in range(40):
+            d = rta.Scene.default(8 if k % 4 == 1 else 5 + k % 3).device()
+            if k % 4 == 1:
+                data, _ = d.render_tiles((w, h, 1), regs, SKIP, want_stats=False)
+                assert tile_crcs(data, regs) == case["tile_crc32"]
+            elif k % 4 == 2:
+                for size in ((320, 200), (640, 360), (333, 77), (w, h)):                         # four new lists queued one behind the other
+                    d.render_tiles((size[0], size[1], 1), bucket_list(*size), SKIP, want_stats=False)
+            elif k % 4 == 3:
+                for _ in range(12):
+                    d.render_tiles((w, h, 1), regs, SKIP, want_stats=False)
+            d.close()
+        assert _native_threads() <= before
+
+
 def test_level9_pyramid_and_ragged_tiles():
     # 87,381 spheres (BASELINE config 5's scene) on ragged 50x50 tiles whose last block row / column is clipped to 2 pixels
     s, o = rta.Scene.default(9), oracle.Scene.default(level=9)
