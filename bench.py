@@ -375,6 +375,17 @@ def main():
                     ("step_mix_10_valu_12_salu", "traversal-step mix: 10 VALU + 12 SALU per 22"))}
                 if v.get("valu_active_quad_cycles"):
                     out["valu_busy_frac"] = round(v["valu_active_quad_cycles"] * 4 / (N_SIMD * CLOCK_HZ * t), 4)     # SQ_ACTIVE_INST_VALU x 4 / (1,024 SIMDs x 2.4 GHz x t)
+                if v.get("wave_quad_cycles") and v.get("wait_any_quad_cycles") is not None:
+                    wc = v["wave_quad_cycles"]
+                    out["wave_cycles"] = {
+                        "waiting": round(v["wait_any_quad_cycles"] / wc, 4), "issuing": round((v.get("active_inst_any_quad_cycles") or 0) / wc, 4),
+                        "stalled_at_issue": round((v.get("wait_inst_any_quad_cycles") or 0) / wc, 4),
+                        "note": "SQ_WAIT_ANY / SQ_ACTIVE_INST_ANY / SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES: the share of its cycles a wave is parked at "
+                                "s_waitcnt (here: for node records from the scalar cache), issuing, or ready but not issued"}
+                if v.get("sqc_dcache_req"):
+                    rq = v["sqc_dcache_req"]
+                    out["scalar_cache"] = {"requests_per_launch": rq, "hit": round((v.get("sqc_dcache_hits") or 0) / rq, 4), "miss": round((v.get("sqc_dcache_misses") or 0) / rq, 4),
+                                           "miss_on_a_line_already_requested": round((v.get("sqc_dcache_misses_duplicate") or 0) / rq, 4)}
                 if insts:
                     out["instruction_issue"] = {
                         "wave_instructions_per_launch": insts, "valu": v.get("valu_insts"), "salu": v.get("salu_insts"), "smem": v.get("smem_insts"),
@@ -419,6 +430,9 @@ def main():
             out["traffic"] = fp["hbm_traffic"]["bytes_per_launch"]
         if "valu_busy_frac" in fp:
             out["valu_busy_frac"] = fp["valu_busy_frac"]
+        for k in ("wave_cycles", "scalar_cache"):
+            if k in fp:
+                out[k] = fp[k]
         valu = (fp.get("instruction_issue") or {}).get("valu")
         if valu and "path_arithmetic" in out:
             out["valu_lane_utilisation"] = round(out["path_arithmetic"]["lane_ops"] / (valu * LANES), 4)

@@ -179,23 +179,31 @@ __global__ void k_build_fstream64(const Node<double> *__restrict__ prim, const N
     if (i >= n_total) return;
     const Node<double> p = prim[i];
     {
-        // shadow walk: the f32 OUTER bound only (rt_skip_rot.hpp F64FS) -- the centre in the plane perpendicular to the light (formed in
-        // double, rounded once) and R2o from the f32 walk's formula with rr rounded UP (its margins cover an f32 reference's roundings, a
-        // superset of what the f64 reference needs)
+        // shadow walk: the f32 walk's TWO-SIDED bound (rt_skip_rot.hpp F64FS) -- the centre in the plane perpendicular to the light and along
+        // it (formed in double, rounded once), R2o from the f32 walk's formula with rr rounded UP, R2i with rr rounded DOWN: their margins
+        // cover an f32 reference's roundings, a superset of what the f64 reference needs
         const Node<double> sn = shad[i];
         const bool s_end = (sn.item & kNodeEnd) != 0u, s_item = (sn.item & kNodeItem) != 0u;
         const double cx = sn.a0 - (double)fc.m0[0], cy = sn.a1 - (double)fc.m0[1], cz = sn.a2 - (double)fc.m0[2];
         FNodeS fs;
         fs.w1 = s_end ? 0.0f : (float)((cx * (double)fc.e1[0] + cy * (double)fc.e1[1]) + cz * (double)fc.e1[2]);
         fs.w2 = s_end ? 0.0f : (float)((cx * (double)fc.e2[0] + cy * (double)fc.e2[1]) + cz * (double)fc.e2[2]);
-        fs.cl = 0.0f;
-        float rr_up = (float)sn.a3;
-        if ((double)rr_up < sn.a3) rr_up = next_f32_above(rr_up);
-        float r2i_unused;
-        shadow_filter_bounds(fc, s_end ? __builtin_huge_valf() : rr_up, fs.r2o, r2i_unused);
-        if (!(__builtin_fabsf(fs.w1) < 3e38f && __builtin_fabsf(fs.w2) < 3e38f)) fs.r2o = __builtin_huge_valf();      // nothing known: never "beyond"
-        if (s_end || s_item) fs.r2o = -fs.r2o;
-        fs.r2i = -1.0f; fs.r2o_own = s_end ? -0.0f : 0.0f; fs.r2i_own = -1.0f;
+        fs.cl = s_end ? 3e38f : (float)((cx * (double)fc.l[0] + cy * (double)fc.l[1]) + cz * (double)fc.l[2]);
+        auto up = [](double v) { float f = (float)v; if ((double)f < v) f = next_f32_above(f); return f; };
+        auto down = [](double v) { float f = (float)v; if ((double)f > v) f = next_f32_below(f); return f; };
+        float unused;
+        shadow_filter_bounds(fc, s_end ? __builtin_huge_valf() : up(sn.a3), fs.r2o, unused);
+        shadow_filter_bounds(fc, s_end ? __builtin_huge_valf() : down(sn.a3), unused, fs.r2i);
+        const bool known = __builtin_fabsf(fs.w1) < 3e38f && __builtin_fabsf(fs.w2) < 3e38f && __builtin_fabsf(fs.cl) < 3e38f;
+        if (!s_end && !known) { fs.r2o = __builtin_huge_valf(); fs.r2i = -1.0f; }      // nothing known: never "beyond", never "inside"
+        if (s_end || s_item) fs.r2o = -fs.r2o;                                   // sign bit: ITEM or END
+        fs.r2o_own = 0.0f; fs.r2i_own = -1.0f;
+        if (compacted && !s_end && !s_item) {
+            shadow_filter_bounds(fc, up(sn.own_rr), fs.r2o_own, unused);
+            shadow_filter_bounds(fc, down(sn.own_rr), unused, fs.r2i_own);
+            if (!known) { fs.r2o_own = __builtin_huge_valf(); fs.r2i_own = -1.0f; }
+        }
+        if (s_end) fs.r2o_own = -0.0f;                                           // sign bit: END
         fs.skip_off = sn.skip_off / 2u;
         xshad[i] = fs;
     }
@@ -312,11 +320,12 @@ __device__ __forceinline__ void shadow_filter_origin(const FilterConsts &fc, flo
     if (!(d2 <= fc.ro2)) q1 = __builtin_nanf("");
 }
 // ... of an f64 scene's shadow ray: the origin relative to m0 formed in double and rounded once, then the same f32 chains.
-__device__ __forceinline__ void shadow_filter_origin64(const FilterConsts &fc, double ox, double oy, double oz, float &q1, float &q2)
+__device__ __forceinline__ void shadow_filter_origin64(const FilterConsts &fc, double ox, double oy, double oz, float &q1, float &q2, float &ol)
 {
     const float x = (float)(ox - (double)fc.m0[0]), y = (float)(oy - (double)fc.m0[1]), z = (float)(oz - (double)fc.m0[2]);
     q1 = __builtin_fmaf(z, fc.e1[2], __builtin_fmaf(y, fc.e1[1], x * fc.e1[0]));
     q2 = __builtin_fmaf(z, fc.e2[2], __builtin_fmaf(y, fc.e2[1], x * fc.e2[0]));
+    ol = __builtin_fmaf(z, fc.l[2], __builtin_fmaf(y, fc.l[1], x * fc.l[0]));
     const float d2 = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
     if (!(d2 <= fc.ro2)) q1 = __builtin_nanf("");
 }
@@ -652,13 +661,13 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
                         constexpr unsigned kFStride = (unsigned)sizeof(FNodeS);
                         const unsigned nbf = ((VAR & 4) ? sc.n_fnodes : sc.n_nodes) * kFStride;
                         const FilterConsts fc = *sc.fc;
-                        float fq1, fq2;
-                        shadow_filter_origin64(fc, sp.x, sp.y, sp.z, fq1, fq2);
+                        float fq1, fq2, fql;
+                        shadow_filter_origin64(fc, sp.x, sp.y, sp.z, fq1, fq2, fql);
                         resume = walk_s ? 0u : nbf;
                         while (i < nbf) {
                             unsigned fin;
-                            if constexpr ((VAR & 4) != 0) i = skip_shadow_rot_filt_fused(sc.xfshad, nbf, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, fq1, fq2, sc.fshad);
-                            else i = skip_shadow_rot_filt(sc.xshad, nbf, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, fq1, fq2, sc.shad);
+                            if constexpr ((VAR & 4) != 0) i = skip_shadow_rot_filt_fused(sc.xfshad, nbf, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, fq1, fq2, fql, fc.a0, fc.k1, fc.kc, sc.fshad);
+                            else i = skip_shadow_rot_filt(sc.xshad, nbf, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, fq1, fq2, fql, fc.a0, fc.k1, fc.kc, sc.shad);
                             if (i >= nbf) break;
                             if (fin) { occluded = true; resume = nbf; }
                             i = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_min_u32(resume >= nbf ? nbf : (resume > i ? resume : i + kFStride)));
@@ -684,7 +693,7 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
                 [[maybe_unused]] float fq1 = 0.0f, fq2 = 0.0f, fql = 0.0f;
                 [[maybe_unused]] FilterConsts cfc{};
                 if constexpr (COUNT && sizeof(T) == 4) { if (sc.xshad) { cfc = *sc.fc; shadow_filter_origin(cfc, sp.x, sp.y, sp.z, fq1, fq2, fql); } }
-                if constexpr (COUNT && sizeof(T) == 8) { if (sc.xshad) { cfc = *sc.fc; shadow_filter_origin64(cfc, sp.x, sp.y, sp.z, fq1, fq2); } }
+                if constexpr (COUNT && sizeof(T) == 8) { if (sc.xshad) { cfc = *sc.fc; shadow_filter_origin64(cfc, sp.x, sp.y, sp.z, fq1, fq2, fql); } }
                 Node<T> nd = sc.shad[0];
                 for (;;) {
                     const bool active = i >= resume;
@@ -697,11 +706,10 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
                         if (pos) hit = !((b + ((VAR & 1) ? sqrt_rn_lean(disc) : rsqrt_exact(disc))) < T(0.0));
                     }
                     if constexpr (COUNT && sizeof(T) == 8) {
-                        if (sc.xshad && active) {              // the f64 shadow walk's f32 outer bound: "beyond it" must mean miss
-                            const FNodeS fsn = sc.xshad[i];
-                            const bool beyond = shadow_p2<true>(fsn.w1, fsn.w2, fq1, fq2) > __builtin_fabsf(fsn.r2o);
-                            c_fpass += beyond ? 0u : 1u;
-                            c_fviol += (beyond && hit) ? 1u : 0u;
+                        if (sc.xshad && active) {              // the f64 shadow walk's f32 bounds: MISS and HIT must be what the f64 test says
+                            const int verdict = shadow_filter_verdict<true>(sc.xshad[i], cfc, fq1, fq2, fql);
+                            c_fpass += verdict == 1 ? 1u : 0u;
+                            c_fviol += ((verdict == 0 && hit) || (verdict == 2 && !hit)) ? 1u : 0u;
                         }
                     }
                     if constexpr (COUNT && sizeof(T) == 4) {

@@ -107,6 +107,7 @@ class Prec:
     shadow_extra_out = ""
     shadow_extra_decl = ""
     shadow_vclobbers = []            # vector registers the shadow loops name directly (packed_p2)
+    ftmp = "%[t0]"                   # an f32 scratch register of the two-sided shadow bound
     shadow_subst = ()                # named operands that are such registers
 
     def kind_test(self, a, c, lab):
@@ -543,11 +544,13 @@ class F64F(F64):
 
 
 class F64FS(F64F):
-    """The SHADOW walk of f64 scenes behind the f32 OUTER bound (round 4): the walk reads FNodeS records {w1, w2, -, R2o | ITEM / END
-    flag, -, -, -, skip_off} -- the centre's coordinates in the plane perpendicular to the light and the squared distance beyond which the
-    reference's test says miss, exactly the quantities of the f32 walk (their margins cover f32 reference roundings, a superset of what
-    an f64 reference needs) -- and fetches the node's Node<double> record for the reference's own sixteen operations only when some
-    live lane is inside that bound.  No inner bound: a hit is always established by the f64 arithmetic."""
+    """The SHADOW walk of f64 scenes behind the f32 walk's TWO-SIDED bound (round 4): the walk reads FNodeS records {w1, w2, cl, R2o | ITEM /
+    END flag, R2i, R2o_own | END flag, R2i_own, skip_off} -- the centre in the plane perpendicular to the light and along it, formed in double
+    and rounded once, and the f32 walk's bounds with rr rounded up (outer) / down (inner): their margins cover an f32 reference's roundings,
+    a superset of what the f64 reference needs -- and decides a step like shadow_copy_filt: beyond the outer bound a miss, inside the inner
+    one (and in front) a hit, behind the origin a miss; only a lane between the bounds fetches the node's Node<double> record and runs the
+    reference's sixteen f64 operations (and the f64 root where b < 0) for every lane.  Counting launches hold every verdict against the
+    f64 test (rt_skip.hpp, shadow_filter_verdict)."""
     primary_only = False
 
     def item(self, b):
@@ -562,9 +565,17 @@ class F64FS(F64F):
     def kind_test(self, a, c, lab):
         F64.kind_test(self, a, c, lab)
 
+    # FNodeS: {w1, w2, cl, R2o | ITEM flag, R2i, R2o_own | END flag, R2i_own, skip_off}
+    def s_cl(self, b): return "s%d" % (self.fbank(b) + 2)
+    def s_r2o(self, b): return "s%d" % (self.fbank(b) + 3)
+    def s_r2i(self, b): return "s%d" % (self.fbank(b) + 4)
+    def s_r2o_own(self, b): return "s%d" % (self.fbank(b) + 5)
+    def s_r2i_own(self, b): return "s%d" % (self.fbank(b) + 6)
+    ftmp = "%[tf0]"
+
     def shadow_filter(self, a, c):
-        packed_p2(a, self.fbank(c), "%[tf1]")
-        a.op("v_cmp_ngt_f32_e64 vcc, %%[tf1], |s%d|" % (self.fbank(c) + 3), "not beyond the outer bound (a NaN -- a ray the bounds do not cover -- passes)")
+        packed_p2(a, self.fbank(c), "%[p2]")
+        a.op("v_cmp_ngt_f32_e64 vcc, %%[p2], |%s|" % self.s_r2o(c), "not beyond the outer bound (a NaN -- a ray the bounds do not cover -- passes)")
 
     def shadow_terms(self, a, c):
         tmp = "s76"
@@ -574,9 +585,9 @@ class F64FS(F64F):
         a.op("s_waitcnt lgkmcnt(0)")
         F64.shadow_terms(self, a, c)
 
-    shadow_decl = F64.shadow_decl + "\n    float tf1;" + QQ_DECL
-    shadow_out = F64.shadow_out + ', [tf1] "=&v"(tf1)'
-    shadow_extra_in = ', ' + QQ_IN + ', [base2] "s"(exact)'
+    shadow_decl = F64.shadow_decl + "\n    float tf0, p2, av, inn;" + QQ_DECL
+    shadow_out = F64.shadow_out + ', [tf0] "=&v"(tf0), [p2] "=&v"(p2), [av] "=&v"(av), [inn] "=&v"(inn)'
+    shadow_extra_in = ', ' + QQ_IN + ', [ol] "v"(ol), [a0] "s"(a0), [k1] "s"(k1), [kc] "v"(kc), [base2] "s"(exact)'
     shadow_vclobbers = PACKED_CLOBBERS
 
 
@@ -778,8 +789,8 @@ def shadow_exact(k, P, src, lab, tag, rr_reg):
 def shadow_two_sided(a, P, r2i, exact_label, tag):
     a.op("v_cmp_le_f32_e64 %s, %%[inn], %s" % (P.M56, r2i), "origin inside the sphere, by a margin")
     a.op("s_or_b64 %s, %s, %s" % (P.M56, P.M56, P.M58), "... or b >= 0, by a margin")
-    a.op("v_fma_f32 %[t0], %[inn], %[k1], %[p2]", "P2 + k1 |centre - origin|^2: the reference's rounding of disc grows with the distance")
-    a.op("v_cmp_le_f32_e64 %s, %%[t0], %s" % (P.M54, r2i), "inside the inner bound: disc >= 0, by a margin")
+    a.op("v_fma_f32 %s, %%[inn], %%[k1], %%[p2]" % P.ftmp, "P2 + k1 |centre - origin|^2: the reference's rounding of disc grows with the distance")
+    a.op("v_cmp_le_f32_e64 %s, %s, %s" % (P.M54, P.ftmp, r2i), "inside the inner bound: disc >= 0, by a margin")
     a.op("s_and_b64 %s, %s, %s" % (P.M54, P.M54, P.M56), "sure hits")
     a.op("s_andn2_b64 %s, vcc, %s" % (P.M56, P.M54), "lanes between the bounds: the reference's test decides")
     a.op("s_cbranch_scc1 %s" % exact_label)
@@ -789,8 +800,8 @@ def shadow_second_chance(k, P, r2o, exact2, none_label, some_label):
     """Lanes between the bounds before the reference's arithmetic is fetched: most of them have the sphere BEHIND them -- b < 0 by a
     margin while the origin is clearly outside the sphere (P2 + a^2 >= R2o (1 + 4 tau)): disc < 0, or the root is smaller than |b| and
     t2 = b + root < 0 -- the reference's test says miss.  vcc = lanes inside the outer bound, M56 = those not settled yet."""
-    k.op("v_mul_f32_e32 %[t0], %[kc], %[inn]", "(P2 + a^2) / (1 + 4 tau)")
-    k.op("v_cmp_le_f32_e64 %s, |%s|, %%[t0]" % (P.TINY, r2o), "the origin is clearly outside the sphere")
+    k.op("v_mul_f32_e32 %s, %%[kc], %%[inn]" % P.ftmp, "(P2 + a^2) / (1 + 4 tau)")
+    k.op("v_cmp_le_f32_e64 %s, |%s|, %s" % (P.TINY, r2o, P.ftmp), "the origin is clearly outside the sphere")
     k.op("v_cmp_le_f32_e64 %s, %%[av], -%%[a0]" % P.M54, "b < 0, by a margin")
     k.op("s_and_b64 %s, %s, %s" % (P.TINY, P.TINY, P.M54), "sure misses")
     k.op("s_andn2_b64 %s, %s, %s" % (P.M56, P.M56, P.TINY), "still between the bounds")
@@ -863,6 +874,71 @@ def shadow_copy_filt(P, name, fused):
         k.op("s_cbranch_vccz %s" % lab("next"))
         k.op("s_branch %s" % lab("owndecided"))
         P.tiny(k, lab("ytiny"), lab("yrooted"))
+    return m, k
+
+
+def shadow_exact64(k, P, c, lab, tag, own):
+    """F64FS: the reference's own test for every lane -- the node's Node<double> record (fetched here), the sixteen f64 operations, the root where
+    b < 0.  vcc = live lanes (P.ACT) whose ray hits the sphere (own: the group's own sphere, same centre, its rr)."""
+    P.shadow_terms(k, c)
+    if own:
+        P.fused_disc(k, c)
+    P.cand_cmp(k)
+    k.op("s_and_b64 vcc, vcc, %s" % P.ACT)
+    shadow_decide(k, P, lab, tag)
+
+
+def shadow_copy_filt64(P, name, fused):
+    """shadow_copy_filt for f64 scenes (F64FS): the same two-sided f32 bound in front, the f64 arithmetic behind it."""
+    c, n, s = COPIES[name]
+    lab = lambda x: ".Lrt_%s_%s_%%=" % (name, x)
+    m, k = Asm(), Asm()
+    m.label(lab("top"))
+    step_top(m, P, c, n, s, P.shadow_terms)
+    m.op("s_cbranch_vccnz %s" % lab("hit"))
+    emit_skip(m, P, name, c, lab, P.s_skip(c))
+    # ---------------- some live lane is inside the outer bound ----------------
+    k.label(lab("hit"))
+    k.op("v_sub_f32_e32 %%[av], %s, %%[ol]" % P.s_cl(c), "a ~ b = dot(centre - origin, dir)")
+    k.op("v_cmp_le_f32_e64 %s, %%[a0], %%[av]" % P.M58, "b >= 0, by a margin")
+    k.op("v_fma_f32 %[inn], %[av], %[av], %[p2]", "~ |centre - origin|^2")
+    shadow_two_sided(k, P, P.s_r2i(c), lab("exact"), "")
+    k.label(lab("decided"))
+    k.op("s_bitcmp1_b32 %s, 31" % P.s_r2o(c), "an ITEM or the END node?  (sign bit of the outer bound)")
+    k.op("s_cbranch_scc1 %s" % lab("flagged"))
+    k.op("s_andn2_b64 exec, %s, vcc" % P.ACT, "lanes that may not enter sleep until `skip`")
+    k.op("v_mov_b32_e32 %%[resume], %s" % P.s_skip(c))
+    k.op("s_mov_b64 exec, %s" % P.EX)
+    if fused:
+        k.op("s_mov_b64 %s, vcc" % P.ACT, "the lanes that are live at the next node")
+        k.op("v_cmp_ngt_f32_e64 vcc, %%[p2], |%s|" % P.s_r2o_own(c), "the group's own sphere: same centre, its own bounds")
+        k.op("s_and_b64 vcc, vcc, %s" % P.ACT)
+        k.op("s_cbranch_vccz %s" % lab("next"))
+        shadow_two_sided(k, P, P.s_r2i_own(c), lab("exactown"), "own")
+        k.label(lab("owndecided"))
+        k.op("s_branch .Lrt_fin_%=", "any hit ends those rays; hand them to the caller (it starts again behind this node)")
+    k.label(lab("next"))
+    P.load(k, n, P.NX, "somebody entered: fetch the group's first child")
+    emit_next(k, P, name)
+    k.label(lab("flagged"))
+    k.op("s_bitcmp1_b32 %s, 31" % P.s_r2o_own(c))
+    k.op("s_cbranch_scc1 .Lrt_exit_%=", "END: every lane is awake here and hits it")
+    k.op("s_branch .Lrt_fin_%=")
+    # ---- lanes between the bounds: first the behind-the-origin test, then the reference's f64 arithmetic
+    k.label(lab("exact"))
+    shadow_second_chance(k, P, P.s_r2o(c), lab("exact2"), lab("skip"), lab("decided"))
+    k.label(lab("exact2"))
+    shadow_exact64(k, P, c, lab, "x", False)
+    k.op("s_cbranch_vccz %s" % lab("skip"))
+    k.op("v_cmp_le_f32_e64 %s, %%[a0], %%[av]" % P.M58, "(the exact path used this mask: form `b >= 0 by a margin` again)")
+    k.op("s_branch %s" % lab("decided"))
+    if fused:
+        k.label(lab("exactown"))
+        shadow_second_chance(k, P, P.s_r2o_own(c), lab("exactown2"), lab("next"), lab("owndecided"))
+        k.label(lab("exactown2"))
+        shadow_exact64(k, P, c, lab, "y", True)
+        k.op("s_cbranch_vccz %s" % lab("next"))
+        k.op("s_branch %s" % lab("owndecided"))
     return m, k
 
 
@@ -996,7 +1072,7 @@ def shadow(P, fused):
     a.op("s_mov_b64 %s, exec" % P.EX)
     P.load(a, 0, "%[start]")
     a.op("s_waitcnt lgkmcnt(0)")
-    assemble(a, P, shadow_copy_filt if (P.filt and not isinstance(P, F64FS)) else shadow_copy, fused)
+    assemble(a, P, shadow_copy_filt64 if isinstance(P, F64FS) else shadow_copy_filt if P.filt else shadow_copy, fused)
     a.label(".Lrt_fin_%=")
     a.op("v_cndmask_b32_e64 %[fin], 0, 1, vcc", "the lanes whose ray hit the ITEM (or the group's own sphere) of the current node")
     a.op("s_sub_u32 %%[stop], %s, %d" % (P.NX, P.stride), "its position")
@@ -1027,7 +1103,7 @@ def main():
             elif isinstance(P, F64F):
                 S = F64FS()
                 sc = dict(common, shadow_extra_in=S.shadow_extra_in, shadow_extra_out="", shadow_extra_decl="", clobbers=clobbers(S, S.shadow_vclobbers),
-                          shadow_extra_args=", float q1, float q2, const void *exact")
+                          shadow_extra_args=", float q1, float q2, float ol, float a0, float k1, float kc, const void *exact")
                 text += SHADOW_FN % dict(sc, name="skip_shadow_rot" + sfx, body=shadow(S, fused), decl=S.shadow_decl, out=S.shadow_out)
     text += "}  // namespace rt\n"
     with open(OUT, "w") as f:

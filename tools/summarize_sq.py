@@ -17,7 +17,7 @@ KERNELS = [("k_render_skip_f32<false", "k_render_skip"), ("k_render_skip<float, 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     out = collections.defaultdict(dict)
-    for part in ("sq1", "sq2", "sq3"):
+    for part in ("sq1", "sq2", "sq3", "sq4"):
         for f in glob.glob(os.path.join(src, "%s_%s" % (part, tag), "*", "*_counter_collection.csv")):
             agg = collections.defaultdict(list)
             dur = collections.defaultdict(list)
@@ -45,7 +45,13 @@ def main():
             quote[k + "_n1"] = {"valu_insts": d["SQ_INSTS_VALU"], "salu_insts": d.get("SQ_INSTS_SALU"), "smem_insts": d.get("SQ_INSTS_SMEM"),
                                 "branch_insts": d.get("SQ_INSTS_BRANCH"), "other_insts": (d.get("SQ_INSTS_SENDMSG") or 0) + (d.get("SQ_INSTS_VMEM") or 0) +
                                 (d.get("SQ_INSTS_LDS") or 0), "waves": d.get("SQ_WAVES"),
-                                "valu_active_quad_cycles": d.get("SQ_ACTIVE_INST_VALU")}
+                                "valu_active_quad_cycles": d.get("SQ_ACTIVE_INST_VALU"),
+                                # where a wave's cycles go (MI355X_MICROARCH.md: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, disjoint)
+                                "wave_quad_cycles": d.get("SQ_WAVE_CYCLES"), "wait_any_quad_cycles": d.get("SQ_WAIT_ANY"),
+                                "wait_inst_any_quad_cycles": d.get("SQ_WAIT_INST_ANY"), "active_inst_any_quad_cycles": d.get("SQ_ACTIVE_INST_ANY"),
+                                # the scalar data cache (tools/profile_sq.sh, fourth pass)
+                                "sqc_dcache_req": d.get("SQC_DCACHE_REQ"), "sqc_dcache_hits": d.get("SQC_DCACHE_HITS"), "sqc_dcache_misses": d.get("SQC_DCACHE_MISSES"),
+                                "sqc_dcache_misses_duplicate": d.get("SQC_DCACHE_MISSES_DUPLICATE")}
     a, b = quote.get("k_flat_primary_sc_n1"), quote.get("k_flat_shadow_sc_n1")
     if a and b:                     # one flat frame = the primary pass + two shadow passes (the counters are per-launch averages)
         quote["k_flat_pipeline_n1"] = {k: (a.get(k) or 0) + 2 * (b.get(k) or 0) for k in a}
