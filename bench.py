@@ -433,6 +433,10 @@ def main():
         for k in ("wave_cycles", "scalar_cache"):
             if k in fp:
                 out[k] = fp[k]
+        if "wave_cycles" in fp:
+            out["what_binds"] = ("`frac` is the contract's compute roofline (the reference's 17 flops per test over the nominal vector peak); what the launch "
+                                 "actually waits for is the scalar data cache -- `wave_cycles.waiting` of a wave's cycles at s_waitcnt, "
+                                 "`scalar_cache.miss` + `miss_on_a_line_already_requested` of its node fetches an L2 round trip (DESIGN.md 4.1)")
         valu = (fp.get("instruction_issue") or {}).get("valu")
         if valu and "path_arithmetic" in out:
             out["valu_lane_utilisation"] = round(out["path_arithmetic"]["lane_ops"] / (valu * LANES), 4)
@@ -627,8 +631,8 @@ def main():
                 "ms_per_step_each": [round(v, 4) for v in in_flight["ms_reps"]], "frame_crc_ok": in_flight["crc_ok"],
                 "note": "NOT `value`: the same launches dealt round-robin over two HIP streams through the asynchronous entry point (rt_render_frame_device), "
                         "each stream its own frame buffer, host wall time over the steps.  `value` / `ms_per_step` time the launches in order on ONE stream, "
-                        "where a frame ends with its few longest waves on an otherwise idle chip; with a second frame in flight those SIMDs are busy, and a "
-                        "frame costs what its instructions cost (SQ_ACTIVE_INST_VALU x 4 cycles / 1,024 SIMDs).  The difference is the frame's tail."}
+                        "where a frame ends with its few longest waves on an otherwise idle chip and its waves spend half their cycles waiting for node "
+                        "records (`roofline.wave_cycles`); a second frame in flight fills both.  The difference is the frame's tail and part of its waiting."}
             ok_in_flight = in_flight["crc_ok"] is not False
         else:
             ok_in_flight = True
