@@ -1082,7 +1082,7 @@ rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std:
         total_blocks += (uint64_t)td.blks_x * (((unsigned)(td.t - td.b) + rt::kBlockH - 1) / rt::kBlockH);
     }
     const long long rays = knob(RT_DEBUG_SKIP_RAYS);
-    const bool two_rays = s->fused && (rays < 0 ? skip2_by_default(total_px, 1, s->n_fnodes) : rays == 2);      // k_render_skip2 knows no cooperative quads
+    const bool two_rays = rays < 0 ? skip2_by_default(total_px, 1, s->fused ? s->n_fnodes : s->n_nodes) : rays == 2;      // k_render_skip2 knows no cooperative quads
     std::vector<int> percents;
     if (coop_pass && map && !two_rays && total_blocks <= kCoopPassBlocks && knob(RT_DEBUG_COOP) < 0 && knob(RT_DEBUG_COOP_THR) < 0) percents = { 0, 28, 34, 40, 48, 58 };
     else if (coop_pass && (knob(RT_DEBUG_COOP) > 0 || knob(RT_DEBUG_COOP_THR) >= 0)) percents = { 0, -1 };       // as asked, behind the plain one
@@ -1437,9 +1437,11 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
 {
     // two rays per lane (rt_skip2.hpp): f32, fused assembly loops, launches that neither count nor trace
     bool two_rays = false;
-    if constexpr (!COUNT && (VAR & 15) == 7 && sizeof(T) == 4) {
+    // (fused scenes: the fused assembly loops, filtered or not; other scenes: the filtered assembly loops over the plain streams)
+    constexpr bool kTwoRayFlavour = !COUNT && sizeof(T) == 4 && ((VAR & 15) == 7 || (VAR & 31) == 19);
+    if constexpr (kTwoRayFlavour) {
         const long long k = knob(RT_DEBUG_SKIP_RAYS);
-        two_rays = k < 0 ? skip2_by_default(total_px, spp, s->n_fnodes) : k == 2;
+        two_rays = k < 0 ? skip2_by_default(total_px, spp, (VAR & 4) ? s->n_fnodes : s->n_nodes) : k == 2;
         two_rays = two_rays && (spp == 1 || (use_split(spp) && packed_samples(spp)));
     }
     // an order with cooperative quads needs the COOP flavour of k_render_skip: everything else renders the plain order of the same list
@@ -1477,10 +1479,10 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     rt::SampleBuf<T> sb{ nullptr, nullptr, (unsigned)total_px };
     const dim3 b2(rt::kSkip2Threads);
     if (!use_split(spp)) {
-        if constexpr (!COUNT && (VAR & 15) == 7 && sizeof(T) == 4) {
+        if constexpr (kTwoRayFlavour) {
             if (two_rays) {
                 g_count[RT_DEBUG_COUNT_TWO_RAY_LAUNCHES].fetch_add(1, std::memory_order_relaxed);
-                hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipOne, (VAR & 16) != 0>), rgrid, b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt, d_out, sb, frame_w,
+                hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipOne, (VAR & 16) != 0, (VAR & 4) != 0>), rgrid, b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt, d_out, sb, frame_w,
                                    order.d, order.wg_first);
                 return RT_OK;
             }
@@ -1510,10 +1512,10 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     sb.state = c->d_sample_state;
     const bool packed = packed_samples(spp);
     bool done2 = false;
-    if constexpr (!COUNT && (VAR & 15) == 7 && sizeof(T) == 4) {
+    if constexpr (kTwoRayFlavour) {
         if (two_rays) {
             g_count[RT_DEBUG_COUNT_TWO_RAY_LAUNCHES].fetch_add(1, std::memory_order_relaxed);
-            hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipPacked, (VAR & 16) != 0>), dim3(rgrid.x, (unsigned)ns), b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt,
+            hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipPacked, (VAR & 16) != 0, (VAR & 4) != 0>), dim3(rgrid.x, (unsigned)ns), b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt,
                                d_out, sb, frame_w, order.d, order.wg_first);
             done2 = true;
         }

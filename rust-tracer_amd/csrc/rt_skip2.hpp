@@ -1,4 +1,4 @@
-// rt_skip2.hpp -- k_render_skip2: RT_TRAVERSAL_SKIP for f32 fused scenes with TWO rays per lane (rt_skip2_rot.hpp).
+// rt_skip2.hpp -- k_render_skip2: RT_TRAVERSAL_SKIP for f32 scenes with TWO rays per lane (rt_skip2_rot.hpp).
 //
 // The walk, the node streams and every arithmetic operation are k_render_skip's (rt_skip.hpp); what changes is who carries the
 // rays.  A lane holds two of them in VGPR pairs, so that one packed instruction does one operation of the sphere test for both
@@ -8,7 +8,7 @@
 //                        of the lane's own (narrowed descriptors: 2pw x pw patches in the first pw*pw lanes, pw = 8 >> level)
 //   kSkipPacked (spp 2 / 4 / 8): a wave's lanes enumerate the samples of 4x4 / 2x2 / 1 pixels as in k_render_skip, and ray h
 //                        belongs to the same sample of the pixel group ppw pixels to the right; blockIdx.y picks the sub-block
-// Launches that count tests, scenes that are not fused, f64 and other spp stay with k_render_skip (there is no C++ flavour of
+// Launches that count tests, f64 and other spp stay with k_render_skip (there is no C++ flavour of
 // these loops; tests/test_gpu_parity.py compares the two kernels' frames byte for byte).
 #pragma once
 #include "rt_skip.hpp"
@@ -21,7 +21,9 @@ constexpr unsigned kSkip2Threads = kBlockThreads / kSkip2Rays;
 
 // FILT: the shadow walk reads the two-sided bounds of the filtered streams (skip2_shadow_rot_filt_fused) instead of forming the
 // reference's sixteen operations at every node; the primary walk is filtered in both flavours.
-template <int MODE, bool FILT>
+// FUSED = false: a scene whose bounds have no sphere of their own (the automatic hierarchy of an arbitrary sphere list): the plain filtered
+// streams, the plain-stream loops (FILT only).
+template <int MODE, bool FILT, bool FUSED = true>
 __global__ __launch_bounds__(kSkip2Threads) void k_render_skip2(SkipView<float> sc, unsigned width, unsigned height, unsigned spp_arg,
                                                                const TileDev *__restrict__ tiles, unsigned n_tiles, uint8_t *__restrict__ out,
                                                                SampleBuf<float> sb, unsigned frame_w, const BlockDesc *__restrict__ order,
@@ -29,6 +31,7 @@ __global__ __launch_bounds__(kSkip2Threads) void k_render_skip2(SkipView<float> 
 {
     typedef float T;
     static_assert(MODE == kSkipOne || MODE == kSkipPacked, "two rays per lane: spp 1 or the sample-packed modes");
+    static_assert(FUSED || FILT, "the plain-stream loops exist in the filtered flavour only");
     constexpr bool PACKED = MODE == kSkipPacked, ONE = MODE == kSkipOne;
     constexpr unsigned R = kSkip2Rays;
     const unsigned spp = ONE ? 1u : spp_arg;
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(kSkip2Threads) void k_render_skip2(SkipView<float> 
         const V3<T> AMBIENT = { BACKGROUND.x * T(0.8), BACKGROUND.y * T(0.8), BACKGROUND.z * T(0.8) };
         const V3<T> sdir = mulf(light, T(-1.0));                        // render.rs:206
         constexpr unsigned kStride = (unsigned)sizeof(Node<T>);
-        const unsigned nb = sc.n_fnodes * kStride;
+        const unsigned nb = (FUSED ? sc.n_fnodes : sc.n_nodes) * kStride;
 
         const unsigned ssx = PACKED ? sample / spp : 0u, ssy = PACKED ? sample % spp : 0u;
         const T yres = ONE ? T(y) : T(y) + T(ssy) / ssf;             // render.rs:238-243
@@ -104,9 +107,11 @@ __global__ __launch_bounds__(kSkip2Threads) void k_render_skip2(SkipView<float> 
         // ---------------- primary rays: s.group.intersect(&mut h, r)  render.rs:188-189 ----------------
         T best[R];
         unsigned best_item[R];
-        skip2_primary_rot_fused(sc.xfprim, dx, dy, dz, resume, best, best_item);
-        for (unsigned h = 0; h < R; ++h)  // a group's own sphere won: the walk recorded the offset behind its BOUND node
-            if (best_item[h] != 0u && !(best_item[h] & kNodeItem)) best_item[h] = sc.xown[best_item[h] / (unsigned)sizeof(FNode) - 1u];
+        if constexpr (FUSED) {
+            skip2_primary_rot_fused(sc.xfprim, dx, dy, dz, resume, best, best_item);
+            for (unsigned h = 0; h < R; ++h)  // a group's own sphere won: the walk recorded the offset behind its BOUND node
+                if (best_item[h] != 0u && !(best_item[h] & kNodeItem)) best_item[h] = sc.xown[best_item[h] / (unsigned)sizeof(FNode) - 1u];
+        } else skip2_primary_rot(sc.xprim, dx, dy, dz, resume, best, best_item);
 
         // ---------------- shade  render.rs:190-199 ----------------
         bool need_shadow[R];
@@ -139,9 +144,10 @@ __global__ __launch_bounds__(kSkip2Threads) void k_render_skip2(SkipView<float> 
             for (unsigned h = 0; h < R; ++h) resume[h] = need_shadow[h] ? 0u : nb;      // rays without a shadow ray sleep until END
             if constexpr (FILT) {
                 // one invocation: rays retire inside the loop (resume = nb + 1) and the walk goes on at the next wanted node
-                skip2_shadow_rot_filt_fused(sc.xfshad, nb, ox, oy, oz, resume, sc.fc, sc.fshad);
+                if constexpr (FUSED) skip2_shadow_rot_filt_fused(sc.xfshad, nb, ox, oy, oz, resume, sc.fc, sc.fshad);
+                else skip2_shadow_rot_filt(sc.xshad, nb, ox, oy, oz, resume, sc.fc, sc.shad);
                 for (unsigned h = 0; h < R; ++h) occluded[h] = resume[h] == nb + 1u;
-            } else {
+            } else if constexpr (FUSED) {
                 unsigned i = 0;
                 while (i < nb) {
                     unsigned fin[R];

@@ -92,6 +92,30 @@ def test_two_rays_per_lane_walk_on_random_concentric_scenes(seed):
         np.testing.assert_array_equal(two, one)
 
 
+@pytest.mark.parametrize("seed", [2201, 2204, 2207, 2210, 2213, 2216, 2219, 2222])
+def test_two_rays_per_lane_walk_on_random_scenes_whose_bounds_have_no_sphere_of_their_own(seed):
+    # round 4: the plain-stream flavour of k_render_skip2 (non-concentric hierarchies: what the library builds for an arbitrary sphere
+    # list) -- bounds that need not enclose their subtrees, the eye often inside them, ragged sizes, spp 1 / 2 / 4 / 8
+    rng = np.random.default_rng(seed)
+    depth, fan, leaf = int(rng.integers(2, 6)), int(rng.integers(2, 5)), int(rng.integers(1, 4))
+    items, bounds, ranges = util.random_nested_scene(seed, depth=depth, fan=fan, leaf_items=leaf, concentric=False)
+    eye = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-4.5, -1.0)))
+    light = (float(rng.uniform(-2, 2)), float(rng.uniform(-3, -0.5)), float(rng.uniform(-2, 2)))
+    s, o = util.scene_pair_ranges(items, bounds, ranges, rta.RT_F32, light=light, eye=eye)
+    before = rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_TWO_RAY_LAUNCHES)
+    for spp in (1, 2, 4, 8):
+        w, h = int(rng.integers(2, 7)) * 32 + int(rng.integers(0, 17)), int(rng.integers(2, 5)) * 24 + int(rng.integers(0, 13))
+        regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
+        ref, rst, _ = o.render(w, h, spp, os.cpu_count() or 1, HIER_EXIT)
+        with rta.capi.debug(rta.capi.DEBUG_SKIP_RAYS, 2):
+            two, _ = s.device().render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
+        with rta.capi.debug(rta.capi.DEBUG_SKIP_RAYS, 1):
+            one, _ = s.device().render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
+        np.testing.assert_array_equal(util.stitch((w, h), regs, two), ref)
+        np.testing.assert_array_equal(two, one)
+    assert rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_TWO_RAY_LAUNCHES) >= before + 4
+
+
 @pytest.mark.parametrize("scale", [1e-20, 1e-10, 1e6, 5e13])
 def test_two_rays_per_lane_walk_on_scaled_scenes(scale):
     # the exact path of the two-ray loops per half, including the scaled `tiny` branches (1e-20: every square is a denormal)

@@ -333,6 +333,7 @@ def primary_update(a, r, h, c, done, own=False):
     a.label(done)
 
 
+FUSED = True                    # the flavour being generated: False = plain streams (a BOUND has no sphere of its own: non-concentric scenes)
 KK = 82                         # s82: 1 + 2^-20 (bound_shortcut), the low half of the pair a packed instruction reads it through
 G = (sp(78), sp(80))            # primary loop, per half: the rays the root-free decision lets enter (the shadow loops keep the light there)
 SGPR_LAST_PRIMARY = 83
@@ -387,16 +388,17 @@ def primary_copy(r, name):
     k.op("s_cbranch_scc0 %s" % lab("skip"), "nobody enters (the rays that culled it are awake again at `skip`)")
     load(k, n, NX, "somebody enters: fetch the group's first child")
     sleep_culled(k, r, c)
-    # the group's own sphere, for the rays that entered: same centre, so v, b and b*b - vv are the values just formed
-    pk(k, "add", r.DISC.p, None, r.Q.p, sx=own(c), comment="disc = (b*b - vv) + rr of the group's own sphere")
-    k.op("v_cmp_le_f32_e64 %s, 0, %s" % (M, r.DISC.h[0]))
-    k.op("v_cmp_le_f32_e32 vcc, 0, %s" % r.DISC.h[1])
-    k.op("s_and_b64 %s, %s, %s" % (C[0], C[0], M))
-    k.op("s_and_b64 %s, %s, vcc" % (C[1], C[1]))
-    k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
-    k.op("s_cbranch_scc0 %s" % lab("next"))
-    for h in range(2):
-        primary_update(k, r, h, c, primary_go(k, r, h, "f", lab, tinies), own=True)
+    if FUSED:
+        # the group's own sphere, for the rays that entered: same centre, so v, b and b*b - vv are the values just formed
+        pk(k, "add", r.DISC.p, None, r.Q.p, sx=own(c), comment="disc = (b*b - vv) + rr of the group's own sphere")
+        k.op("v_cmp_le_f32_e64 %s, 0, %s" % (M, r.DISC.h[0]))
+        k.op("v_cmp_le_f32_e32 vcc, 0, %s" % r.DISC.h[1])
+        k.op("s_and_b64 %s, %s, %s" % (C[0], C[0], M))
+        k.op("s_and_b64 %s, %s, vcc" % (C[1], C[1]))
+        k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+        k.op("s_cbranch_scc0 %s" % lab("next"))
+        for h in range(2):
+            primary_update(k, r, h, c, primary_go(k, r, h, "f", lab, tinies), own=True)
     k.label(lab("next"))
     emit_next(k, name)
     # ITEM (primitive.rs:77-84) or END
@@ -613,16 +615,17 @@ def shadow_copy_filt(r, name):
         k.op("s_andn2_b64 exec, %s, %s" % (ACT[h], C[h]), "rays that may not enter sleep until `skip`" if h == 0 else None)
         k.op("v_mov_b32_e32 %s, %s" % (r.RES.h[h], s_skip(c)))
     k.op("s_mov_b64 exec, %s" % EX)
-    for h in range(2):
-        k.op("s_mov_b64 %s, %s" % (ACT[h], C[h]), "the rays that are awake at the next node" if h == 0 else None)
-    outer_cmp(k, r, s_r2o_own(c))
-    for h in range(2):
-        k.op("s_and_b64 %s, %s, %s" % (C[h], C[h], ACT[h]), "the group's own sphere: same centre, its own bounds" if h == 0 else None)
-    k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
-    k.op("s_cbranch_scc0 %s" % lab("next"))
-    two_sided(k, r, s_r2i_own(c), lab("exactown"))
-    k.label(lab("owndecided"))
-    k.op("s_branch .Lr2_fin_%=", "any hit ends those rays; hand them to the caller (it starts again behind this node)")
+    if FUSED:
+        for h in range(2):
+            k.op("s_mov_b64 %s, %s" % (ACT[h], C[h]), "the rays that are awake at the next node" if h == 0 else None)
+        outer_cmp(k, r, s_r2o_own(c))
+        for h in range(2):
+            k.op("s_and_b64 %s, %s, %s" % (C[h], C[h], ACT[h]), "the group's own sphere: same centre, its own bounds" if h == 0 else None)
+        k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+        k.op("s_cbranch_scc0 %s" % lab("next"))
+        two_sided(k, r, s_r2i_own(c), lab("exactown"))
+        k.label(lab("owndecided"))
+        k.op("s_branch .Lr2_fin_%=", "any hit ends those rays; hand them to the caller (it starts again behind this node)")
     k.label(lab("next"))
     load(k, n, NX, "somebody entered: fetch the group's first child")
     emit_next(k, name)
@@ -644,17 +647,18 @@ def shadow_copy_filt(r, name):
     k.op("s_cbranch_scc0 %s" % lab("skip"))
     inner_terms(k, r)                                # the own sphere's bounds read INN and TT again
     k.op("s_branch %s" % lab("decided"))
-    k.label(lab("exactown"))
-    second_chance(k, r, s_r2o_own(c), lab("exactown2"), lab("next"), lab("owndecided"))
-    k.label(lab("exactown2"))
-    k.op("s_sub_u32 %s, %s, %d" % (tmp, NX, STRIDE), "this node's offset")
-    k.op("s_waitcnt lgkmcnt(0)", "the skip successor's fetch may still be in flight INTO this bank, and scalar loads land out of order")
-    k.op("s_load_dwordx8 s[%d:%d], %%[base2], %s" % (BANK[s], BANK[s] + 7, tmp), "its Node record (the skip bank is free: the group is entered)")
-    k.op("s_waitcnt lgkmcnt(0)")
-    exact_packed(k, r, s, own(s), lab, "y", tinies)
-    k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
-    k.op("s_cbranch_scc0 %s" % lab("next"))
-    k.op("s_branch %s" % lab("owndecided"))
+    if FUSED:
+        k.label(lab("exactown"))
+        second_chance(k, r, s_r2o_own(c), lab("exactown2"), lab("next"), lab("owndecided"))
+        k.label(lab("exactown2"))
+        k.op("s_sub_u32 %s, %s, %d" % (tmp, NX, STRIDE), "this node's offset")
+        k.op("s_waitcnt lgkmcnt(0)", "the skip successor's fetch may still be in flight INTO this bank, and scalar loads land out of order")
+        k.op("s_load_dwordx8 s[%d:%d], %%[base2], %s" % (BANK[s], BANK[s] + 7, tmp), "its Node record (the skip bank is free: the group is entered)")
+        k.op("s_waitcnt lgkmcnt(0)")
+        exact_packed(k, r, s, own(s), lab, "y", tinies)
+        k.op("s_or_b64 %s, %s, %s" % (M, C[0], C[1]))
+        k.op("s_cbranch_scc0 %s" % lab("next"))
+        k.op("s_branch %s" % lab("owndecided"))
     for disc, tl, dl in tinies:
         tiny(k, r, disc, tl, dl)
     return m, k
@@ -832,7 +836,7 @@ PRIMARY_FN = """// Primary-ray traversal: s.group.intersect(&mut h, r) for the w
 // (three packed instructions) and forms the reference's discriminant only when some ray passes.
 // resume[h]: 0 for a ray, n * 32 for a lane half without one (it sleeps until END).  Returns hit.distance and, per ray, either
 // item | bit 31 or -- bit 31 clear, a group's own sphere -- the byte offset behind its BOUND node (look the item up in own_item).
-__device__ __forceinline__ void skip2_primary_rot_fused(const void *nodes, const float (&dx)[2], const float (&dy)[2], const float (&dz)[2],
+__device__ __forceinline__ void %(name)s(const void *nodes, const float (&dx)[2], const float (&dy)[2], const float (&dz)[2],
                                                         const unsigned (&resume)[2], float (&best_out)[2], unsigned (&item_out)[2])
 {
     const float tiny = 0x1p-96f, kk = 0x1.00001p+0f;       // kk = 1 + 2^-20 (bound_shortcut)
@@ -876,7 +880,7 @@ SHADOW_FN_FILT = """// The shadow walk over the FILTERED stream (FNodeS[n + 3], 
 // only when a ray stays between the bounds does the step fetch the node's Node record from `exact` (the compacted exact stream, same
 // offsets) and run the reference's arithmetic for every ray.  fc: the scene's FilterConsts (its l is the rays' direction).
 // resume[h] in: 0 for a shadow ray, n_bytes for a lane half without one.  resume[h] out: n_bytes + 1 iff the ray hit something.
-__device__ __forceinline__ void skip2_shadow_rot_filt_fused(const void *nodes, unsigned n_bytes, const float (&ox)[2], const float (&oy)[2],
+__device__ __forceinline__ void %(name)s(const void *nodes, unsigned n_bytes, const float (&ox)[2], const float (&oy)[2],
                                                             const float (&oz)[2], unsigned (&resume)[2], const void *fc, const void *exact)
 {
     const float tiny = 0x1p-96f;
@@ -906,9 +910,17 @@ def clobbers(last=SGPR_LAST):
 
 def main():
     text = HEADER
-    text += PRIMARY_FN % {"body": primary(), "clobbers": clobbers(SGPR_LAST_PRIMARY)}
+    global FUSED
+    text += PRIMARY_FN % {"name": "skip2_primary_rot_fused", "body": primary(), "clobbers": clobbers(SGPR_LAST_PRIMARY)}
     text += SHADOW_FN % {"body": shadow(), "clobbers": clobbers()}
-    text += SHADOW_FN_FILT % {"body": shadow_filt(), "clobbers": clobbers(SGPR_LAST_FILT)}
+    text += SHADOW_FN_FILT % {"name": "skip2_shadow_rot_filt_fused", "body": shadow_filt(), "clobbers": clobbers(SGPR_LAST_FILT)}
+    # the same two loops over PLAIN filtered streams: scenes whose bounds have no sphere of their own (the automatic hierarchy of an
+    # arbitrary sphere list) -- a BOUND step ends where somebody enters
+    FUSED = False
+    text += "// The plain-stream flavours (a BOUND node carries no sphere of its own): FNode / FNodeS of the scene's plain streams.\n"
+    text += PRIMARY_FN % {"name": "skip2_primary_rot", "body": primary(), "clobbers": clobbers(SGPR_LAST_PRIMARY)}
+    text += SHADOW_FN_FILT % {"name": "skip2_shadow_rot_filt", "body": shadow_filt(), "clobbers": clobbers(SGPR_LAST_FILT)}
+    FUSED = True
     text += "}  // namespace rt\n"
     with open(OUT, "w") as f:
         f.write(text)

@@ -87,7 +87,7 @@ while time.time() < t_end:
         filter_tests += st["sphere_tests"] + st["bound_tests"]
     rta.capi.debug_set(rta.capi.DEBUG_SKIP_VARIANT, -1)
     if prec == rta.RT_F32:
-        if seed % 2 == 1:                                        # concentric = fused: the two-ray kernel exists (spp 1 and 2)
+        if True:                                                 # the two-ray kernel: fused loops for concentric scenes, plain-stream loops for the others
             with rta.capi.debug(rta.capi.DEBUG_SKIP_RAYS, 2):
                 got, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
             assert np.array_equal(got, ref), "seed %d: two rays per lane differ" % seed
