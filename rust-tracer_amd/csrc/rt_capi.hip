@@ -1178,16 +1178,18 @@ void worker_main(rt_scene *s)
     (void)hipSetDevice(s->device);
     for (;;) {
         std::function<void()> job;
+        bool stopping;
         {
             std::unique_lock<std::mutex> lk(s->wmu);
             s->wcv.wait(lk, [s] { return s->wstop || !s->wjobs.empty(); });
             if (s->wjobs.empty()) return;
             job = std::move(s->wjobs.front());
             s->wjobs.pop_front();
+            stopping = s->wstop;
         }
         // let the caller's first launch (and whoever waits for it) have the runtime to itself: the orders' allocations and blocking copies
         // took 20-50 us out of a one-shot caller's first frame when they started at once, and nobody misses them for another 0.3 ms
-        if (!s->wstop) std::this_thread::sleep_for(std::chrono::microseconds(300));
+        if (!stopping) std::this_thread::sleep_for(std::chrono::microseconds(300));
         job();
     }
 }
