@@ -34,7 +34,7 @@ typedef enum rt_debug_key {
                                     (the rest as four 4x4 ones); default: all in a pass of <= 4,096 blocks, none otherwise */
     RT_DEBUG_FLAT_KERNELS = 11,  /* 0: the f32 flat traversal runs round 1's LDS-staged packed-math kernels (rt_flat_wf.hpp, what f64 always
                                     runs) instead of the scalar-fed scan (rt_flat_sc.hpp) */
-    RT_DEBUG_SKIP_RAYS = 12,     /* rays per lane of the f32 fused hierarchy walk: 1 = k_render_skip always; 2 = k_render_skip2 (two rays per lane on
+    RT_DEBUG_SKIP_RAYS = 12,     /* rays per lane of the f32 hierarchy walk (assembly loops): 1 = k_render_skip always; 2 = k_render_skip2 (two rays per lane on
                                     packed math, rt_skip2.hpp) wherever it exists (spp 1, 2, 4, 8; launches that do not count tests);
                                     default: the library's choice per workload (large spp-1 frames, large scenes) */
     RT_DEBUG_FRAME_AHEAD = 13,   /* 0: rt_render_region never serves a bucket from a whole-grid pass rendered ahead (every call its own device pass,
