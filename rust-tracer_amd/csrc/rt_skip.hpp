@@ -817,8 +817,10 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
     }       // descriptors of this workgroup
 }
 
+// (f64 and the counting launches.  Held to six waves per SIMD: the f64 walk waits for its node records like the f32 one, its 81 vector
+// registers were one too many for the sixth wave -- 80 without a spill, 1080p f64 69.8 -> 65.0 us; a seventh costs 20 bytes of scratch and buys nothing.)
 template <typename T, bool COUNT, int VAR, int MODE, bool COOP = false>
-__global__ __launch_bounds__(kBlockThreads) void k_render_skip(SkipView<T> sc, unsigned width, unsigned height, unsigned spp_arg,
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(6))) void k_render_skip(SkipView<T> sc, unsigned width, unsigned height, unsigned spp_arg,
                                                               const TileDev *__restrict__ tiles, unsigned n_tiles,
                                                               uint8_t *__restrict__ out, Counters *__restrict__ counters,
                                                               SampleBuf<T> sb, unsigned frame_w,

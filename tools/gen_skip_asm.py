@@ -585,8 +585,11 @@ class F64FS(F64F):
         a.op("s_waitcnt lgkmcnt(0)")
         F64.shadow_terms(self, a, c)
 
-    shadow_decl = F64.shadow_decl + "\n    float tf0, p2, av, inn;" + QQ_DECL
-    shadow_out = F64.shadow_out + ', [tf0] "=&v"(tf0), [p2] "=&v"(p2), [av] "=&v"(av), [inn] "=&v"(inn)'
+    # (the bound's scratch register and P2 + a^2 live in the halves of TT, free between two steps' P2: two vector registers fewer, and the f64
+    # kernel's 81 become 79 -- six waves per SIMD instead of five)
+    shadow_decl = F64.shadow_decl + "\n    float p2, av;" + QQ_DECL
+    shadow_out = F64.shadow_out + ', [p2] "=&v"(p2), [av] "=&v"(av)'
+    shadow_subst = (("%[tf0]", "v%d" % TT[0]), ("%[inn]", "v%d" % TT[1]))
     shadow_extra_in = ', ' + QQ_IN + ', [ol] "v"(ol), [a0] "s"(a0), [k1] "s"(k1), [kc] "v"(kc), [base2] "s"(exact)'
     shadow_vclobbers = PACKED_CLOBBERS
 
