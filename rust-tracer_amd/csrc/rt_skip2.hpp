@@ -21,10 +21,14 @@ constexpr unsigned kSkip2Threads = kBlockThreads / kSkip2Rays;
 
 // FILT: the shadow walk reads the two-sided bounds of the filtered streams (skip2_shadow_rot_filt_fused) instead of forming the
 // reference's sixteen operations at every node; the primary walk is filtered in both flavours.
+// Held to 8 waves per SIMD (round 4): the loops' operands are bound to the loops' own registers (tools/gen_skip2_asm.py: eight copies and
+// eight registers fewer at the statement), 94 scalar registers as in k_render_skip_f32 -- 64 vector registers, no scratch (round 3 had
+// forced 64 on a 72-register kernel and paid 12 bytes of scratch for it).  The walk waits for node records like the one-ray walk does:
+// config 5 2.93 -> 2.86 ms, the 100,000-sphere frame 19.9 -> 18.7 ms.
 // FUSED = false: a scene whose bounds have no sphere of their own (the automatic hierarchy of an arbitrary sphere list): the plain filtered
 // streams, the plain-stream loops (FILT only).
 template <int MODE, bool FILT, bool FUSED = true>
-__global__ __launch_bounds__(kSkip2Threads) void k_render_skip2(SkipView<float> sc, unsigned width, unsigned height, unsigned spp_arg,
+__global__ __launch_bounds__(kSkip2Threads) __attribute__((amdgpu_num_sgpr(94), amdgpu_waves_per_eu(8))) void k_render_skip2(SkipView<float> sc, unsigned width, unsigned height, unsigned spp_arg,
                                                                const TileDev *__restrict__ tiles, unsigned n_tiles, uint8_t *__restrict__ out,
                                                                SampleBuf<float> sb, unsigned frame_w, const BlockDesc *__restrict__ order,
                                                                const uint32_t *__restrict__ wg_first)

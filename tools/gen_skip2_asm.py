@@ -670,13 +670,9 @@ def shadow_filt():
     node any ray still wants (the wave minimum of max(resume, NX), a DPP reduction).  The operands are dead once copied in."""
     a, r = Asm(), RegsSF()
     a.op("s_load_dwordx16 s[%d:%d], %%[fc], 0x0" % (FC, FC + 15), "FilterConsts: m0, e1, e2, l, a0, k1, kc, ro2")
-    for h in range(2):
-        a.op("v_mov_b32_e32 %s, %%[ox%d]" % (r.DX.h[h], h), "operands into the loop's own registers" if h == 0 else None)
-        a.op("v_mov_b32_e32 %s, %%[oy%d]" % (r.DY.h[h], h))
-        a.op("v_mov_b32_e32 %s, %%[oz%d]" % (r.DZ.h[h], h))
-        a.op("v_mov_b32_e32 %s, %%[res%d]" % (r.RES.h[h], h))
     a.op("s_mov_b64 %s, exec" % EX)
     a.op("s_waitcnt lgkmcnt(0)")
+    # (origins and resume arrive in the loop's own registers: see primary())
     # shadow_filter_origin (rt_skip.hpp) for both rays: q = ((o - m0) . e1, (o - m0) . e2), ol = (o - m0) . l, FMA chains in its order
     x, y, z, d2 = r.E[0], r.E[1], r.E[2], r.E[3]
     pk(a, "add", x.p, r.DX.p, None, sy=FC + 0, neg_y=True, comment="o - m0")
@@ -742,8 +738,6 @@ def shadow_filt():
     a.op("s_branch %s" % top_of("A"))
     a.label(".Lr2_exit_%=")
     a.op("s_waitcnt lgkmcnt(0)")
-    for h in range(2):
-        a.op("v_mov_b32_e32 %%[rout%d], %s" % (h, r.RES.h[h]))
     return a.render()
 
 
@@ -759,11 +753,9 @@ def assemble(a, r, copy_fn):
 
 def primary():
     a, r = Asm(), Regs(False)
+    # (the rays' directions, resume and the results ARE the loop's registers: the statement binds its operands to v32.. directly -- eight
+    # copies and eight registers fewer at the statement, which is what stood between k_render_skip2 and its eighth wave per SIMD)
     for h in range(2):
-        a.op("v_mov_b32_e32 %s, %%[dx%d]" % (r.DX.h[h], h), "operands into the loop's own registers" if h == 0 else None)
-        a.op("v_mov_b32_e32 %s, %%[dy%d]" % (r.DY.h[h], h))
-        a.op("v_mov_b32_e32 %s, %%[dz%d]" % (r.DZ.h[h], h))
-        a.op("v_mov_b32_e32 %s, %%[res%d]" % (r.RES.h[h], h))
         a.op("v_mov_b32_e32 %s, 0x7f800000" % r.BEST.h[h], "hit.distance = INF (primitive.rs:96)" if h == 0 else None)
         a.op("v_mov_b32_e32 %s, 0" % r.BITEM.h[h])
     a.op("s_mov_b32 %s, %d" % (NX, STRIDE))
@@ -774,9 +766,6 @@ def primary():
     assemble(a, r, primary_copy)
     a.label(".Lr2_exit_%=")
     a.op("s_waitcnt lgkmcnt(0)")
-    for h in range(2):
-        a.op("v_mov_b32_e32 %%[best%d], %s" % (h, r.BEST.h[h]))
-        a.op("v_mov_b32_e32 %%[item%d], %s" % (h, r.BITEM.h[h]))
     return a.render()
 
 
@@ -840,11 +829,13 @@ __device__ __forceinline__ void %(name)s(const void *nodes, const float (&dx)[2]
                                                         const unsigned (&resume)[2], float (&best_out)[2], unsigned (&item_out)[2])
 {
     const float tiny = 0x1p-96f, kk = 0x1.00001p+0f;       // kk = 1 + 2^-20 (bound_shortcut)
+    unsigned res0 = resume[0], res1 = resume[1];          // (the loop's RES pair; what it leaves there is of no interest)
     asm volatile(
 %(body)s
-        : [best0] "=v"(best_out[0]), [best1] "=v"(best_out[1]), [item0] "=v"(item_out[0]), [item1] "=v"(item_out[1])
-        : [base] "s"(nodes), [dx0] "v"(dx[0]), [dx1] "v"(dx[1]), [dy0] "v"(dy[0]), [dy1] "v"(dy[1]), [dz0] "v"(dz[0]), [dz1] "v"(dz[1]),
-          [res0] "v"(resume[0]), [res1] "v"(resume[1]), [tiny] "s"(tiny), [kk] "s"(kk)
+        : [best0] "={v52}"(best_out[0]), [best1] "={v53}"(best_out[1]), [item0] "={v54}"(item_out[0]), [item1] "={v55}"(item_out[1]),
+          [res0] "+{v38}"(res0), [res1] "+{v39}"(res1)
+        : [base] "s"(nodes), [dx0] "{v32}"(dx[0]), [dx1] "{v33}"(dx[1]), [dy0] "{v34}"(dy[0]), [dy1] "{v35}"(dy[1]), [dz0] "{v36}"(dz[0]), [dz1] "{v37}"(dz[1]),
+          [tiny] "s"(tiny), [kk] "s"(kk)
         : %(clobbers)s);
 }
 
@@ -886,17 +877,22 @@ __device__ __forceinline__ void %(name)s(const void *nodes, unsigned n_bytes, co
     const float tiny = 0x1p-96f;
     asm volatile(
 %(body)s
-        : [rout0] "=v"(resume[0]), [rout1] "=v"(resume[1])
-        : [base] "s"(nodes), [n] "s"(n_bytes), [ox0] "v"(ox[0]), [ox1] "v"(ox[1]), [oy0] "v"(oy[0]), [oy1] "v"(oy[1]),
-          [oz0] "v"(oz[0]), [oz1] "v"(oz[1]), [res0] "v"(resume[0]), [res1] "v"(resume[1]), [tiny] "s"(tiny), [fc] "s"(fc), [base2] "s"(exact)
+        : [res0] "+{v38}"(resume[0]), [res1] "+{v39}"(resume[1])
+        : [base] "s"(nodes), [n] "s"(n_bytes), [ox0] "{v32}"(ox[0]), [ox1] "{v33}"(ox[1]), [oy0] "{v34}"(oy[0]), [oy1] "{v35}"(oy[1]),
+          [oz0] "{v36}"(oz[0]), [oz1] "{v37}"(oz[1]), [tiny] "s"(tiny), [fc] "s"(fc), [base2] "s"(exact)
         : %(clobbers)s);
 }
 
 """
 
 
-def clobbers(last=SGPR_LAST):
-    regs = ['"s%d"' % r for r in range(36, last + 1)] + ['"v%d"' % r for r in range(VGPR_FIRST, VGPR_LAST + 1)]
+PRIMARY_BOUND = tuple(range(32, 40)) + tuple(range(52, 56))      # DX, DY, DZ, RES in; BEST, BITEM out  (Regs(False))
+SHADOW_BOUND = tuple(range(32, 40))                                # DX, DY, DZ (the origins), RES in / out  (RegsSF)
+
+
+def clobbers(last=SGPR_LAST, bound=()):
+    """bound: vector registers of the loops that ARE operands of the statement (the caller's values arrive in / leave from them directly)."""
+    regs = ['"s%d"' % r for r in range(36, last + 1)] + ['"v%d"' % r for r in range(VGPR_FIRST, VGPR_LAST + 1) if r not in bound]
     lines, cur = [], '"memory", "vcc", "scc"'
     for r in regs:
         if len(cur) + len(r) + 2 > 118:
@@ -911,15 +907,15 @@ def clobbers(last=SGPR_LAST):
 def main():
     text = HEADER
     global FUSED
-    text += PRIMARY_FN % {"name": "skip2_primary_rot_fused", "body": primary(), "clobbers": clobbers(SGPR_LAST_PRIMARY)}
+    text += PRIMARY_FN % {"name": "skip2_primary_rot_fused", "body": primary(), "clobbers": clobbers(SGPR_LAST_PRIMARY, PRIMARY_BOUND)}
     text += SHADOW_FN % {"body": shadow(), "clobbers": clobbers()}
-    text += SHADOW_FN_FILT % {"name": "skip2_shadow_rot_filt_fused", "body": shadow_filt(), "clobbers": clobbers(SGPR_LAST_FILT)}
+    text += SHADOW_FN_FILT % {"name": "skip2_shadow_rot_filt_fused", "body": shadow_filt(), "clobbers": clobbers(SGPR_LAST_FILT, SHADOW_BOUND)}
     # the same two loops over PLAIN filtered streams: scenes whose bounds have no sphere of their own (the automatic hierarchy of an
     # arbitrary sphere list) -- a BOUND step ends where somebody enters
     FUSED = False
     text += "// The plain-stream flavours (a BOUND node carries no sphere of its own): FNode / FNodeS of the scene's plain streams.\n"
-    text += PRIMARY_FN % {"name": "skip2_primary_rot", "body": primary(), "clobbers": clobbers(SGPR_LAST_PRIMARY)}
-    text += SHADOW_FN_FILT % {"name": "skip2_shadow_rot_filt", "body": shadow_filt(), "clobbers": clobbers(SGPR_LAST_FILT)}
+    text += PRIMARY_FN % {"name": "skip2_primary_rot", "body": primary(), "clobbers": clobbers(SGPR_LAST_PRIMARY, PRIMARY_BOUND)}
+    text += SHADOW_FN_FILT % {"name": "skip2_shadow_rot_filt", "body": shadow_filt(), "clobbers": clobbers(SGPR_LAST_FILT, SHADOW_BOUND)}
     FUSED = True
     text += "}  // namespace rt\n"
     with open(OUT, "w") as f:
