@@ -1428,7 +1428,8 @@ rt_status launch_flat_wavefront(const rt_scene *s, Context *c, hipStream_t strea
 template <typename T, bool COUNT, int VAR, int MODE, bool COOP = false>
 constexpr auto skip_kernel()
 {
-    if constexpr (sizeof(T) == 4 && !COUNT) return &rt::k_render_skip_f32<COUNT, VAR, MODE, COOP>;
+    if constexpr (sizeof(T) == 4 && !COUNT && COOP) return &rt::k_render_skip_f32_coop<COUNT, VAR, MODE>;
+    else if constexpr (sizeof(T) == 4 && !COUNT) return &rt::k_render_skip_f32<COUNT, VAR, MODE>;
     else return &rt::k_render_skip<T, COUNT, VAR, MODE, COOP>;
 }
 

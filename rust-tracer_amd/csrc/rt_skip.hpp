@@ -831,17 +831,31 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(6
     render_skip_body<T, COUNT, VAR, MODE, COOP>(sc, width, height, spp_arg, tiles, n_tiles, out, counters, sb, frame_w, order, lane_cost, wg_first, cv, holes, n_holes);
 }
 
-// The same kernel for f32 launches that do not count, held to 94 scalar registers (100 with the hardware's six): 8 waves per SIMD instead
-// of the 7 that the 106 of the unconstrained build allow -- the compiler parks eight values in vector-register lanes (v_writelane /
-// v_readlane outside the loops) and the 1080p frame goes from 46.9 to 44.3 us (tools/ab_libs.sh, same box, interleaved).  The f64 loops own
-// s[36:97] and cannot live under that limit, hence a kernel of its own rather than an attribute on the template.
-template <bool COUNT, int VAR, int MODE, bool COOP = false>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(94))) void k_render_skip_f32(
+// The same kernel for f32 launches that do not count, held to 74 scalar registers -- 80 with the hardware's six, and 80 is what a CU admits
+// EIGHT 256-thread workgroups at (MI355X_MICROARCH.md, "Residency": .sgpr_count <= 80 -> 8, 82 - 96 -> 7 whatever the compiler's occupancy
+// remark says, 98+ -> 6).  The loops themselves own s[36:73]; everything the kernel keeps across them beyond s[0:35] is parked in
+// vector-register lanes (v_writelane / v_readlane outside the loops; the kernel has 47 of its 64 vector registers to spare).  History: the
+// unconstrained build has 106 (6 workgroups per CU); round 4 first capped it at 94 (-> 92: 7 per CU, 1080p 46.9 -> 44.3 us, and was
+// taken for 8), then at 74 (-> 80: 8 per CU, 42.7 -> 41.8 us).  The walk waits for its node records half of its time: a
+// wave more per SIMD is a fetch more in flight.  The f64 loops own s[36:97] and cannot live under such a limit, hence kernels of their
+// own rather than an attribute on the template.
+template <bool COUNT, int VAR, int MODE>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(74))) void k_render_skip_f32(
     SkipView<float> sc, unsigned width, unsigned height, unsigned spp_arg, const TileDev *__restrict__ tiles, unsigned n_tiles, uint8_t *__restrict__ out,
     Counters *__restrict__ counters, SampleBuf<float> sb, unsigned frame_w, const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost,
     const uint32_t *__restrict__ wg_first, CoopView cv = CoopView{}, const uint64_t *__restrict__ holes = nullptr, unsigned n_holes = 0)
 {
-    render_skip_body<float, COUNT, VAR, MODE, COOP>(sc, width, height, spp_arg, tiles, n_tiles, out, counters, sb, frame_w, order, lane_cost, wg_first, cv, holes, n_holes);
+    render_skip_body<float, COUNT, VAR, MODE, false>(sc, width, height, spp_arg, tiles, n_tiles, out, counters, sb, frame_w, order, lane_cost, wg_first, cv, holes, n_holes);
+}
+// ... and its flavour with the lane-cooperative walk (rt_coop.hpp), which keeps more state across the loops: at 74 it parks 41 values and
+// the small passes it serves lose 2 % (800x600 28.7 -> 29.4 us); at 94 (7 workgroups per CU) they do not miss the eighth.
+template <bool COUNT, int VAR, int MODE>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(94))) void k_render_skip_f32_coop(
+    SkipView<float> sc, unsigned width, unsigned height, unsigned spp_arg, const TileDev *__restrict__ tiles, unsigned n_tiles, uint8_t *__restrict__ out,
+    Counters *__restrict__ counters, SampleBuf<float> sb, unsigned frame_w, const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost,
+    const uint32_t *__restrict__ wg_first, CoopView cv = CoopView{}, const uint64_t *__restrict__ holes = nullptr, unsigned n_holes = 0)
+{
+    render_skip_body<float, COUNT, VAR, MODE, true>(sc, width, height, spp_arg, tiles, n_tiles, out, counters, sb, frame_w, order, lane_cost, wg_first, cv, holes, n_holes);
 }
 
 // Second pass of the SPLIT path: render.rs:233-252 for one pixel -- its samples' contributions accumulated strictly
