@@ -21,10 +21,11 @@ constexpr unsigned kSkip2Threads = kBlockThreads / kSkip2Rays;
 
 // FILT: the shadow walk reads the two-sided bounds of the filtered streams (skip2_shadow_rot_filt_fused) instead of forming the
 // reference's sixteen operations at every node; the primary walk is filtered in both flavours.
-// Held to 8 waves per SIMD (round 4): the loops' operands are bound to the loops' own registers (tools/gen_skip2_asm.py: eight copies and
-// eight registers fewer at the statement), 94 scalar registers as in k_render_skip_f32 -- 64 vector registers, no scratch (round 3 had
-// forced 64 on a 72-register kernel and paid 12 bytes of scratch for it).  The walk waits for node records like the one-ray walk does:
-// config 5 2.93 -> 2.86 ms, the 100,000-sphere frame 19.9 -> 18.7 ms.
+// Round 4: the loops' operands are bound to the loops' own registers (tools/gen_skip2_asm.py: eight copies and eight registers fewer at
+// the statement) -- 64 vector registers, no scratch (round 3 had forced 64 on a 72-register kernel and paid 12 bytes of scratch for it) --
+// and the kernel is held to 94 scalar registers (.sgpr_count 92: a CU admits SEVEN 256-thread workgroups' worth at 82 - 96,
+// MI355X_MICROARCH.md "Residency"; eight would need 80, and these loops own s[36:85]).  The walk waits for node records like the one-ray
+// walk does: config 5 2.93 -> 2.86 ms, the 100,000-sphere frame 19.9 -> 18.7 ms.
 // FUSED = false: a scene whose bounds have no sphere of their own (the automatic hierarchy of an arbitrary sphere list): the plain filtered
 // streams, the plain-stream loops (FILT only).
 template <int MODE, bool FILT, bool FUSED = true>
