@@ -23,13 +23,14 @@ constexpr unsigned kSkip2Threads = kBlockThreads / kSkip2Rays;
 // reference's sixteen operations at every node; the primary walk is filtered in both flavours.
 // Round 4: the loops' operands are bound to the loops' own registers (tools/gen_skip2_asm.py: eight copies and eight registers fewer at
 // the statement) -- 64 vector registers, no scratch (round 3 had forced 64 on a 72-register kernel and paid 12 bytes of scratch for it) --
-// and the kernel is held to 94 scalar registers (.sgpr_count 92: a CU admits SEVEN 256-thread workgroups' worth at 82 - 96,
-// MI355X_MICROARCH.md "Residency"; eight would need 80, and these loops own s[36:85]).  The walk waits for node records like the one-ray
-// walk does: config 5 2.93 -> 2.86 ms, the 100,000-sphere frame 19.9 -> 18.7 ms.
+// and the loops' fifty scalar registers start at s24, the kernel held to 74: .sgpr_count 80, which is what a CU admits EIGHT workgroups'
+// worth of waves per SIMD at (MI355X_MICROARCH.md "Residency": 82 - 96 admit seven whatever the occupancy remark says); what the kernel
+// keeps across the loops beyond s[0:23] is parked in vector-register lanes.  The walk waits for node records like the one-ray walk does:
+// config 5 2.93 -> 2.86 (64 vector registers, seven per SIMD) -> 2.83 ms (eight), the 100,000-sphere frame 19.9 -> 18.7 ms.
 // FUSED = false: a scene whose bounds have no sphere of their own (the automatic hierarchy of an arbitrary sphere list): the plain filtered
 // streams, the plain-stream loops (FILT only).
 template <int MODE, bool FILT, bool FUSED = true>
-__global__ __launch_bounds__(kSkip2Threads) __attribute__((amdgpu_num_sgpr(94), amdgpu_waves_per_eu(8))) void k_render_skip2(SkipView<float> sc, unsigned width, unsigned height, unsigned spp_arg,
+__global__ __launch_bounds__(kSkip2Threads) __attribute__((amdgpu_num_sgpr(74), amdgpu_waves_per_eu(8))) void k_render_skip2(SkipView<float> sc, unsigned width, unsigned height, unsigned spp_arg,
                                                                const TileDev *__restrict__ tiles, unsigned n_tiles, uint8_t *__restrict__ out,
                                                                SampleBuf<float> sb, unsigned frame_w, const BlockDesc *__restrict__ order,
                                                                const uint32_t *__restrict__ wg_first)

@@ -18,7 +18,7 @@ A lane's two rays have their own `resume`, hit.distance and item; a wave walks t
 pairs rays that share most of their walk (two samples' worth of neighbouring pixels).
 
 The halves of a register pair have to be named, which inline-asm operands cannot do: the loops own FIXED registers (v[32:63],
-s[36:81]; listed as clobbers) and move their operands in and out.
+s[24:73]; listed as clobbers).
 
 Run:  python3 tools/gen_skip2_asm.py   (writes the header; the build does not need this script)."""
 import os
@@ -32,19 +32,23 @@ SKIP_COPY = {"A": "C", "B": "C", "C": "B"}
 LAYOUT = "ACB"
 FLAG_LIMIT = "0x3fffffff"
 STRIDE = 32
-BANK = (36, 44, 52)
-NX = "s60"
-LIGHT = 78                                                           # s78..s80: the shadow rays' direction (s81 pads the pair)
-SGPR_LAST, VGPR_FIRST, VGPR_LAST = 81, 32, 63
+# The loops' scalar registers start at SB.  24 (not the 36 of the one-ray loops): the filtered shadow walk needs 50, and a CU admits eight
+# workgroups' worth of waves only up to .sgpr_count 80 (MI355X_MICROARCH.md, "Residency") -- s[24:73] + the hardware's six; the kernel keeps
+# what it needs across the loops in s[0:23] and parks the rest in vector-register lanes (k_render_skip2 is held to 74: rt_skip2.hpp).
+SB = 24
+BANK = (SB, SB + 8, SB + 16)
+NX = "s%d" % (SB + 24)
+LIGHT = SB + 42                                                      # three registers: the shadow rays' direction (the fourth pads the pair)
+SGPR_LAST, VGPR_FIRST, VGPR_LAST = SB + 45, 32, 63
 
 
 def sp(first):
     return "s[%d:%d]" % (first, first + 1)
 
 
-ACT = (sp(62), sp(64))          # per half: the rays awake at the current node
-C = (sp(66), sp(68))            # per half: candidates -> the rays that go on (enter / hit)
-M, M2, TINY, EX = sp(70), sp(76), sp(72), sp(74)
+ACT = (sp(SB + 26), sp(SB + 28))          # per half: the rays awake at the current node
+C = (sp(SB + 30), sp(SB + 32))            # per half: candidates -> the rays that go on (enter / hit)
+M, M2, TINY, EX = sp(SB + 34), sp(SB + 40), sp(SB + 36), sp(SB + 38)
 
 
 class Pair:
@@ -156,11 +160,11 @@ class Regs:
         self.t0, self.t1, self.t3, self.t4, self.t5 = self.T0.h[0], self.T0.h[1], self.T1.h[0], self.T1.h[1], self.T2.h[0]
 
 
-U = (TINY, sp(82))             # filtered shadow walk, per half: the candidates the bounds cannot settle (TINY is only the root's scratch)
+U = (TINY, sp(SB + 46))             # filtered shadow walk, per half: the candidates the bounds cannot settle (TINY is only the root's scratch)
 K1 = LIGHT + 3                  # s81: k1 of the inner bound (the pad of the light's pair)
-A0, KC = "s84", "s85"           # a >= a0 proves b >= 0;  (P2 + a^2) kc >= R2o proves the origin clearly outside
-SGPR_LAST_FILT = 85
-FC = 36                         # FilterConsts (rt_skip.hpp) arrive in s[36:51] before the walk starts: m0, e1, e2, l, a0, k1, kc, ro2
+A0, KC = "s%d" % (SB + 48), "s%d" % (SB + 49)           # a >= a0 proves b >= 0;  (P2 + a^2) kc >= R2o proves the origin clearly outside
+SGPR_LAST_FILT = SB + 49
+FC = SB                         # FilterConsts (rt_skip.hpp) arrive in s[36:51] before the walk starts: m0, e1, e2, l, a0, k1, kc, ro2
 
 
 class RegsSF:
@@ -334,9 +338,9 @@ def primary_update(a, r, h, c, done, own=False):
 
 
 FUSED = True                    # the flavour being generated: False = plain streams (a BOUND has no sphere of its own: non-concentric scenes)
-KK = 82                         # s82: 1 + 2^-20 (bound_shortcut), the low half of the pair a packed instruction reads it through
-G = (sp(78), sp(80))            # primary loop, per half: the rays the root-free decision lets enter (the shadow loops keep the light there)
-SGPR_LAST_PRIMARY = 83
+KK = SB + 46                         # s82: 1 + 2^-20 (bound_shortcut), the low half of the pair a packed instruction reads it through
+G = (sp(SB + 42), sp(SB + 44))            # primary loop, per half: the rays the root-free decision lets enter (the shadow loops keep the light there)
+SGPR_LAST_PRIMARY = SB + 47
 
 
 def bound_shortcut(a, r, c, lab):
@@ -810,9 +814,9 @@ HEADER = """// rt_skip2_rot.hpp -- GENERATED by tools/gen_skip2_asm.py; edit the
 // half on the 32-bit registers of the pairs; each ray has its own resume, hit.distance and item.  Same arithmetic, operation
 // for operation, and the same walk as the one-ray loops (tools/gen_skip_asm.py documents it).
 //
-// The loops own v[32:63] and s[36:81] (clobbers): s[36:59] three node banks, s60 NX, s[62:65] awake masks, s[66:69] candidate /
-// go masks, s[70:77] scratch masks and EXEC at entry, s[78:80] the shadow rays' direction (primary loop: s[78:81] the masks of the
-// root-free BOUND decision, s82 its constant).
+// The loops own v[32:63] and s[24:73] (clobbers): s[24:47] three node banks, s48 NX, s[50:53] awake masks, s[54:57] candidate /
+// go masks, s[58:65] scratch masks and EXEC at entry, s[66:68] the shadow rays' direction (primary loop: s[66:69] the masks of the
+// root-free BOUND decision, s70 its constant), s[70:73] the filtered shadow walk's second scratch mask and constants.
 #pragma once
 #include "rt_kernels.hpp"
 
@@ -892,7 +896,7 @@ SHADOW_BOUND = tuple(range(32, 40))                                # DX, DY, DZ 
 
 def clobbers(last=SGPR_LAST, bound=()):
     """bound: vector registers of the loops that ARE operands of the statement (the caller's values arrive in / leave from them directly)."""
-    regs = ['"s%d"' % r for r in range(36, last + 1)] + ['"v%d"' % r for r in range(VGPR_FIRST, VGPR_LAST + 1) if r not in bound]
+    regs = ['"s%d"' % r for r in range(SB, last + 1)] + ['"v%d"' % r for r in range(VGPR_FIRST, VGPR_LAST + 1) if r not in bound]
     lines, cur = [], '"memory", "vcc", "scc"'
     for r in regs:
         if len(cur) + len(r) + 2 > 118:
