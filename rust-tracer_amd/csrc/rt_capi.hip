@@ -691,11 +691,16 @@ bool packed_samples(unsigned spp)
 // 138.5 / 131.7, 3840x2160 181.5 / 153.8; sample-packed: 1280x720 spp 2 163.3 / 175.1, 640x480 spp 4 187.9 / 194.6, 800x600 spp 4
 // 247.7 / 242.5, 1920x1080 spp 4 724 / 625, 4096x4096 spp 4 4206 / 3420.  (Round 2, before the bounds: spp 1 from 3.5 M / 6 M pixels,
 // sample-packed modes only on the large scene.)
+// End of round 4, both kernels at eight waves per SIMD (the one-ray kernel gained more from its eighth than the two-ray kernel: it was the
+// one waiting more).  21,845 spheres, spp 1: 1920x1080 41.4 / 58.4, 2560x1440 69.3 / 70.2, 3200x1800 99.7 / 96.9, 3840x2160 133.4 / 127.6;
+// sample-packed: 1920x1080 spp 2 158.6 / 165.8, 640x480 spp 4 125.5 / 140.8, 800x600 spp 4 170.9 / 177.9, 1024x768 spp 4 206.7 / 210.9,
+// 1920x1080 spp 4 475 / 465, 2048x2048 spp 4 732 / 700.  87,381 spheres, spp 1: 2560x1440 95.1 / 117.7, 3840x2160 163.3 / 146.4;
+// sample-packed: 1024x768 spp 4 271.5 / 257.9, 1920x1080 spp 4 591 / 519, 4096x4096 spp 4 3437 / 2841.
 bool skip2_by_default(uint64_t total_px, unsigned spp, uint32_t n_nodes)
 {
     const bool large_scene = n_nodes >= 65536u;
-    if (spp == 1) return total_px >= (large_scene ? 5000000ull : 2900000ull);
-    return total_px * spp * spp >= 6000000ull;
+    if (spp == 1) return total_px >= (large_scene ? 5000000ull : 4000000ull);
+    return total_px * spp * spp >= (large_scene ? 6000000ull : 20000000ull);
 }
 
 constexpr size_t kMaxCachedTables = 32;
