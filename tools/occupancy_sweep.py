@@ -11,7 +11,7 @@ import torch
 import rust_tracer_amd as rta
 from rust_tracer_amd import capi
 
-WORK = {"1080p": (1920, 1080, 1, 8, 5), "make_image": (1024, 768, 4, 8, 3), "config5": (4096, 4096, 4, 9, 1), "4k": (3840, 2160, 1, 8, 3)}
+WORK = {"config2": (800, 600, 1, 8, 20), "vga": (640, 480, 1, 8, 20), "1080p": (1920, 1080, 1, 8, 5), "make_image": (1024, 768, 4, 8, 3), "config5": (4096, 4096, 4, 9, 1), "4k": (3840, 2160, 1, 8, 3)}
 
 
 def main():
