@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RTRACE_HIP_ABI_VERSION 2
+#define RTRACE_HIP_ABI_VERSION 3
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -85,6 +85,8 @@ typedef struct rt_stats {
     uint64_t tests_executed;/* ray x record tests the kernels actually ran: SKIP = sphere_tests + bound_tests;
                                FLAT = primary * n_items + (shadow rays) * first chunk + (survivors) * rest --
                                the any-hit passes stop early, so FLAT's figure is below sphere_tests         */
+    uint64_t primary_tests; /* of sphere_tests + bound_tests (FLAT: of sphere_tests), the tests made for PRIMARY rays; the rest were made
+                               for shadow rays (8 vs 16 arithmetic operations per test with the ray-independent terms pre-formed)  */
     double device_ms;       /* hipEvent time of all kernels of this call on its stream.  A call that asks for
                                stats runs the counting flavour of the kernels (same bytes, about 2.5x slower):
                                it is not the product's speed -- time calls without stats with your own events */
@@ -229,6 +231,22 @@ const char *rt_strerror(rt_status status);
 /* Detail of the last RT_ERR_HIP on the calling thread (static thread-local storage; never NULL). */
 const char *rt_last_error_message(void);
 int rt_abi_version(void);
+
+/* Which kernels the LAST render call of the calling thread launched (read-only diagnostic; the bytes never depend on it):
+ *   RT_LAUNCH_TWO_RAYS         the hierarchy walk with two rays per lane (k_render_skip2: large frames / large scenes)
+ *   RT_LAUNCH_COOPERATIVE      the launch carried lane-cooperative quads (the heaviest 2x2-pixel quads of a small pass)
+ *   RT_LAUNCH_SAMPLE_PARALLEL  one thread per SAMPLE + an ordered resolve pass (samples_per_pixel > 1)
+ *   RT_LAUNCH_ORDERED          blocks dispatched most-expensive-first from the scene's cost map (else: through the tile table)
+ *   RT_LAUNCH_FLAT_PIPELINE    RT_TRAVERSAL_FLAT's wavefront pipeline
+ *   RT_LAUNCH_COUNTING         the counting flavour of the kernels (the call asked for rt_stats) */
+enum { RT_LAUNCH_TWO_RAYS = 1u, RT_LAUNCH_COOPERATIVE = 2u, RT_LAUNCH_SAMPLE_PARALLEL = 4u, RT_LAUNCH_ORDERED = 8u, RT_LAUNCH_FLAT_PIPELINE = 16u,
+       RT_LAUNCH_COUNTING = 32u };
+uint32_t rt_last_launch_flags(void);
+
+/* The toolchain this library was built with, e.g. "hipcc: HIP version: 7.2.x ... | clang ... | kernels <sha1 of the kernel sources>"
+ * (static storage).  The generated traversal loops are gfx950 assembly whose register windows were validated against THIS compiler:
+ * tests/test_kernel_resources.py pins the string together with every hot kernel's register counts. */
+const char *rt_build_info(void);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,7 @@
 // backend.  Flags that do not exist in the reference (--device, --devices, --traversal, --level, --stats) only
 // add GPU selection; none of the reference's flags changes meaning.
 #include <cerrno>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -12,7 +13,9 @@
 #include <vector>
 
 #include "render.hpp"
-#include "../rt_debug.h"
+#ifdef RT_TEST_HOOKS
+#include "../rt_debug.h"      // tests/c/rtrace_test only: the shipped rtrace binds nothing but include/rtrace_hip.h
+#endif
 
 using namespace rtrace;
 
@@ -51,6 +54,7 @@ const char *USAGE =
     "        --scene <file>                  render a sphere list instead (text: `cx cy cz r` per line, optional `light x y z` /\n"
     "                                        `eye x y z` lines; *.f32: raw f32 quadruples); a bounding-sphere hierarchy is built for it\n"
     "        --stats                         print ray counters and device time on stderr\n"
+    "        --timings                       print where the process spent its wall time (one JSON object on stderr)\n"
     "        --strict-64                     panic like the reference unless width and height are multiples of 64\n\n"
     "ARGS:\n"
     "    <output>    Either a file with .tga extension, or - to write file to stdout\n";
@@ -94,6 +98,9 @@ std::string with_tga_extension(const std::string &path)
 
 int main(int argc, char **argv)
 {
+    using Clock = std::chrono::steady_clock;
+    const Clock::time_point t_main = Clock::now();
+    auto ms_since = [](Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); };
     // main.rs:24-29: RTRACEMAXPROCS, default 1, unparsable -> 1
     size_t nc_from_env = 1;
     if (const char *e = getenv("RTRACEMAXPROCS")) {
@@ -105,7 +112,7 @@ int main(int argc, char **argv)
 
     std::string width = "1024", height = "1024", ssp = "1", numcores = "1", output;
     std::string device = "0", devices = "1", traversal = "skip", level = "8", gather = "", scene_file = "", rccl_stand_in = "";
-    bool have_output = false, stats = false, strict64 = false;
+    bool have_output = false, stats = false, strict64 = false, timings = false;
     auto take = [&](int &i, const std::string &arg, const char *name, std::string &dst) -> bool {
         const std::string flag = std::string("--") + name;
         if (arg == flag) {
@@ -122,11 +129,16 @@ int main(int argc, char **argv)
         if (a == "-V" || a == "--version") { puts("rtrace 0.2.0"); return 0; }
         if (a == "--stats") { stats = true; continue; }
         if (a == "--strict-64") { strict64 = true; continue; }
+        if (a == "--timings") { timings = true; continue; }
         if (take(i, a, "width", width) || take(i, a, "height", height) || take(i, a, "samples-per-pixel", ssp) ||
             take(i, a, "num-cores", numcores) || take(i, a, "device", device) || take(i, a, "devices", devices) ||
-            take(i, a, "traversal", traversal) || take(i, a, "level", level) || take(i, a, "gather", gather) || take(i, a, "scene", scene_file) ||
-            take(i, a, "rccl-stand-in", rccl_stand_in))
+            take(i, a, "traversal", traversal) || take(i, a, "level", level) || take(i, a, "gather", gather) || take(i, a, "scene", scene_file))
             continue;
+#ifdef RT_TEST_HOOKS
+        // tests/c/rtrace_test (linked against the -DRT_TEST_HOOKS library): --rccl-stand-in <library> sends the gather through that library
+        // instead of librccl.so with all N ranks on --device, so that the N > 1 path runs on a one-GPU box (tests/c/fake_rccl.cpp)
+        if (take(i, a, "rccl-stand-in", rccl_stand_in)) continue;
+#endif
         if (a.size() > 1 && a[0] == '-' && a != "-") {
             fprintf(stderr, "error: Found argument '%s' which wasn't expected, or isn't valid in this context\n\nFor more information try --help\n", a.c_str());
             return 1;
@@ -168,7 +180,18 @@ int main(int argc, char **argv)
     int status = 0;
     try {
         // Arc::new(Default::default())  main.rs:23 -- or, not in the reference, a sphere list with an automatically built hierarchy
+        const double t_args = ms_since(t_main);
+        Clock::time_point t0 = Clock::now();
         const Scene scene = scene_file.empty() ? Scene::with_level(parse_or_panic<uint32_t>(level)) : Scene::from_file(scene_file);
+        const double t_host_scene = ms_since(t0);
+        double t_runtime = 0.0;
+        if (timings) {                                            // the first runtime call of the process: HIP initialisation on its own
+            t0 = Clock::now();
+            int n_visible = 0;
+            (void)rt_device_count(&n_visible);
+            t_runtime = ms_since(t0);
+        }
+        t0 = Clock::now();
         Backend be;
         be.strict_64 = strict64;
         be.want_stats = stats;
@@ -181,10 +204,10 @@ int main(int argc, char **argv)
         // more than one GPU: the native gather (rt_gang: ncclCommInitAll + one ncclGather per frame); `--gather rccl` takes
         // that path with a single GPU too (a one-rank communicator), `--gather host` keeps the per-device host copies
         if (gather == "rccl" || (gather.empty() && ndev > 1)) {
-            // (not in the help text: --rccl-stand-in <library> is test infrastructure -- the gather goes through that library instead of
-            // librccl.so and all N ranks sit on --device, so that the N > 1 path runs on a one-GPU box; tests/c/fake_rccl.cpp)
+#ifdef RT_TEST_HOOKS
             if (!rccl_stand_in.empty() && rt_debug_rccl_library(rccl_stand_in.c_str()) != RT_OK)
                 throw std::runtime_error(std::string("--rccl-stand-in: ") + rt_last_error_message());
+#endif
             std::vector<int> ids;
             for (int d = 0; d < ndev; ++d) ids.push_back(rccl_stand_in.empty() ? dev0 + d : dev0);
             rt_status gst = RT_OK;
@@ -200,12 +223,21 @@ int main(int argc, char **argv)
             for (int d = 0; d < ndev; ++d) be.devices.push_back(std::make_shared<DeviceScene>(scene, dev0 + d));
         }
 
+        const double t_device_scene = ms_since(t0);
+        t0 = Clock::now();
         ThreadPool pool(pool_size);
         RenderStats st;
+        double t_render = 0.0;
         {
             PPMStdoutRGBABufferWriter writer(true, sink);                                // main.rs:84-87
             st = Renderer::render(options, be, writer, pool);
+            t_render = ms_since(t0);
+            t0 = Clock::now();
         }                                                                                // Drop writes the final image
+        const double t_drop_write = ms_since(t0);
+        if (timings)
+            fprintf(stderr, "{\"args_ms\": %.3f, \"host_scene_ms\": %.3f, \"runtime_init_ms\": %.3f, \"device_scene_ms\": %.3f, \"render_and_first_write_ms\": %.3f, "
+                            "\"drop_write_ms\": %.3f, \"main_to_here_ms\": %.3f}\n", t_args, t_host_scene, t_runtime, t_device_scene, t_render, t_drop_write, ms_since(t_main));
         if (stats)
             fprintf(stderr, "primary %llu hits %llu shadow %llu occluded %llu item_tests %llu bound_tests %llu device_ms %.3f\n",
                     (unsigned long long)st.primary, (unsigned long long)st.hits, (unsigned long long)st.shadow,

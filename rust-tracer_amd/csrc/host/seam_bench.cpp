@@ -23,7 +23,9 @@
 #include <unistd.h>
 
 #include "render.hpp"
-#include "../rt_debug.h"
+#ifdef RT_TEST_HOOKS
+#include "../rt_debug.h"      // diagnostic legs only when built against the -DRT_TEST_HOOKS library; bench.py runs the product
+#endif
 
 using namespace rtrace;
 using Clock = std::chrono::steady_clock;
@@ -77,8 +79,10 @@ int main(int argc, char **argv)
         else if (a == "--spp") spp = (unsigned)atoi(argv[i + 1]);
         else if (a == "--level") level = atoi(argv[i + 1]);
         else if (a == "--dir") dir = argv[i + 1];
+#ifdef RT_TEST_HOOKS
         else if (a == "--leaders") rt_debug_set(RT_DEBUG_COALESCE, atoi(argv[i + 1]));       // diagnostic: merged passes in flight (0: no merging)
         else if (a == "--frame-ahead") rt_debug_set(RT_DEBUG_FRAME_AHEAD, atoi(argv[i + 1])); // diagnostic: 0 / 1 / 2 (rt_debug.h)
+#endif
         else { fprintf(stderr, "seam_bench: unknown option %s\n", a.c_str()); return 2; }
     }
     frames = std::max(frames, 3); threads = std::max(threads, 1);
@@ -141,7 +145,9 @@ int main(int argc, char **argv)
         Series s;
         const int reps = std::max(3, nt == 1 ? frames / 6 : frames / 2);
         ThreadPool pool((size_t)nt);
+#ifdef RT_TEST_HOOKS
         const long long calls0 = rt_debug_count(RT_DEBUG_COUNT_REGION_CALLS), passes0 = rt_debug_count(RT_DEBUG_COUNT_REGION_PASSES);
+#endif
         for (int f = 0; f < reps + 1; ++f) {
             std::fill(frame.begin(), frame.end(), 0);
             const auto t0 = Clock::now();
@@ -158,8 +164,10 @@ int main(int argc, char **argv)
         char name[64];
         snprintf(name, sizeof name, "host_region_%s", nt == 1 ? "1_thread" : "T_threads");
         stats_json(name, s, rays);
+#ifdef RT_TEST_HOOKS
         printf("  \"%s_calls_per_device_pass\": %.2f,\n", name, (double)(rt_debug_count(RT_DEBUG_COUNT_REGION_CALLS) - calls0) /
                                                                   (double)std::max(1ll, rt_debug_count(RT_DEBUG_COUNT_REGION_PASSES) - passes0));
+#endif
         if (threads == 1) break;
     }
 

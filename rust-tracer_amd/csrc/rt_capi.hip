@@ -37,7 +37,14 @@ namespace {
 
 thread_local char g_err[512] = "";
 
+// What the last render call of this thread launched (rt_last_launch_flags, include/rtrace_hip.h).
+thread_local uint32_t g_launch_flags = 0;
+
 // Diagnostic controls (rt_debug.h): process-wide, -1 = default.  The library reads no environment variable.
+// They exist only in the build with -DRT_TEST_HOOKS (tests/c/librtrace_hip_test.so: the parity tests and tools/); in the product
+// library every control is a compile-time -1, the rt_debug_* entry points do not exist and the loop flavours only a control can
+// select are not instantiated.
+#ifdef RT_TEST_HOOKS
 struct KnobArray {
     std::atomic<long long> v[RT_DEBUG_KEYS];
     KnobArray() { for (auto &k : v) k.store(-1, std::memory_order_relaxed); }
@@ -50,6 +57,15 @@ std::string g_trace_path;
 // (a background builder of dispatch orders works for a caller that had no control set: it must not see one that is set meanwhile)
 thread_local bool g_knobs_at_default = false;
 inline long long knob(int key) { return g_knobs_at_default ? -1 : g_knob[key].load(std::memory_order_relaxed); }
+inline void count_event(int counter, long long n = 1) { g_count[counter].fetch_add(n, std::memory_order_relaxed); }
+inline void count_store(int counter, long long v) { g_count[counter].store(v, std::memory_order_relaxed); }
+inline void knobs_at_default() { g_knobs_at_default = true; }
+#else
+constexpr long long knob(int) { return -1; }
+inline void count_event(int, long long = 1) {}
+inline void count_store(int, long long) {}
+inline void knobs_at_default() {}
+#endif
 
 rt_status hip_fail(hipError_t e, const char *what, int line)
 {
@@ -147,7 +163,8 @@ struct rt_scene {
     // how much of the pass is tail, which no estimate made here predicted as well as three measurements do.
     struct Order { rt::BlockDesc *dev_order = nullptr; uint32_t n_order = 0; uint32_t *dev_wg = nullptr; uint32_t n_wg = 0; uint64_t *dev_holes = nullptr; uint32_t n_holes = 0;
                    // the trial: kOrderTrialSamples timed launches, each with an event pair of its own (they may all be in flight at once)
-                   hipEvent_t e0[3] = { nullptr, nullptr, nullptr }, e1[3] = { nullptr, nullptr, nullptr }; int issued = 0, harvested = 0; float best_ms = 1e30f; };
+                   // (slot = count % kOrderTrialSamples; a sample whose events could not be read is LOST and issued again)
+                   hipEvent_t e0[3] = { nullptr, nullptr, nullptr }, e1[3] = { nullptr, nullptr, nullptr }; int issued = 0, harvested = 0, good = 0; float best_ms = 1e30f; };
     struct CachedTable { std::vector<rt::TileDev> host; unsigned w = 0, h = 0, passes = 0; rt::TileDev *dev = nullptr; std::vector<Order> orders; int chosen = 0; unsigned turn = 0; bool building = false;
                          void *order_arena = nullptr;      // ONE device allocation holds every order's arrays (allocation calls wait for a busy device)
                          long long coop_key = 0;
@@ -436,7 +453,7 @@ void filter_constants(rt_scene *s, const std::vector<rt::RawNode<T>> &raw, const
     const double eye_abs = std::fabs(s->eye[0]) + std::fabs(s->eye[1]) + std::fabs(s->eye[2]), m0_abs = std::fabs(m0[0]) + std::fabs(m0[1]) + std::fabs(m0[2]);
     // shadow origins lie on an item's surface, pushed out by hit.distance * sqrt(eps) (render.rs:199): 1 % and a bit of room
     double ro = 1.01 * rit + 1e-3 * (eye_d + rit) + 1e-5 * (eye_abs + m0_abs);
-    if (const long long pc = g_knob[RT_DEBUG_FILTER_RO_PERCENT].load(std::memory_order_relaxed); pc >= 0) ro *= (double)pc / 100.0;   // tests only
+    if (const long long pc = knob(RT_DEBUG_FILTER_RO_PERCENT); pc >= 0) ro *= (double)pc / 100.0;   // tests only
     const double eps = 0x1p-24;
     // plane perpendicular to the shadow direction l = -light (f32 components)
     // plane perpendicular to the shadow direction l = -light: the f32 components an f32 scene's reference uses, the f64 ones for an f64 scene
@@ -707,7 +724,7 @@ constexpr size_t kMaxCachedTables = 32;
 
 // Device copy of `tab`: from the scene's cache when seen before (or cacheable now), else through the context.
 rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, const rt::TileDev **out,
-                       int slot = 0, const rt_options *o = nullptr, rt::BlockList *order_out = nullptr, bool cacheable = true);
+                       int slot = 0, const rt_options *o = nullptr, rt::BlockList *order_out = nullptr, bool cacheable = true, bool will_be_timed = false);
 
 // Copies the tile table through the context's pinned buffer; truly asynchronous on `stream`.  A table of one or two tiles
 // is read by the kernel straight from the pinned copy instead (one PCIe read per workgroup beats a copy operation on the stream).
@@ -1018,7 +1035,7 @@ void release_order(rt_scene::Order &od)           // (its arrays live in the tab
 // launch; all of them may be in flight at once -- a caller that enqueues far ahead of the device is not waited for); results are collected
 // here as they complete, and once every sample is in, the candidate with the smallest one stays.
 constexpr int kOrderTrialSamples = 3;
-rt::BlockList pick_order(rt_scene::CachedTable &t)
+rt::BlockList pick_order(rt_scene::CachedTable &t, bool will_be_timed)      // will_be_timed: a non-counting hierarchy-walk launch (launch_render records the pair)
 {
     if (t.orders.empty()) return rt::BlockList{};
     // (orders[0] never has holes: what a launch that cannot walk cooperatively -- counters, f64, two rays per lane -- falls back to)
@@ -1030,13 +1047,14 @@ rt::BlockList pick_order(rt_scene::CachedTable &t)
     if (t.chosen >= 0) return list_of(t.orders[(size_t)t.chosen]);
     bool all_done = true;
     for (auto &od : t.orders) {
-        while (od.harvested < od.issued && hipEventQuery(od.e1[od.harvested]) == hipSuccess) {
+        while (od.harvested < od.issued && hipEventQuery(od.e1[od.harvested % kOrderTrialSamples]) == hipSuccess) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, od.e0[od.harvested], od.e1[od.harvested]) == hipSuccess && ms > 0.f) od.best_ms = std::min(od.best_ms, ms);
+            const int slot = od.harvested % kOrderTrialSamples;
+            if (hipEventElapsedTime(&ms, od.e0[slot], od.e1[slot]) == hipSuccess && ms > 0.f) { od.best_ms = std::min(od.best_ms, ms); ++od.good; }
             ++od.harvested;
         }
         (void)hipGetLastError();                         // hipErrorNotReady is not an error here
-        all_done = all_done && od.harvested >= kOrderTrialSamples;
+        all_done = all_done && od.good >= kOrderTrialSamples;
     }
     auto best_known = [&t] {
         size_t best = 0;
@@ -1053,12 +1071,13 @@ rt::BlockList pick_order(rt_scene::CachedTable &t)
         }
         return list_of(t.orders[best]);
     }
-    for (size_t k = 0; k < t.orders.size(); ++k) {
+    for (size_t k = 0; will_be_timed && k < t.orders.size(); ++k) {
         rt_scene::Order &od = t.orders[(t.turn + k) % t.orders.size()];
-        if (od.issued >= kOrderTrialSamples) continue;
+        const int in_flight = od.issued - od.harvested;
+        if (od.good + in_flight >= kOrderTrialSamples) continue;     // (in_flight < kOrderTrialSamples follows: the slot is free)
         t.turn = (unsigned)((t.turn + k + 1) % t.orders.size());
         rt::BlockList l = list_of(od);
-        l.ev0 = od.e0[od.issued]; l.ev1 = od.e1[od.issued];
+        l.ev0 = od.e0[od.issued % kOrderTrialSamples]; l.ev1 = od.e1[od.issued % kOrderTrialSamples];
         ++od.issued;
         return l;
     }
@@ -1088,9 +1107,13 @@ rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std:
     }
     const long long rays = knob(RT_DEBUG_SKIP_RAYS);
     const bool two_rays = rays < 0 ? skip2_by_default(total_px, 1, s->fused ? s->n_fnodes : s->n_nodes) : rays == 2;      // k_render_skip2 knows no cooperative quads
+    // Candidate 0 is ALWAYS the plain order of a pass that could walk cooperatively (coop_percent 0: no holes, no cooperative descriptors):
+    // pick_order and launch_skip_one hand it to every launch that cannot take holes (counters, f64, two rays per lane).
     std::vector<int> percents;
-    if (coop_pass && map && !two_rays && total_blocks <= kCoopPassBlocks && knob(RT_DEBUG_COOP) < 0 && knob(RT_DEBUG_COOP_THR) < 0) percents = { 0, 28, 34, 40, 48, 58 };
-    else if (coop_pass && (knob(RT_DEBUG_COOP) > 0 || knob(RT_DEBUG_COOP_THR) >= 0)) percents = { 0, -1 };       // as asked, behind the plain one
+    if (coop_pass && map && !two_rays && total_blocks <= kCoopPassBlocks && knob(RT_DEBUG_COOP) < 0 && knob(RT_DEBUG_COOP_THR) < 0 && knob(RT_DEBUG_COOP_MAX) < 0)
+        percents = { 0, 28, 34, 40, 48, 58 };
+    else if (coop_pass && !two_rays && (knob(RT_DEBUG_COOP) > 0 || knob(RT_DEBUG_COOP_THR) >= 0 || knob(RT_DEBUG_COOP_MAX) >= 0)) percents = { 0, -1 };       // as asked, behind the plain one
+    else if (coop_pass) percents = { 0 };
     else percents = { -1 };
     // every candidate on the host first, then ONE device allocation for all their arrays: hipMalloc / hipFree wait for a busy device,
     // and this may run in the background of a caller who keeps it busy
@@ -1128,6 +1151,12 @@ rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std:
             off += up(c.wg_first.size() * sizeof(uint32_t));
         }
         orders.push_back(od);
+    }
+    if (!orders.empty() && orders[0].dev_holes) {       // (cannot happen: candidate 0 is made with coop_percent 0 wherever holes are possible)
+        for (auto &od : orders) release_order(od);
+        orders.clear(); (void)hipFree(arena);
+        snprintf(g_err, sizeof g_err, "internal: the plain dispatch order has holes");
+        return RT_ERR_INVALID_ARGUMENT;
     }
     chosen = 0;
     if (orders.size() > 1 && percents.size() == 2) chosen = 1;      // asked for explicitly
@@ -1179,7 +1208,7 @@ void forget_scene(rt_scene *s)
 // may be waiting for `building` to clear).
 void worker_main(rt_scene *s)
 {
-    g_knobs_at_default = true;                    // it only ever serves lists that were first seen with no dispatch control set
+    knobs_at_default();                           // it only ever serves lists that were first seen with no dispatch control set
     (void)hipSetDevice(s->device);
     for (;;) {
         std::function<void()> job;
@@ -1211,7 +1240,7 @@ void stop_worker(rt_scene *s)
 // under the scene's lock.  Whatever fails here only costs the ordering: the table keeps rendering through the tile table.
 void build_orders_async(rt_scene *s, size_t index, std::vector<rt::TileDev> tab, unsigned w, unsigned h, unsigned passes)
 {
-    g_knobs_at_default = true;                    // this thread only exists because no dispatch control was set when the list was first seen
+    knobs_at_default();                           // this thread only exists because no dispatch control was set when the list was first seen
     std::vector<rt_scene::Order> orders;
     int chosen = 0;
     void *arena = nullptr;
@@ -1230,7 +1259,7 @@ void build_orders_async(rt_scene *s, size_t index, std::vector<rt::TileDev> tab,
 }
 
 rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, const rt::TileDev **out, int slot,
-                       const rt_options *o, rt::BlockList *order_out, bool cacheable)
+                       const rt_options *o, rt::BlockList *order_out, bool cacheable, bool will_be_timed)
 {
     const size_t bytes = tab.size() * sizeof(rt::TileDev);
     const unsigned w = o ? o->width : 0u, h = o ? o->height : 0u;
@@ -1240,7 +1269,7 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
     // the cooperative walk's controls (rt_debug.h) are part of a dispatch table's identity: tests render one tile list with and without
     long long coop_key = 0;
     if (o && order_out)
-        for (int k : { RT_DEBUG_COOP, RT_DEBUG_COOP_THR, RT_DEBUG_COOP_MAX, RT_DEBUG_COOP_LEVEL, RT_DEBUG_COOP_REST, RT_DEBUG_NARROW_MAX, RT_DEBUG_NARROW_L2 })
+        for (int k : { RT_DEBUG_COOP, RT_DEBUG_COOP_THR, RT_DEBUG_COOP_MAX, RT_DEBUG_COOP_LEVEL, RT_DEBUG_COOP_REST, RT_DEBUG_NARROW_MAX, RT_DEBUG_NARROW_L2, RT_DEBUG_SKIP_RAYS })
             coop_key = coop_key * 1000003ll + (knob(k) + 2);
     if (cacheable) {
         std::lock_guard<std::mutex> lk(s->mu);
@@ -1255,7 +1284,7 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
                         if (stream != t.landed_on) HIP_TRY(hipStreamWaitEvent(stream, t.landed, 0));
                     }
                 }
-                if (order_out && block_order_enabled()) *order_out = pick_order(t);
+                if (order_out && block_order_enabled()) *order_out = pick_order(t, will_be_timed);
                 return RT_OK;
             }
         if (s->tables.size() < kMaxCachedTables) {
@@ -1310,9 +1339,9 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
                 if (s->worker.joinable()) {
                     { std::lock_guard<std::mutex> wl(s->wmu); s->wjobs.emplace_back([s, index, tab, w, h, passes] { build_orders_async(s, index, tab, w, h, passes); }); }
                     s->wcv.notify_one();
-                } else s->builders.emplace_back([s, index, tab, w, h, passes] { g_knobs_at_default = true; build_orders_async(s, index, tab, w, h, passes); });
+                } else s->builders.emplace_back([s, index, tab, w, h, passes] { knobs_at_default(); build_orders_async(s, index, tab, w, h, passes); });
             }
-            if (order_out && block_order_enabled()) *order_out = pick_order(s->tables.back());
+            if (order_out && block_order_enabled()) *order_out = pick_order(s->tables.back(), will_be_timed);
             return RT_OK;
         }
     }
@@ -1330,7 +1359,9 @@ int skip_variant(const rt_scene *s)
     if (v & 2) v |= 1;                                  // the assembly loops imply the lean sqrt in what C++ remains
     if (!s->fused || !(v & 2)) v &= ~4;
     if (!s->d_xprim || !(v & 2)) v &= ~16;      // the filtered loops (f32: both walks; f64: the primary walk) need their streams
+#ifdef RT_TEST_HOOKS
     if ((v & 3) == 3 && g_trace_on.load(std::memory_order_relaxed)) v |= 8;      // diagnostic build of the assembly variants
+#endif
     return v;
 }
 
@@ -1416,6 +1447,12 @@ rt_status launch_flat_wavefront(const rt_scene *s, Context *c, hipStream_t strea
             return RT_OK;
         }
     }
+#ifndef RT_TEST_HOOKS
+    // (round 1's unfiltered LDS kernels, rt_flat_wf.hpp: only rt_debug.h's RT_DEBUG_FLAT_KERNELS = 0 selects them)
+    (void)d_tab32; (void)blocks32; (void)view;
+    snprintf(g_err, sizeof g_err, "internal: no flat-scan kernels for this precision");
+    return RT_ERR_UNSUPPORTED;
+#else
     hipLaunchKernelGGL((rt::k_flat_primary<T, CHUNK>), dim3(blocks32, (unsigned)ns), b, 0, stream, view, w, h, spp, d_tab32, nt, sb, q1, c->d_queues, cnt);
     HIP_TRY(hipGetLastError());
     const unsigned rays_per_block = rt::kBlockThreads * rt::kFlatR;
@@ -1427,6 +1464,7 @@ rt_status launch_flat_wavefront(const rt_scene *s, Context *c, hipStream_t strea
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL((rt::k_resolve_samples<T>), dim3(blocks16), b, 0, stream, sb, spp, d_tab16, nt, d_out, frame_w, false);
     return RT_OK;
+#endif
 }
 
 // The render kernel of a hierarchy-walk launch: f32 launches that do not count run the build held to 8 waves per SIMD (rt_skip.hpp).
@@ -1464,7 +1502,9 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     // rt_debug_wave_trace(<file>) (diagnostic, tools/wave_timeline.py): the launch records every wave's start / end /
     // placement and the records are written to <file> -- synchronous, one file per launch (overwritten).
     std::string trace_file;
+#ifdef RT_TEST_HOOKS
     if (VAR & 8) { std::lock_guard<std::mutex> lk(g_trace_mu); trace_file = g_trace_path; }
+#endif
     const char *trace_path = trace_file.empty() ? nullptr : trace_file.c_str();
     const dim3 rgrid(order.d ? (order.wg_first ? order.n_wg : order.n) : grid.x);      // render workgroups: one per descriptor, or dealt
     const size_t trace_words = (size_t)(order.d ? order.n : grid.x) * 4 * 4 * (use_split(spp) ? (size_t)spp * spp : 1);
@@ -1489,7 +1529,7 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     if (!use_split(spp)) {
         if constexpr (kTwoRayFlavour) {
             if (two_rays) {
-                g_count[RT_DEBUG_COUNT_TWO_RAY_LAUNCHES].fetch_add(1, std::memory_order_relaxed);
+                count_event(RT_DEBUG_COUNT_TWO_RAY_LAUNCHES); g_launch_flags |= RT_LAUNCH_TWO_RAYS;
                 hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipOne, (VAR & 16) != 0, (VAR & 4) != 0>), rgrid, b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt, d_out, sb, frame_w,
                                    order.d, order.wg_first);
                 return RT_OK;
@@ -1497,7 +1537,7 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
         }
         if constexpr (!COUNT && sizeof(T) == 4 && (VAR == 19 || VAR == 23 || VAR == 31)) {
             if (spp == 1 && order.d && order.holes && !order.wg_first) {        // some quads of the pass are walked cooperatively (rt_coop.hpp)
-                g_count[RT_DEBUG_COUNT_COOP_LAUNCHES].fetch_add(1, std::memory_order_relaxed);
+                count_event(RT_DEBUG_COUNT_COOP_LAUNCHES); g_launch_flags |= RT_LAUNCH_COOPERATIVE;
                 hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipOne, true>()), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
                                    frame_w, order.d, no_cost, order.wg_first, s->coop, order.holes, order.n_holes);
                 return RT_OK;
@@ -1522,7 +1562,7 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     bool done2 = false;
     if constexpr (kTwoRayFlavour) {
         if (two_rays) {
-            g_count[RT_DEBUG_COUNT_TWO_RAY_LAUNCHES].fetch_add(1, std::memory_order_relaxed);
+            count_event(RT_DEBUG_COUNT_TWO_RAY_LAUNCHES); g_launch_flags |= RT_LAUNCH_TWO_RAYS;
             hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipPacked, (VAR & 16) != 0, (VAR & 4) != 0>), dim3(rgrid.x, (unsigned)ns), b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt,
                                d_out, sb, frame_w, order.d, order.wg_first);
             done2 = true;
@@ -1557,22 +1597,38 @@ rt_status launch_skip_var(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     // a counting launch always runs the C++ loops: the assembly bits would only duplicate kernels
     const int v = skip_variant(s);
     if constexpr (COUNT) {
-        if (v & 1) return launch_skip_one<T, true, 1>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
-        return launch_skip_one<T, true, 0>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+#ifdef RT_TEST_HOOKS
+        if (!(v & 1)) return launch_skip_one<T, true, 0>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+#endif
+        return launch_skip_one<T, true, 1>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
     } else {
         switch (v) {
-        case 0: return launch_skip_one<T, false, 0>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
-        case 3: return launch_skip_one<T, false, 3>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
-        case 7: return launch_skip_one<T, false, 7>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+        // what a scene gets by itself: the filtered assembly loops, fused where the scene is concentric (f64 scenes too large for the
+        // filter streams' 32-bit offsets: the unfiltered ones)
         case 19: return launch_skip_one<T, false, 19>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
         case 23: return launch_skip_one<T, false, 23>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+        case 3: if constexpr (sizeof(T) == 8) return launch_skip_one<T, false, 3>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order); else break;
+        case 7: if constexpr (sizeof(T) == 8) return launch_skip_one<T, false, 7>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order); else break;
+#ifdef RT_TEST_HOOKS
+        // flavours only rt_debug.h's RT_DEBUG_SKIP_VARIANT / rt_debug_wave_trace can ask for
+        case 0: return launch_skip_one<T, false, 0>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
         case 27: if constexpr (sizeof(T) == 4) return launch_skip_one<T, false, 27>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order); else break;
         case 31: if constexpr (sizeof(T) == 4) return launch_skip_one<T, false, 31>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order); else break;
         case 11: return launch_skip_one<T, false, 11>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
         case 15: return launch_skip_one<T, false, 15>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+#endif
         default: break;
         }
+#ifdef RT_TEST_HOOKS
+        if constexpr (sizeof(T) == 4) {
+            if (v == 3) return launch_skip_one<T, false, 3>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+            if (v == 7) return launch_skip_one<T, false, 7>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+        }
         return launch_skip_one<T, false, 1>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
+#else
+        snprintf(g_err, sizeof g_err, "internal: no traversal loops for variant %d", v);      // (skip_variant cannot return anything else without a control)
+        return RT_ERR_UNSUPPORTED;
+#endif
     }
 }
 
@@ -1608,6 +1664,8 @@ rt_status launch_render(rt_scene *s, Context *c, const rt_options *o, rt_travers
 {
     const dim3 grid(total_blocks);
     const unsigned w = o->width, h = o->height, spp = o->samples_per_pixel;
+    g_launch_flags = (trav == RT_TRAVERSAL_FLAT ? RT_LAUNCH_FLAT_PIPELINE : 0u) | (order.d ? RT_LAUNCH_ORDERED : 0u) |
+                     (trav == RT_TRAVERSAL_SKIP && use_split(spp) ? RT_LAUNCH_SAMPLE_PARALLEL : 0u) | (cnt ? RT_LAUNCH_COUNTING : 0u);
     // a dispatch order that is being timed against others (pick_order); never a counting launch: its loops are different ones
     const bool timed = order.ev0 && order.ev1 && !cnt && trav == RT_TRAVERSAL_SKIP;
     if (timed) HIP_TRY(hipEventRecord(order.ev0, stream));
@@ -1637,7 +1695,7 @@ rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversa
     const rt::TileDev *d_tab = nullptr, *d_tab16 = nullptr;
     rt::BlockList order;
     {
-        rt_status ust = trav == RT_TRAVERSAL_SKIP ? device_table(s, c, tab, stream, &d_tab, 0, o, &order, cacheable)
+        rt_status ust = trav == RT_TRAVERSAL_SKIP ? device_table(s, c, tab, stream, &d_tab, 0, o, &order, cacheable, !want_counters)
                                                   : device_table(s, c, tab, stream, &d_tab, 0, nullptr, nullptr, cacheable);
         if (ust != RT_OK) return ust;
         if (tab16) {
@@ -1670,12 +1728,13 @@ rt_status read_stats(rt_scene *s, Context *c, hipStream_t stream, rt_traversal t
         h.wave_item_steps += k.wave_item_steps;
         h.filter_pass += k.filter_pass; h.filter_violations += k.filter_violations; h.primary_tests += k.primary_tests;
     }
-    g_count[RT_DEBUG_COUNT_FILTER_PASS].fetch_add((long long)h.filter_pass, std::memory_order_relaxed);
-    g_count[RT_DEBUG_COUNT_FILTER_VIOLATIONS].fetch_add((long long)h.filter_violations, std::memory_order_relaxed);
-    g_count[RT_DEBUG_COUNT_PRIMARY_TESTS].store((long long)h.primary_tests, std::memory_order_relaxed);
+    count_event(RT_DEBUG_COUNT_FILTER_PASS, (long long)h.filter_pass);
+    count_event(RT_DEBUG_COUNT_FILTER_VIOLATIONS, (long long)h.filter_violations);
+    count_store(RT_DEBUG_COUNT_PRIMARY_TESTS, (long long)h.primary_tests);
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     st->primary = h.primary; st->hits = h.hits; st->shadow = h.shadow; st->occluded = h.occluded;
+    st->primary_tests = trav == RT_TRAVERSAL_FLAT ? h.primary * (uint64_t)s->n_items : h.primary_tests;
     if (trav == RT_TRAVERSAL_FLAT) {
         st->sphere_tests = (h.primary + h.shadow) * (uint64_t)s->n_items;
         st->bound_tests = 0;
@@ -1725,6 +1784,7 @@ extern "C" {
 
 int rt_abi_version(void) { return RTRACE_HIP_ABI_VERSION; }
 
+#ifdef RT_TEST_HOOKS
 rt_status rt_debug_set(int key, long long value)
 {
     if (key < 0 || key >= RT_DEBUG_KEYS) { snprintf(g_err, sizeof g_err, "rt_debug_set: unknown key %d", key); return RT_ERR_INVALID_ARGUMENT; }
@@ -1772,7 +1832,23 @@ rt_status rt_debug_wave_trace(const char *path)
     return RT_OK;
 }
 
+#endif  // RT_TEST_HOOKS
+
 const char *rt_last_error_message(void) { return g_err; }
+
+uint32_t rt_last_launch_flags(void) { return g_launch_flags; }
+
+#ifndef RT_BUILD_INFO
+#define RT_BUILD_INFO "unknown toolchain (built without csrc/Makefile)"
+#endif
+const char *rt_build_info(void)
+{
+#ifdef RT_TEST_HOOKS
+    return RT_BUILD_INFO " | RT_TEST_HOOKS";
+#else
+    return RT_BUILD_INFO;
+#endif
+}
 
 const char *rt_strerror(rt_status st)
 {
@@ -1961,7 +2037,7 @@ static rt_status render_device(rt_scene *s, const rt_options *o, rt_traversal tr
         // Fast path: a cached tile table and no per-call device state -> the call enqueues exactly one kernel.
         const rt::TileDev *d_tab = nullptr;
         rt::BlockList order;
-        if ((st = device_table(s, nullptr, tab, stream, &d_tab, 0, o, &order)) != RT_OK) return st;
+        if ((st = device_table(s, nullptr, tab, stream, &d_tab, 0, o, &order, true, trav == RT_TRAVERSAL_SKIP)) != RT_OK) return st;
         if (d_tab)
             return launch_render(s, nullptr, o, trav, d_tab, (unsigned)tab.size(), total_blocks, total_px, out, frame_w, stream, nullptr, nullptr, 0, order);
     }
@@ -2379,8 +2455,8 @@ static void run_region_batch(rt_scene *s, const std::vector<rt_scene::RegionReq 
     std::vector<rt_region> regs(batch.size());
     std::vector<uint8_t *> outs(batch.size());
     for (size_t i = 0; i < batch.size(); ++i) { regs[i] = batch[i]->region; outs[i] = batch[i]->out; }
-    g_count[RT_DEBUG_COUNT_REGION_CALLS].fetch_add((long long)batch.size(), std::memory_order_relaxed);
-    g_count[RT_DEBUG_COUNT_REGION_PASSES].fetch_add(1, std::memory_order_relaxed);
+    count_event(RT_DEBUG_COUNT_REGION_CALLS, (long long)batch.size());
+    count_event(RT_DEBUG_COUNT_REGION_PASSES);
     g_err[0] = '\0';
     rt_status st = RT_OK;
     if (batch.size() == 1) {
@@ -2474,7 +2550,7 @@ static bool region_from_frame_ahead(rt_scene *s, const rt_options *o, rt_travers
         }
         a.served.assign(a.grid.size(), 0);
         a.valid = true;
-        g_count[RT_DEBUG_COUNT_FRAME_AHEAD_PASSES].fetch_add(1, std::memory_order_relaxed);
+        count_event(RT_DEBUG_COUNT_FRAME_AHEAD_PASSES);
         if (knob(RT_DEBUG_FRAME_AHEAD) != 1 && sample_bytes <= kFrameAheadMaxSampleBytes / 4) {
             // the next frame's pass, asynchronously, on a stream of its own; whatever fails here only costs the overlap
             hipError_t e = hipSuccess;
@@ -2604,6 +2680,7 @@ static Rccl *real_rccl()
 
 // Test infrastructure (rt_debug.h rt_debug_rccl_library): a stand-in library given by path takes the place of librccl.so for the gangs
 // created while it is set, and such gangs may put several ranks on ONE device -- how the N > 1 code is executed on a one-GPU box.
+#ifdef RT_TEST_HOOKS
 static std::mutex g_standin_mu;
 static std::shared_ptr<Rccl> g_standin;
 
@@ -2612,6 +2689,9 @@ static std::shared_ptr<Rccl> current_standin()
     std::lock_guard<std::mutex> lk(g_standin_mu);
     return g_standin;
 }
+#else
+static std::shared_ptr<Rccl> current_standin() { return nullptr; }      // the product only ever talks to librccl.so
+#endif
 
 static thread_local const Rccl *g_err_rccl = nullptr;       // whose error strings rccl_fail prints
 
@@ -2859,6 +2939,7 @@ static rt_status gang_render(rt_gang *g, const rt_options *o, rt_traversal trav,
                 if (stats && f == 0) {
                     total.primary += st.primary; total.hits += st.hits; total.shadow += st.shadow; total.occluded += st.occluded;
                     total.sphere_tests += st.sphere_tests; total.bound_tests += st.bound_tests; total.tests_executed += st.tests_executed;
+                    total.primary_tests += st.primary_tests;
                     total.device_ms = std::max(total.device_ms, st.device_ms);
                 }
             }
@@ -2926,6 +3007,7 @@ rt_status rt_gang_render_frames(rt_gang *g, const rt_options *o, rt_traversal tr
     return gang_render(g, o, trav, tiles, n, frames_rgba_host, n_frames, stats);
 }
 
+#ifdef RT_TEST_HOOKS
 // Test infrastructure (rt_debug.h): a stand-in for librccl.so, by path; NULL: the real library again.  Gangs keep the one they were made with.
 rt_status rt_debug_rccl_library(const char *path)
 {
@@ -2980,5 +3062,6 @@ rt_status rt_debug_shard_costs(rt_scene *s, const rt_options *o, const rt_region
     }
     return RT_OK;
 }
+#endif  // RT_TEST_HOOKS
 
 }  // extern "C"

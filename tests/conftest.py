@@ -15,9 +15,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The parity tests need the diagnostic controls of csrc/rt_debug.h (loop flavours, forced cooperative walk, violation counters, the stand-in
+# for librccl.so): they load tests/c/librtrace_hip_test.so -- the product's sources built with -DRT_TEST_HOOKS -- instead of the product
+# library, which has none of them.  Child processes that must run the PRODUCT (rtrace, bench.py) get an environment without this.
+# (tests/util.py product_env)
+os.environ["RTRACE_HIP_LIBRARY"] = os.path.join(ROOT, "tests", "c", "librtrace_hip_test.so")
+
+
 # The test modules import the package (and the oracle) at module scope, and both need their built libraries: on a fresh
 # checkout (the .so files are git-ignored) build them here, before collection, instead of failing with an ImportError.
-if not (os.path.exists(os.path.join(ROOT, "rust-tracer_amd", "librtrace_hip.so")) and
+if not (os.path.exists(os.path.join(ROOT, "rust-tracer_amd", "librtrace_hip.so")) and os.path.exists(os.environ["RTRACE_HIP_LIBRARY"]) and
         os.path.exists(os.path.join(ROOT, "oracle", "librt_oracle.so")) and
         os.path.exists(os.path.join(ROOT, "rust-tracer_amd", "rtrace"))):
     import __graft_entry__
@@ -67,4 +74,4 @@ def _check_both_launch_flavours(request, monkeypatch):
     yield
     # every counting launch of the f32 hierarchy walk also evaluated the filtered loops' bounds for each test it made
     # (rt_skip.hpp): none that returned a finite distance may have been ruled out
-    assert rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_FILTER_VIOLATIONS) == 0, "the filtered loops' bound ruled out a hit"
+    assert rta.capi.debug_count(rta.capi.DEBUG_COUNT_FILTER_VIOLATIONS) == 0, "the filtered loops' bound ruled out a hit"

@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RTRACE = os.path.join(ROOT, "rust-tracer_amd", "rtrace")
 RTRACE64 = os.path.join(ROOT, "rust-tracer_amd", "rtrace64")
 HOST_TESTS = os.path.join(ROOT, "rust-tracer_amd", "host_tests")
+RTRACE_TEST = os.path.join(ROOT, "tests", "c", "rtrace_test")      # rtrace built with -DRT_TEST_HOOKS: has --rccl-stand-in (test infrastructure)
 
 
 def run(args, env=None, exe=RTRACE, cwd=None):
@@ -23,7 +24,7 @@ def run(args, env=None, exe=RTRACE, cwd=None):
 
 
 def test_binaries_built():
-    for p in (RTRACE, RTRACE64, HOST_TESTS):
+    for p in (RTRACE, RTRACE64, HOST_TESTS, RTRACE_TEST):
         assert os.access(p, os.X_OK), "%s missing: run __graft_entry__.build()" % p
 
 
@@ -125,20 +126,27 @@ def test_make_image_reproduces_the_reference_image(tmp_path, golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ndev", [1, 2])
+@pytest.mark.parametrize("ndev", [1, 2, 8])
 def test_cli_native_rccl_gather_writes_the_reference_bytes(tmp_path, ndev):
     # rtrace --devices N: buckets dealt round-robin over N GPUs of this process, ONE ncclGather of the u8 shards to the first
     # GPU, blit there (rt_gang, include/rtrace_hip.h).  --gather rccl takes that path with one GPU too (a one-rank communicator).
     # N = 2 on a one-GPU box: both ranks on GPU 0, the gather through the stand-in for librccl.so (--rccl-stand-in, test infrastructure:
-    # tests/c/fake_rccl.cpp) -- the binary's N > 1 path runs either way.
+    # tests/c/fake_rccl.cpp) -- the binary's N > 1 path runs either way.  The flag exists only in tests/c/rtrace_test (the same sources with
+    # -DRT_TEST_HOOKS against the hooks build of the library); the shipped rtrace refuses it.
+    # N = 8 is BASELINE config 4's own rank count: 1920x1080 -> 510 buckets -> 64 / 63 per rank, padded equal-length shards (render.rs:273-298 order).
     import rust_tracer_amd as rta
     out = str(tmp_path / "out.tga")
-    args = ["--width=800", "--height=600", "--devices=%d" % ndev, "--gather=rccl", "--stats", out]
+    w, h = (1920, 1080) if ndev == 8 else (800, 600)
+    args = ["--width=%d" % w, "--height=%d" % h, "--devices=%d" % ndev, "--gather=rccl", "--stats", out]
+    exe = RTRACE
     if rta.device_count() < ndev:
         args.insert(0, "--rccl-stand-in=" + rta.capi.FAKE_RCCL)
-    r = run(args)
+        exe = RTRACE_TEST
+        refused = run(args)
+        assert refused.returncode == 1 and b"--rccl-stand-in" in refused.stderr      # not a flag of the product binary
+    r = run(args, exe=exe)
     assert r.returncode == 0, r.stderr.decode()
-    ref, st = _oracle_ppm(tmp_path, 800, 600, 1)
+    ref, st = _oracle_ppm(tmp_path, w, h, 1)
     assert open(out, "rb").read() == ref
     assert ("primary %d hits %d shadow %d occluded %d" % (st["primary"], st["hits"], st["shadow"], st["occluded"])).encode() in r.stderr
 

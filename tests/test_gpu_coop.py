@@ -21,7 +21,7 @@ COOP_LAUNCHES = rta.capi.DEBUG_COUNT_COOP_LAUNCHES
 
 
 def coop_launches():
-    return rta.capi.lib.rt_debug_count(COOP_LAUNCHES)
+    return rta.capi.debug_count(COOP_LAUNCHES)
 
 
 def render(scene, w, h, regs, mode):

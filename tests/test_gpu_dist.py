@@ -124,11 +124,11 @@ def test_tiles_mode_batched_gather_blits_every_frame_of_a_batch(one_rank_rccl):
     np.testing.assert_array_equal(fs.frame_host(), ref)
 
 
-@pytest.mark.parametrize("ndev", [1, 2, 4])
+@pytest.mark.parametrize("ndev", [1, 2, 4, 8])
 @pytest.mark.parametrize("size", [(1920, 1080, 1), (200, 130, 2)])
 def test_native_gang_rccl_gather_is_byte_identical(ndev, size):
     # rt_gang_*: one process, N ranks, bucket i -> rank i % N, one ncclGather to the root, blit, frame to the host.  Byte-identical
-    # to the oracle for N in {1, 2, 4}, counters summed over the ranks equal the CPU path's.  With fewer GPUs than ranks the ranks share
+    # to the oracle for N in {1, 2, 4, 8} (8 = BASELINE config 4's own rank count: 510 buckets -> 64 / 63 per rank, the short shards padded), counters summed over the ranks equal the CPU path's.  With fewer GPUs than ranks the ranks share
     # GPU 0 and the gather goes through the stand-in for librccl.so (tests/c/fake_rccl.cpp, rt_debug_rccl_library): the N > 1 code --
     # sharding, equal-length padded shards, the grouped gather, the blit of the device-major gathered buffer -- runs either way.
     import contextlib
@@ -181,6 +181,7 @@ def test_bench_collective_path_checks_its_own_frame(multi):
     s.close()
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env.pop("RTRACE_HIP_LIBRARY", None)                            # bench.py runs the product library
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-collective", "--multi", multi, "--steps", "4",
                         "--warmup", "2", "--repeats", "2", "--min-timed-region", "0", "--no-cpu-baseline", "--no-flat", "--no-seam"], capture_output=True, text=True, env=env,
                        timeout=300)
@@ -192,3 +193,72 @@ def test_bench_collective_path_checks_its_own_frame(multi):
     assert d["config"]["rccl_world_size"] == 1 and d["n_gpus"] == 1
     assert d["scaling"] == "strong" and d["roofline"]["bound"] == "valu_issue" and 0 < d["roofline"]["frac"] <= 1
     assert d["repeats"]["n"] == 2 and d["value"] > 1000
+    assert d["library"]["test_hooks"] is False and d["library"]["path"].endswith("librtrace_hip.so")
+
+
+@pytest.mark.parametrize("multi,extra", [("tiles", []), ("frames", ["--no-extras"])])
+def test_two_real_bench_ranks_share_gpu_0(multi, extra):
+    # First contact for the code the driver's scaling run executes: TWO bench.py processes (RANK 0 / 1, WORLD_SIZE 2), fresh children, both on
+    # GPU 0.  RCCL refuses two ranks on one device, so the collective is the test-only host-staged one (--collective-backend gloo: shard ->
+    # pinned host memory -> CPU gather -> rank 0's device buffer); everything else is what an RCCL job runs on real kernels: rank 1's
+    # render / gather / buffer-reuse ordering (dist.py op_*), partial batches (7 steps in batches of 3 = 3 + 3 + 1), rank 0's blits of
+    # two ranks' shards, the N > 1 keys of the JSON line (frame_latency_ms ...), weak_frames and config5_tiles riding along.  Rank 0's
+    # frame CRC must be the committed oracle vector's (/root/reference/src/rust/render.rs:273-307 is what the deal + gather replaces).
+    import json
+    import subprocess
+    import sys
+    import rust_tracer_amd  # noqa: F401
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for rank in (0, 1):
+        env = util.product_env(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--collective-backend", "gloo", "--multi", multi,
+                                       "--frames-per-gather", "3", "--steps", "7", "--warmup", "3", "--repeats", "2", "--min-timed-region", "0",
+                                       "--no-cpu-baseline"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d: %s" % (rank, se[-3000:])
+    assert outs[1][0].strip() == "", "only rank 0 prints the line"
+    lines = [l for l in outs[0][0].splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_world_size"] == 2 and d["steps"] == 7
+    assert d["frame_crc_ok"] is True and d["value"] > 100 and d["library"]["test_hooks"] is False
+    if multi == "tiles":
+        assert d["frame_crc32"] == 4168428064 and d["scaling"] == "strong" and d["config"]["parallelism"] == "tiles/2"
+        assert d["frame_latency_ms"] > 0 and d["frames_per_gather"] == 3
+        assert d["weak_frames"]["frame_crc_ok"] is True and d["weak_frames"]["frames_per_step"] == 2
+        assert d["config5_tiles"]["frame_crc_ok"] is True
+        assert d["config"]["primary_rays"] == 2073600 and d["config"]["shadow_rays"] == 1337403      # summed over the two ranks
+    else:
+        assert d["scaling"] == "weak" and d["config"]["frames_per_step"] == 2 and d["config"]["primary_rays"] == 2 * 2073600
+
+
+@pytest.mark.parametrize("ndev", [1, 8])
+def test_native_gang_bench(ndev):
+    # bench.py's `native_gang` side key (rust-tracer_amd/gang_bench: ONE process, rt_gang_render_frames over N devices, no torch.distributed
+    # on the path).  N = 1: the product binary on a one-rank RCCL communicator.  N = 8, BASELINE config 4's own rank count: the -DRT_TEST_HOOKS
+    # twin with all eight ranks on GPU 0 through the stand-in for librccl.so -- 510 buckets -> 64 / 63 per rank, padded shards, pipelined.
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if ndev == 1:
+        cmd = [os.path.join(root, "rust-tracer_amd", "gang_bench"), "--devices", "1", "--frames", "30"]
+    else:
+        cmd = [os.path.join(root, "tests", "c", "gang_bench_test"), "--devices", str(ndev), "--frames", "30", "--rccl-stand-in", rta.capi.FAKE_RCCL]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["devices"] == ndev and d["frame_crc32"] == 4168428064 and d["both_buffers_equal"] is True
+    assert d["primary"] == 2073600 and d["shadow"] == 1337403 and d["ms_per_frame"] > 0 and d["frame_latency_ms"] > 0

@@ -102,7 +102,7 @@ def test_two_rays_per_lane_walk_on_random_scenes_whose_bounds_have_no_sphere_of_
     eye = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-4.5, -1.0)))
     light = (float(rng.uniform(-2, 2)), float(rng.uniform(-3, -0.5)), float(rng.uniform(-2, 2)))
     s, o = util.scene_pair_ranges(items, bounds, ranges, rta.RT_F32, light=light, eye=eye)
-    before = rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_TWO_RAY_LAUNCHES)
+    before = rta.capi.debug_count(rta.capi.DEBUG_COUNT_TWO_RAY_LAUNCHES)
     for spp in (1, 2, 4, 8):
         w, h = int(rng.integers(2, 7)) * 32 + int(rng.integers(0, 17)), int(rng.integers(2, 5)) * 24 + int(rng.integers(0, 13))
         regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
@@ -113,7 +113,7 @@ def test_two_rays_per_lane_walk_on_random_scenes_whose_bounds_have_no_sphere_of_
             one, _ = s.device().render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
         np.testing.assert_array_equal(util.stitch((w, h), regs, two), ref)
         np.testing.assert_array_equal(two, one)
-    assert rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_TWO_RAY_LAUNCHES) >= before + 4
+    assert rta.capi.debug_count(rta.capi.DEBUG_COUNT_TWO_RAY_LAUNCHES) >= before + 4
 
 
 @pytest.mark.parametrize("scale", [1e-20, 1e-10, 1e6, 5e13])

@@ -736,7 +736,7 @@ def test_concurrent_render_region_calls_are_merged_and_stay_exact(leaders):
     jobs = [((256, 192, 1), r) for r in bucket_list(256, 192)] + [((200, 130, 2), r) for r in bucket_list(200, 130, 2)]
     refs = {(256, 192, 1): o.render(256, 192, 1, nthreads=4)[0], (200, 130, 2): o.render(200, 130, 2, nthreads=4)[0]}
     out = [None] * len(jobs)
-    calls0 = rta.capi.lib.rt_debug_count(0)
+    calls0 = rta.capi.debug_count(0)
     nxt, lock = [0], threading.Lock()
 
     def work():
@@ -754,7 +754,7 @@ def test_concurrent_render_region_calls_are_merged_and_stay_exact(leaders):
         [t.join() for t in th]
     for (opts, (l, t, r, b)), got in zip(jobs, out):
         np.testing.assert_array_equal(got, refs[opts][b:t, l:r])
-    assert rta.capi.lib.rt_debug_count(0) - calls0 == (len(jobs) if leaders else 0)
+    assert rta.capi.debug_count(0) - calls0 == (len(jobs) if leaders else 0)
 
 
 def test_a_bad_region_fails_alone_in_a_merged_pass():

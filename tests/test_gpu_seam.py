@@ -69,7 +69,7 @@ def test_render_region_frame_ahead_serves_a_frame_from_one_pass():
     w, h = 800, 600
     regs = bucket_list(w, h)
     ref, _, _ = o.render(w, h, 1, nthreads=os.cpu_count() or 1)
-    count = lambda: rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_FRAME_AHEAD_PASSES)
+    count = lambda: rta.capi.debug_count(rta.capi.DEBUG_COUNT_FRAME_AHEAD_PASSES)
     # default: the pass for the next frame is started while this frame's buckets are handed out (frames 2 and 3 below come out of such
     # passes); RT_DEBUG_FRAME_AHEAD = 1: every pass is rendered when its frame is first asked for.  One pass per frame either way.
     for mode in (-1, 1):
@@ -107,7 +107,7 @@ def test_render_region_lone_requests_stay_cheap_and_device_pointers_are_refused(
     d = s.device()
     w, h = 1024, 768
     regs = bucket_list(w, h)
-    count = lambda: rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_FRAME_AHEAD_PASSES)
+    count = lambda: rta.capi.debug_count(rta.capi.DEBUG_COUNT_FRAME_AHEAD_PASSES)
     c0 = count()
     for _ in range(3):                                           # the same bucket again and again: never a whole-grid pass
         got, _ = d.render_region((w, h, 1), regs[17], SKIP)
@@ -266,7 +266,7 @@ def test_gang_pipelined_frames_one_rank(tmp_path):
     import sys
     script = tmp_path / "gang_frames.py"
     script.write_text(_GANG_SCRIPT)
-    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=300, env=util.product_env())      # (the product library: no control needed)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     if "SKIP" in r.stdout:
         pytest.skip("no RCCL")

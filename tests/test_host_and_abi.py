@@ -19,10 +19,33 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "rtrace_hip.h")).read()
     declared = set(re.findall(r"\b(rt_[a-z_]+)\s*\(", hdr))
     assert declared == set(capi.SYMBOLS)
-    lib = ctypes.CDLL(capi.LIB_PATH)
-    for name in declared:
-        assert getattr(lib, name) is not None
-    assert lib.rt_abi_version() == capi.ABI_VERSION
+    import subprocess
+    for path in (capi.PRODUCT_LIB_PATH, capi.TEST_LIB_PATH):
+        lib = ctypes.CDLL(path)
+        for name in declared:
+            assert getattr(lib, name) is not None
+        assert lib.rt_abi_version() == capi.ABI_VERSION
+    # the PRODUCT exports the ABI and nothing else: no rt_debug_* hook, no kernel stub, no C++ symbol (csrc/exports.map)
+    exported = {l.split()[-1] for l in subprocess.run(["nm", "-D", "--defined-only", capi.PRODUCT_LIB_PATH], capture_output=True, text=True, check=True).stdout.splitlines() if l.strip()}
+    assert exported == declared, sorted(exported ^ declared)
+
+
+def test_the_tests_run_on_the_hooks_build_and_the_product_has_no_hooks():
+    # tests/conftest.py points the binding at tests/c/librtrace_hip_test.so (same sources, -DRT_TEST_HOOKS); the product is what rtrace,
+    # `make image`, bench.py and smoke() load, and it carries no diagnostic entry point and no stand-in for librccl.so
+    assert capi.HAVE_TEST_HOOKS and os.path.samefile(capi.LIB_PATH, capi.TEST_LIB_PATH)
+    assert "RT_TEST_HOOKS" in capi.build_info()
+    product = ctypes.CDLL(capi.PRODUCT_LIB_PATH)
+    product.rt_build_info.restype = ctypes.c_char_p
+    info = product.rt_build_info().decode()
+    assert "RT_TEST_HOOKS" not in info and info == capi.build_info().replace(" | RT_TEST_HOOKS", "")      # the same sources, the same toolchain
+    for name in capi.DEBUG_SYMBOLS:
+        assert not hasattr(product, name), name
+        assert hasattr(capi.lib, name), name
+    blob = open(capi.PRODUCT_LIB_PATH, "rb").read()
+    assert b"rt_debug" not in blob and b"rccl-stand-in" not in blob and b"fake_rccl" not in blob
+    rtrace = open(os.path.join(ROOT, "rust-tracer_amd", "rtrace"), "rb").read()
+    assert b"rccl-stand-in" not in rtrace and b"rt_debug" not in rtrace
 
 
 def test_product_never_touches_the_oracle():
@@ -155,8 +178,8 @@ def test_header_is_plain_c_and_the_library_links_from_c(tmp_path):
     import subprocess
     exe = str(tmp_path / "abi_check")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "c", "abi_check.c"), "-o", exe, "-L", os.path.dirname(capi.LIB_PATH),
-                           "-lrtrace_hip", "-Wl,-rpath," + os.path.dirname(capi.LIB_PATH)])
+                           os.path.join(ROOT, "tests", "c", "abi_check.c"), "-o", exe, "-L", os.path.dirname(capi.PRODUCT_LIB_PATH),
+                           "-lrtrace_hip", "-Wl,-rpath," + os.path.dirname(capi.PRODUCT_LIB_PATH)])      # the product library
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "sizeof rt_options 6 rt_region 8 rt_range 8 rt_stats %d" % ctypes.sizeof(capi.Stats) in out.stdout
@@ -184,9 +207,10 @@ def test_library_reads_no_environment_variable_and_keeps_diagnostics_out_of_the_
     # diagnostic switches live behind rt_debug_set (csrc/rt_debug.h, not in include/): the shipped library neither imports
     # getenv nor carries RT_* switch names a stray environment variable could trigger
     import subprocess
-    syms = subprocess.run(["nm", "-D", "--undefined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    assert "getenv" not in syms
-    blob = open(capi.LIB_PATH, "rb").read()
+    for path in (capi.PRODUCT_LIB_PATH, capi.TEST_LIB_PATH):
+        syms = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+        assert "getenv" not in syms
+    blob = open(capi.PRODUCT_LIB_PATH, "rb").read()
     assert re.findall(rb"RT_[A-Z_]{3,}", blob) == []
     hdr = open(os.path.join(ROOT, "include", "rtrace_hip.h")).read()
     assert "rt_debug" not in hdr

@@ -13,15 +13,34 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "rust-tracer_amd", "librtrace_hip.so")
+TEST_LIB = os.path.join(ROOT, "tests", "c", "librtrace_hip_test.so")
 LLVM = "/opt/rocm/lib/llvm/bin"
 
+# What the generated assembly loops (csrc/rt_skip_rot.hpp, rt_skip2_rot.hpp, rt_flat_rot.hpp) were validated against.  They own fixed
+# scalar-register windows inside kernels held to amdgpu_num_sgpr(74) -- s[62:73] is a window LLVM calls reserved there, hence the
+# -Winline-asm warnings -- so a different compiler must not go unnoticed: these expectations change only together with a fresh parity
+# run + soak on the GPU (tools/soak.py), never on their own.
+PINNED_TOOLCHAIN = "HIP version: 7.2.26015-fc0010cf6a | AMD clang version 22.0.0git"
+PINNED_INLINE_ASM_WARNINGS = {"product": 24, "test_hooks": 76}
+# (.sgpr_count, .vgpr_count) of the product's hot kernels, exactly
+PINNED_REGISTERS = {
+    "rt::k_render_skip_f32<false, 19, 0>": (80, 52), "rt::k_render_skip_f32<false, 19, 1>": (80, 44), "rt::k_render_skip_f32<false, 19, 2>": (80, 47),
+    "rt::k_render_skip_f32<false, 19, 3>": (80, 46), "rt::k_render_skip_f32<false, 23, 0>": (80, 52), "rt::k_render_skip_f32<false, 23, 1>": (80, 44),
+    "rt::k_render_skip_f32<false, 23, 2>": (80, 47), "rt::k_render_skip_f32<false, 23, 3>": (80, 46),
+    "rt::k_render_skip_f32_coop<false, 19, 2>": (92, 61), "rt::k_render_skip_f32_coop<false, 23, 2>": (92, 61),
+    "rt::k_render_skip2<2, true, false>": (80, 64), "rt::k_render_skip2<2, true, true>": (80, 64), "rt::k_render_skip2<3, true, false>": (80, 64),
+    "rt::k_render_skip2<3, true, true>": (80, 64),
+    "rt::k_render_skip<double, false, 19, 2, false>": (106, 75), "rt::k_render_skip<double, false, 23, 2, false>": (106, 80),
+    "rt::k_flat_primary_sc": (94, 64), "rt::k_flat_shadow_sc": (94, 71),
+}
 
-def _kernels(tmp_path):
+
+def _kernels(tmp_path, LIB=LIB):
     tools = [os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
     if not os.path.exists(LIB) or not all(os.path.exists(t) for t in tools) or shutil.which("c++filt") is None:
         pytest.skip("librtrace_hip.so or the LLVM object tools are not here")
     fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "gfx950.co")
-    subprocess.run([tools[0], "--dump-section", ".hip_fatbin=" + fat, LIB], check=True)
+    subprocess.run([tools[0], "--dump-section", ".hip_fatbin=" + fat, LIB, str(tmp_path / "copy.so")], check=True)      # (with no output name objcopy rewrites its INPUT)
     subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co], check=True)
     notes = subprocess.run([tools[2], "--notes", co], check=True, capture_output=True, text=True).stdout
     out = {}
@@ -50,3 +69,37 @@ def test_the_hot_kernels_keep_the_registers_their_residency_needs(tmp_path):
         assert k[n]["vgpr"] <= 80, (n, k[n])
         if ", 2, false>" in n:                      # the spp-1 flavour (BASELINE config 3) without a spill
             assert k[n]["scratch"] == 0, (n, k[n])
+
+
+def test_the_toolchain_and_the_register_windows_are_the_pinned_ones(tmp_path):
+    # rt_build_info travels inside the library (include/rtrace_hip.h): a library built by another compiler says so, here and to its caller
+    import ctypes
+    lib = ctypes.CDLL(LIB)
+    lib.rt_build_info.restype = ctypes.c_char_p
+    info = lib.rt_build_info().decode()
+    assert info.startswith(PINNED_TOOLCHAIN + " | kernel sources "), info
+    k = _kernels(tmp_path)
+    for name, (sgpr, vgpr) in PINNED_REGISTERS.items():
+        assert name in k, name
+        assert (k[name]["sgpr"], k[name]["vgpr"]) == (sgpr, vgpr), (name, k[name])
+    # the loop flavours only a control of csrc/rt_debug.h can select exist in the hooks build alone
+    hooks = _kernels(tmp_path, TEST_LIB)
+    assert set(k) < set(hooks)
+    only_hooks = set(hooks) - set(k)
+    assert any("k_render_skip_f32<false, 3, " in n for n in only_hooks) and any("k_render_skip_f32<false, 31, " in n for n in only_hooks)
+    assert not any(re.search(r"k_render_skip(_f32)?<(float, )?false, (0|1|3|7|11|15|27|31), ", n) for n in k)
+    for n in PINNED_REGISTERS:                       # ... and the kernels both builds have are the same kernels
+        assert (hooks[n]["sgpr"], hooks[n]["vgpr"]) == PINNED_REGISTERS[n], n
+
+
+def test_the_build_printed_the_warnings_it_is_known_to_print():
+    # the build logs are written by csrc/Makefile; a log older than the library (a partial rebuild) proves nothing
+    for which, log, lib in (("product", os.path.join(ROOT, "rust-tracer_amd", "build_product.log"), LIB),
+                            ("test_hooks", os.path.join(ROOT, "tests", "c", "build_test_hooks.log"), TEST_LIB)):
+        if not os.path.exists(log) or os.path.getmtime(log) + 120 < os.path.getmtime(lib):
+            pytest.skip("no build log next to %s" % os.path.basename(lib))
+        text = open(log).read()
+        assert len(re.findall(r"warning: .*\[-Winline-asm\]", text)) == PINNED_INLINE_ASM_WARNINGS[which], which
+        other = [l for l in text.splitlines() if "warning:" in l and "-Winline-asm" not in l]
+        assert other == [], other[:3]
+        assert " error" not in text

@@ -6,6 +6,15 @@ import rust_tracer_amd as rta
 
 PREC = {rta.RT_F32: oracle.F32, rta.RT_F64: oracle.F64}
 
+
+def product_env(**extra):
+    """os.environ for a child process that must load the PRODUCT library (rust-tracer_amd/librtrace_hip.so), not the -DRT_TEST_HOOKS build
+    tests/conftest.py points this process at."""
+    import os
+    env = {k: v for k, v in os.environ.items() if k != "RTRACE_HIP_LIBRARY"}
+    env.update(extra)
+    return env
+
 THREE_SPHERES = [(0.0, -1.0, 0.0, 1.0), (-1.2, 0.2, 0.0, 0.5), (1.2, 0.2, 0.0, 0.5)]
 THREE_BOUND = (0.0, -1.0, 0.0, 3.0)
 

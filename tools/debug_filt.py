@@ -12,7 +12,7 @@ dev = scene.device(0)
 regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
 counted, st = dev.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=True)
 print("stats", {k: st[k] for k in ("primary", "hits", "shadow", "occluded")})
-print("filter unsure/pass", rta.capi.lib.rt_debug_count(2), "violations", rta.capi.lib.rt_debug_count(3))
+print("filter unsure/pass", rta.capi.debug_count(2), "violations", rta.capi.debug_count(3))
 for v in (3, 7, 19, 23):
     with rta.capi.debug(rta.capi.DEBUG_SKIP_VARIANT, v):
         plain, _ = dev.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)

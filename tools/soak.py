@@ -83,7 +83,7 @@ while time.time() < t_end:
     if True:
         # the counting launch evaluated the filtered loops' bounds NEXT TO the reference's arithmetic for every test it made and
         # counts a violation whenever a bound rules out what the arithmetic finds (rt_skip.hpp, COUNT mode)
-        assert rta.capi.lib.rt_debug_count(rta.capi.DEBUG_COUNT_FILTER_VIOLATIONS) == 0, "seed %d: a bound ruled out a hit" % seed
+        assert rta.capi.debug_count(rta.capi.DEBUG_COUNT_FILTER_VIOLATIONS) == 0, "seed %d: a bound ruled out a hit" % seed
         filter_tests += st["sphere_tests"] + st["bound_tests"]
     rta.capi.debug_set(rta.capi.DEBUG_SKIP_VARIANT, -1)
     if prec == rta.RT_F32:
