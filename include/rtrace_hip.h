@@ -133,6 +133,22 @@ typedef void (*rt_tile_callback)(void *user, uint32_t tile_index, const rt_regio
 rt_status rt_render_tiles_stream(rt_scene *scene, const rt_options *options, rt_traversal traversal,
                                  const rt_region *tiles, uint32_t n_tiles, rt_tile_callback callback, void *user);
 
+/* The same pass for a writer that keeps its image in the FILE's pixel format (PPMStdoutRGBABufferWriter, render.rs:373-401): every listed
+ * bucket is rendered and put -- converted on the device -- into its place in a row-major frame of options->width x options->height pixels:
+ *   RT_FRAME_RGBA  4 B/px  what set_pixels_from_buffer leaves in the writer's image (render.rs:112-126, 422-424)
+ *   RT_FRAME_RGB   3 B/px  R, G, B -- the P6 payload (render.rs:392-396: alpha dropped)
+ *   RT_FRAME_GREY  1 B/px  ((r + g + b) as f32 / 3.0) as u8 -- the P5 payload (render.rs:399)
+ * frame_out: HOST memory, 4-byte aligned, width * height * {4, 3, 1} bytes; bytes outside the listed buckets are left alone.  Memory from
+ * rt_host_alloc / rt_host_register is written by the device directly (a 1080p P6 image: 6.2 MB over PCIe instead of 8.3 MB and no
+ * conversion on the CPU); pageable memory goes through pinned staging and a CPU copy.  Batches as for rt_render_tiles_stream: `callback`
+ * (may be NULL) is invoked on the calling thread after each batch is in place -- tiles [first_tile, first_tile + n_tiles) of the list --
+ * while later batches are still rendering (the writer's once-per-second rewrite, render.rs:427-432, hangs off it). */
+typedef enum rt_frame_format { RT_FRAME_RGBA = 0, RT_FRAME_RGB = 1, RT_FRAME_GREY = 2 } rt_frame_format;
+typedef void (*rt_batch_callback)(void *user, uint32_t first_tile, uint32_t n_tiles);
+rt_status rt_render_frame_stream(rt_scene *scene, const rt_options *options, rt_traversal traversal,
+                                 const rt_region *tiles, uint32_t n_tiles, rt_frame_format format, uint8_t *frame_out,
+                                 rt_batch_callback callback, void *user);
+
 /* Host memory for RGBABuffer storage (render.rs:74-90 allocates it with vec![0; area * 4]) that the device can reach
  * directly.  rt_render_tiles / rt_render_region recognise such memory by address (any pointer inside a range this library
  * pinned -- memory pinned by other means counts as pageable) and then

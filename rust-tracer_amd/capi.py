@@ -25,7 +25,7 @@ SYMBOLS = ("rt_abi_version", "rt_device_count", "rt_scene_create", "rt_scene_des
            "rt_render_tiles_device", "rt_render_frame_device", "rt_render_region", "rt_blit_tiles_device", "rt_selftest_sqrt", "rt_selftest_rcp", "rt_tiles_rgba_bytes", "rt_strerror", "rt_last_error_message",
            "rt_host_alloc", "rt_host_free", "rt_host_register", "rt_host_unregister",
            "rt_gang_create", "rt_gang_destroy", "rt_gang_size", "rt_gang_render_frame", "rt_gang_render_frames", "rt_render_tiles_stream",
-           "rt_last_launch_flags", "rt_build_info")
+           "rt_last_launch_flags", "rt_build_info", "rt_render_frame_stream")
 # csrc/rt_debug.h: only in the -DRT_TEST_HOOKS build
 DEBUG_SYMBOLS = ("rt_debug_set", "rt_debug_count", "rt_debug_wave_trace", "rt_debug_flat_filter_check", "rt_debug_gang_layout", "rt_debug_rccl_library",
                  "rt_debug_shard_costs")
@@ -87,6 +87,9 @@ lib.rt_gang_render_frame.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.
 lib.rt_gang_render_frames.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(Stats)]
 TILE_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.POINTER(Region), C.POINTER(C.c_uint8))      # rt_tile_callback
 lib.rt_render_tiles_stream.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_void_p, C.c_uint32, TILE_CALLBACK, C.c_void_p]
+BATCH_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32)                                        # rt_batch_callback
+RT_FRAME_RGBA, RT_FRAME_RGB, RT_FRAME_GREY = 0, 1, 2
+lib.rt_render_frame_stream.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, BATCH_CALLBACK, C.c_void_p]
 lib.rt_selftest_sqrt.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
 lib.rt_selftest_rcp.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
 lib.rt_scene_traits.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]

@@ -4,6 +4,7 @@
 // add GPU selection; none of the reference's flags changes meaning.
 #include <cerrno>
 #include <chrono>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -235,6 +236,7 @@ int main(int argc, char **argv)
             t0 = Clock::now();
         }                                                                                // Drop writes the final image
         const double t_drop_write = ms_since(t0);
+        if (sink.is_file) { fclose(sink.f); sink.f = nullptr; } else fflush(stdout);
         if (timings)
             fprintf(stderr, "{\"args_ms\": %.3f, \"host_scene_ms\": %.3f, \"runtime_init_ms\": %.3f, \"device_scene_ms\": %.3f, \"render_and_first_write_ms\": %.3f, "
                             "\"drop_write_ms\": %.3f, \"main_to_here_ms\": %.3f}\n", t_args, t_host_scene, t_runtime, t_device_scene, t_render, t_drop_write, ms_since(t_main));
@@ -242,10 +244,15 @@ int main(int argc, char **argv)
             fprintf(stderr, "primary %llu hits %llu shadow %llu occluded %llu item_tests %llu bound_tests %llu device_ms %.3f\n",
                     (unsigned long long)st.primary, (unsigned long long)st.hits, (unsigned long long)st.shadow,
                     (unsigned long long)st.occluded, (unsigned long long)st.sphere_tests, (unsigned long long)st.bound_tests, st.device_ms);
+        // process::exit(0)  main.rs:89 -- like it, without unwinding main's locals: the image is complete and closed, and tearing the
+        // device scene, its worker thread and the GPU runtime down in order costs a one-shot caller some 100 ms it has no use for
+        // (bench.py make_image: process start -> exit is what `time make image` shows, /root/reference/Makefile:6-7)
+        fflush(stderr);
+        _exit(0);
     } catch (const std::exception &e) {
         fprintf(stderr, "thread 'main' panicked at '%s'\n", e.what());
         status = 101;
     }
-    if (sink.is_file) fclose(sink.f); else fflush(stdout);
+    if (sink.is_file && sink.f) fclose(sink.f); else fflush(stdout);
     return status;                                                // process::exit(0)  main.rs:89
 }

@@ -4,6 +4,7 @@
 
 #include <cstring>
 #include <exception>
+#include <mutex>
 
 namespace rtrace {
 
@@ -69,18 +70,96 @@ static void rgba_to_rgb(const uint8_t *b, uint8_t *w, size_t n)
     for (size_t i = 0; i < n; ++i, b += 4, w += 3) { w[0] = b[0]; w[1] = b[1]; w[2] = b[2]; }
 }
 
+// Pinning memory costs about a millisecond per 6 MB and so does giving it back: a process that writes frame after frame (a new writer per
+// frame, like seam_bench or a viewer) keeps ONE released image around for the next writer.
+namespace {
+struct SpareImage {
+    std::mutex mu;
+    uint8_t *p = nullptr; size_t cap = 0; bool pinned = false;
+    ~SpareImage() { if (p) { if (pinned) rt_host_free(p); else free(p); } }
+} g_spare;
+}  // namespace
+
+void PPMStdoutRGBABufferWriter::allocate_image(size_t pixel_bytes)
+{
+    char header[64];
+    const int hl = snprintf(header, sizeof header, "%s\n%u %u\n255\n", rgb_ ? "P6" : "P5", (unsigned)*width_, (unsigned)*height_);
+    const size_t front = ((size_t)hl + 3) & ~(size_t)3, need = front + pixel_bytes + 16;      // (+ 16: the SSSE3 conversion stores whole vectors)
+    if (image_cap_ < need) {
+        release_image();
+        std::lock_guard<std::mutex> lk(g_spare.mu);
+        if (g_spare.p && g_spare.cap >= need) { image_ = g_spare.p; image_cap_ = g_spare.cap; image_pinned_ = g_spare.pinned; g_spare.p = nullptr; g_spare.cap = 0; }
+    }
+    if (image_cap_ < need) {
+        void *p = nullptr;
+        if (rt_host_alloc(need, &p) == RT_OK) image_pinned_ = true;          // memory the device writes directly; without a device: plain memory
+        else { p = malloc(need); image_pinned_ = false; }
+        if (!p) throw std::bad_alloc();
+        image_ = static_cast<uint8_t *>(p);
+        image_cap_ = need;
+    }
+    pixels_ = image_ + front;
+    pixel_bytes_ = pixel_bytes;
+    header_len_ = (size_t)hl;
+    memcpy(pixels_ - hl, header, (size_t)hl);
+}
+
+void PPMStdoutRGBABufferWriter::release_image()
+{
+    if (!image_) return;
+    {
+        std::lock_guard<std::mutex> lk(g_spare.mu);
+        if (image_cap_ > g_spare.cap) { std::swap(image_, g_spare.p); std::swap(image_cap_, g_spare.cap); std::swap(image_pinned_, g_spare.pinned); }
+    }
+    if (image_) { if (image_pinned_) rt_host_free(image_); else free(image_); }
+    image_ = pixels_ = nullptr; image_cap_ = 0;
+}
+
+void PPMStdoutRGBABufferWriter::buckets_arrived(const ImageRegion *regions, size_t n)
+{
+    if (!width_ || !height_) throw std::runtime_error("begin() called");
+    for (size_t i = 0; i < n; ++i) {
+        if (regions[i].r > *width_ || regions[i].t > *height_) throw std::runtime_error("assertion failed: self.reg.contains(&b.reg)");
+        rows_with_data_ = std::max<uint32_t>(rows_with_data_, regions[i].t);
+        for (uint16_t y = regions[i].b; y < regions[i].t; ++y) row_cover_[y] += regions[i].width();
+    }
+    // The device wrote these buckets into an image nobody zeroed (6 MB of memset per frame for nothing when every pixel arrives): a
+    // rewrite of the file shows the rows that have arrived COMPLETELY -- Renderer::render's batches are whole bucket rows, so that is
+    // every bucket that has arrived -- and leaves the rest of the file a hole (zeros), like rows no bucket has reached.
+    while (complete_rows_ < *height_ && row_cover_[complete_rows_] >= *width_) ++complete_rows_;
+    buffer_dirty_ = true;
+    const auto now = std::chrono::steady_clock::now();            // render.rs:427-432
+    if (out_.is_file && (!last_written_at_ || *last_written_at_ + std::chrono::seconds(1) <= now)) {
+        last_written_at_ = now;
+        write_buffer_with_header();
+    }
+}
+
 void PPMStdoutRGBABufferWriter::blit_encoded(const RGBABuffer &b)
 {
     const ImageRegion &r = b.region();
     if (!width_ || !height_ || r.r > *width_ || r.t > *height_) throw std::runtime_error("assertion failed: self.reg.contains(&b.reg)");
     const size_t bpp = rgb_ ? 3 : 1, pitch = (size_t)*width_ * bpp;
+    if (zero_pending_) { memset(pixels_, 0, pixel_bytes_); zero_pending_ = false; }      // pixels no bucket has reached read as zeros
     const uint8_t *src = b.data();
     rows_with_data_ = std::max<uint32_t>(rows_with_data_, r.t);
     for (uint16_t y = r.b; y < r.t; ++y, src += (size_t)r.width() * 4) {
-        uint8_t *dst = encoded_.data() + (size_t)y * pitch + (size_t)r.l * bpp;
+        uint8_t *dst = pixels_ + (size_t)y * pitch + (size_t)r.l * bpp;
         if (rgb_) rgba_to_rgb(src, dst, r.width());
         else for (size_t i = 0; i < r.width(); ++i) dst[i] = (uint8_t)(((float)src[4 * i] + (float)src[4 * i + 1] + (float)src[4 * i + 2]) / 3.0f);      // render.rs:399
     }
+}
+
+// header + pixels in ONE positioned write.  (Writing a large image from several threads side by side was tried: on tmpfs it doubles the
+// time of the write AND of the truncating fopen before it -- the page cache serialises them; profiles/r05_write_helpers_ab.log.)
+bool PPMStdoutRGBABufferWriter::positioned_write(int fd, const uint8_t *p, size_t n)
+{
+    for (size_t done = 0; done < n;) {
+        const ssize_t w = pwrite(fd, p + done, n - done, (off_t)done);
+        if (w <= 0) return false;
+        done += (size_t)w;
+    }
+    return true;
 }
 
 void PPMStdoutRGBABufferWriter::write_buffer_with_header()
@@ -88,11 +167,9 @@ void PPMStdoutRGBABufferWriter::write_buffer_with_header()
     if (!buffer_dirty_) return;
     FILE *out = out_.f;
     if (!width_ || !height_) throw std::runtime_error("begin() called");
-    char header[64];
-    const int hl = snprintf(header, sizeof header, "%s\n%u %u\n255\n", rgb_ ? "P6" : "P5", (unsigned)*width_, (unsigned)*height_);
+    const uint8_t *file_image = pixels_ - header_len_;            // header + pixels, contiguous
     if (!out_.is_file) {
-        fwrite(header, 1, (size_t)hl, out);
-        if (fwrite(encoded_.data(), 1, encoded_.size(), out) != encoded_.size()) throw std::runtime_error("called `Result::unwrap()` on an `Err` value: write");
+        if (fwrite(file_image, 1, header_len_ + pixel_bytes_, out) != header_len_ + pixel_bytes_) throw std::runtime_error("called `Result::unwrap()` on an `Err` value: write");
         fflush(out);
         buffer_dirty_ = false;
         return;
@@ -101,19 +178,21 @@ void PPMStdoutRGBABufferWriter::write_buffer_with_header()
     // page cache (two thirds of a 1080p frame's 1.9 ms through the scheduler were these writes: seam_bench's *_parts_ms).  The file is
     // emptied on this writer's FIRST write only -- later writes overwrite in place: same length, no pages to give back and take again --
     // and rows no bucket has reached yet are left as a hole behind the last row that has data: a hole reads as the zeros those rows
-    // hold in `encoded_`.  1080p, the write that the first batch of buckets triggers: 1.1 of 6.2 MB.
+    // hold in the image.  1080p, the write that the first batch of buckets triggers: 1.1 of 6.2 MB.  Header and pixels lie back to
+    // back in the image, so a rewrite is ONE positioned write.
     fflush(out);
     const int fd = fileno(out);
     if (!emptied_) {
         if (ftruncate(fd, 0) != 0) throw std::runtime_error("called `Result::unwrap()` on an `Err` value: ftruncate");
         emptied_ = true;
     }
-    fseek(out, 0, SEEK_SET);
-    const size_t pitch = (size_t)*width_ * (rgb_ ? 3 : 1), live = std::min(encoded_.size(), (size_t)rows_with_data_ * pitch);
-    if (fwrite(header, 1, (size_t)hl, out) != (size_t)hl || fwrite(encoded_.data(), 1, live, out) != live)
-        throw std::runtime_error("called `Result::unwrap()` on an `Err` value: write");
-    fflush(out);
-    if (ftruncate(fd, (off_t)((size_t)hl + encoded_.size())) != 0) throw std::runtime_error("called `Result::unwrap()` on an `Err` value: ftruncate");
+    const size_t pitch = (size_t)*width_ * (rgb_ ? 3 : 1);
+    const size_t live = header_len_ + std::min(pixel_bytes_, (size_t)(zero_pending_ ? complete_rows_ : rows_with_data_) * pitch);
+    if (!positioned_write(fd, file_image, live)) throw std::runtime_error("called `Result::unwrap()` on an `Err` value: write");
+    if (!full_length_) {                                          // (rows behind the last one that has data: a hole; later rewrites leave the length alone)
+        if (ftruncate(fd, (off_t)(header_len_ + pixel_bytes_)) != 0) throw std::runtime_error("called `Result::unwrap()` on an `Err` value: ftruncate");
+        full_length_ = true;
+    }
     fseek(out, 0, SEEK_END);
     buffer_dirty_ = false;
 }
@@ -180,8 +259,26 @@ RenderStats Renderer::render(const RenderOptions &o, const Backend &be, RGBABuff
         // staging and the callback -- this thread, the channel's consumer (render.rs:301-307) -- receives each bucket as a view of
         // that staging as soon as its batch is complete, while later batches are still rendering: no per-batch host call, no
         // intermediate copies.  (The pool keeps its meaning for the paths below; here the producers are the GPU's workgroups.)
-        struct Ctx { RGBABufferWriter *writer; size_t delivered = 0; std::exception_ptr err; } ctx{ &writer, 0, nullptr };
         const rt_options opts1{ o.width, o.height, o.samples_per_pixel };
+        if (auto *ppm = dynamic_cast<PPMStdoutRGBABufferWriter *>(&writer); ppm && ppm->accepts_device_frames() && ppm->pixels()) {
+            // The library's own writer keeps its image in the file's pixel format in memory the GPU can write: the device converts and
+            // places the buckets itself (rt_render_frame_stream: 6.2 MB of P6 payload over PCIe for a 1080p frame instead of 8.3 MB of RGBA,
+            // no conversion on this thread), and the writer is told which buckets have arrived -- its first write of the file after the
+            // first batch, the once-per-second rewrite, the final write on Drop stay what they are (render.rs:427-432, 331-335).
+            struct Arrived { PPMStdoutRGBABufferWriter *writer; const ImageRegion *all; size_t delivered = 0; std::exception_ptr err; } ctx{ ppm, all.data(), 0, nullptr };
+            check(rt_render_frame_stream(be.devices[0]->handle(), &opts1, be.traversal, reinterpret_cast<const rt_region *>(all.data()), (uint32_t)all.size(),
+                                         ppm->frame_format(), ppm->pixels(),
+                                         [](void *user, uint32_t first, uint32_t n) {
+                                             Arrived *c = static_cast<Arrived *>(user);
+                                             if (c->err) return;
+                                             try { c->writer->buckets_arrived(c->all + first, n); c->delivered += n; } catch (...) { c->err = std::current_exception(); }
+                                         }, &ctx),
+                  "rt_render_frame_stream");
+            if (ctx.err) std::rethrow_exception(ctx.err);
+            if (ctx.delivered != all.size()) throw std::runtime_error("We really should have processed all chunks here");
+            return RenderStats{};
+        }
+        struct Ctx { RGBABufferWriter *writer; size_t delivered = 0; std::exception_ptr err; } ctx{ &writer, 0, nullptr };
         check(rt_render_tiles_stream(be.devices[0]->handle(), &opts1, be.traversal, reinterpret_cast<const rt_region *>(all.data()), (uint32_t)all.size(),
                                      [](void *user, uint32_t, const rt_region *region, const uint8_t *rgba) {
                                          Ctx *c = static_cast<Ctx *>(user);

@@ -11,6 +11,7 @@
 #include <memory>
 #include <optional>
 #include <stdexcept>
+#include <typeinfo>
 #include <string>
 #include <vector>
 
@@ -85,7 +86,10 @@ public:
     ~PPMStdoutRGBABufferWriter() override                         // Drop, render.rs:331-335
     {
         try { write_buffer_with_header(); } catch (...) {}
+        release_image();
     }
+    PPMStdoutRGBABufferWriter(const PPMStdoutRGBABufferWriter &) = delete;
+    PPMStdoutRGBABufferWriter &operator=(const PPMStdoutRGBABufferWriter &) = delete;
 
     void begin(uint16_t x, uint16_t y) override                   // render.rs:411-420
     {
@@ -93,9 +97,11 @@ public:
         // The reference keeps the frame as an RGBABuffer and turns it into P6 / P5 bytes on every write of the file
         // (render.rs:373-401).  Here the frame is kept in the file's own pixel format: a bucket is converted once, when it
         // arrives (while the device is still rendering the next ones), and a write of the file is the header plus one write.
-        encoded_.assign((size_t)x * y * (rgb_ ? 3 : 1), 0);
+        allocate_image((size_t)x * y * (rgb_ ? 3 : 1));
         rows_with_data_ = 0;
-        emptied_ = false;                                         // a second frame through the same writer: its first write empties the file again,
+        zero_pending_ = true;                                     // (the image is zeroed when the first bucket is blitted on this thread; a frame the
+        row_cover_.assign(y, 0); complete_rows_ = 0;              // device delivers is never zeroed: its writes cover complete rows only)
+        emptied_ = false; full_length_ = false;                   // a second frame through the same writer: its first write empties the file again,
                                                                   // so rows it has not reached read as zeros, never as the previous frame's (render.rs:366)
     }
     void write_rgba_buffer(const RGBABuffer &buffer) override     // render.rs:422-433
@@ -110,16 +116,36 @@ public:
     }
     void write_buffer_with_header();                              // render.rs:359-407
 
+    // The device side of the writer (not in the reference): the image is kept in the file's own pixel format in memory the GPU can write
+    // (rt_host_alloc), so Renderer::render lets the device convert and place the buckets (rt_render_frame_stream) and tells the writer
+    // which ones have arrived -- the same bookkeeping as write_rgba_buffer (dirty flag, the once-per-second rewrite), without its copy.
+    uint8_t *pixels() { return pixels_; }                         // width * height * (rgb ? 3 : 1) bytes, row-major, 4-byte aligned
+    rt_frame_format frame_format() const { return rgb_ ? RT_FRAME_RGB : RT_FRAME_GREY; }
+    virtual void buckets_arrived(const ImageRegion *regions, size_t n);
+    // Renderer::render takes the device path only for THIS class: a subclass that overrides write_rgba_buffer to see every bucket keeps
+    // seeing them (it may opt in by overriding this together with buckets_arrived)
+    virtual bool accepts_device_frames() const { return typeid(*this) == typeid(PPMStdoutRGBABufferWriter); }
+
 private:
     void blit_encoded(const RGBABuffer &b);
+    static bool positioned_write(int fd, const uint8_t *p, size_t n);
+    void allocate_image(size_t pixel_bytes);
+    void release_image();
     FileOrAnyWriter &out_;
     std::optional<uint16_t> width_, height_;
-    std::vector<uint8_t> encoded_;                                // the frame as the file holds it: RGB (P6) or grey (P5), row-major
+    // the file as it is written: [pad][header][pixels], `pixels_` 4-byte aligned, header right in front of it -- ONE write per rewrite
+    uint8_t *image_ = nullptr, *pixels_ = nullptr;
+    size_t image_cap_ = 0, pixel_bytes_ = 0, header_len_ = 0;
+    bool image_pinned_ = false;
     bool rgb_;
     std::optional<std::chrono::steady_clock::time_point> last_written_at_;
     bool buffer_dirty_ = false;
     bool emptied_ = false;                                        // this writer has emptied the file once (render.rs:366 does it on every write)
-    uint32_t rows_with_data_ = 0;                                 // rows [0, n) of `encoded_` may hold pixels; the rest is still zero
+    bool full_length_ = false;                                    // ... and given it its final length
+    uint32_t rows_with_data_ = 0;                                 // rows [0, n) of the image may hold pixels; the rest is still zero
+    bool zero_pending_ = false;                                   // begin() has not zeroed the image yet
+    std::vector<uint32_t> row_cover_;                             // device path: pixels of row y that have arrived
+    uint32_t complete_rows_ = 0;                                  // ... rows [0, n) have arrived completely
 };
 
 // Device copies of a Scene on one GPU (replaces handing Arc<Scene> to the pool threads, render.rs:279).

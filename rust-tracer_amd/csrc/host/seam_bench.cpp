@@ -136,6 +136,17 @@ int main(int argc, char **argv)
         check(static_cast<uint8_t *>(pinned), "host_tiles (pinned)");
         stats_json("host_tiles_pinned", p, rays);
         die(rt_host_free(pinned), "rt_host_free");
+        // the same frame delivered in the FILE's pixel format (P6 payload, 3 B/px), converted and placed by the device (rt_render_frame_stream)
+        void *rgb = nullptr;
+        die(rt_host_alloc((size_t)width * height * 3, &rgb), "rt_host_alloc");
+        Series q;
+        for (int f = 0; f < frames + 3; ++f) {
+            const auto t0 = Clock::now();
+            die(rt_render_frame_stream(h, &opts, RT_TRAVERSAL_SKIP, regs, n, RT_FRAME_RGB, static_cast<uint8_t *>(rgb), nullptr, nullptr), "rt_render_frame_stream");
+            if (f >= 3) q.v.push_back(ms_since(t0));
+        }
+        stats_json("host_frame_rgb_pinned", q, rays);
+        die(rt_host_free(rgb), "rt_host_free");
     }
 
     // ---------------- host_region ----------------
@@ -181,7 +192,7 @@ int main(int argc, char **argv)
         for (int f = 0; f < frames + 2; ++f) {
             const auto t0 = Clock::now();
             die(rt_render_tiles(h, &opts, RT_TRAVERSAL_SKIP, &whole, 1, static_cast<uint8_t *>(pinned), nullptr), "rt_render_tiles");
-            // the library's own writer, fed the whole frame as ONE RGBABuffer: one conversion, one write of the file
+            // the library's own writer, fed the whole frame as ONE RGBABuffer: one conversion (on this thread), one write of the file
             FileOrAnyWriter sink;
             sink.f = fopen(path.c_str(), "wb");
             sink.is_file = true;
@@ -194,7 +205,46 @@ int main(int argc, char **argv)
             fclose(sink.f);
             if (f >= 2) s.v.push_back(ms_since(t0));
         }
-        stats_json("end_to_end_frame", s, rays);
+        stats_json("end_to_end_frame_cpu_encode", s, rays);
+        // the same frame with the P6 encoding on the device (rt_render_frame_stream): the writer's image is memory the GPU writes, the
+        // frame arrives converted (6.2 MB over PCIe instead of 8.3), the file is one positioned write of header + pixels
+        Series d;
+        uint32_t crc_file = 0;
+        for (int f = 0; f < frames + 2; ++f) {
+            const auto t0 = Clock::now();
+            FileOrAnyWriter sink;
+            sink.f = fopen(path.c_str(), "wb");
+            sink.is_file = true;
+            if (!sink.f) { fprintf(stderr, "seam_bench: cannot write %s\n", path.c_str()); return 5; }
+            {
+                PPMStdoutRGBABufferWriter writer(true, sink);
+                writer.begin((uint16_t)width, (uint16_t)height);
+                die(rt_render_frame_stream(h, &opts, RT_TRAVERSAL_SKIP, regs, n, writer.frame_format(), writer.pixels(), nullptr, nullptr), "rt_render_frame_stream");
+                writer.buckets_arrived(bl.data(), bl.size());
+            }
+            fclose(sink.f);
+            if (f >= 2) d.v.push_back(ms_since(t0));
+        }
+        stats_json("end_to_end_frame", d, rays);
+        {
+            // the file the device-encoded path wrote must be the file the CPU-encoded path writes: P6 header + R, G, B of the reference frame
+            std::vector<uint8_t> want;
+            char hdr[64];
+            const int hl = snprintf(hdr, sizeof hdr, "P6\n%u %u\n255\n", width, height);
+            want.insert(want.end(), hdr, hdr + hl);
+            std::vector<uint8_t> frame((size_t)width * height * 4);
+            for (uint32_t i = 0; i < n; ++i)
+                for (uint16_t y = bl[i].b; y < bl[i].t; ++y)
+                    memcpy(frame.data() + ((size_t)y * width + bl[i].l) * 4, ref.data() + off[i] + (size_t)(y - bl[i].b) * bl[i].width() * 4, (size_t)bl[i].width() * 4);
+            for (size_t px = 0; px < (size_t)width * height; ++px) { want.push_back(frame[4 * px]); want.push_back(frame[4 * px + 1]); want.push_back(frame[4 * px + 2]); }
+            std::vector<uint8_t> got(want.size() + 1);
+            FILE *rf = fopen(path.c_str(), "rb");
+            const size_t nread = rf ? fread(got.data(), 1, got.size(), rf) : 0;
+            if (rf) fclose(rf);
+            if (nread != want.size() || memcmp(got.data(), want.data(), want.size()) != 0) { fprintf(stderr, "seam_bench: the device-encoded file differs from the reference bytes\n"); return 4; }
+            crc_file = crc32_of(want.data(), want.size());
+        }
+        printf("  \"end_to_end_frame_file_crc32\": %u,\n", crc_file);
         die(rt_host_free(pinned), "rt_host_free");
     }
 
@@ -211,6 +261,13 @@ int main(int argc, char **argv)
             {
                 const auto t = Clock::now();
                 PPMStdoutRGBABufferWriter::write_rgba_buffer(b);
+                in_writer += ms_since(t);
+            }
+            bool accepts_device_frames() const override { return true; }
+            void buckets_arrived(const ImageRegion *regions, size_t count) override
+            {
+                const auto t = Clock::now();
+                PPMStdoutRGBABufferWriter::buckets_arrived(regions, count);
                 in_writer += ms_since(t);
             }
         };

@@ -83,6 +83,7 @@ rt_status hip_fail(hipError_t e, const char *what, int line)
 // concurrent callers (the reference's pool threads, render.rs:283) never share one.
 struct Context {
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;     // rt_render_frame_stream: a batch is encoded here while the next one renders on `stream` (made when first needed)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // two upload slots (a flat pass uses two tables); pinned host side: the H2D copy is truly asynchronous
     rt::TileDev *d_tiles[2] = { nullptr, nullptr };
@@ -121,6 +122,7 @@ struct Context {
         if (d_queues) (void)hipFree(d_queues);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        if (stream2) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -145,6 +147,11 @@ struct rt_scene {
     rt::CoopView coop{};
     void *d_fprim = nullptr, *d_fprim_rr = nullptr, *d_fshad = nullptr;   // pre-formed per-item terms (RT_TRAVERSAL_FLAT)
     uint32_t n_padded = 0;
+    // The flat-scan arrays are derived when RT_TRAVERSAL_FLAT is first asked for (ensure_flat): a caller of the hierarchy walk -- the default,
+    // `make image` -- never pays for them.  h_items: the caller's items, kept for that day.
+    std::vector<unsigned char> h_items;
+    std::mutex flat_mu;
+    bool flat_ready = false;
     void *d_f64_pf = nullptr, *d_f64_sf = nullptr, *d_f64_sg = nullptr;        // f64, the filtered LDS scan (rt_flat_f64.hpp)
     double flat_centre64[3] = { 0, 0, 0 };
     void *d_pf = nullptr, *d_pe = nullptr, *d_sg = nullptr, *d_se = nullptr;   // f32, the scalar-fed scan (rt_flat_sc.hpp): filter groups of four
@@ -1643,12 +1650,25 @@ rt_status launch_skip(const rt_scene *s, Context *c, dim3 grid, hipStream_t stre
                : launch_skip_var<double, false>(s, c, grid, stream, w, h, spp, d_tab, nt, total_px, d_out, cnt, frame_w, order);
 }
 
-rt_status check_traversal(const rt_scene *s, rt_traversal trav)
+rt_status ensure_flat(rt_scene *s)
+{
+    std::lock_guard<std::mutex> lk(s->flat_mu);
+    if (s->flat_ready) return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    rt_status st = s->precision == RT_F32 ? upload_flat<float>(s, s->h_items.data()) : upload_flat<double>(s, s->h_items.data());
+    if (st != RT_OK) return st;
+    s->flat_ready = true;
+    std::vector<unsigned char>().swap(s->h_items);
+    return RT_OK;
+}
+
+rt_status check_traversal(rt_scene *s, rt_traversal trav)
 {
     if (trav != RT_TRAVERSAL_FLAT && trav != RT_TRAVERSAL_SKIP) {
         snprintf(g_err, sizeof g_err, "unknown traversal %d", (int)trav);
         return RT_ERR_INVALID_ARGUMENT;
     }
+    if (trav == RT_TRAVERSAL_FLAT) return ensure_flat(s);
     if (trav == RT_TRAVERSAL_SKIP && s->n_nodes == 0) {
         snprintf(g_err, sizeof g_err, "the hierarchy (skip) traversal needs a scene created with subtree bounds");
         return RT_ERR_UNSUPPORTED;
@@ -1801,7 +1821,8 @@ long long rt_debug_count(int counter)
 // ray of a width x height x spp frame and every item.  counts: {disc >= 0, bound >= 0, disc >= 0 && bound < 0} primary, then shadow.
 rt_status rt_debug_flat_filter_check(rt_scene *s, uint32_t width, uint32_t height, uint32_t spp, unsigned long long counts[6])
 {
-    if (!s || !counts || !width || !height || !spp || (s->precision == RT_F32 ? !s->d_pf : !s->d_f64_pf)) return RT_ERR_INVALID_ARGUMENT;
+    if (!s || !counts || !width || !height || !spp) return RT_ERR_INVALID_ARGUMENT;
+    if (rt_status fst = ensure_flat(s); fst != RT_OK) return fst;
     HIP_TRY(hipSetDevice(s->device));
     unsigned long long *d = nullptr;
     HIP_TRY(hipMalloc(&d, 6 * sizeof(unsigned long long)));
@@ -1954,10 +1975,7 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
     if ((e = hipMalloc(&s->d_items, esz * 4 * n_items)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(items)", __LINE__));
     if ((e = hipMemcpy(s->d_items, dfs_items, esz * 4 * n_items, hipMemcpyHostToDevice)) != hipSuccess)
         return fail(hip_fail(e, "hipMemcpy(items)", __LINE__));
-    {
-        rt_status fst = f32 ? upload_flat<float>(s.get(), dfs_items) : upload_flat<double>(s.get(), dfs_items);
-        if (fst != RT_OK) return fail(fst);
-    }
+    s->h_items.assign(static_cast<const unsigned char *>(dfs_items), static_cast<const unsigned char *>(dfs_items) + esz * 4 * n_items);
     if (n_bounds) {
         rt_status sst = f32 ? upload_streams<float>(s.get(), dfs_items, bounds, ranges) : upload_streams<double>(s.get(), dfs_items, bounds, ranges);
         if (sst != RT_OK) return fail(sst);
@@ -2306,6 +2324,119 @@ rt_status rt_render_tiles_stream(rt_scene *s, const rt_options *o, rt_traversal 
             off += (size_t)(tiles[i].r - tiles[i].l) * (tiles[i].t - tiles[i].b) * 4;
         }
     }
+    return RT_OK;
+}
+
+// The same streaming pass for a writer that keeps its image in the FILE's pixel format (render.rs:373-401): the buckets of a batch are
+// rendered tile-major into device memory and k_encode_tiles puts them -- converted -- into their place in the caller's row-major frame;
+// memory this library pinned is written by that kernel itself, anything else through pinned staging and a CPU copy of the batch's rows.
+rt_status rt_render_frame_stream(rt_scene *s, const rt_options *o, rt_traversal trav, const rt_region *tiles, uint32_t n, rt_frame_format format,
+                                 uint8_t *frame_out, rt_batch_callback callback, void *user)
+{
+    if (!check_common(s, o, tiles, n, frame_out)) return RT_ERR_INVALID_ARGUMENT;
+    if (format != RT_FRAME_RGBA && format != RT_FRAME_RGB && format != RT_FRAME_GREY) { snprintf(g_err, sizeof g_err, "rt_render_frame_stream: unknown frame format %d", (int)format); return RT_ERR_INVALID_ARGUMENT; }
+    if ((reinterpret_cast<uintptr_t>(frame_out) & 3u) != 0) { snprintf(g_err, sizeof g_err, "rt_render_frame_stream: frame_out must be 4-byte aligned"); return RT_ERR_INVALID_ARGUMENT; }
+    rt_status st = check_traversal(s, trav);
+    if (st != RT_OK) return st;
+    const unsigned bpp = format == RT_FRAME_RGBA ? 4u : format == RT_FRAME_RGB ? 3u : 1u;
+    const size_t frame_bytes = (size_t)o->width * o->height * bpp;
+    const bool flat2 = trav == RT_TRAVERSAL_FLAT;
+    // Batches: at most kStreamMaxBatches, each at least a million samples (a 1080p frame at one sample per pixel: two batches -- progress
+    // reports matter for renders that take long, and a short batch leaves most of the chip idle), and -- where the list is the scheduler's
+    // row-major grid (render.rs:273-298) -- whole bucket ROWS, so that what a batch delivers is complete rows of the image.
+    constexpr uint32_t kStreamMaxBatches = 16;
+    const uint64_t ns = (uint64_t)o->samples_per_pixel * o->samples_per_pixel;
+    uint32_t per = std::max<uint32_t>((n + kStreamMaxBatches - 1) / kStreamMaxBatches, (uint32_t)std::clamp<uint64_t>((1ull << 20) / (4096ull * ns), 16, 256));
+    {
+        uint32_t row = 1;
+        while (row < n && tiles[row].b == tiles[0].b) ++row;
+        bool grid = n % row == 0;
+        for (uint32_t i = 0; grid && i < n; ++i) grid = tiles[i].b == tiles[i - i % row].b && tiles[i].t == tiles[i - i % row].t && tiles[i].l == tiles[i % row].l && tiles[i].r == tiles[i % row].r;
+        if (grid) per = (per + row - 1) / row * row;
+    }
+    const uint32_t n_batches = (n + per - 1) / per;
+    struct Batch { std::vector<rt::TileDev> tab, tab16; uint64_t px = 0; uint32_t blocks = 0, blocks16 = 0; size_t byte_off = 0; };
+    std::vector<Batch> batches(n_batches);
+    size_t total_bytes = 0;
+    for (uint32_t k = 0; k < n_batches; ++k) {
+        Batch &b = batches[k];
+        const uint32_t first = k * per, cnt = std::min(per, n - first);
+        if ((st = build_tile_table(o, tiles + first, cnt, b.tab, &b.px, &b.blocks, flat2 ? rt::kFlatBlockW : rt::kBlockW, flat2 ? rt::kFlatBlockH : rt::kBlockH)) != RT_OK) return st;
+        if (flat2) { uint64_t px16 = 0; if ((st = build_tile_table(o, tiles + first, cnt, b.tab16, &px16, &b.blocks16)) != RT_OK) return st; }
+        b.byte_off = total_bytes;
+        total_bytes += (size_t)b.px * 4;
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    const HostDest dest = classify_host_pointer(frame_out);
+    if (dest.bad) { snprintf(g_err, sizeof g_err, "rt_render_frame_stream: frame_out is device memory"); return RT_ERR_INVALID_ARGUMENT; }
+    const bool direct = dest.pinned && dest.dev_alias && dest.room >= frame_bytes;
+    Context *c = nullptr;
+    if ((st = acquire(s, &c)) != RT_OK) return st;
+    Lease lease{ s, c };
+    if (c->out_cap < total_bytes) {
+        if (c->d_out) HIP_TRY(hipFree(c->d_out));
+        c->d_out = nullptr; c->out_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_out, total_bytes));
+        c->out_cap = total_bytes;
+    }
+    uint8_t *target = dest.dev_alias;
+    if (!direct) {
+        if (c->h_out_cap < frame_bytes) {
+            if (c->h_out) HIP_TRY(hipHostFree(c->h_out));
+            c->h_out = nullptr; c->h_out_cap = 0;
+            HIP_TRY(hipHostMalloc(&c->h_out, std::max(frame_bytes, (size_t)1 << 20), hipHostMallocDefault));
+            c->h_out_cap = std::max(frame_bytes, (size_t)1 << 20);
+        }
+        void *alias = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&alias, c->h_out, 0));
+        target = static_cast<uint8_t *>(alias);
+    }
+    while (c->chunk_ev.size() < n_batches) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->chunk_ev.push_back(e);
+    }
+    // several batches: a batch is encoded (PCIe-bound, a handful of waves) on a second stream while the next one renders
+    hipStream_t enc = c->stream;
+    if (n_batches > 1) {
+        if (!c->stream2 && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->stream2 = nullptr; }
+        if (c->stream2) enc = c->stream2;
+    }
+    auto drain = [&](rt_status code) { (void)hipStreamSynchronize(c->stream); if (c->stream2) (void)hipStreamSynchronize(c->stream2); (void)hipGetLastError(); return code; };   // nothing may still be writing the frame
+    for (uint32_t k = 0; k < n_batches; ++k) {
+        Batch &b = batches[k];
+        st = enqueue_pass(s, c, o, trav, b.tab, b.blocks, b.px, c->d_out + b.byte_off, 0u, c->stream, false, flat2 ? &b.tab16 : nullptr, b.blocks16, true);
+        if (st != RT_OK) return drain(st);
+        const rt::TileDev *d_tab = nullptr;
+        if ((st = device_table(s, c, b.tab, c->stream, &d_tab)) != RT_OK) return drain(st);
+        if (enc != c->stream) {                                      // (enqueue_pass recorded ev1 behind the batch's kernels)
+            const hipError_t we = hipStreamWaitEvent(enc, c->ev1, 0);
+            if (we != hipSuccess) return drain(hip_fail(we, "rt_render_frame_stream(wait)", __LINE__));
+        }
+        const unsigned *src = reinterpret_cast<const unsigned *>(c->d_out + b.byte_off);
+        const dim3 grid((unsigned)b.tab.size()), blk(rt::kBlockThreads);
+        if (bpp == 4) hipLaunchKernelGGL((rt::k_encode_tiles<4>), grid, blk, 0, enc, (unsigned)o->width, d_tab, (unsigned)b.tab.size(), src, target);
+        else if (bpp == 3) hipLaunchKernelGGL((rt::k_encode_tiles<3>), grid, blk, 0, enc, (unsigned)o->width, d_tab, (unsigned)b.tab.size(), src, target);
+        else hipLaunchKernelGGL((rt::k_encode_tiles<1>), grid, blk, 0, enc, (unsigned)o->width, d_tab, (unsigned)b.tab.size(), src, target);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(c->chunk_ev[k], enc);
+        if (e != hipSuccess) return drain(hip_fail(e, "rt_render_frame_stream(encode)", __LINE__));
+    }
+    for (uint32_t k = 0; k < n_batches; ++k) {
+        hipError_t e = hipEventSynchronize(c->chunk_ev[k]);
+        if (e != hipSuccess) return drain(hip_fail(e, "hipEventSynchronize(stream batch)", __LINE__));
+        const uint32_t first = k * per, cnt = std::min(per, n - first);
+        if (!direct)
+            for (uint32_t i = first; i < first + cnt; ++i) {
+                const size_t seg = (size_t)(tiles[i].r - tiles[i].l) * bpp;
+                for (unsigned y = tiles[i].b; y < tiles[i].t; ++y) {
+                    const size_t off = ((size_t)y * o->width + tiles[i].l) * bpp;
+                    memcpy(frame_out + off, c->h_out + off, seg);
+                }
+            }
+        if (callback) callback(user, first, cnt);
+    }
+    // (the last batch's event is behind everything on both streams: the context goes back idle)
     return RT_OK;
 }
 

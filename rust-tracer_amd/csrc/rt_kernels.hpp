@@ -151,4 +151,45 @@ __global__ __launch_bounds__(kBlockThreads) void k_blit_tiles(unsigned width, co
         frame[(size_t)y * width + x] = src[(size_t)tile.out_px + (size_t)(y - tile.b) * (tile.r - tile.l) + (x - tile.l)];
 }
 
+// The writer's conversion on the device (render.rs:373-401): tile-major RGBA tiles -> their place in a row-major frame in the FILE's pixel
+// format -- BPP 3: R, G, B (P6, render.rs:392-396), BPP 1: ((r + g + b) as f32 / 3.0) as u8 (P5, render.rs:399), BPP 4: RGBA (the blit).
+// One workgroup per tile, a wave per row (rows w, w + 4, ...), a lane per aligned 32-bit word of the row's bytes: the destination may be
+// pinned HOST memory, where 256 contiguous bytes per wave store travel as full PCIe writes; the unaligned head / tail bytes of a row
+// segment (odd widths) go out as byte stores.  Bytes outside the listed tiles are not touched.
+template <int BPP>
+__device__ __forceinline__ unsigned encoded_byte(const unsigned *__restrict__ row_src, unsigned rel)      // byte `rel` of the row segment's encoding
+{
+    const unsigned px = rel / BPP, rgba = row_src[px];
+    if constexpr (BPP == 1) return (unsigned)(unsigned char)(((float)(rgba & 255u) + (float)((rgba >> 8) & 255u) + (float)((rgba >> 16) & 255u)) / 3.0f);
+    else return (rgba >> (8u * (rel % BPP))) & 255u;
+}
+
+template <int BPP>
+__global__ __launch_bounds__(kBlockThreads) void k_encode_tiles(unsigned width, const TileDev *__restrict__ tiles, unsigned n_tiles,
+                                                               const unsigned *__restrict__ src, unsigned char *__restrict__ frame)
+{
+    if (blockIdx.x >= n_tiles) return;
+    const TileDev tile = tiles[blockIdx.x];
+    const unsigned tw = (unsigned)tile.r - tile.l, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (unsigned y = tile.b + wave; y < tile.t; y += kBlockThreads / 64) {
+        const unsigned *row_src = src + (size_t)tile.out_px + (size_t)(y - tile.b) * tw;
+        const size_t a = ((size_t)y * width + tile.l) * BPP, e = a + (size_t)tw * BPP;      // this row segment's bytes [a, e) of the frame
+        const size_t a4 = (a + 3) & ~(size_t)3, e4 = e & ~(size_t)3;
+        if (a4 >= e4) {                                                                    // shorter than an aligned word: bytes
+            for (size_t j = a + lane; j < e; j += 64) frame[j] = (unsigned char)encoded_byte<BPP>(row_src, (unsigned)(j - a));
+            continue;
+        }
+        for (size_t j = a4 + 4 * (size_t)lane; j < e4; j += 256) {
+            const unsigned rel = (unsigned)(j - a);
+            unsigned w;
+            if constexpr (BPP == 4) w = row_src[rel >> 2];
+            else w = encoded_byte<BPP>(row_src, rel) | encoded_byte<BPP>(row_src, rel + 1) << 8 | encoded_byte<BPP>(row_src, rel + 2) << 16 |
+                     encoded_byte<BPP>(row_src, rel + 3) << 24;
+            *reinterpret_cast<unsigned *>(frame + j) = w;
+        }
+        if (lane < a4 - a) frame[a + lane] = (unsigned char)encoded_byte<BPP>(row_src, lane);
+        if (lane < e - e4) frame[e4 + lane] = (unsigned char)encoded_byte<BPP>(row_src, (unsigned)(e4 - a) + lane);
+    }
+}
+
 }  // namespace rt

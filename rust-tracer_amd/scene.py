@@ -245,6 +245,32 @@ class DeviceScene:
             raise err[0]
         capi.check(rc, "rt_render_tiles_stream")
 
+    def render_frame_stream(self, options, regions, frame_format, out, on_batch=None, traversal=None):
+        """rt_render_frame_stream: the listed buckets, converted on the device, into their place in `out` -- a row-major uint8 frame in
+        the file's pixel format (capi.RT_FRAME_RGBA / _RGB / _GREY: 4 / 3 / 1 bytes per pixel).  on_batch(first_tile, n_tiles) after each
+        batch is in place.  A capi.HostBuffer array is written by the device directly."""
+        traversal = self.default_traversal() if traversal is None else traversal
+        arr = regions if isinstance(regions, C.Array) else self._regions(regions)
+        bpp = {capi.RT_FRAME_RGBA: 4, capi.RT_FRAME_RGB: 3, capi.RT_FRAME_GREY: 1}[frame_format]
+        if out.dtype != np.uint8 or out.size != options[0] * options[1] * bpp or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous uint8 array of width * height * %d bytes" % bpp)
+        err = []
+
+        def cb(_user, first, count):
+            if err or on_batch is None:
+                return
+            try:
+                on_batch(int(first), int(count))
+            except BaseException as e:      # noqa: BLE001  (must not unwind through the C frames)
+                err.append(e)
+
+        o = capi.Options(*options)
+        rc = capi.lib.rt_render_frame_stream(self._h, C.byref(o), traversal, arr, len(arr), frame_format, out.ctypes.data, capi.BATCH_CALLBACK(cb), None)
+        if err:
+            raise err[0]
+        capi.check(rc, "rt_render_frame_stream")
+        return out
+
     def default_traversal(self):
         """The reference's hierarchy walk whenever the scene has bounds; the flat scan otherwise."""
         return capi.RT_TRAVERSAL_SKIP if self.scene.bounds is not None and len(self.scene.bounds) else capi.RT_TRAVERSAL_FLAT

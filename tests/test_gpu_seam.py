@@ -313,3 +313,83 @@ def test_filter_bounds_hold_at_the_edges_of_the_accepted_light_length(scale):
         with rta.capi.debug(rta.capi.DEBUG_SKIP_VARIANT, variant):
             plain, _ = s.device().render_tiles((192, 160, 2), regs, SKIP, want_stats=False)
         np.testing.assert_array_equal(plain, counted)
+
+
+_REF_FRAMES = {}
+
+
+def _ref_frame(w, h, spp):
+    if (w, h, spp) not in _REF_FRAMES:
+        _, o = util.scene_pair_default()
+        _REF_FRAMES[(w, h, spp)] = o.render(w, h, spp, nthreads=os.cpu_count() or 1)[0]
+    return _REF_FRAMES[(w, h, spp)]
+
+
+def _encode(ref, fmt):
+    """The writer's conversion on the CPU (render.rs:392-399): P6 keeps R, G, B; P5 is ((r + g + b) as f32 / 3.0) as u8."""
+    if fmt == rta.capi.RT_FRAME_RGBA:
+        return ref
+    if fmt == rta.capi.RT_FRAME_RGB:
+        return ref[..., :3]
+    f = ref[..., 0].astype(np.float32) + ref[..., 1].astype(np.float32) + ref[..., 2].astype(np.float32)
+    return (f / np.float32(3.0)).astype(np.uint8)[..., None]
+
+
+@pytest.mark.parametrize("pinned", [True, False], ids=["pinned", "pageable"])
+@pytest.mark.parametrize("fmt", [rta.capi.RT_FRAME_RGBA, rta.capi.RT_FRAME_RGB, rta.capi.RT_FRAME_GREY], ids=["rgba", "rgb", "grey"])
+@pytest.mark.parametrize("size", [(1920, 1080, 1), (201, 131, 2), (800, 600, 1)])
+def test_device_encoded_frame_is_the_writers_image(size, fmt, pinned):
+    # rt_render_frame_stream: the buckets rendered, converted ON THE DEVICE to the file's pixel format and put in their place in the caller's
+    # row-major image (render.rs:373-401 is the writer's CPU loop this replaces; 112-126 the blit) -- bit for bit what the CPU conversion of
+    # the oracle's frame gives, for aligned and odd widths (201 x 3 bytes per row: every row segment starts and ends inside a 32-bit word),
+    # into memory the device writes directly and into pageable memory; batches reported once each, in order.
+    w, h, spp = size
+    s, _ = util.scene_pair_default()
+    want = _encode(_ref_frame(w, h, spp), fmt)
+    bpp = want.shape[2]
+    regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
+    keep = rta.capi.HostBuffer(w * h * bpp) if pinned else None
+    out = keep.array if pinned else np.empty(w * h * bpp, dtype=np.uint8)
+    out[:] = 0xAB
+    seen = []
+    s.device().render_frame_stream((w, h, spp), regs, fmt, out, on_batch=lambda first, n: seen.append((first, n)))
+    np.testing.assert_array_equal(out.reshape(h, w, bpp), want)
+    assert [f for f, _ in seen] == sorted(f for f, _ in seen) and sum(n for _, n in seen) == len(regs) and seen[0][0] == 0
+    # a partial list: the bytes of the other buckets are left alone (row segments of neighbours share 32-bit words at odd widths)
+    out[:] = 0xAB
+    part = regs[::2]
+    s.device().render_frame_stream((w, h, spp), part, fmt, out)
+    got = out.reshape(h, w, bpp)
+    mask = np.zeros((h, w), dtype=bool)
+    for (l, t, r, b) in part:
+        mask[b:t, l:r] = True
+        np.testing.assert_array_equal(got[b:t, l:r], want[b:t, l:r])
+    assert (got[~mask] == 0xAB).all()
+
+
+def test_device_encoded_frame_ragged_regions_and_flat_traversal():
+    # regions that are no buckets: odd origins and widths, one pixel wide, one row high; and the flat traversal's pipeline in front of the encoder
+    w, h = 201, 131
+    s, _ = util.scene_pair_default()
+    ref = _ref_frame(w, h, 1)
+    regs = [(3, 50, 40, 7), (41, 131, 200, 60), (200, 131, 201, 0), (0, 1, 199, 0), (100, 59, 101, 58)]
+    for fmt in (rta.capi.RT_FRAME_RGB, rta.capi.RT_FRAME_GREY):
+        want = _encode(ref, fmt)
+        bpp = want.shape[2]
+        for trav in (rta.RT_TRAVERSAL_SKIP, rta.RT_TRAVERSAL_FLAT):
+            buf = rta.capi.HostBuffer(w * h * bpp)
+            buf.array[:] = 0x5A
+            s.device().render_frame_stream((w, h, 1), regs, fmt, buf.array, traversal=trav)
+            got = buf.array.reshape(h, w, bpp)
+            mask = np.zeros((h, w), dtype=bool)
+            for (l, t, r, b) in regs:
+                mask[b:t, l:r] = True
+                np.testing.assert_array_equal(got[b:t, l:r], want[b:t, l:r])
+            assert (got[~mask] == 0x5A).all()
+    import ctypes
+    o = rta.capi.Options(w, h, 1)
+    arr = s.device()._regions(regs)
+    junk = np.zeros(w * h * 4, dtype=np.uint8)
+    cb = rta.capi.BATCH_CALLBACK(lambda *_: None)
+    assert rta.capi.lib.rt_render_frame_stream(s.device()._h, ctypes.byref(o), rta.RT_TRAVERSAL_SKIP, arr, len(arr), 7, junk.ctypes.data, cb, None) == rta.capi.RT_ERR_INVALID_ARGUMENT
+    assert rta.capi.lib.rt_render_frame_stream(s.device()._h, ctypes.byref(o), rta.RT_TRAVERSAL_SKIP, arr, len(arr), 1, junk.ctypes.data + 1, cb, None) == rta.capi.RT_ERR_INVALID_ARGUMENT
