@@ -5,7 +5,7 @@ set -e
 OLD=$1; NEW=$2; ROUNDS=${3:-2}
 # CFGS: newline-separated "w h spp level" lines (default: the one-ray kernel's three workloads)
 DEFAULT_CFGS=$'1920 1080 1 8\n800 600 1 8\n1024 768 4 8'
-LIB=rust-tracer_amd/librtrace_hip.so
+LIB=${AB_LIB:-tests/c/librtrace_hip_test.so}      # what tools/ab.py loads (the -DRT_TEST_HOOKS build)
 cp $LIB /tmp/_lib_keep.so
 for r in $(seq $ROUNDS); do
   for leg in old new; do

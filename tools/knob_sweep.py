@@ -7,6 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("RTRACE_HIP_LIBRARY", os.path.join(ROOT, "tests", "c", "librtrace_hip_test.so"))      # the controls of csrc/rt_debug.h live in the hooks build
 import numpy as np
 import torch
 import rust_tracer_amd as rta
@@ -29,10 +30,10 @@ for v in values:
     f = out.cpu().numpy().copy()
     ref = f if ref is None else ref
     assert np.array_equal(f, ref), "value %d changes pixels" % v
-capi.debug_set(key, -1)
 times = {v: [] for v in values}
 for r in range(10):
     for v in values:                                    # interleaved: one process, same clocks
+        capi.debug_set(key, v)                          # (the controls are part of a dispatch table's identity: a launch finds ITS table only with the control set)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(launches):
@@ -41,4 +42,5 @@ for r in range(10):
         torch.cuda.synchronize()
         if r >= 2:
             times[v].append(e0.elapsed_time(e1) / launches * 1e3)
+capi.debug_set(key, -1)
 print("%s on %dx%d spp %d L%d:" % (sys.argv[1], w, h, spp, level), "  ".join("%d: %.1f us" % (v, float(np.median(t))) for v, t in times.items()))

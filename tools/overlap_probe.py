@@ -6,6 +6,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RTRACE_HIP_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "c", "librtrace_hip_test.so"))      # rt_debug.h's controls: the hooks build
 import numpy as np
 import torch
 import rust_tracer_amd as rta
