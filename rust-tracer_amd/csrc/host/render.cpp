@@ -9,7 +9,8 @@
 namespace rtrace {
 
 static constexpr uint16_t CHUNK_SIZE = 64;                        // render.rs:264
-static constexpr size_t kMaxBucketsPerCall = 64, kMinBucketsPerCall = 16;      // per device call (a pass of < 16 buckets leaves most CUs idle)
+static constexpr size_t kMaxBucketsPerCall = 64, kMinBucketsPerCall = 16;
+static constexpr size_t kDeviceEncodeFromPixels = (size_t)6 << 20;     // Renderer::render: frames from here on arrive in the file's pixel format, converted by the device      // per device call (a pass of < 16 buckets leaves most CUs idle)
 
 static void check(rt_status st, const char *what)
 {
@@ -260,7 +261,12 @@ RenderStats Renderer::render(const RenderOptions &o, const Backend &be, RGBABuff
         // that staging as soon as its batch is complete, while later batches are still rendering: no per-batch host call, no
         // intermediate copies.  (The pool keeps its meaning for the paths below; here the producers are the GPU's workgroups.)
         const rt_options opts1{ o.width, o.height, o.samples_per_pixel };
-        if (auto *ppm = dynamic_cast<PPMStdoutRGBABufferWriter *>(&writer); ppm && ppm->accepts_device_frames() && ppm->pixels()) {
+        // (from kDeviceEncodeFromPixels on: measured end to end, frame + file, same box -- 4096 x 4096: 14.9 ms against 19.6 ms with the
+        // conversion on this thread; 2560 x 1440: 3.0 against 2.6, 1920 x 1080: 1.6 against 1.2 -- the file write reads what the GPU wrote
+        // from DRAM, what this thread converted from its cache, and below a few million pixels that outweighs the conversion;
+        // profiles/r05_end_to_end_encoders.log)
+        if (auto *ppm = dynamic_cast<PPMStdoutRGBABufferWriter *>(&writer);
+            ppm && ppm->accepts_device_frames() && ppm->pixels() && (size_t)o.width * o.height >= kDeviceEncodeFromPixels) {
             // The library's own writer keeps its image in the file's pixel format in memory the GPU can write: the device converts and
             // places the buckets itself (rt_render_frame_stream: 6.2 MB of P6 payload over PCIe for a 1080p frame instead of 8.3 MB of RGBA,
             // no conversion on this thread), and the writer is told which buckets have arrived -- its first write of the file after the

@@ -2398,7 +2398,7 @@ rt_status rt_render_frame_stream(rt_scene *s, const rt_options *o, rt_traversal 
     }
     // several batches: a batch is encoded (PCIe-bound, a handful of waves) on a second stream while the next one renders
     hipStream_t enc = c->stream;
-    if (n_batches > 1) {
+    if (n_batches >= 4) {                                            // (a stream is a hardware queue: 5 - 9 ms to create, once per context)
         if (!c->stream2 && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->stream2 = nullptr; }
         if (c->stream2) enc = c->stream2;
     }

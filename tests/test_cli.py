@@ -157,3 +157,16 @@ def test_cli_strict_64_panics_like_the_reference(tmp_path):
     assert r.returncode == 101 and b"TODO: handle chunk sizes" in r.stderr
     r = run(["--width=128", "--height=64", "--strict-64", str(tmp_path / "o.tga")])
     assert r.returncode == 0
+
+
+@pytest.mark.gpu
+def test_cli_large_frame_takes_the_device_encoder_and_writes_the_reference_bytes(tmp_path):
+    # from 6 M pixels on Renderer::render lets the DEVICE convert the buckets to the file's pixel format and place them in the writer's
+    # pinned image (rt_render_frame_stream; csrc/host/render.cpp kDeviceEncodeFromPixels): 4096 x 1600 = 6.5 M pixels, 64 x 25 buckets in
+    # batches of whole bucket rows -- the file must be the oracle's PPM byte for byte (render.rs:359-407 is the writer this replaces)
+    out = str(tmp_path / "out.tga")
+    r = run(["--width=4096", "--height=1600", out])
+    assert r.returncode == 0, r.stderr.decode()
+    ref, _ = _oracle_ppm(tmp_path, 4096, 1600, 1)
+    got = open(out, "rb").read()
+    assert len(got) == len(ref) and got == ref

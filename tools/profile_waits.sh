@@ -8,7 +8,7 @@ cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 : > gpurun_out/waits_$TAG.log
 for WL in "$@"; do
-  B="python3 bench.py --workload $WL --no-cpu-baseline --no-seam --no-flat --no-extras --no-configs --steps 4 --warmup 40 --repeats 1 --min-timed-region 0"
+  B="python3 bench.py --workload $WL --no-cpu-baseline --no-seam --no-make-image --no-flat --no-extras --no-configs --steps 4 --warmup 40 --repeats 1 --min-timed-region 0"
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d gpurun_out/w1_${TAG}_$WL -- $B > gpurun_out/w1_${TAG}_$WL.log 2>&1
   rocprofv3 --pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE --output-format csv -d gpurun_out/w2_${TAG}_$WL -- $B > gpurun_out/w2_${TAG}_$WL.log 2>&1
   python3 - "$TAG" "$WL" >> gpurun_out/waits_$TAG.log <<'PY'

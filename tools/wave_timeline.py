@@ -58,6 +58,22 @@ def main():
             d = dur[sel]
             print("  %-26s %6d waves: median %.2f  p90 %.2f  p99 %.2f  max %.2f us; sum %.0f us; last end %.1f us" % (
                 name, int(sel.sum()), np.median(d) / 1e3, np.percentile(d, 90) / 1e3, np.percentile(d, 99) / 1e3, d.max() / 1e3, d.sum() / 1e3, end[sel].max() / 1e3))
+    if os.environ.get("WAVE_TIMELINE_JSON"):
+        # what bench.py prints as roofline.longest_wave_us / span_us (profiles/roofline_waves.json, stamped with the kernel sources)
+        import json
+        from bench import kernel_src_sha, git_head
+        jp = os.environ["WAVE_TIMELINE_JSON"]
+        d = json.load(open(jp)) if os.path.exists(jp) else {}
+        if d.get("kernel_src_sha") != kernel_src_sha():
+            d = {}
+        d.update({"kernel_src_sha": kernel_src_sha(), "git_head": git_head(), "tag": os.environ.get("WAVE_TIMELINE_TAG"),
+                  "_source": "tools/wave_timeline.py: one traced launch (the -DRT_TEST_HOOKS build's trace flavour of the loops)"})
+        if (w, h, spp, level) == (1920, 1080, 1, 8):
+            d["k_render_skip_n1"] = {"span_us": round(end.max() / 1e3, 2), "longest_wave_us": round(dur.max() / 1e3, 2), "waves": int(len(r)),
+                                     "median_wave_us": round(float(np.median(dur)) / 1e3, 2), "p99_wave_us": round(float(np.percentile(dur, 99)) / 1e3, 2),
+                                     "waves_longer_than_0_9_of_the_span": int((dur > 0.9 * end.max()).sum()),
+                                     "slot_time_over_8192_slots_us": round(dur.sum() / 1e3 / 8192, 2), "last_wave_start_us": round(start.max() / 1e3, 2)}
+        json.dump(d, open(jp, "w"), indent=1, sort_keys=True)
     order = np.argsort(-dur)[:16]
     print("16 longest waves: (start, end, dur us, dispatch index)")
     idx = np.nonzero(ran)[0]
