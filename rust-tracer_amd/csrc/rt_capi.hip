@@ -83,6 +83,8 @@ rt_status hip_fail(hipError_t e, const char *what, int line)
 // concurrent callers (the reference's pool threads, render.rs:283) never share one.
 struct Context {
     hipStream_t stream = nullptr;
+    bool owns_stream = true;           // (a scene's first context works on the scene's own stream: a stream is a hardware queue plus 20 MB of
+                                       // staging the runtime allocates with it -- 11 - 16 ms of a fresh process, each)
     hipStream_t stream2 = nullptr;     // rt_render_frame_stream: a batch is encoded here while the next one renders on `stream` (made when first needed)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // two upload slots (a flat pass uses two tables); pinned host side: the H2D copy is truly asynchronous
@@ -123,7 +125,7 @@ struct Context {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream2) (void)hipStreamDestroy(stream2);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (stream && owns_stream) (void)hipStreamDestroy(stream);
     }
 };
 
@@ -196,6 +198,7 @@ struct rt_scene {
     hipStream_t cost_stream = nullptr;
     void *d_cost_arena = nullptr, *h_cost = nullptr;
     bool cost_started = false;
+    bool main_stream_taken = false;        // cost_stream doubles as the first context's stream (acquire)
     std::vector<uint32_t> cost_map;
     // Concurrent rt_render_region callers (the reference's pool threads, render.rs:283-294) are merged into shared passes:
     // whoever finds no pass running becomes its leader and renders every request that is waiting at that moment.
@@ -256,7 +259,11 @@ rt_status acquire(rt_scene *s, Context **out)
     }
     std::unique_ptr<Context> c(new (std::nothrow) Context());
     if (!c) return RT_ERR_OUT_OF_MEMORY;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (s->cost_stream && !s->main_stream_taken) { s->main_stream_taken = true; c->stream = s->cost_stream; c->owns_stream = false; }
+    }
+    if (!c->stream) HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
     HIP_TRY(hipMalloc(&c->d_counters, sizeof(rt::Counters) * rt::kCounterStripes));
@@ -496,11 +503,11 @@ rt_status derive_fstreams(const rt_scene *s, const void *d_prim, const void *d_s
     HIP_TRY(hipMalloc(d_xprim, sizeof(rt::FNode) * total));
     HIP_TRY(hipMalloc(d_xshad, sizeof(rt::FNodeS) * total));
     if (d_own) HIP_TRY(hipMalloc(d_own, sizeof(uint32_t) * total));
-    hipLaunchKernelGGL(rt::k_build_fstreams, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, static_cast<const rt::Node<float> *>(d_prim),
+    hipLaunchKernelGGL(rt::k_build_fstreams, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s->cost_stream, static_cast<const rt::Node<float> *>(d_prim),
                        static_cast<const rt::Node<float> *>(d_shad), (unsigned)total, compacted, s->fc, static_cast<rt::FNode *>(*d_xprim),
                        static_cast<rt::FNodeS *>(*d_xshad), d_own ? static_cast<uint32_t *>(*d_own) : nullptr);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(s->cost_stream));
     return RT_OK;
 }
 
@@ -555,16 +562,17 @@ rt_status derive_streams(const rt_scene *s, const std::vector<rt::RawNode<T>> &r
     const size_t n = raw.size(), total = n + rt::kNodePad;
     rt::RawNode<T> *d_raw = nullptr;
     HIP_TRY(hipMalloc(&d_raw, sizeof(rt::RawNode<T>) * n));
-    hipError_t e = hipMemcpy(d_raw, raw.data(), sizeof(rt::RawNode<T>) * n, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpyAsync(d_raw, raw.data(), sizeof(rt::RawNode<T>) * n, hipMemcpyHostToDevice, s->cost_stream);      // (`raw` outlives the synchronise below)
     if (e == hipSuccess) e = hipMalloc(d_prim, sizeof(rt::Node<T>) * total);
     if (e == hipSuccess) e = hipMalloc(d_shad, sizeof(rt::Node<T>) * total);
     if (e == hipSuccess) {
         const rt::V3<T> eye = { (T)s->eye[0], (T)s->eye[1], (T)s->eye[2] };
-        hipLaunchKernelGGL((rt::k_build_streams<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, d_raw, (unsigned)n, eye, compacted,
+        hipLaunchKernelGGL((rt::k_build_streams<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s->cost_stream, d_raw, (unsigned)n, eye, compacted,
                            static_cast<rt::Node<T> *>(*d_prim), static_cast<rt::Node<T> *>(*d_shad));
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
     }
+    const hipError_t se = hipStreamSynchronize(s->cost_stream);
+    if (e == hipSuccess) e = se;
     (void)hipFree(d_raw);
     if (e != hipSuccess) return hip_fail(e, "derive_streams", __LINE__);
     return RT_OK;
@@ -621,17 +629,17 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
         // f64: FNode copies of the primary streams for the filtered primary walk (rt_skip.hpp k_build_fstream64)
         filter_constants<T>(s, raw, static_cast<const T *>(items));
         HIP_TRY(hipMalloc(&s->d_fc, sizeof(rt::FilterConsts)));
-        HIP_TRY(hipMemcpy(s->d_fc, &s->fc, sizeof(rt::FilterConsts), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(s->d_fc, &s->fc, sizeof(rt::FilterConsts), hipMemcpyHostToDevice, s->cost_stream));
         auto derive64 = [&](const void *d_prim, const void *d_shad, size_t n_nodes, bool compacted, void **d_x, void **d_xs, void **d_own) -> rt_status {
             const size_t total = n_nodes + rt::kNodePad;
             HIP_TRY(hipMalloc(d_x, sizeof(rt::FNode) * total));
             HIP_TRY(hipMalloc(d_xs, sizeof(rt::FNodeS) * total));
             if (d_own) HIP_TRY(hipMalloc(d_own, sizeof(uint32_t) * total));
-            hipLaunchKernelGGL(rt::k_build_fstream64, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, static_cast<const rt::Node<double> *>(d_prim),
+            hipLaunchKernelGGL(rt::k_build_fstream64, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s->cost_stream, static_cast<const rt::Node<double> *>(d_prim),
                                static_cast<const rt::Node<double> *>(d_shad), (unsigned)total, compacted, s->fc, static_cast<rt::FNode *>(*d_x),
                                static_cast<rt::FNodeS *>(*d_xs), d_own ? static_cast<uint32_t *>(*d_own) : nullptr);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipStreamSynchronize(s->cost_stream));
             return RT_OK;
         };
         if ((uint64_t)(s->n_nodes + rt::kNodePad) * sizeof(rt::Node<T>) <= 0xFFFFFFFFull) {
@@ -642,7 +650,7 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
     if constexpr (sizeof(T) == 4) {
         filter_constants<T>(s, raw, static_cast<const T *>(items));
         HIP_TRY(hipMalloc(&s->d_fc, sizeof(rt::FilterConsts)));
-        HIP_TRY(hipMemcpy(s->d_fc, &s->fc, sizeof(rt::FilterConsts), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(s->d_fc, &s->fc, sizeof(rt::FilterConsts), hipMemcpyHostToDevice, s->cost_stream));
         if ((st = derive_fstreams(s, s->d_prim, s->d_shad, s->n_nodes, false, &s->d_xprim, &s->d_xshad, nullptr)) != RT_OK) return st;
         if (fused && (st = derive_fstreams(s, s->d_cprim, s->d_cshad, s->n_fnodes, true, &s->d_xcprim, &s->d_xcshad, &s->d_xown)) != RT_OK) return st;
         if ((st = upload_coop(s, raw)) != RT_OK) return st;
@@ -678,16 +686,16 @@ rt_status upload_coop(rt_scene *s, const std::vector<rt::RawNode<float>> &raw)
     uint32_t *d_perm = nullptr; uint2 *d_link = nullptr;
     hipError_t e = hipMalloc(&d_perm, sizeof(uint32_t) * n);
     if (e == hipSuccess) e = hipMalloc(&d_link, sizeof(uint2) * n);
-    if (e == hipSuccess) e = hipMemcpy(d_perm, perm.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_link, link.data(), sizeof(uint2) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_perm, perm.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s->cost_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_link, link.data(), sizeof(uint2) * n, hipMemcpyHostToDevice, s->cost_stream);
     if (e == hipSuccess) e = hipMalloc(&s->d_coop_prim, sizeof(rt::CNode) * n);
     if (e == hipSuccess) e = hipMalloc(&s->d_coop_shad, sizeof(rt::CNode) * n);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(rt::k_build_coop, dim3((n + 255) / 256), dim3(256), 0, nullptr, s->d_prim, s->d_shad, (unsigned)sizeof(rt::Node<float>), d_perm, d_link, n,
+        hipLaunchKernelGGL(rt::k_build_coop, dim3((n + 255) / 256), dim3(256), 0, s->cost_stream, s->d_prim, s->d_shad, (unsigned)sizeof(rt::Node<float>), d_perm, d_link, n,
                            static_cast<rt::CNode *>(s->d_coop_prim), static_cast<rt::CNode *>(s->d_coop_shad));
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
     }
+    { const hipError_t se = hipStreamSynchronize(s->cost_stream); if (e == hipSuccess) e = se; }
     if (d_perm) (void)hipFree(d_perm);
     if (d_link) (void)hipFree(d_link);
     if (e != hipSuccess) return hip_fail(e, "upload_coop", __LINE__);
@@ -773,7 +781,6 @@ rt_status start_cost_map(rt_scene *s)
     const rt::TileDev tile{ 0, (uint16_t)R, (uint16_t)R, 0, 0u, 0u, R / rt::kBlockW };
     // ONE device allocation, kept until the scene goes (hipMalloc / hipFree wait for a busy device): tile | frame | costs | counters
     constexpr size_t kTileBytes = 256, kPx = (size_t)R * R * 4, kCnt = sizeof(rt::Counters) * rt::kCounterStripes;
-    HIP_TRY(hipStreamCreateWithFlags(&s->cost_stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&s->d_cost_arena, kTileBytes + 2 * kPx + kCnt));
     HIP_TRY(hipHostMalloc(&s->h_cost, kPx + kTileBytes + kTableStageBytes, hipHostMallocDefault));
     s->h_tab_stage = static_cast<char *>(s->h_cost) + kPx + kTileBytes;
@@ -1145,20 +1152,21 @@ rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std:
     for (const Host &c : cand) {
         rt_scene::Order od;
         od.dev_order = reinterpret_cast<rt::BlockDesc *>(arena + off); od.n_order = (uint32_t)c.order.size();
-        if ((e = hipMemcpy(od.dev_order, c.order.data(), c.order.size() * sizeof(rt::BlockDesc), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+        if ((e = hipMemcpyAsync(od.dev_order, c.order.data(), c.order.size() * sizeof(rt::BlockDesc), hipMemcpyHostToDevice, s->cost_stream)) != hipSuccess) return fail(e);
         off += up(c.order.size() * sizeof(rt::BlockDesc));
         if (c.any_hole) {
             od.dev_holes = reinterpret_cast<uint64_t *>(arena + off); od.n_holes = (uint32_t)c.holes.size();
-            if ((e = hipMemcpy(od.dev_holes, c.holes.data(), c.holes.size() * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+            if ((e = hipMemcpyAsync(od.dev_holes, c.holes.data(), c.holes.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s->cost_stream)) != hipSuccess) return fail(e);
             off += up(c.holes.size() * sizeof(uint64_t));
         }
         if (!c.wg_first.empty()) {
             od.dev_wg = reinterpret_cast<uint32_t *>(arena + off); od.n_wg = (uint32_t)c.wg_first.size() - 1;
-            if ((e = hipMemcpy(od.dev_wg, c.wg_first.data(), c.wg_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+            if ((e = hipMemcpyAsync(od.dev_wg, c.wg_first.data(), c.wg_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s->cost_stream)) != hipSuccess) return fail(e);
             off += up(c.wg_first.size() * sizeof(uint32_t));
         }
         orders.push_back(od);
     }
+    if ((e = hipStreamSynchronize(s->cost_stream)) != hipSuccess) return fail(e);       // (the candidates' host arrays go out of scope; the orders are in device memory from here on)
     if (!orders.empty() && orders[0].dev_holes) {       // (cannot happen: candidate 0 is made with coop_percent 0 wherever holes are possible)
         for (auto &od : orders) release_order(od);
         orders.clear(); (void)hipFree(arena);
@@ -1972,10 +1980,14 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
     }
     auto fail = [&](rt_status code) { rt_scene_destroy(s.release()); return code; };
     hipError_t e;
-    if ((e = hipMalloc(&s->d_items, esz * 4 * n_items)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(items)", __LINE__));
-    if ((e = hipMemcpy(s->d_items, dfs_items, esz * 4 * n_items, hipMemcpyHostToDevice)) != hipSuccess)
-        return fail(hip_fail(e, "hipMemcpy(items)", __LINE__));
     s->h_items.assign(static_cast<const unsigned char *>(dfs_items), static_cast<const unsigned char *>(dfs_items) + esz * 4 * n_items);
+    // ONE stream carries everything this call enqueues (uploads, the kernels that derive the streams, the cost map's counting render) and is
+    // the first context's stream afterwards: the null stream is never touched
+    if ((e = hipStreamCreateWithFlags(&s->cost_stream, hipStreamNonBlocking)) != hipSuccess) return fail(hip_fail(e, "hipStreamCreate(scene)", __LINE__));
+    if ((e = hipMalloc(&s->d_items, esz * 4 * n_items)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(items)", __LINE__));
+    if ((e = hipMemcpyAsync(s->d_items, s->h_items.data(), esz * 4 * n_items, hipMemcpyHostToDevice, s->cost_stream)) != hipSuccess)      // (the scene's own copy of the items)
+        return fail(hip_fail(e, "hipMemcpy(items)", __LINE__));
+    if ((e = hipStreamSynchronize(s->cost_stream)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy(items)", __LINE__));
     if (n_bounds) {
         rt_status sst = f32 ? upload_streams<float>(s.get(), dfs_items, bounds, ranges) : upload_streams<double>(s.get(), dfs_items, bounds, ranges);
         if (sst != RT_OK) return fail(sst);
