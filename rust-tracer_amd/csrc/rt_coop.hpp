@@ -121,6 +121,16 @@ __device__ __forceinline__ CoopSlot coop_slot(unsigned fan)
 }
 __device__ __forceinline__ unsigned coop_uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
+// The lanes of a wave hand each other rays, work-list pairs and minima through LDS.  A wave's LDS operations are issued and served in order,
+// but that is the hardware's promise, not the language's: between a phase that writes and a phase in which OTHER lanes read, the writes are
+// released and the compiler is told not to move LDS accesses across (no instruction beyond the s_waitcnt it would emit anyway).
+__device__ __forceinline__ void coop_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // The primary rays of a quad: lanes [0, n_rays) hold them (dir; `want`: the lane has a ray; n_rays = 16, 4 or 1).  Returns, in those lanes,
 // hit.distance / the DFS index of the nearest item, and `failed` = the ray has to be walked by the skip-pointer loops instead (its winner is
 // nearer than one of its ancestor bounds, or the wave's work list overflowed).  Wave-uniform control flow; `lds` is this wave's.
@@ -140,6 +150,7 @@ __device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, u
     if (mine) lds.stack[coop_lane_rank(wm)] = make_uint2(0u | (cv.n_roots << 24) | (lane << 28), 0u);
     unsigned top = coop_uniform((unsigned)__popcll(wm));
     bool overflow = false;
+    coop_lds_sync();                             // rays, minima and the first pairs are written: every lane may read them
     // (Keeping a second round's records in flight -- fetched while the first is evaluated -- takes the kernel from 59 to 76 vector registers
     // and every wave of the launch from 8 to 6 per SIMD: measured and dropped)
     while (top > 0u) {
@@ -163,6 +174,7 @@ __device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, u
         if (__ballot(item_hit) != 0ull) {
             const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | link_first;
             if (item_hit) atomicMin(&lds.best[ray], key);
+            coop_lds_sync();                     // (every lane's minimum is in before any lane looks whether it holds it)
             if (item_hit && lds.best[ray] == key) lds.best_anc[ray] = anc;
         }
         // BOUND with a finite distance: its children are wanted
@@ -172,7 +184,9 @@ __device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, u
         if (top + n_push > kCoopStack) { overflow = true; break; }
         if (push) lds.stack[top + coop_lane_rank(pm)] = make_uint2(link_first | (link_count << 24) | (ray << 28), max(e.y, __float_as_uint(d)));      // (both >= +0: the bit patterns order like the values)
         top = coop_uniform(top + n_push);
+        coop_lds_sync();                         // the pushed pairs are the next round's reads
     }
+    coop_lds_sync();
     float best = inf<float>();
     unsigned item = 0u;
     bool failed = false;
@@ -202,6 +216,7 @@ __device__ __forceinline__ void coop_shadow(const CoopView &cv, CoopLds &lds, un
     if (mine) lds.stack[coop_lane_rank(wm)] = make_uint2(0u | (cv.n_roots << 24) | (lane << 28), 0u);
     unsigned top = coop_uniform((unsigned)__popcll(wm));
     bool overflow = false;
+    coop_lds_sync();
     while (top > 0u) {
         const unsigned n_e = min(sl.per, top);
         const bool have = sl.e < n_e;
@@ -226,7 +241,9 @@ __device__ __forceinline__ void coop_shadow(const CoopView &cv, CoopLds &lds, un
         if (top + n_push > kCoopStack) { overflow = true; break; }
         if (push) lds.stack[top + coop_lane_rank(pm)] = make_uint2(link.x | (link.y << 24) | (ray << 28), 0u);
         top = coop_uniform(top + n_push);
+        coop_lds_sync();                         // pushed pairs and occluded bits are the next round's reads
     }
+    coop_lds_sync();
     const unsigned occ = lds.occluded;
     occluded_out = mine && ((occ >> (lane & 15u)) & 1u) != 0u;
     // an occluded ray is settled whatever happened to the list afterwards: some item of its closure is hit

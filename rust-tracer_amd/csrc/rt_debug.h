@@ -44,8 +44,10 @@ typedef enum rt_debug_key {
                                     shadow-ray origins, in percent of the library's own value.  A small value leaves real origins
                                     uncovered -- they must then fall back to the reference's arithmetic at every node (tests).  Default 100 */
     RT_DEBUG_COOP = 15,          /* the lane-cooperative walk of the heaviest quads (rt_coop.hpp; read when a tile list is first seen): 0 never,
-                                    2 every quad of every block (parity tests); default: the library's choice by the scene's cost map */
-    RT_DEBUG_COOP_THR = 16,      /* ... the cost-map value (tests per pixel) from which a quad is walked cooperatively; default: 30 % of the pass's largest */
+                                    1 asked for at the default threshold (40 % of the pass's largest estimate) without the trial, 2 every quad of
+                                    every block (parity tests); default: the library TRIES thresholds of 28 / 34 / 40 / 48 / 58 % against the plain
+                                    dispatch over a list's first launches and keeps the fastest (rt_capi.hip build_orders, pick_order) */
+    RT_DEBUG_COOP_THR = 16,      /* ... the cost-map value (tests per pixel) from which a quad is walked cooperatively; default: see RT_DEBUG_COOP */
     RT_DEBUG_COOP_MAX = 17,      /* ... cap on the number of 16x16 blocks that are split for it; default: an eighth of the pass */
     RT_DEBUG_COOP_LEVEL = 18,    /* ... rays per cooperative wave: 1 = 16 (4x4 pixels), 2 = 4 (2x2), 3 = one; default 2 */
     RT_DEBUG_COOP_REST = 19,     /* ... what is left of a block with cooperative quads: 0 = one descriptor (8x8 pixels per wave), 1 = four (4x4 per wave) */
