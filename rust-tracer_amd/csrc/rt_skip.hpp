@@ -836,11 +836,12 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(6
 // remark says, 98+ -> 6).  The loops themselves own s[36:73]; everything the kernel keeps across them beyond s[0:35] is parked in
 // vector-register lanes (v_writelane / v_readlane outside the loops; the kernel has 47 of its 64 vector registers to spare).  History: the
 // unconstrained build has 106 (6 workgroups per CU); round 4 first capped it at 94 (-> 92: 7 per CU, 1080p 46.9 -> 44.3 us, and was
-// taken for 8), then at 74 (-> 80: 8 per CU, 42.7 -> 41.8 us).  The walk waits for its node records half of its time: a
+// taken for 8), then at 74 (-> 80: 8 per CU, 42.7 -> 41.8 us); round 5 asks for 82, which is the same 80 (the loops' s[36:73] + the
+// hardware's six) without LLVM calling the loops' top eight registers reserved.  The walk waits for its node records half of its time: a
 // wave more per SIMD is a fetch more in flight.  The f64 loops own s[36:97] and cannot live under such a limit, hence kernels of their
 // own rather than an attribute on the template.
 template <bool COUNT, int VAR, int MODE>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(74))) void k_render_skip_f32(
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(82))) void k_render_skip_f32(
     SkipView<float> sc, unsigned width, unsigned height, unsigned spp_arg, const TileDev *__restrict__ tiles, unsigned n_tiles, uint8_t *__restrict__ out,
     Counters *__restrict__ counters, SampleBuf<float> sb, unsigned frame_w, const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost,
     const uint32_t *__restrict__ wg_first, CoopView cv = CoopView{}, const uint64_t *__restrict__ holes = nullptr, unsigned n_holes = 0)

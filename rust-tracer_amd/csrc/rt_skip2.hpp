@@ -30,7 +30,7 @@ constexpr unsigned kSkip2Threads = kBlockThreads / kSkip2Rays;
 // FUSED = false: a scene whose bounds have no sphere of their own (the automatic hierarchy of an arbitrary sphere list): the plain filtered
 // streams, the plain-stream loops (FILT only).
 template <int MODE, bool FILT, bool FUSED = true>
-__global__ __launch_bounds__(kSkip2Threads) __attribute__((amdgpu_num_sgpr(74), amdgpu_waves_per_eu(8))) void k_render_skip2(SkipView<float> sc, unsigned width, unsigned height, unsigned spp_arg,
+__global__ __launch_bounds__(kSkip2Threads) __attribute__((amdgpu_num_sgpr(82), amdgpu_waves_per_eu(8))) void k_render_skip2(SkipView<float> sc, unsigned width, unsigned height, unsigned spp_arg,
                                                                const TileDev *__restrict__ tiles, unsigned n_tiles, uint8_t *__restrict__ out,
                                                                SampleBuf<float> sb, unsigned frame_w, const BlockDesc *__restrict__ order,
                                                                const uint32_t *__restrict__ wg_first)

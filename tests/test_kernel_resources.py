@@ -17,11 +17,14 @@ TEST_LIB = os.path.join(ROOT, "tests", "c", "librtrace_hip_test.so")
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 # What the generated assembly loops (csrc/rt_skip_rot.hpp, rt_skip2_rot.hpp, rt_flat_rot.hpp) were validated against.  They own fixed
-# scalar-register windows inside kernels held to amdgpu_num_sgpr(74) -- s[62:73] is a window LLVM calls reserved there, hence the
-# -Winline-asm warnings -- so a different compiler must not go unnoticed: these expectations change only together with a fresh parity
-# run + soak on the GPU (tools/soak.py), never on their own.
+# scalar-register windows (the one-ray f32 loops s[36:73]) inside kernels held to eight waves per SIMD, so a different compiler must not go
+# unnoticed: these expectations change only together with a fresh parity run + soak on the GPU (tools/soak.py), never on their own.
+# Round 5: the kernels ask for amdgpu_num_sgpr(82) instead of 74 -- LLVM then counts s[66:73] among the registers it may hand out (74 + the
+# hardware's six = the same .sgpr_count 80, the same code), and the "clobber list contains reserved registers" warnings of the one-ray loops
+# are gone (76 -> 12 in the hooks build, 24 -> 8 in the product); what is left is the two-ray loops' s32 (the stack pointer of a kernel
+# that has no stack) and s[72:73] under amdgpu_waves_per_eu(8).
 PINNED_TOOLCHAIN = "HIP version: 7.2.26015-fc0010cf6a | AMD clang version 22.0.0git"
-PINNED_INLINE_ASM_WARNINGS = {"product": 24, "test_hooks": 76}
+PINNED_INLINE_ASM_WARNINGS = {"product": 8, "test_hooks": 12}
 # (.sgpr_count, .vgpr_count) of the product's hot kernels, exactly
 PINNED_REGISTERS = {
     "rt::k_render_skip_f32<false, 19, 0>": (80, 52), "rt::k_render_skip_f32<false, 19, 1>": (80, 44), "rt::k_render_skip_f32<false, 19, 2>": (80, 47),
