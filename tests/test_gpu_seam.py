@@ -393,3 +393,16 @@ def test_device_encoded_frame_ragged_regions_and_flat_traversal():
     cb = rta.capi.BATCH_CALLBACK(lambda *_: None)
     assert rta.capi.lib.rt_render_frame_stream(s.device()._h, ctypes.byref(o), rta.RT_TRAVERSAL_SKIP, arr, len(arr), 7, junk.ctypes.data, cb, None) == rta.capi.RT_ERR_INVALID_ARGUMENT
     assert rta.capi.lib.rt_render_frame_stream(s.device()._h, ctypes.byref(o), rta.RT_TRAVERSAL_SKIP, arr, len(arr), 1, junk.ctypes.data + 1, cb, None) == rta.capi.RT_ERR_INVALID_ARGUMENT
+
+
+def test_device_encoded_frame_f64_and_a_large_scene():
+    # the encoder sits behind every render kernel: the f64 walk (BASELINE config 3's type-alias swap) and the two-ray kernel's sample-packed
+    # pass over the 87,381-sphere pyramid (BASELINE config 5's scene), P6 payload against the oracle's frame
+    for precision, level, (w, h, spp) in ((rta.RT_F64, 8, (320, 256, 1)), (rta.RT_F32, 9, (512, 384, 4))):
+        s, o = util.scene_pair_default(precision, level)
+        ref, _, _ = o.render(w, h, spp, nthreads=os.cpu_count() or 1)
+        regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(w, h, spp))]
+        buf = rta.capi.HostBuffer(w * h * 3)
+        buf.array[:] = 0x11
+        s.device().render_frame_stream((w, h, spp), regs, rta.capi.RT_FRAME_RGB, buf.array)
+        np.testing.assert_array_equal(buf.array.reshape(h, w, 3), ref[..., :3])

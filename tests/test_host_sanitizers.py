@@ -54,3 +54,6 @@ def test_ppm_writer_under_sanitizers():
         r = subprocess.run([exe, os.path.join(d, "out.ppm")], capture_output=True, text=True, env=ENV, timeout=300)
         clean(r)
         assert "P5 file bytes 26015" in r.stdout and "P6 file bytes 78015" in r.stdout
+        # the device path's bookkeeping: complete rows in the partial rewrite, the spare image reused by the second writer
+        assert "device path pass 0: partial file 78015 bytes, final 78015 bytes, header 15" in r.stdout
+        assert "device path pass 1: partial file 78015 bytes, final 78015 bytes, header 15" in r.stdout
