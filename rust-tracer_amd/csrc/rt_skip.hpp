@@ -502,6 +502,10 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
             const T yres = ONE ? T(y) : T(y) + T(ssy) / ssf;
             V3<T> dir = { xres - half_w, (fh - yres) - half_h, fw };
             dir = normalized(dir);
+            // (the filtered assembly loops ask their filter for every lane and look at `resume` only where somebody passes: a lane without
+            // a ray carries a direction no bound lets through -- b' = NaN fails `T <= b'`, T = -inf included; nothing else reads it)
+            // (f32 walks only: the f64 loops still compare `resume` at the top of every step, tools/gen_skip_asm.py lazy_wake)
+            if constexpr ((VAR & 2) != 0 && (VAR & 16) != 0 && !COUNT && sizeof(T) == 4) { if (!inside) dir.x = T(__builtin_nanf("")); }
 
             [[maybe_unused]] const unsigned t_before = c_items + c_bounds;
             // ---------------- primary ray: s.group.intersect(&mut h, r)  render.rs:188-189 ----------------
@@ -522,21 +526,23 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
                     if (coop_wave) coop_primary(cv, coop_lds[wave], coop_rays, dir.x, dir.y, dir.z, inside, cbest, citem, walk);
                 }
                 if (!coop_wave || __ballot(walk) != 0) {
+                [[maybe_unused]] float fdx = (float)dir.x;
+                if constexpr (COOP) { if (!walk) fdx = __builtin_nanf(""); }      // (a ray the cooperative walk has settled)
                 if constexpr ((VAR & 16) != 0 && sizeof(T) == 8) {
                     // f64: the walk reads the scene's FNode stream (f32 filter terms; positions in ITS units) and fetches a node's own
                     // Node<double> record only when the filter lets some live lane through
                     constexpr unsigned kFStride = (unsigned)sizeof(FNode);
                     const unsigned nbf = ((VAR & 4) ? sc.n_fnodes : sc.n_nodes) * kFStride;
                     if constexpr ((VAR & 4) != 0) {
-                        skip_primary_rot_filt_fused(sc.xfprim, nbf, dir.x, dir.y, dir.z, walk ? 0u : nbf, best, best_item, (float)dir.x, (float)dir.y, (float)dir.z, sc.fprim);
+                        skip_primary_rot_filt_fused(sc.xfprim, nbf, dir.x, dir.y, dir.z, walk ? 0u : nbf, best, best_item, fdx, (float)dir.y, (float)dir.z, sc.fprim);
                         if (best_item != 0u && !(best_item & kNodeItem)) best_item = sc.xown[best_item / kFStride - 1u];
-                    } else skip_primary_rot_filt(sc.xprim, nbf, dir.x, dir.y, dir.z, walk ? 0u : nbf, best, best_item, (float)dir.x, (float)dir.y, (float)dir.z, sc.prim);
+                    } else skip_primary_rot_filt(sc.xprim, nbf, dir.x, dir.y, dir.z, walk ? 0u : nbf, best, best_item, fdx, (float)dir.y, (float)dir.z, sc.prim);
                 } else if constexpr ((VAR & 16) != 0 && sizeof(T) == 4) {
                     if constexpr ((VAR & 4) != 0) {
-                        skip_primary_rot_filt_fused(sc.xfprim, nb, dir.x, dir.y, dir.z, walk ? 0u : nb, best, best_item);
+                        skip_primary_rot_filt_fused(sc.xfprim, nb, fdx, dir.y, dir.z, walk ? 0u : nb, best, best_item);
                         // a group's own sphere won: the walk recorded the offset behind its BOUND node
                         if (best_item != 0u && !(best_item & kNodeItem)) best_item = sc.xown[best_item / kStride - 1u];
-                    } else skip_primary_rot_filt(sc.xprim, nb, dir.x, dir.y, dir.z, walk ? 0u : nb, best, best_item);
+                    } else skip_primary_rot_filt(sc.xprim, nb, fdx, dir.y, dir.z, walk ? 0u : nb, best, best_item);
                 } else if constexpr ((VAR & 4) != 0) skip_primary_rot_fused(sc.fprim, nb, dir.x, dir.y, dir.z, walk ? 0u : nb, best, best_item);
                 else skip_primary_rot(sc.prim, nb, dir.x, dir.y, dir.z, walk ? 0u : nb, best, best_item);
                 best_item &= kNodeIndexMask;
@@ -653,6 +659,7 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
                     if constexpr ((VAR & 16) != 0 && sizeof(T) == 4) {
                         const FilterConsts fc = *sc.fc;
                         shadow_filter_origin(fc, sp.x, sp.y, sp.z, q1, q2, fol);
+                        if (!walk_s) q1 = inf<float>();          // no shadow ray: an in-plane origin at infinity is beyond every outer bound but END's
                         fa0 = fc.a0; fk1 = fc.k1; fkc = fc.kc;
                     }
                     if constexpr ((VAR & 16) != 0 && sizeof(T) == 8) {
@@ -683,7 +690,7 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
                         } else if constexpr ((VAR & 4) != 0) i = skip_shadow_rot_fused(sc.fshad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
                         else i = skip_shadow_rot(sc.shad, nb, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin);
                         if (i >= nb) break;
-                        if (fin) { occluded = true; resume = nb; }
+                        if (fin) { occluded = true; resume = nb; q1 = inf<float>(); }      // (a retired lane passes no bound any more)
                         // some lane retired at the node at i: go straight to the next node any lane still wants (nb: nobody is left)
                         i = (unsigned)__builtin_amdgcn_readfirstlane(
                             (int)wave_min_u32(resume >= nb ? nb : (resume > i ? resume : i + kStride)));

@@ -27,9 +27,9 @@ PINNED_TOOLCHAIN = "HIP version: 7.2.26015-fc0010cf6a | AMD clang version 22.0.0
 PINNED_INLINE_ASM_WARNINGS = {"product": 8, "test_hooks": 12}
 # (.sgpr_count, .vgpr_count) of the product's hot kernels, exactly
 PINNED_REGISTERS = {
-    "rt::k_render_skip_f32<false, 19, 0>": (80, 52), "rt::k_render_skip_f32<false, 19, 1>": (80, 44), "rt::k_render_skip_f32<false, 19, 2>": (80, 47),
-    "rt::k_render_skip_f32<false, 19, 3>": (80, 46), "rt::k_render_skip_f32<false, 23, 0>": (80, 52), "rt::k_render_skip_f32<false, 23, 1>": (80, 44),
-    "rt::k_render_skip_f32<false, 23, 2>": (80, 47), "rt::k_render_skip_f32<false, 23, 3>": (80, 46),
+    "rt::k_render_skip_f32<false, 19, 0>": (80, 53), "rt::k_render_skip_f32<false, 19, 1>": (80, 45), "rt::k_render_skip_f32<false, 19, 2>": (80, 48),
+    "rt::k_render_skip_f32<false, 19, 3>": (80, 47), "rt::k_render_skip_f32<false, 23, 0>": (80, 53), "rt::k_render_skip_f32<false, 23, 1>": (80, 45),
+    "rt::k_render_skip_f32<false, 23, 2>": (80, 48), "rt::k_render_skip_f32<false, 23, 3>": (80, 47),
     "rt::k_render_skip_f32_coop<false, 19, 2>": (92, 61), "rt::k_render_skip_f32_coop<false, 23, 2>": (92, 61),
     "rt::k_render_skip2<2, true, false>": (80, 64), "rt::k_render_skip2<2, true, true>": (80, 64), "rt::k_render_skip2<3, true, false>": (80, 64),
     "rt::k_render_skip2<3, true, true>": (80, 64),

@@ -624,14 +624,20 @@ def step_top(a, P, c, n, s, terms):
     # child of a group is fetched when somebody enters (enter_group): fetched at the top of every BOUND step it doubled the
     # scalar-cache misses (most of those lines are never walked), which cost more than the late fetch on the entered quarter.
     P.load(a, s, node_skip(P, c, terms), "the likely successor, while this node is processed")
-    a.op("v_cmp_gt_u32_e64 %s, %s, %%[resume]" % (P.ACT, P.NX), "active = i >= resume  (NX = i + stride)")
+    if not lazy_wake(P):
+        a.op("v_cmp_gt_u32_e64 %s, %s, %%[resume]" % (P.ACT, P.NX), "active = i >= resume  (NX = i + stride)")
     if P.filt:
+        # Round 5: the filter is asked for EVERY lane, asleep or not, and who is awake only where somebody passes (hit_entry): a lane that sleeps
+        # missed an enclosing bound and passes the filter of a node inside it in 0.2 % of the quiet steps (1080p, a CPU replay), so the
+        # commonest step loses its compare with `resume` and the s_and -- two of its ten instructions.  Lanes without a ray, and shadow
+        # lanes that have retired, carry a ray no bound lets through (a NaN direction / an in-plane origin at infinity: rt_skip.hpp).
         (P.primary_filter if terms == P.primary_terms else P.shadow_filter)(a, c)
         for _ in range(int(os.environ.get("RT_GEN_PAD_VALU", "0")) if P.ctype == "float" else 0):   # design-time probe: what one more instruction per step costs
             a.op("v_max_f32_e32 %[t2], %[t2], %[t2]")
         for _ in range(int(os.environ.get("RT_GEN_PAD_SALU", "0")) if P.ctype == "float" else 0):
             a.op("s_mov_b32 %s, %s" % (P.TINY.split(":")[0].replace("s[", "s"), P.NX))
-        a.op("s_and_b64 vcc, vcc, %s" % P.ACT, "live lanes the bound cannot rule out")
+        if not lazy_wake(P):
+            a.op("s_and_b64 vcc, vcc, %s" % P.ACT, "live lanes the bound cannot rule out")
         return
     terms(a, c)
     P.cand_cmp(a)
@@ -652,8 +658,24 @@ def kind_test(a, P, c, lab):
     P.kind_test(a, c, lab)
 
 
+def lazy_wake(P):
+    """The f32 filtered loops ask who is awake only where some lane passes the bound (step_top).  The f64 loops keep the compare at the
+    top of the step: their steps are bound by f64 arithmetic, and the poisoned ray costs their kernels a spill."""
+    return P.filt and P.ctype == "float"
+
+
+def hit_entry(a, P, shadow=False):
+    """Lazy loops: some lane passed the bound.  Now: who is awake?  (The primary path ands ACT into its exact test; the shadow path
+    has no other test before it reads vcc.)"""
+    if not lazy_wake(P):
+        return
+    a.op("v_cmp_gt_u32_e64 %s, %s, %%[resume]" % (P.ACT, P.NX), "active = i >= resume  (NX = i + stride)")
+    if shadow:
+        a.op("s_and_b64 vcc, vcc, %s" % P.ACT, "live lanes inside the outer bound")
+
+
 def exact_after_filter(a, P, c, lab, terms):
-    """Filtered loops: some live lane passed the bound -- now the reference's own discriminant, for every lane."""
+    """Filtered loops: some lane passed the bound -- now the reference's own discriminant, for every lane."""
     if not P.filt:
         return
     (P.primary_terms_after_filter if terms == P.primary_terms else terms)(a, c)
@@ -672,6 +694,7 @@ def primary_copy(P, name, fused):
     emit_skip(m, P, name, c, lab)          # nobody can hit the node: a BOUND is jumped over, an ITEM changes nothing
     # ---------------- somebody's line meets the sphere ----------------
     k.label(lab("hit"))
+    hit_entry(k, P)
     exact_after_filter(k, P, c, lab, P.primary_terms)
     kind_test(k, P, c, lab)
     # BOUND (group.rs:73)
@@ -825,6 +848,9 @@ def shadow_copy_filt(P, name, fused):
     emit_skip(m, P, name, c, lab, P.s_skip(c))
     # ---------------- some live lane is inside the outer bound ----------------
     k.label(lab("hit"))
+    if lazy_wake(P):
+        hit_entry(k, P, shadow=True)
+        k.op("s_cbranch_vccz %s" % lab("skip"), "only lanes that sleep: nobody can hit the node")
     k.op("v_sub_f32_e32 %%[av], %s, %%[ol]" % P.s_cl(c), "a ~ b = dot(centre - origin, dir)")
     k.op("v_cmp_le_f32_e64 %s, %%[a0], %%[av]" % P.M58, "b >= 0, by a margin")
     k.op("v_fma_f32 %[inn], %[av], %[av], %[p2]", "~ |centre - origin|^2")
@@ -902,6 +928,9 @@ def shadow_copy_filt64(P, name, fused):
     emit_skip(m, P, name, c, lab, P.s_skip(c))
     # ---------------- some live lane is inside the outer bound ----------------
     k.label(lab("hit"))
+    if lazy_wake(P):
+        hit_entry(k, P, shadow=True)
+        k.op("s_cbranch_vccz %s" % lab("skip"), "only lanes that sleep: nobody can hit the node")
     k.op("v_sub_f32_e32 %%[av], %s, %%[ol]" % P.s_cl(c), "a ~ b = dot(centre - origin, dir)")
     k.op("v_cmp_le_f32_e64 %s, %%[a0], %%[av]" % P.M58, "b >= 0, by a margin")
     k.op("v_fma_f32 %[inn], %[av], %[av], %[p2]", "~ |centre - origin|^2")
