@@ -1488,6 +1488,7 @@ constexpr auto skip_kernel()
 {
     if constexpr (sizeof(T) == 4 && !COUNT && COOP) return &rt::k_render_skip_f32_coop<COUNT, VAR, MODE>;
     else if constexpr (sizeof(T) == 4 && !COUNT) return &rt::k_render_skip_f32<COUNT, VAR, MODE>;
+    else if constexpr (sizeof(T) == 8 && !COUNT && (VAR & 18) == 18) return &rt::k_render_skip_f64<VAR, MODE>;
     else return &rt::k_render_skip<T, COUNT, VAR, MODE, COOP>;
 }
 

@@ -824,8 +824,13 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
     }       // descriptors of this workgroup
 }
 
-// (f64 and the counting launches.  Held to six waves per SIMD: the f64 walk waits for its node records like the f32 one, its 81 vector
-// registers were one too many for the sixth wave -- 80 without a spill, 1080p f64 69.8 -> 65.0 us; a seventh costs 20 bytes of scratch and buys nothing.)
+// (The counting launches and the UNFILTERED f64 loops -- f64 scenes too large for the filter streams' 32-bit offsets.  Held to six waves
+// per SIMD: the f64 walk waits for its node records like the f32 one, its 81 vector registers were one too many for the sixth wave -- 80
+// without a spill, 1080p f64 69.8 -> 65.0 us; these loops own s[36:97], so a seventh wave is not to be had here: k_render_skip_f64 below.)
+#ifndef RT_F64_SGPRS
+#define RT_F64_SGPRS 96
+#define RT_F64_WAVES 7
+#endif
 template <typename T, bool COUNT, int VAR, int MODE, bool COOP = false>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(6))) void k_render_skip(SkipView<T> sc, unsigned width, unsigned height, unsigned spp_arg,
                                                               const TileDev *__restrict__ tiles, unsigned n_tiles,
@@ -864,6 +869,20 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(94)))
     const uint32_t *__restrict__ wg_first, CoopView cv = CoopView{}, const uint64_t *__restrict__ holes = nullptr, unsigned n_holes = 0)
 {
     render_skip_body<float, COUNT, VAR, MODE, true>(sc, width, height, spp_arg, tiles, n_tiles, out, counters, sb, frame_w, order, lane_cost, wg_first, cv, holes, n_holes);
+}
+
+// ... and the f64 launches of the FILTERED loops (VAR & 16), whose window ends at s89 (tools/gen_skip_asm.py F64F): 96 scalar registers with the
+// hardware's six and 72 vector registers are what a SIMD admits seven waves at (round 5: 1080p f64 61.7 -> 59.9 us, 1024x768 spp 4 403.5 ->
+// 389.2, interleaved; the spp-1 flavour parks two doubles in scratch across the primary walk -- 20 bytes, stored and loaded once per ray).
+// LLVM calls s88 and s89 reserved at this limit, as it did s72 and s73 of the f32 kernel at 80: they are below the six the hardware adds.
+template <int VAR, int MODE>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(RT_F64_SGPRS), amdgpu_waves_per_eu(RT_F64_WAVES))) void k_render_skip_f64(
+    SkipView<double> sc, unsigned width, unsigned height, unsigned spp_arg, const TileDev *__restrict__ tiles, unsigned n_tiles, uint8_t *__restrict__ out,
+    Counters *__restrict__ counters, SampleBuf<double> sb, unsigned frame_w, const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost,
+    const uint32_t *__restrict__ wg_first, CoopView cv = CoopView{}, const uint64_t *__restrict__ holes = nullptr, unsigned n_holes = 0)
+{
+    static_assert((VAR & 16) != 0 && (VAR & 2) != 0, "the filtered assembly loops");
+    render_skip_body<double, false, VAR, MODE, false>(sc, width, height, spp_arg, tiles, n_tiles, out, counters, sb, frame_w, order, lane_cost, wg_first, cv, holes, n_holes);
 }
 
 // Second pass of the SPLIT path: render.rs:233-252 for one pixel -- its samples' contributions accumulated strictly

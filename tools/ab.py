@@ -27,7 +27,7 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     w, h, spp, level = (int(a) for a in sys.argv[2:6]) if len(sys.argv) > 5 else (1920, 1080, 1, 8)
     variants = [int(v) for v in os.environ.get("AB_VARIANTS", "1,3,7").split(",")]
-    scene = rta.Scene.default(level)
+    scene = rta.Scene.default(level, rta.RT_F64 if os.environ.get("AB_PRECISION", "f32") == "f64" else rta.RT_F32)
     dev = scene.device(0)
     opts = (w, h, spp)
     regs = [tuple(r) for r in rta.buckets(rta.RenderOptions(*opts))]

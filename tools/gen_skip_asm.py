@@ -470,6 +470,11 @@ class F64F(F64):
     stride = 32
     fbank_first = (36, 44, 52)                       # three filter banks of 8; the exact record lives in s[60:75]
     EXACT = 60
+    # Round 5: s76 scratch, s77 NX, masks s[78:89] -- the filtered f64 loops end at s89 (96 scalar registers with the hardware's six: seven
+    # waves per SIMD where the plain F64 loops' s[36:97] allow six; the f64 walk waits for its node records like the f32 one)
+    NX = "s77"
+    ACT, M54, M56, M58, TINY, EX = sp(78), sp(80), sp(82), sp(84), sp(86), sp(88)
+    clobber_lo, clobber_hi = 36, 89
     load_op = "s_load_dwordx8"
 
     def fbank(self, b):
@@ -500,7 +505,7 @@ class F64F(F64):
         a.op("v_cmp_le_f32_e32 vcc, %s, %%[tf1]" % self.thr(c))
 
     def primary_terms_after_filter(self, a, c):
-        tmp = "s76"                                  # (free: the filter banks end at s59, the exact record at s75, NX and the masks start at s85)
+        tmp = "s76"                                  # (free: the filter banks end at s59, the exact record at s75, NX and the masks start at s77)
         a.op("s_sub_u32 %s, %s, %d" % (tmp, self.NX, self.stride), "this node's offset in the filter stream ...")
         a.op("s_lshl_b32 %s, %s, 1" % (tmp, tmp), "... and in the Node<double> stream")
         a.op("s_load_dwordx16 %s, %%[base2], %s" % (sp(self.EXACT, 16), tmp), "its exact record")
