@@ -451,6 +451,48 @@ def test_render_frame_device_equals_tiles_plus_blit(trav, size):
     np.testing.assert_array_equal(frame2.cpu().numpy().reshape(h, w, 4), expect)
 
 
+def test_the_largest_frame_the_reference_accepts():
+    # RenderOptions holds u16 sizes that must be multiples of 64 (render.rs:35-36, 265-266): 65,472 x 65,472 = 4,286,582,784 pixels, a 17 GB
+    # frame whose byte offsets need 33 bits and whose pixel count still fits 32.  A pixel depends on (x, y, width, height) alone, so every
+    # bucket of the big frame must equal the same bucket rendered by itself (rt_render_tiles, one region) -- which the small-frame tests pin
+    # to the oracle.  Sixty buckets: the corners, the rows in which the byte offset passes 4 / 8 / 12 GiB, the pyramid, anywhere.
+    import torch
+    W = H = 65472
+    if torch.cuda.mem_get_info()[0] < (W * H * 4) * 1.2:
+        pytest.skip("needs 20 GB of free device memory")
+    s, _ = util.scene_pair_default()
+    d = s.device()
+    opts = (W, H, 1)
+    regs = bucket_list(W, H)
+    assert len(regs) == 1023 * 1023
+    frame = torch.full((W * H * 4,), 7, dtype=torch.uint8, device="cuda")
+    st = d.render_frame_device(opts, d._regions(regs), frame.data_ptr(), torch.cuda.current_stream().cuda_stream, SKIP, want_stats=True)
+    torch.cuda.synchronize()
+    assert st["primary"] == W * H
+    f2 = frame.view(H, W, 4)
+    rng = np.random.default_rng(3)
+    nb = W // 64
+    picks = {(0, 0), (nb - 1, 0), (0, nb - 1), (nb - 1, nb - 1), (nb // 2, nb // 2), (nb // 2 - 1, nb // 2), (nb // 2, nb // 2 + 1)}
+    row_4g = ((1 << 30) // W) // 64
+    for yy in (row_4g - 1, row_4g, row_4g + 1, 2 * row_4g, 3 * row_4g):
+        picks.add((int(rng.integers(0, nb)), yy)); picks.add((nb // 2, yy))
+    while len(picks) < 60:
+        if rng.random() < 0.6:
+            picks.add((int(nb // 2 + rng.integers(-nb // 6, nb // 6 + 1)), int(nb // 2 + rng.integers(-nb // 6, nb // 6 + 1))))
+        else:
+            picks.add((int(rng.integers(0, nb)), int(rng.integers(0, nb))))
+    shows_geometry = 0
+    for (bx, by) in sorted(picks):
+        l, b = bx * 64, by * 64
+        tile, _ = d.render_tiles(opts, [(l, b + 64, l + 64, b)], SKIP, want_stats=False)
+        ref = tile.reshape(64, 64, 4)
+        np.testing.assert_array_equal(f2[b:b + 64, l:l + 64].cpu().numpy(), ref, err_msg="bucket %d, %d" % (bx, by))
+        shows_geometry += int((ref[..., :3] != ref[0, 0, :3]).any())
+    assert shows_geometry >= 10
+    del f2, frame
+    torch.cuda.empty_cache()
+
+
 def test_frame_mode_leaves_unlisted_buckets_alone():
     import torch
     s, _ = util.scene_pair_default()
