@@ -722,6 +722,34 @@ def test_every_sample_count_on_a_ragged_image(spp, precision):
     np.testing.assert_array_equal(plain, data)
 
 
+@pytest.mark.parametrize("traversal", [SKIP, FLAT], ids=["skip", "flat"])
+@pytest.mark.parametrize("spp,precision", [(16, rta.RT_F32), (255, rta.RT_F32), (256, rta.RT_F32), (300, rta.RT_F32), (16, rta.RT_F64), (256, rta.RT_F64)],
+                         ids=["16-f32", "255-f32", "256-f32", "300-f32", "16-f64", "256-f64"])
+def test_very_many_samples_per_pixel(spp, precision, traversal):
+    # samples_per_pixel is a u16 (render.rs:37).  Up to 255 (spp^2 <= 65,535) a launch is sample-parallel with one grid row per sample; from
+    # 256 on every thread loops over its pixel's samples in the reference's order.  A 12x6 region across the pyramid's silhouette in a 64x64
+    # frame of the level-4 pyramid (so that samples hit, miss and are shadowed inside single pixels): pixels, alpha and every counter.
+    if traversal == FLAT and spp >= 256:
+        pytest.skip("the flat scan takes at most 65,535 samples per pixel and says so (test_flat_scan_sample_limit)")
+    s, o = util.scene_pair_default(precision, 4)
+    w = h = 64
+    l, t, r, b = 26, 40, 38, 34
+    ref, rst = o.render_region(w, h, spp, l, t, r, b, HIER_EXIT if traversal == SKIP else oracle.MODE_FLAT)
+    assert len(np.unique(ref.reshape(-1, 4), axis=0)) > 8          # not a flat patch
+    data, st = s.device().render_tiles((w, h, spp), [(l, t, r, b)], traversal)
+    np.testing.assert_array_equal(data.reshape(t - b, r - l, 4), ref)
+    if traversal == SKIP:
+        assert util.all_stats(st) == util.all_stats(rst)
+    else:
+        assert (st["primary"], st["hits"], st["shadow"], st["occluded"]) == (rst["primary"], rst["hits"], rst["shadow"], rst["occluded"])
+
+
+def test_flat_scan_sample_limit():
+    s, _ = util.scene_pair_default(rta.RT_F32, 4)
+    with pytest.raises(rta.capi.RtError, match="too many samples"):
+        s.device().render_tiles((64, 64, 256), [(0, 64, 64, 0)], FLAT)
+
+
 # ---------------------------------------------------------------- host-buffer boundary (round 2)
 def test_host_buffers_pinned_registered_and_pageable_deliver_the_same_bytes():
     # rt_render_tiles recognises rt_host_alloc'd / rt_host_register'd memory by address and lets the kernel store into it
