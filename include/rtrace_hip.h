@@ -57,7 +57,9 @@ typedef enum rt_precision { RT_F32 = 0, RT_F64 = 1 } rt_precision;
  *          hierarchy exactly, including its inside-the-bound behaviour. */
 typedef enum rt_traversal { RT_TRAVERSAL_FLAT = 0, RT_TRAVERSAL_SKIP = 1 } rt_traversal;
 
-/* RenderOptions, render.rs:33-38 (u16 fields there too).  samples_per_pixel = k means k*k samples. */
+/* RenderOptions, render.rs:33-38 (u16 fields there too).  samples_per_pixel = k means k*k samples; k = 0 is the reference's black
+ * frame (no sample taken, 0 * inf = NaN, `NaN as u8` = 0: every listed pixel {0, 0, 0, 0}).  width and height must be >= 1 at this
+ * boundary: an empty image has no bucket to hand over (the host scheduler returns before calling, like render.rs:273-298). */
 typedef struct rt_options {
     uint16_t width, height, samples_per_pixel;
 } rt_options;

@@ -219,6 +219,9 @@ RenderStats Renderer::render(const RenderOptions &o, const Backend &be, RGBABuff
 
     const std::vector<ImageRegion> all = buckets(o);
     size_t count = all.size();
+    // width or height 0: the scheduler's loops (render.rs:273-298) produce no bucket, the writer never becomes dirty and its Drop writes
+    // nothing (render.rs:361-363): an empty file, exit code 0.  (The C ABI rejects an empty tile list.)
+    if (all.empty()) return RenderStats{};
     static_assert(sizeof(ImageRegion) == sizeof(rt_region), "ImageRegion is layout-compatible with rt_region");
     if (be.gang) {
         // Several GPUs: gang calls of at most 64 buckets per GPU (bucket i -> GPU i % N, one RCCL gather of the u8 shards to the

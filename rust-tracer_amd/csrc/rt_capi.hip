@@ -1693,6 +1693,14 @@ rt_status launch_render(rt_scene *s, Context *c, const rt_options *o, rt_travers
 {
     const dim3 grid(total_blocks);
     const unsigned w = o->width, h = o->height, spp = o->samples_per_pixel;
+    if (spp == 0) {
+        // render.rs:219-250 with no sample to take: 0 * inf = NaN in every channel, and `NaN as u8` is 0 (set_pixel_from_vector, render.rs:96-108)
+        g_launch_flags = cnt ? RT_LAUNCH_COUNTING : 0u;
+        if (frame_w == 0) HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)total_px * 4, stream));
+        else hipLaunchKernelGGL(rt::k_zero_tiles, dim3(nt), dim3(rt::kBlockThreads), 0, stream, frame_w, d_tab, reinterpret_cast<unsigned *>(d_out));
+        HIP_TRY(hipGetLastError());
+        return RT_OK;
+    }
     g_launch_flags = (trav == RT_TRAVERSAL_FLAT ? RT_LAUNCH_FLAT_PIPELINE : 0u) | (order.d ? RT_LAUNCH_ORDERED : 0u) |
                      (trav == RT_TRAVERSAL_SKIP && use_split(spp) ? RT_LAUNCH_SAMPLE_PARALLEL : 0u) | (cnt ? RT_LAUNCH_COUNTING : 0u);
     // a dispatch order that is being timed against others (pick_order); never a counting launch: its loops are different ones
@@ -1789,8 +1797,8 @@ rt_status read_stats(rt_scene *s, Context *c, hipStream_t stream, rt_traversal t
 bool check_common(rt_scene *s, const rt_options *o, const rt_region *tiles, uint32_t n, const void *out)
 {
     if (!s || !o || !tiles || !out || n == 0) { snprintf(g_err, sizeof g_err, "NULL argument or n_tiles == 0"); return false; }
-    if (o->width == 0 || o->height == 0 || o->samples_per_pixel == 0) {
-        snprintf(g_err, sizeof g_err, "width, height and samples_per_pixel must be >= 1");
+    if (o->width == 0 || o->height == 0) {       // (samples_per_pixel == 0 is the reference's black frame: launch_render)
+        snprintf(g_err, sizeof g_err, "width and height must be >= 1");
         return false;
     }
     return true;
@@ -2359,7 +2367,7 @@ rt_status rt_render_frame_stream(rt_scene *s, const rt_options *o, rt_traversal 
     // row-major grid (render.rs:273-298) -- whole bucket ROWS, so that what a batch delivers is complete rows of the image.
     constexpr uint32_t kStreamMaxBatches = 16;
     const uint64_t ns = (uint64_t)o->samples_per_pixel * o->samples_per_pixel;
-    uint32_t per = std::max<uint32_t>((n + kStreamMaxBatches - 1) / kStreamMaxBatches, (uint32_t)std::clamp<uint64_t>((1ull << 20) / (4096ull * ns), 16, 256));
+    uint32_t per = std::max<uint32_t>((n + kStreamMaxBatches - 1) / kStreamMaxBatches, (uint32_t)std::clamp<uint64_t>((1ull << 20) / (4096ull * std::max<uint64_t>(ns, 1)), 16, 256));
     {
         uint32_t row = 1;
         while (row < n && tiles[row].b == tiles[0].b) ++row;

@@ -151,6 +151,15 @@ __global__ __launch_bounds__(kBlockThreads) void k_blit_tiles(unsigned width, co
         frame[(size_t)y * width + x] = src[(size_t)tile.out_px + (size_t)(y - tile.b) * (tile.r - tile.l) + (x - tile.l)];
 }
 
+// samples_per_pixel == 0 (render.rs:219-250: no sample is taken, the sum 0 is multiplied by (0 * 0).recip() = inf, and `NaN as u8` is 0): every
+// listed pixel is {0, 0, 0, 0}.  One workgroup per tile, into a row-major frame.
+__global__ __launch_bounds__(kBlockThreads) void k_zero_tiles(unsigned width, const TileDev *__restrict__ tiles, unsigned *__restrict__ frame)
+{
+    const TileDev tile = tiles[blockIdx.x];
+    const unsigned tw = tile.r - tile.l, n = tw * (tile.t - tile.b);
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) frame[(size_t)(tile.b + i / tw) * width + (tile.l + i % tw)] = 0u;
+}
+
 // The writer's conversion on the device (render.rs:373-401): tile-major RGBA tiles -> their place in a row-major frame in the FILE's pixel
 // format -- BPP 3: R, G, B (P6, render.rs:392-396), BPP 1: ((r + g + b) as f32 / 3.0) as u8 (P5, render.rs:399), BPP 4: RGBA (the blit).
 // One workgroup per tile, a wave per row (rows w, w + 4, ...), a lane per aligned 32-bit word of the row's bytes: the destination may be

@@ -102,6 +102,29 @@ def test_cli_stdout_sink_and_clipped_sizes(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("trav", ["skip", "flat"])
+def test_cli_zero_samples_and_empty_images_behave_like_the_reference(tmp_path, trav):
+    # --samples-per-pixel=0: no sample is taken, every channel is 0 * (0 * 0).recip() = NaN, and `NaN as u8` is 0 (render.rs:219-250, 96-108):
+    # every bucket is delivered, the file is the header and a black payload -- which the oracle reproduces.
+    out = str(tmp_path / "black.tga")
+    r = run(["--width=192", "--height=128", "--samples-per-pixel=0", "--traversal=" + trav, "--stats", out])
+    assert r.returncode == 0, r.stderr.decode()
+    ref, st = _oracle_ppm(tmp_path, 192, 128, 0)
+    assert ref == b"P6\n192 128\n255\n" + bytes(192 * 128 * 3) and st["primary"] == 0
+    assert open(out, "rb").read() == ref
+    assert b"primary 0 hits 0 shadow 0 occluded 0" in r.stderr
+    # width or height 0: the scheduler produces no bucket (render.rs:273-298), the writer never gets dirty and its Drop writes nothing
+    # (render.rs:361-363): the file main.rs created stays empty, exit code 0
+    for args in (["--width=0", "--height=64"], ["--width=64", "--height=0"], ["--width=0", "--height=0"]):
+        out = str(tmp_path / "empty.tga")
+        r = run(args + ["--traversal=" + trav, out])
+        assert r.returncode == 0, (args, r.stderr.decode())
+        assert os.path.getsize(out) == 0, args
+    r = run(["--width=0", "--height=64", "-"])
+    assert r.returncode == 0 and r.stdout == b""
+
+
+@pytest.mark.gpu
 def test_cli_f64_type_alias_swap(tmp_path):
     out = str(tmp_path / "out.tga")
     r = run(["--width=320", "--height=256", out], exe=RTRACE64)

@@ -744,6 +744,38 @@ def test_very_many_samples_per_pixel(spp, precision, traversal):
         assert (st["primary"], st["hits"], st["shadow"], st["occluded"]) == (rst["primary"], rst["hits"], rst["shadow"], rst["occluded"])
 
 
+@pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64], ids=["f32", "f64"])
+@pytest.mark.parametrize("traversal", [SKIP, FLAT], ids=["skip", "flat"])
+def test_zero_samples_per_pixel_is_the_references_black_frame(traversal, precision):
+    # render.rs:219-250 with samples_per_pixel = 0: the sample loops do not run, g = 0 * inf = NaN, alpha likewise, and set_pixel_from_vector's
+    # `r as u8` turns NaN into 0 -- every listed pixel {0, 0, 0, 0}, no ray cast.  Through every entry point that takes RenderOptions.
+    import torch
+    s, o = util.scene_pair_default(precision, 4)
+    d = s.device()
+    w, h = 150, 70
+    regs = bucket_list(w, h)
+    ref, rst, _ = o.render(w, h, 0, 2, HIER_EXIT if traversal == SKIP else oracle.MODE_FLAT)
+    assert not ref.any() and rst["primary"] == 0
+    buf = np.full(w * h * 4, 9, dtype=np.uint8)
+    data, st = d.render_tiles((w, h, 0), regs, traversal, out=buf)
+    assert not data.any() and util.all_stats(st) == (0, 0, 0, 0, 0, 0)
+    one, _ = d.render_region((w, h, 0), regs[1], traversal)
+    assert not one.any() and one.shape == (regs[1][1] - regs[1][3], regs[1][2] - regs[1][0], 4)
+    # frame mode: only the listed buckets are touched
+    frame = torch.full((w * h * 4,), 7, dtype=torch.uint8, device="cuda")
+    d.render_frame_device((w, h, 0), regs[::2], frame.data_ptr(), torch.cuda.current_stream().cuda_stream, traversal)
+    torch.cuda.synchronize()
+    got = frame.cpu().numpy().reshape(h, w, 4)
+    for i, (l, t, r, b) in enumerate(regs):
+        assert (got[b:t, l:r] == (0 if i % 2 == 0 else 7)).all()
+    seen = []
+    d.render_tiles_stream((w, h, 0), regs, lambda i, reg, rgba: seen.append((i, bool(np.asarray(rgba).any()))), traversal)
+    assert sorted(seen) == [(i, False) for i in range(len(regs))]
+    p6 = np.full(w * h * 3, 5, dtype=np.uint8)
+    d.render_frame_stream((w, h, 0), regs, rta.capi.RT_FRAME_RGB, p6, None, traversal)
+    assert not p6.any()
+
+
 def test_flat_scan_sample_limit():
     s, _ = util.scene_pair_default(rta.RT_F32, 4)
     with pytest.raises(rta.capi.RtError, match="too many samples"):
