@@ -240,7 +240,7 @@ def test_error_codes_instead_of_panics():
         d.render_tiles((64, 64, 1), [(10, 20, 10, 0)], traversal=FLAT)         # empty
     assert e.value.status == rta.capi.RT_ERR_INVALID_REGION
     with pytest.raises(rta.RtError) as e:
-        d.render_tiles((64, 64, 0), [(0, 64, 64, 0)], traversal=FLAT)          # spp == 0
+        d.render_tiles((0, 64, 1), [(0, 64, 64, 0)], traversal=FLAT)           # an image without pixels (spp == 0 is the reference's black frame)
     assert e.value.status == rta.capi.RT_ERR_INVALID_ARGUMENT
     with pytest.raises(rta.RtError) as e:
         rta.Scene.from_spheres([(0, 0, 0, -1.0)], (0, 0, 0, 3.0)).device()
