@@ -454,13 +454,13 @@ def test_render_frame_device_equals_tiles_plus_blit(trav, size):
 def test_the_largest_frame_the_reference_accepts():
     # RenderOptions holds u16 sizes that must be multiples of 64 (render.rs:35-36, 265-266): 65,472 x 65,472 = 4,286,582,784 pixels, a 17 GB
     # frame whose byte offsets need 33 bits and whose pixel count still fits 32.  A pixel depends on (x, y, width, height) alone, so every
-    # bucket of the big frame must equal the same bucket rendered by itself (rt_render_tiles, one region) -- which the small-frame tests pin
-    # to the oracle.  Sixty buckets: the corners, the rows in which the byte offset passes 4 / 8 / 12 GiB, the pyramid, anywhere.
+    # bucket of the big frame must equal the same bucket rendered by itself (rt_render_tiles, one region), and that one the oracle's
+    # render_region at this frame size.  Sixty buckets: the corners, the rows in which the byte offset passes 4 / 8 / 12 GiB, the pyramid, anywhere.
     import torch
     W = H = 65472
     if torch.cuda.mem_get_info()[0] < (W * H * 4) * 1.2:
         pytest.skip("needs 20 GB of free device memory")
-    s, _ = util.scene_pair_default()
+    s, o = util.scene_pair_default()
     d = s.device()
     opts = (W, H, 1)
     regs = bucket_list(W, H)
@@ -488,6 +488,9 @@ def test_the_largest_frame_the_reference_accepts():
         ref = tile.reshape(64, 64, 4)
         np.testing.assert_array_equal(f2[b:b + 64, l:l + 64].cpu().numpy(), ref, err_msg="bucket %d, %d" % (bx, by))
         shows_geometry += int((ref[..., :3] != ref[0, 0, :3]).any())
+        # ... and the bucket by itself is the CPU path's bucket at this frame size (a 64x64 bucket costs the oracle milliseconds)
+        oref, _ = o.render_region(W, H, 1, l, b + 64, l + 64, b, HIER_EXIT)
+        np.testing.assert_array_equal(ref, oref, err_msg="bucket %d, %d against the oracle" % (bx, by))
     assert shows_geometry >= 10
     del f2, frame
     torch.cuda.empty_cache()
