@@ -169,6 +169,23 @@ __device__ __forceinline__ float primary_filter_threshold64(double vv, double rr
     return next_f32_below(tf);
 }
 
+// The other side of that bound (round 5, FNode::a3 of an f64 scene's BOUND nodes): b' >= T_in proves that the f64 test returns a FINITE distance
+// d = t1 with 0 < t1 <= b.  T_in = sqrt(vv - rr) (1 + 1e-14) + 8 * 2^-24 sqrt(vv), rounded up twice (+inf where T is -inf): with | b' - b | <=
+// 5.3 * 2^-24 |v| (above) the reference's b is >= sqrt(vv - rr) + 2.7 * 2^-24 |v|, so b^2 - (vv - rr) >= 2 sqrt(vv - rr) * 2.7 * 2^-24 |v| >= 2^-31 vv
+// (sqrt(vv - rr) >= sqrt(64 * 2^-24) |v| = 2^-9 |v| by the condition below) -- eight orders of magnitude above the f64 discriminant's own rounding
+// error (a few 2^-53 (b^2 + vv + rr)): disc > 0, s = sqrt(disc) < b because vv > rr, t2 > 0 and t1 = RN(b - s) > 0 (b - s >= (vv - rr) / 2b, far
+// from the subnormals for vv >= 1e-30).  With it the walk decides "the lane enters" as b' (1 + 2^-11) < hit.distance: d = t1 <= b <= b' + 5.3 * 2^-24
+// |v| <= b' (1 + 5.3 * 2^-15) for b' >= T_in >= 2^-9 |v| (the product's own f32 rounding included in 2^-11).
+__device__ __forceinline__ float primary_sure_threshold64(double vv, double rr)
+{
+    const double eps = 0x1p-24;
+    if (!(vv >= 1e-30) || !(vv < 1e300) || !(vv - rr >= 64.0 * eps * (vv + rr))) return __builtin_huge_valf();
+    const double t = __builtin_sqrt(vv - rr) * (1.0 + 1e-14) + 8.0 * eps * __builtin_sqrt(vv);
+    float tf = (float)t;
+    if ((double)tf < t) tf = next_f32_above(tf);
+    return next_f32_above(tf);
+}
+
 // FNode copy of an f64 scene's primary stream (plain or compacted; END nodes included) for the filtered f64 primary walk: f32 roundings of
 // v, the threshold above, skip_off in FNode units (half the Node<double> offset), the tag as in the f32 streams (a compacted BOUND's is 0:
 // its own sphere's rr is read from the exact record).
@@ -209,10 +226,17 @@ __global__ void k_build_fstream64(const Node<double> *__restrict__ prim, const N
     }
     const bool end = (p.item & kNodeEnd) != 0u, item = (p.item & kNodeItem) != 0u;
     FNode fp;
-    fp.a0 = (float)p.a0; fp.a1 = (float)p.a1; fp.a2 = (float)p.a2; fp.a3 = 0.0f; fp.a4 = 0.0f;
+    fp.a0 = (float)p.a0; fp.a1 = (float)p.a1; fp.a2 = (float)p.a2;
     fp.f5 = end ? -__builtin_huge_valf() : primary_filter_threshold64(p.a3, p.a4);
+    // BOUND nodes: a3 = T_in (above; +inf: never sure), a4 = T_own -- the filter threshold of the group's own sphere in a compacted stream
+    // (b' < T_own: it returns INF, as an ITEM node's f5 says of an item), +inf where the BOUND carries no sphere.  (rt_skip_rot.hpp, F64F.sure_enter_path)
+    const bool bound = !end && !item;
+    fp.a3 = bound && fp.f5 > -__builtin_huge_valf() ? primary_sure_threshold64(p.a3, p.a4) : __builtin_huge_valf();
+    fp.a4 = bound && compacted ? primary_filter_threshold64(p.a3, p.own_rr) : __builtin_huge_valf();
     // an f32 rounding that overflowed (|v| > 3.4e38 cannot happen: coordinates are <= 1e15) or lost everything (|v| < 1e-45) says nothing
-    if (!end && !(__builtin_fabsf(fp.a0) < 3e38f && __builtin_fabsf(fp.a1) < 3e38f && __builtin_fabsf(fp.a2) < 3e38f)) fp.f5 = -__builtin_huge_valf();
+    if (!end && !(__builtin_fabsf(fp.a0) < 3e38f && __builtin_fabsf(fp.a1) < 3e38f && __builtin_fabsf(fp.a2) < 3e38f)) {
+        fp.f5 = -__builtin_huge_valf(); fp.a3 = __builtin_huge_valf(); fp.a4 = -__builtin_huge_valf();
+    }
     fp.skip_off = p.skip_off / 2u;
     fp.tag = end ? (kNodeItem | kNodeEnd) : item ? (kNodeItem | (p.item & kNodeIndexMask)) : 0u;
     xprim[i] = fp;
@@ -575,6 +599,13 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
                             const bool pass = primary_filter_pass(fn, (float)dir.x, (float)dir.y, (float)dir.z);
                             c_fpass += pass ? 1u : 0u;
                             c_fviol += (!pass && d < inf<T>()) ? 1u : 0u;
+                            if (nd.is_bound()) {      // ... the step that needs no exact record (F64F.sure_enter_path): finite for sure, enters for sure
+                                const float bf = __builtin_fmaf(fn.a2, (float)dir.z, __builtin_fmaf(fn.a1, (float)dir.y, fn.a0 * (float)dir.x));
+                                if (bf >= fn.a3) {
+                                    c_fviol += !(d < inf<T>() && d <= b && d > 0.0) ? 1u : 0u;
+                                    if ((double)(bf * 0x1.002p+0f) < best) c_fviol += !(d < best) ? 1u : 0u;
+                                }
+                            }
                             if (nd.is_bound() && pos && fn.f5 > -inf<float>()) {      // ... and the BOUND step's root-free decision, in f64
                                 int v = 1;
                                 if (!(0.0 < b)) v = 0;

@@ -100,6 +100,7 @@ class Prec:
     """Register plan and the precision-dependent instruction sequences."""
     filt = False
     shortcut = False                 # the primary BOUND step's root-free decision (F32F.bound_shortcut)
+    sure_enter = False               # the f64 primary BOUND step that needs no exact record at all (F64F.sure_enter_path)
     primary_extra_args = ""
     primary_extra_in = ""
     primary_only = False
@@ -457,6 +458,9 @@ class F32F(F32):
     shadow_subst = (("%[t0]", "v%d" % TT[0]), ("%[t1]", "v%d" % TT[1]), ("%[q]", "%[vy]"), ("%[disc]", "%[vx]"))
 
 
+SPECULATE_EXACT = os.environ.get("RT_GEN_SPECULATE_EXACT", "0") == "1"      # design-time A/B: the exact record requested at the top of the hit path
+
+
 class F64F(F64):
     """f64 PRIMARY walk behind the f32 filter (round 4; the shadow walk of f64 scenes stays the plain F64 loop).  The walk reads the scene's
     FNode stream -- f32 roundings of {vx, vy, vz}, a threshold T for the f32 fma-chain b' on an f32 rounding of the ray direction, skip_off
@@ -504,11 +508,15 @@ class F64F(F64):
         a.op("v_fma_f32 %%[tf1], s%d, %%[dzf], %%[tf1]" % (self.fbank(c) + 2))
         a.op("v_cmp_le_f32_e32 vcc, %s, %%[tf1]" % self.thr(c))
 
-    def primary_terms_after_filter(self, a, c):
+    def fetch_exact(self, a):
         tmp = "s76"                                  # (free: the filter banks end at s59, the exact record at s75, NX and the masks start at s77)
         a.op("s_sub_u32 %s, %s, %d" % (tmp, self.NX, self.stride), "this node's offset in the filter stream ...")
         a.op("s_lshl_b32 %s, %s, 1" % (tmp, tmp), "... and in the Node<double> stream")
         a.op("s_load_dwordx16 %s, %%[base2], %s" % (sp(self.EXACT, 16), tmp), "its exact record")
+
+    def primary_terms_after_filter(self, a, c):
+        if not (self.sure_enter and SPECULATE_EXACT):
+            self.fetch_exact(a)
         a.op("s_waitcnt lgkmcnt(0)")
         self.primary_terms(a, c)
 
@@ -535,6 +543,41 @@ class F64F(F64):
         a.op("s_cbranch_scc1 %s" % lab("bexact"), "(vcc lost only lanes with b <= 0, which the root path rejects as well)")
         a.op("s_and_b64 vcc, vcc, %s" % self.M56, "go")
         a.op("s_branch %s" % lab("bdecided"))
+
+    sure_enter = True
+
+    def t_in(self, b):
+        return "s%d" % (self.fbank(b) + 3)           # FNode::a3 of an f64 scene: b' >= T_in proves a finite distance t1 > 0 (rt_skip.hpp)
+
+    def t_own(self, b):
+        return "s%d" % (self.fbank(b) + 4)           # FNode::a4: b' < T_own proves the group's own sphere returns INF (+inf: it has none)
+
+    def sure_enter_path(self, a, c, n, name, lab):
+        """Round 5.  An entered BOUND step of the f64 walk fetched the node's Node<double> record BEHIND the filter's verdict (a dependent
+        scalar load more than the f32 walk, whose filter record is the exact one) and ran eight f64 operations and the root-free decision
+        on it.  Most such steps need neither: when every candidate lane has b' >= T_in (the f64 test returns a finite t1 > 0, so d <= b),
+        b' (1 + 2^-11) < hit.distance (b <= b' + 6 eps |v| <= b' (1 + 2^-11) for b' >= T_in >= 2^-9 |v|: d <= b < hit.distance, the lane
+        enters) and b' < T_own (the group's own sphere returns INF), the step is decided by the filter record alone.  Any candidate lane
+        that is not sure of all three sends the wave down the exact path.  Counting launches hold both verdicts against the f64 test."""
+        if SPECULATE_EXACT:
+            self.fetch_exact(a)                      # (requested before it is known to be needed: every path waits for lgkmcnt(0) before the next step)
+        a.op("s_bitcmp1_b32 %s, 31" % self.item(c), "an ITEM or the END node: the exact path")
+        a.op("s_cbranch_scc1 %s" % lab("exact"))
+        a.op("v_cmp_le_f32_e64 %s, %s, %%[tf1]" % (self.M54, self.t_in(c)), "b' >= T_in: a finite distance for sure")
+        a.op("s_andn2_b64 %s, vcc, %s" % (self.M56, self.M54), "candidates that are not")
+        a.op("s_cbranch_scc1 %s" % lab("exact"))
+        a.op("v_mul_f32_e32 %[tf0], 0x3f801000, %[tf1]", "b' (1 + 2^-11) >= b >= d")
+        a.op("v_cvt_f64_f32_e32 %[t0], %[tf0]")
+        a.op("v_cmp_gt_f64_e64 %s, %%[best], %%[t0]" % self.M56, "< hit.distance: enters")
+        a.op("s_andn2_b64 %s, vcc, %s" % (self.M56, self.M56), "candidates that may not")
+        a.op("s_cbranch_scc1 %s" % lab("exact"))
+        a.op("v_cmp_le_f32_e64 %s, %s, %%[tf1]" % (self.M56, self.t_own(c)), "b' >= T_own: the own sphere may be hit")
+        a.op("s_and_b64 %s, %s, vcc" % (self.M56, self.M56))
+        a.op("s_cbranch_scc1 %s" % lab("exact"))
+        enter_group(a, self, c, n)
+        sleep_culled(a, self, c)
+        a.op("s_branch %s" % lab("next"), "every candidate enters, nobody can hit the own sphere: no exact record needed")
+        a.label(lab("exact"))
 
     def own_item_update(self, a, c):
         a.op("s_mov_b64 exec, vcc", "primitive.rs:80-83")
@@ -700,6 +743,8 @@ def primary_copy(P, name, fused):
     # ---------------- somebody's line meets the sphere ----------------
     k.label(lab("hit"))
     hit_entry(k, P)
+    if P.sure_enter and P.filt:
+        P.sure_enter_path(k, c, n, name, lab)
     exact_after_filter(k, P, c, lab, P.primary_terms)
     kind_test(k, P, c, lab)
     # BOUND (group.rs:73)
