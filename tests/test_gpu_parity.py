@@ -779,6 +779,23 @@ def test_zero_samples_per_pixel_is_the_references_black_frame(traversal, precisi
     assert not p6.any()
 
 
+def test_python_host_degenerate_options(tmp_path):
+    # render.py, the thin mirror: no samples -> every bucket arrives black (render.rs:219-250); no pixels -> no bucket, a writer that never
+    # gets dirty writes nothing (render.rs:361-363)
+    s, _ = util.scene_pair_default(rta.RT_F32, 4)
+    path = str(tmp_path / "black.tga")
+    w = rta.PPMStdoutRGBABufferWriter(True, path)
+    rta.Renderer.render(rta.RenderOptions(192, 128, 0), s, w, pool=2)
+    w.close()
+    assert open(path, "rb").read() == b"P6\n192 128\n255\n" + bytes(192 * 128 * 3)
+    for wh in ((0, 64), (64, 0)):
+        path = str(tmp_path / "empty.tga")
+        w = rta.PPMStdoutRGBABufferWriter(True, path)
+        rta.Renderer.render(rta.RenderOptions(wh[0], wh[1], 1), s, w)
+        w.close()
+        assert not os.path.exists(path)          # (the Python writer opens its file when it first writes; main.rs creates it before: the CLI test sees it empty)
+
+
 def test_flat_scan_sample_limit():
     s, _ = util.scene_pair_default(rta.RT_F32, 4)
     with pytest.raises(rta.capi.RtError, match="too many samples"):
