@@ -458,9 +458,6 @@ class F32F(F32):
     shadow_subst = (("%[t0]", "v%d" % TT[0]), ("%[t1]", "v%d" % TT[1]), ("%[q]", "%[vy]"), ("%[disc]", "%[vx]"))
 
 
-SPECULATE_EXACT = os.environ.get("RT_GEN_SPECULATE_EXACT", "0") == "1"      # design-time A/B: the exact record requested at the top of the hit path
-
-
 class F64F(F64):
     """f64 PRIMARY walk behind the f32 filter (round 4; the shadow walk of f64 scenes stays the plain F64 loop).  The walk reads the scene's
     FNode stream -- f32 roundings of {vx, vy, vz}, a threshold T for the f32 fma-chain b' on an f32 rounding of the ray direction, skip_off
@@ -515,8 +512,7 @@ class F64F(F64):
         a.op("s_load_dwordx16 %s, %%[base2], %s" % (sp(self.EXACT, 16), tmp), "its exact record")
 
     def primary_terms_after_filter(self, a, c):
-        if not (self.sure_enter and SPECULATE_EXACT):
-            self.fetch_exact(a)
+        self.fetch_exact(a)
         a.op("s_waitcnt lgkmcnt(0)")
         self.primary_terms(a, c)
 
@@ -559,8 +555,6 @@ class F64F(F64):
         b' (1 + 2^-11) < hit.distance (b <= b' + 6 eps |v| <= b' (1 + 2^-11) for b' >= T_in >= 2^-9 |v|: d <= b < hit.distance, the lane
         enters) and b' < T_own (the group's own sphere returns INF), the step is decided by the filter record alone.  Any candidate lane
         that is not sure of all three sends the wave down the exact path.  Counting launches hold both verdicts against the f64 test."""
-        if SPECULATE_EXACT:
-            self.fetch_exact(a)                      # (requested before it is known to be needed: every path waits for lgkmcnt(0) before the next step)
         a.op("s_bitcmp1_b32 %s, 31" % self.item(c), "an ITEM or the END node: the exact path")
         a.op("s_cbranch_scc1 %s" % lab("exact"))
         a.op("v_cmp_le_f32_e64 %s, %s, %%[tf1]" % (self.M54, self.t_in(c)), "b' >= T_in: a finite distance for sure")
