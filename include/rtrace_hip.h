@@ -37,7 +37,8 @@ extern "C" {
 
 typedef enum rt_status {
     RT_OK = 0,
-    RT_ERR_INVALID_ARGUMENT = 1,  /* NULL pointer, n == 0, spp == 0, non-finite / non-positive-radius sphere ...  */
+    RT_ERR_INVALID_ARGUMENT = 1,  /* NULL pointer, n == 0, width or height 0, non-finite / non-positive-radius sphere ... (NOT
+                                     samples_per_pixel == 0: that is the reference's black frame, see rt_options)           */
     RT_ERR_INVALID_REGION = 2,    /* region outside the image or t <= b / r <= l  (reference: assert!/index panic)  */
     RT_ERR_NO_DEVICE = 3,         /* no gfx950 device visible, or device index out of range                        */
     RT_ERR_HIP = 4,               /* a HIP runtime call or kernel launch failed; rt_last_error_message() has detail */
@@ -256,9 +257,10 @@ int rt_abi_version(void);
  *   RT_LAUNCH_SAMPLE_PARALLEL  one thread per SAMPLE + an ordered resolve pass (samples_per_pixel > 1)
  *   RT_LAUNCH_ORDERED          blocks dispatched most-expensive-first from the scene's cost map (else: through the tile table)
  *   RT_LAUNCH_FLAT_PIPELINE    RT_TRAVERSAL_FLAT's wavefront pipeline
- *   RT_LAUNCH_COUNTING         the counting flavour of the kernels (the call asked for rt_stats) */
+ *   RT_LAUNCH_COUNTING         the counting flavour of the kernels (the call asked for rt_stats)
+ *   RT_LAUNCH_FAST_KERNEL      the single-pass kernel of steady-state frames (f32, one sample per pixel, ordered: k_render_skip_fast) */
 enum { RT_LAUNCH_TWO_RAYS = 1u, RT_LAUNCH_COOPERATIVE = 2u, RT_LAUNCH_SAMPLE_PARALLEL = 4u, RT_LAUNCH_ORDERED = 8u, RT_LAUNCH_FLAT_PIPELINE = 16u,
-       RT_LAUNCH_COUNTING = 32u };
+       RT_LAUNCH_COUNTING = 32u, RT_LAUNCH_FAST_KERNEL = 64u };
 uint32_t rt_last_launch_flags(void);
 
 /* The toolchain this library was built with, e.g. "hipcc: HIP version: 7.2.x ... | clang ... | kernels <sha1 of the kernel sources>"

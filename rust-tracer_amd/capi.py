@@ -101,7 +101,7 @@ lib.rt_strerror.argtypes = [C.c_int]
 lib.rt_last_error_message.restype = C.c_char_p
 lib.rt_last_launch_flags.restype = C.c_uint32
 lib.rt_build_info.restype = C.c_char_p
-RT_LAUNCH_TWO_RAYS, RT_LAUNCH_COOPERATIVE, RT_LAUNCH_SAMPLE_PARALLEL, RT_LAUNCH_ORDERED, RT_LAUNCH_FLAT_PIPELINE, RT_LAUNCH_COUNTING = 1, 2, 4, 8, 16, 32
+RT_LAUNCH_TWO_RAYS, RT_LAUNCH_COOPERATIVE, RT_LAUNCH_SAMPLE_PARALLEL, RT_LAUNCH_ORDERED, RT_LAUNCH_FLAT_PIPELINE, RT_LAUNCH_COUNTING, RT_LAUNCH_FAST_KERNEL = 1, 2, 4, 8, 16, 32, 64
 HAVE_TEST_HOOKS = hasattr(lib, "rt_debug_set")
 
 if lib.rt_abi_version() != ABI_VERSION:
@@ -126,7 +126,7 @@ def last_launch():
     """rt_last_launch_flags of the calling thread as a set of names."""
     f = lib.rt_last_launch_flags()
     names = (("two_rays", RT_LAUNCH_TWO_RAYS), ("cooperative", RT_LAUNCH_COOPERATIVE), ("sample_parallel", RT_LAUNCH_SAMPLE_PARALLEL),
-             ("ordered", RT_LAUNCH_ORDERED), ("flat_pipeline", RT_LAUNCH_FLAT_PIPELINE), ("counting", RT_LAUNCH_COUNTING))
+             ("ordered", RT_LAUNCH_ORDERED), ("flat_pipeline", RT_LAUNCH_FLAT_PIPELINE), ("counting", RT_LAUNCH_COUNTING), ("fast_kernel", RT_LAUNCH_FAST_KERNEL))
     return {n for n, bit in names if f & bit}
 
 
@@ -177,7 +177,8 @@ def selftest_rcp(device=0):
 # ---- csrc/rt_debug.h: diagnostic controls (not part of the drop-in ABI; the library reads no environment variable) ----
 (DEBUG_SKIP_VARIANT, DEBUG_BLOCK_ORDER, DEBUG_NARROW_MAX, DEBUG_PACKED_SAMPLES, DEBUG_PRINT_STEPS, DEBUG_PRINT_COSTS,
  DEBUG_HOST_COPY, DEBUG_COALESCE, DEBUG_LDS_BYTES, DEBUG_WG_POLICY, DEBUG_NARROW_L2, DEBUG_FLAT_KERNELS, DEBUG_SKIP_RAYS,
- DEBUG_FRAME_AHEAD, DEBUG_FILTER_RO_PERCENT, DEBUG_COOP, DEBUG_COOP_THR, DEBUG_COOP_MAX, DEBUG_COOP_LEVEL, DEBUG_COOP_REST, DEBUG_ASYNC_ORDERS) = range(21)
+ DEBUG_FRAME_AHEAD, DEBUG_FILTER_RO_PERCENT, DEBUG_COOP, DEBUG_COOP_THR, DEBUG_COOP_MAX, DEBUG_COOP_LEVEL, DEBUG_COOP_REST, DEBUG_ASYNC_ORDERS,
+ DEBUG_FAST_KERNEL) = range(22)
 if HAVE_TEST_HOOKS:
     lib.rt_debug_set.argtypes = [C.c_int, C.c_longlong]
     lib.rt_debug_wave_trace.argtypes = [C.c_char_p]

@@ -170,6 +170,13 @@ void PPMStdoutRGBABufferWriter::write_buffer_with_header()
     if (!width_ || !height_) throw std::runtime_error("begin() called");
     const uint8_t *file_image = pixels_ - header_len_;            // header + pixels, contiguous
     if (!out_.is_file) {
+        // a device-delivered frame is never zeroed (buckets_arrived): if it stopped short -- a failed batch, then this Drop write -- the rows
+        // that did not arrive completely are memory nobody wrote (a reused image: the previous frame's rows); they read as zeros, like rows
+        // no bucket has reached on the other path
+        if (zero_pending_ && complete_rows_ < *height_) {
+            const size_t pitch = (size_t)*width_ * (rgb_ ? 3 : 1), have = std::min(pixel_bytes_, (size_t)complete_rows_ * pitch);
+            memset(pixels_ + have, 0, pixel_bytes_ - have);
+        }
         if (fwrite(file_image, 1, header_len_ + pixel_bytes_, out) != header_len_ + pixel_bytes_) throw std::runtime_error("called `Result::unwrap()` on an `Err` value: write");
         fflush(out);
         buffer_dirty_ = false;

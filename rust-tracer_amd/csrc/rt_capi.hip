@@ -5,6 +5,7 @@
 #include "rt_debug.h"
 #include "rt_kernels.hpp"
 #include "rt_skip.hpp"
+#include "rt_skip_fast.hpp"
 #include "rt_skip2.hpp"
 #include "rt_flat.hpp"
 #include "rt_flat_wf.hpp"
@@ -91,6 +92,7 @@ struct Context {
     rt::TileDev *d_tiles[2] = { nullptr, nullptr };
     rt::TileDev *h_tiles[2] = { nullptr, nullptr };
     size_t tiles_cap[2] = { 0, 0 };
+    bool tiles_live[2] = { false, false };   // the slot was uploaded through during the current lease: what this context enqueued may still read it (upload_tiles)
     rt::Counters *d_counters = nullptr;
     uint8_t *d_out = nullptr;
     size_t out_cap = 0;
@@ -239,7 +241,7 @@ rt_status acquire(rt_scene *s, Context **out)
                 if (hipEventQuery(c->ev1) != hipSuccess) { (void)hipGetLastError(); continue; }
                 c->inflight = false;
             }
-            c->busy = true; *out = c.get(); return RT_OK;
+            c->busy = true; c->tiles_live[0] = c->tiles_live[1] = false; *out = c.get(); return RT_OK;
         }
         // A caller that keeps enqueuing asynchronous passes without ever synchronising must not grow the pool (and its
         // per-sample buffers) without bound: past kMaxAsyncContexts, take the oldest pass still in flight and wait for it
@@ -254,6 +256,7 @@ rt_status acquire(rt_scene *s, Context **out)
         hipError_t e = hipEventSynchronize(victim->ev1);
         if (e != hipSuccess) { release(s, victim, true); return hip_fail(e, "hipEventSynchronize(context)", __LINE__); }
         victim->inflight = false;
+        victim->tiles_live[0] = victim->tiles_live[1] = false;
         *out = victim;
         return RT_OK;
     }
@@ -445,6 +448,19 @@ rt::SkipView<T> skip_view_of(const rt_scene *s)
     v.fc = static_cast<const rt::FilterConsts *>(s->d_fc);
     return v;
 }
+
+// The one argument of the render kernels (rt_skip.hpp SkipArgs: what a wave needs first lies first).
+template <typename T>
+rt::SkipArgs<T> skip_args(const rt_scene *s, const rt::BlockDesc *order, const uint32_t *wg_first, unsigned w, unsigned h, unsigned frame_w, uint8_t *out,
+                          const rt::TileDev *tiles, unsigned n_tiles, unsigned spp, rt::Counters *counters, uint32_t *lane_cost, rt::SampleBuf<T> sb,
+                          rt::CoopView cv = rt::CoopView{}, const uint64_t *holes = nullptr, unsigned n_holes = 0)
+{
+    rt::SkipArgs<T> a{};
+    a.order = order; a.wg_first = wg_first; a.width = w; a.height = h; a.frame_w = frame_w; a.out = out; a.tiles = tiles; a.n_tiles = n_tiles;
+    a.spp_arg = spp; a.sc = skip_view_of<T>(s); a.counters = counters; a.lane_cost = lane_cost; a.holes = holes; a.n_holes = n_holes; a.sb = sb; a.cv = cv;
+    return a;
+}
+
 
 // Constants of the filtered loops' shadow bounds (rt_skip.hpp FilterConsts, shadow_filter_bounds; derivation in DESIGN.md 4.1).
 // eps = 2^-24, eta = | |l|^2 - 1 | for the f32 shadow direction l, Rc = max |c - m0| over every node centre, Ro = the radius around
@@ -748,6 +764,15 @@ constexpr size_t kZeroCopyTableTiles = 2;
 rt_status upload_tiles(Context *c, const std::vector<rt::TileDev> &tab, hipStream_t stream, int slot, const rt::TileDev **out)
 {
     const size_t tab_bytes = tab.size() * sizeof(rt::TileDev);
+    // A second table through the same slot within one lease (the batches of rt_render_tiles_stream / rt_render_frame_stream once the scene's
+    // table cache is full): the copy queued for the previous batch may not have read the pinned staging yet, and that batch's kernels --
+    // on either of the context's streams -- may still be reading the device copy.  Rare and slow on purpose: wait for all of it.
+    if (c->tiles_live[slot]) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c->stream && c->stream != stream) HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->stream2 && c->stream2 != stream) HIP_TRY(hipStreamSynchronize(c->stream2));
+    }
+    c->tiles_live[slot] = true;
     if (c->tiles_cap[slot] < tab.size()) {
         if (c->d_tiles[slot]) HIP_TRY(hipFree(c->d_tiles[slot]));
         if (c->h_tiles[slot]) HIP_TRY(hipHostFree(c->h_tiles[slot]));
@@ -795,7 +820,7 @@ rt_status start_cost_map(rt_scene *s)
     HIP_TRY(hipMemsetAsync(d_cost, 0, kPx + kCnt, stream));
     rt::SampleBuf<T> sb{ nullptr, nullptr, R * R };
     hipLaunchKernelGGL((rt::k_render_skip<T, true, 1, rt::kSkipLoop>), dim3((R / rt::kBlockW) * (R / rt::kBlockH)), dim3(rt::kBlockThreads), 0, stream,
-                       skip_view_of<T>(s), R, R, 1u, d_tile, 1u, d_out, d_cnt, sb, 0u, (const rt::BlockDesc *)nullptr, d_cost, (const uint32_t *)nullptr);
+                       skip_args<T>(s, nullptr, nullptr, R, R, 0u, d_out, d_tile, 1u, 1u, d_cnt, d_cost, sb));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(s->h_cost, d_cost, kPx, hipMemcpyDeviceToHost, stream));
     s->cost_started = true;
@@ -1523,7 +1548,7 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
 #endif
     const char *trace_path = trace_file.empty() ? nullptr : trace_file.c_str();
     const dim3 rgrid(order.d ? (order.wg_first ? order.n_wg : order.n) : grid.x);      // render workgroups: one per descriptor, or dealt
-    const size_t trace_words = (size_t)(order.d ? order.n : grid.x) * 4 * 4 * (use_split(spp) ? (size_t)spp * spp : 1);
+    const size_t trace_words = (size_t)(order.d ? order.n : grid.x) * 4 * 8 * (use_split(spp) ? (size_t)spp * spp : 1);
     struct Trace {
         uint32_t *d = nullptr; const char *path; size_t words; hipStream_t stream;
         ~Trace()
@@ -1554,17 +1579,36 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
         if constexpr (!COUNT && sizeof(T) == 4 && (VAR == 19 || VAR == 23 || VAR == 31)) {
             if (spp == 1 && order.d && order.holes && !order.wg_first) {        // some quads of the pass are walked cooperatively (rt_coop.hpp)
                 count_event(RT_DEBUG_COUNT_COOP_LAUNCHES); g_launch_flags |= RT_LAUNCH_COOPERATIVE;
-                hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipOne, true>()), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
-                                   frame_w, order.d, no_cost, order.wg_first, s->coop, order.holes, order.n_holes);
+                hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipOne, true>()), rgrid, b, lds, stream, 
+                                   skip_args<T>(s, order.d, order.wg_first, w, h, frame_w, d_out, d_tab, nt, spp, cnt, no_cost, sb, s->coop, order.holes, order.n_holes));
+                return RT_OK;
+            }
+        }
+        // Steady-state frames -- f32, one sample per pixel, a dispatch list, the filtered assembly loops -- run the kernel that was written
+        // around a wave's fixed costs (rt_skip_fast.hpp); everything else the generic one.
+        if constexpr (!COUNT && sizeof(T) == 4 && ((VAR & ~8) == 19 || (VAR & ~8) == 23)) {
+            if (spp == 1 && order.d && !order.wg_first && !order.holes && lds == 0 && knob(RT_DEBUG_FAST_KERNEL) != 0) {
+                rt::FastArgs fa{};
+                const rt::SkipView<float> sv = skip_view_of<float>(s);
+                constexpr bool kFused = (VAR & 4) != 0;
+                fa.order = order.d;
+                fa.walk_prim = kFused ? sv.xfprim : sv.xprim;
+                fa.width = w; fa.height = h; fa.nb = (kFused ? sv.n_fnodes : sv.n_nodes) * (unsigned)sizeof(rt::Node<float>); fa.frame_w = frame_w; fa.out = d_out;
+                fa.eye[0] = sv.eye.x; fa.eye[1] = sv.eye.y; fa.eye[2] = sv.eye.z; fa.light[0] = sv.light.x; fa.light[1] = sv.light.y; fa.light[2] = sv.light.z;
+                fa.items = sv.items; fa.own = sv.xown; fa.walk_shad = kFused ? sv.xfshad : sv.xshad; fa.exact_shad = kFused ? sv.fshad : sv.shad;
+                memcpy(fa.fc, &s->fc, sizeof fa.fc);
+                fa.trace = no_cost;
+                g_launch_flags |= RT_LAUNCH_FAST_KERNEL;
+                hipLaunchKernelGGL((rt::k_render_skip_fast<(VAR & ~8), (VAR & 8) != 0>), rgrid, b, 0, stream, fa);
                 return RT_OK;
             }
         }
         if (spp == 1)
-            hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipOne>()), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
-                               frame_w, order.d, no_cost, order.wg_first, rt::CoopView{}, (const uint64_t *)nullptr, 0u);
+            hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipOne>()), rgrid, b, lds, stream, 
+                               skip_args<T>(s, order.d, order.wg_first, w, h, frame_w, d_out, d_tab, nt, spp, cnt, no_cost, sb));
         else
-            hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipLoop>()), rgrid, b, lds, stream, skip_view_of<T>(s), w, h, spp, d_tab, nt, d_out, cnt, sb,
-                               frame_w, order.d, no_cost, order.wg_first, rt::CoopView{}, (const uint64_t *)nullptr, 0u);
+            hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipLoop>()), rgrid, b, lds, stream, 
+                               skip_args<T>(s, order.d, order.wg_first, w, h, frame_w, d_out, d_tab, nt, spp, cnt, no_cost, sb));
         return RT_OK;
     }
     const size_t ns = (size_t)spp * spp;
@@ -1586,11 +1630,11 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     }
     if (done2) {
     } else if (packed)
-        hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipPacked>()), dim3(rgrid.x, (unsigned)ns), b, lds, stream, skip_view_of<T>(s), w, h, spp,
-                           d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost, order.wg_first, rt::CoopView{}, (const uint64_t *)nullptr, 0u);
+        hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipPacked>()), dim3(rgrid.x, (unsigned)ns), b, lds, stream, 
+                           skip_args<T>(s, order.d, order.wg_first, w, h, frame_w, d_out, d_tab, nt, spp, cnt, no_cost, sb));
     else
-        hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipSplit>()), dim3(rgrid.x, (unsigned)ns), b, lds, stream, skip_view_of<T>(s), w, h, spp,
-                           d_tab, nt, d_out, cnt, sb, frame_w, order.d, no_cost, order.wg_first, rt::CoopView{}, (const uint64_t *)nullptr, 0u);
+        hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipSplit>()), dim3(rgrid.x, (unsigned)ns), b, lds, stream, 
+                           skip_args<T>(s, order.d, order.wg_first, w, h, frame_w, d_out, d_tab, nt, spp, cnt, no_cost, sb));
     HIP_TRY(hipGetLastError());
     if constexpr (sizeof(T) == 4) {
         if (packed) {        // one word per sample, [pixel][sample] (rt_kernels.hpp sample_word)
@@ -1665,7 +1709,14 @@ rt_status ensure_flat(rt_scene *s)
     if (s->flat_ready) return RT_OK;
     HIP_TRY(hipSetDevice(s->device));
     rt_status st = s->precision == RT_F32 ? upload_flat<float>(s, s->h_items.data()) : upload_flat<double>(s, s->h_items.data());
-    if (st != RT_OK) return st;
+    if (st != RT_OK) {
+        // a later call tries again from nothing: what this attempt had already allocated goes back (nothing was launched against it
+        // that has not been waited for: the failing call was an allocation, a launch or the synchronise itself)
+        (void)hipDeviceSynchronize(); (void)hipGetLastError();
+        for (void **p : { &s->d_fprim, &s->d_fprim_rr, &s->d_fshad, &s->d_pf, &s->d_pe, &s->d_sg, &s->d_se, &s->d_f64_pf, &s->d_f64_sf, &s->d_f64_sg })
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+        return st;
+    }
     s->flat_ready = true;
     std::vector<unsigned char>().swap(s->h_items);
     return RT_OK;
@@ -1727,17 +1778,20 @@ rt_status launch_render(rt_scene *s, Context *c, const rt_options *o, rt_travers
 // (tile-major) or the whole frame (frame_w != 0).
 rt_status enqueue_pass(rt_scene *s, Context *c, const rt_options *o, rt_traversal trav, const std::vector<rt::TileDev> &tab,
                        uint32_t total_blocks, uint64_t total_px, uint8_t *d_out, unsigned frame_w, hipStream_t stream, bool want_counters,
-                       const std::vector<rt::TileDev> *tab16 = nullptr, uint32_t blocks16 = 0, bool cacheable = true)
+                       const std::vector<rt::TileDev> *tab16 = nullptr, uint32_t blocks16 = 0, bool cacheable = true,
+                       const rt::TileDev **d_tab_out = nullptr)       // the device copy of `tab` the pass was launched with
 {
     const rt::TileDev *d_tab = nullptr, *d_tab16 = nullptr;
     rt::BlockList order;
     {
-        rt_status ust = trav == RT_TRAVERSAL_SKIP ? device_table(s, c, tab, stream, &d_tab, 0, o, &order, cacheable, !want_counters)
+        // (will_be_timed: launch_render records the trial's event pair -- a pass without samples launches nothing and records none)
+        rt_status ust = trav == RT_TRAVERSAL_SKIP ? device_table(s, c, tab, stream, &d_tab, 0, o, &order, cacheable, !want_counters && o->samples_per_pixel != 0)
                                                   : device_table(s, c, tab, stream, &d_tab, 0, nullptr, nullptr, cacheable);
         if (ust != RT_OK) return ust;
         if (tab16) {
             if ((ust = device_table(s, c, *tab16, stream, &d_tab16, 1, nullptr, nullptr, cacheable)) != RT_OK) return ust;
         }
+        if (d_tab_out) *d_tab_out = d_tab;
     }
     if (want_counters) {
         HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(rt::Counters) * rt::kCounterStripes, stream));
@@ -2076,7 +2130,7 @@ static rt_status render_device(rt_scene *s, const rt_options *o, rt_traversal tr
         // Fast path: a cached tile table and no per-call device state -> the call enqueues exactly one kernel.
         const rt::TileDev *d_tab = nullptr;
         rt::BlockList order;
-        if ((st = device_table(s, nullptr, tab, stream, &d_tab, 0, o, &order, true, trav == RT_TRAVERSAL_SKIP)) != RT_OK) return st;
+        if ((st = device_table(s, nullptr, tab, stream, &d_tab, 0, o, &order, true, trav == RT_TRAVERSAL_SKIP && o->samples_per_pixel != 0)) != RT_OK) return st;
         if (d_tab)
             return launch_render(s, nullptr, o, trav, d_tab, (unsigned)tab.size(), total_blocks, total_px, out, frame_w, stream, nullptr, nullptr, 0, order);
     }
@@ -2426,10 +2480,13 @@ rt_status rt_render_frame_stream(rt_scene *s, const rt_options *o, rt_traversal 
     auto drain = [&](rt_status code) { (void)hipStreamSynchronize(c->stream); if (c->stream2) (void)hipStreamSynchronize(c->stream2); (void)hipGetLastError(); return code; };   // nothing may still be writing the frame
     for (uint32_t k = 0; k < n_batches; ++k) {
         Batch &b = batches[k];
-        st = enqueue_pass(s, c, o, trav, b.tab, b.blocks, b.px, c->d_out + b.byte_off, 0u, c->stream, false, flat2 ? &b.tab16 : nullptr, b.blocks16, true);
-        if (st != RT_OK) return drain(st);
+        // the encode reads the very table the batch was rendered with (looking it up again could upload it a second time, unordered with
+        // the encode: ADVICE r5); a table that is NOT the scene's immutable cached copy -- the cache is full, it went through the context's
+        // one upload slot -- is only safe in stream order, so such a batch is encoded on the render stream
         const rt::TileDev *d_tab = nullptr;
-        if ((st = device_table(s, c, b.tab, c->stream, &d_tab)) != RT_OK) return drain(st);
+        st = enqueue_pass(s, c, o, trav, b.tab, b.blocks, b.px, c->d_out + b.byte_off, 0u, c->stream, false, flat2 ? &b.tab16 : nullptr, b.blocks16, true, &d_tab);
+        if (st != RT_OK) return drain(st);
+        if (c->tiles_live[0]) enc = c->stream;
         if (enc != c->stream) {                                      // (enqueue_pass recorded ev1 behind the batch's kernels)
             const hipError_t we = hipStreamWaitEvent(enc, c->ev1, 0);
             if (we != hipSuccess) return drain(hip_fail(we, "rt_render_frame_stream(wait)", __LINE__));

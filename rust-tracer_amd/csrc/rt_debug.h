@@ -54,7 +54,9 @@ typedef enum rt_debug_key {
     RT_DEBUG_ASYNC_ORDERS = 20,  /* 0: the dispatch orders of a tile list (and the scene's cost map) are made by the first call that uses the list, as they are
                                     whenever another dispatch control here is set; default: by a background thread, the first launches finding their blocks
                                     through the tile table */
-    RT_DEBUG_KEYS = 21
+    RT_DEBUG_FAST_KERNEL = 21,   /* 0: steady-state frames (f32, one sample per pixel, a dispatch list) run the generic k_render_skip_f32 instead of
+                                    k_render_skip_fast (rt_skip_fast.hpp; A/B and parity: both must render the same bytes).  Default 1 */
+    RT_DEBUG_KEYS = 22
 } rt_debug_key;
 
 /* value < 0 restores the default. */

@@ -28,6 +28,17 @@ struct BlockDesc {
     uint32_t pitch, base;
 };
 static_assert(sizeof(BlockDesc) == 16, "one s_load_dwordx4");
+// Descriptor i of a dispatch list (i wave-uniform) as ONE scalar load.  Left to itself the compiler fetches the two 16-bit clip edges with
+// per-lane global_load_ushort -- they are compared with per-lane coordinates -- and every wave then starts with a vector-memory round trip
+// on top of the scalar ones: part of the 1.4 us a wave spent before its first ray (round 6, tools/wave_timeline.py "prologue").
+__device__ __forceinline__ BlockDesc load_block_desc(const BlockDesc *__restrict__ list, unsigned i)
+{
+    const uint4 raw = *reinterpret_cast<const uint4 *>(list + i);
+    BlockDesc d;
+    d.x0 = (uint16_t)(raw.x & 0xFFFFu); d.y0 = (uint16_t)(raw.x >> 16); d.r = (uint16_t)(raw.y & 0xFFFFu); d.t = (uint16_t)(raw.y >> 16);
+    d.pitch = raw.z; d.base = raw.w;
+    return d;
+}
 // Narrow blocks (pitch >> 16 = level; a tile is at most 65,535 wide): at level 1 the descriptor covers an 8x8 quadrant of
 // a block and each of the workgroup's four waves traces a 4x4 patch with 16 live lanes.  A wave walks the union of its rays'
 // nodes and the pass is as long as its longest wave, so the few most expensive blocks are dealt out as four such workgroups

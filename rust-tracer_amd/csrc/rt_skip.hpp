@@ -391,6 +391,24 @@ __device__ __forceinline__ int shadow_filter_verdict(const FNodeS &f, const Filt
     return (av <= -fc.a0 && __builtin_fabsf(f.r2o) <= fc.kc * inn) ? 0 : 1;      // behind the origin, origin outside: t2 < 0
 }
 
+// ---- The kernels' one argument (round 6) ----------------------------------------------------------------------------------------------
+// What a wave needs first lies first: the dispatch list, the frame, then the SkipView -- the compiler fetches kernel arguments in
+// instalments, in the order of their first uses, and every instalment is a scalar-memory round trip of a wave that has not started yet
+// (tools/wave_timeline.py "prologue").  Steady-state frames do not run these kernels at all but k_render_skip_fast (rt_skip_fast.hpp), which
+// was written around that prologue; these serve every other mode.
+template <typename T> struct SkipArgs {
+    const BlockDesc *order; const uint32_t *wg_first;
+    unsigned width, height, frame_w, spp_arg;
+    uint8_t *out; const TileDev *tiles;
+    unsigned n_tiles, pad_;
+    SkipView<T> sc;
+    Counters *counters; uint32_t *lane_cost; const uint64_t *holes; unsigned n_holes; SampleBuf<T> sb; CoopView cv;
+};
+typedef unsigned rt_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned rt_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned rt_u32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned rt_u32x16 __attribute__((ext_vector_type(16)));
+
 // VAR bits (all bit-identical in output and counters):
 //   1 = sqrt_rn_lean in the C++ loops (same value as the IEEE sqrt for every input, about half the instructions)
 //   2 = (launches that do not count tests) the generated assembly traversal loops, rt_skip_rot.hpp
@@ -420,12 +438,12 @@ enum { kSkipLoop = 0, kSkipSplit = 1, kSkipOne = 2, kSkipPacked = 3 };
 //   otherwise; the rays the cooperative walk hands back (rt_coop.hpp: `failed`) are walked by the loops.  The 16x16 block those quads
 //   belong to is descriptor di < n_holes of the same list (or its four quarters, level 1), and holes[di] tells its own waves which 2x2-pixel quads to leave out.
 template <typename T, bool COUNT, int VAR, int MODE, bool COOP>
-__device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width, unsigned height, unsigned spp_arg,
-                                                 const TileDev *__restrict__ tiles, unsigned n_tiles,
-                                                 uint8_t *__restrict__ out, Counters *__restrict__ counters,
-                                                 SampleBuf<T> sb, unsigned frame_w,
-                                                 const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost,
-                                                 const uint32_t *__restrict__ wg_first, CoopView cv, const uint64_t *__restrict__ holes, unsigned n_holes)
+__device__ __forceinline__ void render_skip_body(const BlockDesc *__restrict__ order, const uint32_t *__restrict__ wg_first,
+                                                 unsigned width, unsigned height, unsigned frame_w, uint8_t *__restrict__ out,
+                                                 const TileDev *__restrict__ tiles, unsigned n_tiles, unsigned spp_arg,
+                                                 Counters *__restrict__ counters, uint32_t *__restrict__ lane_cost,
+                                                 const uint64_t *__restrict__ holes, unsigned n_holes, SampleBuf<T> sb, SkipView<T> sc, CoopView cv,
+                                                 [[maybe_unused]] unsigned long long r_entry)      // (wave trace: the wave's very first instruction)
 {
     constexpr bool PACKED = MODE == kSkipPacked, SPLIT = MODE == kSkipSplit || PACKED, ONE = MODE == kSkipOne;
     static_assert(!COOP || (sizeof(T) == 4 && !COUNT && ONE && (VAR & 2) != 0), "the cooperative walk serves f32 spp-1 passes of the assembly loops");
@@ -443,7 +461,7 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
     unsigned level = 0;             // 0: 8x8 pixels per wave; 1: 4x4 (16 live lanes); 2: 2x2 (4 live lanes); 3: one pixel
     [[maybe_unused]] unsigned coop_mask = 0;
     if (order) {
-        const BlockDesc bd = order[di];
+        const BlockDesc bd = load_block_desc(order, di);
         bx0 = bd.x0; by0 = bd.y0; tile_r = bd.r; tile_t = bd.t; pitch = bd.pitch & 0xFFFFu; base = bd.base;
         level = (bd.pitch >> kBlockNarrowShift) & 3u;
         if constexpr (COOP) coop_mask = (bd.pitch >> kBlockCoopShift) & 15u;
@@ -823,11 +841,17 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
 
     if (trace && lane_cost && lane == 0) {
         const unsigned n_desc = (order && wg_first) ? wg_first[gridDim.x] : gridDim.x;
-        uint32_t *rec = lane_cost + (((size_t)blockIdx.y * n_desc + di) * 4 + wave) * 4;     // in descriptor order
+        // eight words per wave, in descriptor order:
+        // start, end, HW_ID | XCC_ID << 16, descriptor | coop << 31, entry (the wave's first instruction), ack (the pixel store has been
+        // acknowledged: s_endpgm waits for that too, so the slot is held until then), 0, 0
+        uint32_t *rec = lane_cost + (((size_t)blockIdx.y * n_desc + di) * 4 + wave) * 8;
         rec[0] = (uint32_t)r_start;
         rec[1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
         rec[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16);  // HW_ID | XCC_ID << 16
         rec[3] = gblock | (coop_wave ? 0x80000000u : 0u);
+        rec[4] = (uint32_t)r_entry;
+        __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0) expcnt(0) lgkmcnt(0): the pixel store (and the four words above) have landed
+        rec[5] = (uint32_t)__builtin_amdgcn_s_memrealtime();
     }
     if (COUNT) {
         Counters *const stripe = counters + (gblock + blockIdx.y) % kCounterStripes;
@@ -863,15 +887,13 @@ __device__ __forceinline__ void render_skip_body(SkipView<T> sc, unsigned width,
 #define RT_F64_WAVES 7
 #endif
 template <typename T, bool COUNT, int VAR, int MODE, bool COOP = false>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(6))) void k_render_skip(SkipView<T> sc, unsigned width, unsigned height, unsigned spp_arg,
-                                                              const TileDev *__restrict__ tiles, unsigned n_tiles,
-                                                              uint8_t *__restrict__ out, Counters *__restrict__ counters,
-                                                              SampleBuf<T> sb, unsigned frame_w,
-                                                              const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost,
-                                                              const uint32_t *__restrict__ wg_first, CoopView cv = CoopView{},
-                                                              const uint64_t *__restrict__ holes = nullptr, unsigned n_holes = 0)
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(6))) void k_render_skip(SkipArgs<T> args)
 {
-    render_skip_body<T, COUNT, VAR, MODE, COOP>(sc, width, height, spp_arg, tiles, n_tiles, out, counters, sb, frame_w, order, lane_cost, wg_first, cv, holes, n_holes);
+    unsigned long long r_entry = 0;
+    if constexpr (!COUNT && (VAR & 8) != 0) r_entry = __builtin_amdgcn_s_memrealtime();
+    const SkipArgs<T> &a = args;
+    render_skip_body<T, COUNT, VAR, MODE, COOP>(a.order, a.wg_first, a.width, a.height, a.frame_w, a.out, a.tiles, a.n_tiles, a.spp_arg, a.counters, a.lane_cost, a.holes,
+                     a.n_holes, a.sb, a.sc, a.cv, r_entry);
 }
 
 // The same kernel for f32 launches that do not count, held to 74 scalar registers -- 80 with the hardware's six, and 80 is what a CU admits
@@ -884,22 +906,24 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(6
 // wave more per SIMD is a fetch more in flight.  The f64 loops own s[36:97] and cannot live under such a limit, hence kernels of their
 // own rather than an attribute on the template.
 template <bool COUNT, int VAR, int MODE>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(82))) void k_render_skip_f32(
-    SkipView<float> sc, unsigned width, unsigned height, unsigned spp_arg, const TileDev *__restrict__ tiles, unsigned n_tiles, uint8_t *__restrict__ out,
-    Counters *__restrict__ counters, SampleBuf<float> sb, unsigned frame_w, const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost,
-    const uint32_t *__restrict__ wg_first, CoopView cv = CoopView{}, const uint64_t *__restrict__ holes = nullptr, unsigned n_holes = 0)
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(82))) void k_render_skip_f32(SkipArgs<float> args)
 {
-    render_skip_body<float, COUNT, VAR, MODE, false>(sc, width, height, spp_arg, tiles, n_tiles, out, counters, sb, frame_w, order, lane_cost, wg_first, cv, holes, n_holes);
+    unsigned long long r_entry = 0;
+    if constexpr (!COUNT && (VAR & 8) != 0) r_entry = __builtin_amdgcn_s_memrealtime();
+    const SkipArgs<float> &a = args;
+    render_skip_body<float, COUNT, VAR, MODE, false>(a.order, a.wg_first, a.width, a.height, a.frame_w, a.out, a.tiles, a.n_tiles, a.spp_arg, a.counters, a.lane_cost, a.holes,
+                     a.n_holes, a.sb, a.sc, a.cv, r_entry);
 }
 // ... and its flavour with the lane-cooperative walk (rt_coop.hpp), which keeps more state across the loops: at 74 it parks 41 values and
 // the small passes it serves lose 2 % (800x600 28.7 -> 29.4 us); at 94 (7 workgroups per CU) they do not miss the eighth.
 template <bool COUNT, int VAR, int MODE>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(94))) void k_render_skip_f32_coop(
-    SkipView<float> sc, unsigned width, unsigned height, unsigned spp_arg, const TileDev *__restrict__ tiles, unsigned n_tiles, uint8_t *__restrict__ out,
-    Counters *__restrict__ counters, SampleBuf<float> sb, unsigned frame_w, const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost,
-    const uint32_t *__restrict__ wg_first, CoopView cv = CoopView{}, const uint64_t *__restrict__ holes = nullptr, unsigned n_holes = 0)
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(94))) void k_render_skip_f32_coop(SkipArgs<float> args)
 {
-    render_skip_body<float, COUNT, VAR, MODE, true>(sc, width, height, spp_arg, tiles, n_tiles, out, counters, sb, frame_w, order, lane_cost, wg_first, cv, holes, n_holes);
+    unsigned long long r_entry = 0;
+    if constexpr (!COUNT && (VAR & 8) != 0) r_entry = __builtin_amdgcn_s_memrealtime();
+    const SkipArgs<float> &a = args;
+    render_skip_body<float, COUNT, VAR, MODE, true>(a.order, a.wg_first, a.width, a.height, a.frame_w, a.out, a.tiles, a.n_tiles, a.spp_arg, a.counters, a.lane_cost, a.holes,
+                     a.n_holes, a.sb, a.sc, a.cv, r_entry);
 }
 
 // ... and the f64 launches of the FILTERED loops (VAR & 16), whose window ends at s89 (tools/gen_skip_asm.py F64F): 96 scalar registers with the
@@ -907,13 +931,14 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(94)))
 // 389.2, interleaved; the spp-1 flavour parks two doubles in scratch across the primary walk -- 20 bytes, stored and loaded once per ray).
 // LLVM calls s88 and s89 reserved at this limit, as it did s72 and s73 of the f32 kernel at 80: they are below the six the hardware adds.
 template <int VAR, int MODE>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(RT_F64_SGPRS), amdgpu_waves_per_eu(RT_F64_WAVES))) void k_render_skip_f64(
-    SkipView<double> sc, unsigned width, unsigned height, unsigned spp_arg, const TileDev *__restrict__ tiles, unsigned n_tiles, uint8_t *__restrict__ out,
-    Counters *__restrict__ counters, SampleBuf<double> sb, unsigned frame_w, const BlockDesc *__restrict__ order, uint32_t *__restrict__ lane_cost,
-    const uint32_t *__restrict__ wg_first, CoopView cv = CoopView{}, const uint64_t *__restrict__ holes = nullptr, unsigned n_holes = 0)
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(RT_F64_SGPRS), amdgpu_waves_per_eu(RT_F64_WAVES))) void k_render_skip_f64(SkipArgs<double> args)
 {
     static_assert((VAR & 16) != 0 && (VAR & 2) != 0, "the filtered assembly loops");
-    render_skip_body<double, false, VAR, MODE, false>(sc, width, height, spp_arg, tiles, n_tiles, out, counters, sb, frame_w, order, lane_cost, wg_first, cv, holes, n_holes);
+    unsigned long long r_entry = 0;
+    if constexpr ((VAR & 8) != 0) r_entry = __builtin_amdgcn_s_memrealtime();
+    const SkipArgs<double> &a = args;
+    render_skip_body<double, false, VAR, MODE, false>(a.order, a.wg_first, a.width, a.height, a.frame_w, a.out, a.tiles, a.n_tiles, a.spp_arg, a.counters, a.lane_cost, a.holes,
+                     a.n_holes, a.sb, a.sc, a.cv, r_entry);
 }
 
 // Second pass of the SPLIT path: render.rs:233-252 for one pixel -- its samples' contributions accumulated strictly

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kSkip2Threads) __attribute__((amdgpu_num_sgpr(82), 
         unsigned bx0, by0, tile_r, tile_t, pitch, base;
         unsigned level = 0;
         if (order) {
-            const BlockDesc bd = order[di];
+            const BlockDesc bd = load_block_desc(order, di);
             bx0 = bd.x0; by0 = bd.y0; tile_r = bd.r; tile_t = bd.t; pitch = bd.pitch & 0xFFFFu; base = bd.base;
             level = (bd.pitch >> kBlockNarrowShift) & 3u;         // (a cooperative mask in the bits above is ignored: those quads are walked like any other)
         } else {

@@ -19,12 +19,22 @@ if ROOT not in sys.path:
 # for librccl.so): they load tests/c/librtrace_hip_test.so -- the product's sources built with -DRT_TEST_HOOKS -- instead of the product
 # library, which has none of them.  Child processes that must run the PRODUCT (rtrace, bench.py) get an environment without this.
 # (tests/util.py product_env)
-os.environ["RTRACE_HIP_LIBRARY"] = os.path.join(ROOT, "tests", "c", "librtrace_hip_test.so")
+#
+# RTRACE_PARITY_ON_PRODUCT=1 (tests/test_gpu_product.py starts such a child `pytest -m gpu`): this process loads the PRODUCT library instead and
+# runs every test that needs no control -- the library that ships under the same oracle comparisons.  A test that reaches for a control
+# (capi.debug / debug_set / debug_count / the stand-in for librccl.so ...) is SKIPPED at that point; the fixture below then only compares the
+# counting launch with the one that does not count.
+PRODUCT_RUN = os.environ.get("RTRACE_PARITY_ON_PRODUCT") == "1"
+TEST_LIB = os.path.join(ROOT, "tests", "c", "librtrace_hip_test.so")
+if PRODUCT_RUN:
+    os.environ.pop("RTRACE_HIP_LIBRARY", None)
+else:
+    os.environ["RTRACE_HIP_LIBRARY"] = TEST_LIB
 
 
 # The test modules import the package (and the oracle) at module scope, and both need their built libraries: on a fresh
 # checkout (the .so files are git-ignored) build them here, before collection, instead of failing with an ImportError.
-if not (os.path.exists(os.path.join(ROOT, "rust-tracer_amd", "librtrace_hip.so")) and os.path.exists(os.environ["RTRACE_HIP_LIBRARY"]) and
+if not (os.path.exists(os.path.join(ROOT, "rust-tracer_amd", "librtrace_hip.so")) and os.path.exists(TEST_LIB) and
         os.path.exists(os.path.join(ROOT, "oracle", "librt_oracle.so")) and
         os.path.exists(os.path.join(ROOT, "rust-tracer_amd", "rtrace"))):
     import __graft_entry__
@@ -35,6 +45,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if PRODUCT_RUN:
+        import rust_tracer_amd as rta
+        assert rta.capi.LIB_PATH == rta.capi.PRODUCT_LIB_PATH and not rta.capi.HAVE_TEST_HOOKS, "RTRACE_PARITY_ON_PRODUCT: the product library did not load"
+
+        def needs_hooks(what):
+            pytest.skip("needs a control of csrc/rt_debug.h (%s): not in the library that ships" % what)
+        rta.capi._need_hooks = needs_hooks
 
 
 @pytest.fixture(scope="session")
@@ -53,6 +70,26 @@ def _check_both_launch_flavours(request, monkeypatch):
     import numpy as np
     import rust_tracer_amd as rta
     orig = rta.DeviceScene.render_tiles
+    if PRODUCT_RUN:
+        def both_product(self, options, regions, traversal=None, want_stats=True, out=None):
+            import time
+            data, st = orig(self, options, regions, traversal, want_stats, out)
+            if want_stats:
+                plain, _ = orig(self, options, regions, traversal, False)
+                assert np.array_equal(plain, data), "the launch without counters renders different bytes"
+                if options[2] == 1 and traversal in (None, rta.RT_TRAVERSAL_SKIP):
+                    # the library makes a new tile list's dispatch orders in the background (a few ms): the launches above found their blocks
+                    # through the tile table.  Once more when the orders are there -- f32: k_render_skip_fast, what a scheduler's frames run
+                    for _ in range(100):
+                        again, _ = orig(self, options, regions, traversal, False)
+                        assert np.array_equal(again, data), "a later launch of the same list renders different bytes (%r)" % (rta.capi.last_launch(),)
+                        if "ordered" in rta.capi.last_launch():
+                            break
+                        time.sleep(0.002)
+            return data, st
+        monkeypatch.setattr(rta.DeviceScene, "render_tiles", both_product)
+        yield
+        return
     # the dispatch orders of a tile list are normally made by a background thread while the first launches walk the tile table
     # (rt_capi.hip build_orders_async); the tests want the ordered / narrowed / cooperative dispatch in the very launch they look at
     rta.capi.debug_set(rta.capi.DEBUG_ASYNC_ORDERS, 0)
@@ -68,6 +105,10 @@ def _check_both_launch_flavours(request, monkeypatch):
                 with rta.capi.debug(rta.capi.DEBUG_COOP, 2):
                     coop, _ = orig(self, options, regions, traversal, False)
                 assert np.array_equal(coop, data), "the lane-cooperative walk renders different bytes"
+                # ... and with the generic kernel where `plain` ran k_render_skip_fast (rt_skip_fast.hpp: f32, a dispatch list)
+                with rta.capi.debug(rta.capi.DEBUG_FAST_KERNEL, 0):
+                    generic, _ = orig(self, options, regions, traversal, False)
+                assert np.array_equal(generic, data), "k_render_skip_f32 and k_render_skip_fast render different bytes"
         return data, st
 
     monkeypatch.setattr(rta.DeviceScene, "render_tiles", both)

@@ -25,7 +25,12 @@ def coop_launches():
 
 
 def render(scene, w, h, regs, mode):
-    """mode: 0 never cooperative, 2 every quad, -1 the library's choice."""
+    """mode: 0 never cooperative, 2 every quad, -1 the library's choice.  Returns the bytes and the number of cooperative launches -- None on the
+    library that ships (tests/conftest.py RTRACE_PARITY_ON_PRODUCT: no control, no counter): there the frame is rendered as the library
+    chooses, twice (the second launch finds the dispatch orders the first one ordered), and still has to be the oracle's."""
+    if not rta.capi.HAVE_TEST_HOOKS:
+        data, _ = scene.device().render_tiles((w, h, 1), regs, SKIP, want_stats=True)
+        return data, None
     with rta.capi.debug(rta.capi.DEBUG_COOP, mode):
         before = coop_launches()
         data, _ = scene.device().render_tiles((w, h, 1), regs, SKIP, want_stats=False)
@@ -51,7 +56,7 @@ def test_baseline_frames_forced_and_by_default(name):
     for mode, expect_coop in ((2, True), (1, name == "config2_800x600"), (0, False)):
         s = rta.Scene.default()
         data, n = render(s, w, h, regs, mode)
-        assert (n > 0) == expect_coop, (mode, n)
+        assert n is None or (n > 0) == expect_coop, (mode, n)
         assert tile_crcs(data, regs) == case["tile_crc32"], (name, mode)
 
 
@@ -164,7 +169,7 @@ def test_level9_pyramid_and_ragged_tiles():
     w, h = 1280, 720
     regs = [(x, y + 50, x + 50, y) for y in range(280, 480, 50) for x in range(560, 760, 50)]
     data, n = render(s, w, h, regs, 2)
-    assert n > 0
+    assert n is None or n > 0
     off = 0
     for (l, t, r, b) in regs:
         ref, _ = o.render_region(w, h, 1, l, t, r, b, HIER_EXIT)
@@ -188,7 +193,7 @@ def test_random_nested_scenes(seed):
     regs = bucket_list(w, h)
     ref, _, _ = o.render(w, h, 1, os.cpu_count() or 1, HIER_EXIT)
     data, n = render(s, w, h, regs, 2)
-    assert n > 0
+    assert n is None or n > 0
     np.testing.assert_array_equal(util.stitch((w, h), regs, data), ref)
 
 
@@ -205,7 +210,7 @@ def test_scaled_scenes(scale):
         ref, rst, _ = o.render(w, h, 1, os.cpu_count() or 1, HIER_EXIT)
         assert rst["hits"] > 500 and rst["shadow"] > 100
         data, n = render(s, w, h, regs, 2)
-        assert n > 0
+        assert n is None or n > 0
         np.testing.assert_array_equal(util.stitch((w, h), regs, data), ref)
 
 
@@ -218,13 +223,13 @@ def test_inside_bound_quirk_and_tie_break():
     flat, _ = o.render_region(64, 64, 1, 0, 64, 64, 0, oracle.MODE_FLAT)
     assert not np.array_equal(ref, flat)
     data, n = render(s, 64, 64, regs, 2)
-    assert n > 0
+    assert n is None or n > 0
     np.testing.assert_array_equal(data.reshape(64, 64, 4), ref)
     # two spheres hit at exactly the same f32 distance: the first in DFS order keeps the hit (primitive.rs:79, strict <)
     s, o = util.scene_pair_spheres(util.TIE_SPHERES, util.TIE_BOUND)
     ref, _ = o.render_region(64, 64, 1, 0, 64, 64, 0, HIER_EXIT)
     data, n = render(s, 64, 64, regs, 2)
-    assert n > 0
+    assert n is None or n > 0
     np.testing.assert_array_equal(data.reshape(64, 64, 4), ref)
 
 
@@ -251,7 +256,7 @@ def test_work_list_overflow_goes_back_to_the_loops():
     ref, rst, _ = o.render(w, h, 1, os.cpu_count() or 1, HIER_EXIT)
     assert rst["hits"] > 100
     data, n = render(s, w, h, regs, 2)
-    assert n > 0
+    assert n is None or n > 0
     np.testing.assert_array_equal(util.stitch((w, h), regs, data), ref)
 
 
@@ -264,7 +269,7 @@ def test_scenes_without_a_cooperative_copy_render_as_before():
     regs = bucket_list(96, 64)
     ref, _, _ = o.render(96, 64, 1, os.cpu_count() or 1, HIER_EXIT)
     data, n = render(s, 96, 64, regs, 2)
-    assert n == 0
+    assert n is None or n == 0
     np.testing.assert_array_equal(util.stitch((96, 64), regs, data), ref)
 
 
@@ -276,5 +281,5 @@ def test_100k_spheres_automatic_hierarchy():
     regs = bucket_list(w, h)
     ref, _, _ = o.render(w, h, 1, os.cpu_count() or 1, HIER_EXIT)
     data, n = render(s, w, h, regs, 2)
-    assert n > 0
+    assert n is None or n > 0
     np.testing.assert_array_equal(util.stitch((w, h), regs, data), ref)

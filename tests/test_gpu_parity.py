@@ -619,7 +619,7 @@ def test_every_skip_loop_flavour_on_deep_random_scenes(variant, concentric, prec
     assert s.device().traits() == rta.capi.RT_SCENE_HAS_BOUNDS | (rta.capi.RT_SCENE_CONCENTRIC if concentric else 0)
     regs = bucket_list(192, 160, 2)
     ref, rst, _ = o.render(192, 160, 2, os.cpu_count() or 1, HIER_EXIT)
-    with rta.capi.debug(rta.capi.DEBUG_SKIP_VARIANT, variant):
+    with util.loop_flavour(variant):
         plain, _ = s.device().render_tiles((192, 160, 2), regs, SKIP, want_stats=False)
         counted, st = s.device().render_tiles((192, 160, 2), regs, SKIP, want_stats=True)
     np.testing.assert_array_equal(util.stitch((192, 160), regs, plain), ref)
@@ -640,7 +640,7 @@ def test_block_dispatch_order_never_changes_a_pixel(size):
     scrambled = [regs[i] for i in rng.permutation(len(regs))]
     out = {}
     for flag in (b"0", b"1"):
-        with rta.capi.debug(rta.capi.DEBUG_BLOCK_ORDER, int(flag)):
+        with util.control(rta.capi.DEBUG_BLOCK_ORDER, int(flag)):
             a, sa = d.render_tiles((w, h, spp), regs, SKIP, want_stats=True)
             b, _ = d.render_tiles((w, h, spp), scrambled, SKIP, want_stats=False)
         out[flag] = (util.stitch((w, h), regs, a), util.stitch((w, h), scrambled, b), util.all_stats(sa))
@@ -691,7 +691,7 @@ def test_narrow_blocks_on_ragged_tiles(narrow_max):
     s, o = rta.Scene.default(), oracle.Scene.default()      # a fresh device scene: its table cache has not seen this tile list
     w, h = 1920, 1080
     regs = [(x, y + 50, x + 50, y) for y in range(440, 640, 50) for x in range(860, 1060, 50)]
-    with rta.capi.debug(rta.capi.DEBUG_NARROW_MAX, narrow_max):
+    with util.control(rta.capi.DEBUG_NARROW_MAX, narrow_max):
         d = s.device()
         plain, _ = d.render_tiles((w, h, 1), regs, SKIP, want_stats=False)
         counted, st = d.render_tiles((w, h, 1), regs, SKIP, want_stats=True)
@@ -720,7 +720,7 @@ def test_every_sample_count_on_a_ragged_image(spp, precision):
     data, st = s.device().render_tiles((w, h, spp), regs, SKIP)
     np.testing.assert_array_equal(util.stitch((w, h), regs, data), ref)
     assert util.all_stats(st) == util.all_stats(rst)
-    with rta.capi.debug(rta.capi.DEBUG_PACKED_SAMPLES, 0):
+    with util.control(rta.capi.DEBUG_PACKED_SAMPLES, 0):
         plain, _ = s.device().render_tiles((w, h, spp), regs, SKIP, want_stats=False)
     np.testing.assert_array_equal(plain, data)
 
@@ -1106,10 +1106,10 @@ def test_two_rays_per_lane_walk_on_the_default_scene(w, h, spp, level):
     s = rta.Scene.default(level)
     regs = bucket_list(w, h, spp)
     d = s.device()
-    with rta.capi.debug(rta.capi.DEBUG_SKIP_RAYS, 1):
+    with util.control(rta.capi.DEBUG_SKIP_RAYS, 1):
         one, _ = d.render_tiles((w, h, spp), regs, SKIP, want_stats=False)
         one = one.copy()
-    with rta.capi.debug(rta.capi.DEBUG_SKIP_RAYS, 2):
+    with util.control(rta.capi.DEBUG_SKIP_RAYS, 2):
         two, _ = d.render_tiles((w, h, spp), regs, SKIP, want_stats=False)
         two = two.copy()
     auto, _ = d.render_tiles((w, h, spp), regs, SKIP, want_stats=False)
@@ -1134,7 +1134,7 @@ def test_shadow_origins_the_bounds_do_not_cover_run_the_reference_arithmetic(per
             ref, _ = d.render_tiles((w, h, spp), regs, SKIP, want_stats=True)      # also checks the bounds next to every test it makes
             ref = ref.copy()
         for rays in (1, 2):
-            with rta.capi.debug(rta.capi.DEBUG_SKIP_RAYS, rays):
+            with util.control(rta.capi.DEBUG_SKIP_RAYS, rays):
                 got, _ = d.render_tiles((w, h, spp), regs, SKIP, want_stats=False)
             assert np.array_equal(got, ref), (percent, w, h, spp, rays)
     d.close()

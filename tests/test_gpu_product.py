@@ -91,3 +91,27 @@ def test_smoke_runs_on_the_product_library():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=util.product_env())
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     assert "smoke ok" in r.stdout and "librtrace_hip.so" in r.stdout and "librtrace_hip_test" not in r.stdout
+
+
+def test_the_parity_suite_on_the_library_that_ships():
+    """the oracle comparisons of the whole `-m gpu` suite -- fuzz scenes, ragged regions, 2 .. 300 samples per pixel, the
+    tie-break scenes in f32 and f64, zero samples, the largest frame, config 5 at full size -- run once more in a child pytest whose process
+    loads rust-tracer_amd/librtrace_hip.so itself (tests/conftest.py, RTRACE_PARITY_ON_PRODUCT): what ships, not its -DRT_TEST_HOOKS twin.
+    Tests that reach for a control of csrc/rt_debug.h skip themselves there; the rest must pass, and there must be many of them."""
+    import re
+    if os.environ.get("RTRACE_PARITY_ON_PRODUCT") == "1":
+        pytest.skip("this IS the child run")
+    log = os.path.join(ROOT, "gpurun_out", "product_parity.log")
+    os.makedirs(os.path.dirname(log), exist_ok=True)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-v", "-m", "gpu", "-p", "no:cacheprovider", "-rs"],
+                       env=util.product_env(RTRACE_PARITY_ON_PRODUCT="1"), cwd=ROOT, capture_output=True, text=True, timeout=2400)
+    open(log, "w").write(r.stdout + r.stderr)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    assert r.returncode == 0, (tail, r.stdout[-3000:], r.stderr[-2000:])
+    m = re.search(r"(\d+) passed", tail)
+    assert m, tail
+    assert "failed" not in tail and "error" not in tail, tail
+    assert int(m.group(1)) >= MIN_PRODUCT_PASSES, "only %s tests ran on the product library: %s" % (m.group(1), tail)
+
+
+MIN_PRODUCT_PASSES = 300

@@ -68,3 +68,26 @@ from tests.scenes import random_nested_scene  # noqa: E402,F401  (pure numpy; to
 
 def all_stats(st):
     return tuple(int(st[k]) for k in ("primary", "hits", "shadow", "occluded", "sphere_tests", "bound_tests"))
+
+
+def loop_flavour(variant):
+    """with util.loop_flavour(v): the traversal-loop flavour v (csrc/rt_debug.h RT_DEBUG_SKIP_VARIANT) for the launches inside.  The library that
+    ships has no such control (tests/conftest.py RTRACE_PARITY_ON_PRODUCT): there flavour 23 -- the filtered assembly loops, fused where the
+    scene is concentric: what a scene gets by itself -- is simply the launch as it is, and every other flavour skips the test."""
+    import contextlib
+    import pytest
+    if rta.capi.HAVE_TEST_HOOKS:
+        return rta.capi.debug(rta.capi.DEBUG_SKIP_VARIANT, variant)
+    if variant == 23:
+        return contextlib.nullcontext()
+    pytest.skip("loop flavour %d needs csrc/rt_debug.h: the library that ships runs its own choice (23)" % variant)
+
+
+def control(key, value):
+    """with util.control(rta.capi.DEBUG_X, v): a control of csrc/rt_debug.h for the launches inside -- where the library has them.  On the library
+    that ships (no control) the block runs the library's own choice: the oracle comparison inside still holds, the forced flavour is what
+    the ordinary run of the suite covers.  Use it only where nothing inside asserts WHICH flavour ran."""
+    import contextlib
+    if rta.capi.HAVE_TEST_HOOKS:
+        return rta.capi.debug(key, value)
+    return contextlib.nullcontext()

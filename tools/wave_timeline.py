@@ -24,6 +24,10 @@ def main():
         rta.capi.debug_set(rta.capi.DEBUG_NARROW_MAX, int(sys.argv[7]))
     if len(sys.argv) > 8:
         rta.capi.debug_set(rta.capi.DEBUG_NARROW_L2, int(sys.argv[8]))
+    # any other control of csrc/rt_debug.h by name: WAVE_TIMELINE_KNOBS="COOP_MAX=1024,NARROW_MAX=32"
+    for kv in filter(None, os.environ.get("WAVE_TIMELINE_KNOBS", "").split(",")):
+        k, v = kv.split("=")
+        rta.capi.debug_set(getattr(rta.capi, "DEBUG_" + k.strip().upper()), int(v))
     path = os.path.join(ROOT, "gpurun_out", "wave_trace.bin")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     rta.capi.debug_set(rta.capi.DEBUG_ASYNC_ORDERS, 0)        # the dispatch orders at once, not from the background
@@ -41,7 +45,7 @@ def main():
     dev.render_frame_device(opts, regs_c, out.data_ptr(), stream)
     torch.cuda.synchronize()
     rta.capi.wave_trace(None)
-    rec = np.fromfile(path, dtype=np.uint32).reshape(-1, 4)
+    rec = np.fromfile(path, dtype=np.uint32).reshape(-1, 8)          # rt_skip.hpp: start, end, HW_ID | XCC_ID << 16, descriptor, entry, ack, 0, 0
     ran = rec[:, 1] != 0
     r = rec[ran]
     t0 = r[:, 0].min()
@@ -74,6 +78,27 @@ def main():
                                      "waves_longer_than_0_9_of_the_span": int((dur > 0.9 * end.max()).sum()),
                                      "slot_time_over_8192_slots_us": round(dur.sum() / 1e3 / 8192, 2), "last_wave_start_us": round(start.max() / 1e3, 2)}
         json.dump(d, open(jp, "w"), indent=1, sort_keys=True)
+    print("waves longer than 15 / 20 / 25 / 30 / 35 us: " + " / ".join(str(int((dur > t * 1000).sum())) for t in (15, 20, 25, 30, 35))
+          + "; sum of wave time over 8,192 slots %.1f us" % (dur.sum() / 1e3 / 8192))
+    # What a wave SLOT does between two waves (round 6).  A slot is (XCD = workgroup index % 8 -- the dispatcher deals workgroups round-robin
+    # over the XCDs --, SE, CU, SIMD, wave id of HW_ID); per slot, consecutive occupants: prologue = start - entry (kernel arguments, descriptor),
+    # ack = the pixel store's acknowledgement after `end` (s_endpgm waits for it), relaunch = next entry - this ack (the hardware's part).
+    idx_all = np.nonzero(ran)[0]
+    wg_i = idx_all // 4
+    hw16 = (r[:, 2] & 0xFFFF).astype(np.int64)
+    slot_id = ((((wg_i % 8) * 8 + ((hw16 >> 13) & 7)) * 16 + ((hw16 >> 8) & 15)) * 4 + ((hw16 >> 4) & 3)) * 16 + (hw16 & 15)
+    entry = (r[:, 4].astype(np.int64) - int(t0)) * 10
+    ack = (r[:, 5].astype(np.int64) - int(t0)) * 10
+    o = np.lexsort((start, slot_id))
+    same = slot_id[o][1:] == slot_id[o][:-1]
+    relaunch = (entry[o][1:] - ack[o][:-1])[same]
+    gap = (start[o][1:] - end[o][:-1])[same]
+    pro = start - entry
+    akl = ack - end
+    med = lambda a: float(np.median(a)) / 1e3
+    print("wave slots %d; between two waves of a slot (us, median / mean): end -> next start %.2f / %.2f = store ack %.2f / %.2f + relaunch (hardware) %.2f / %.2f + prologue %.2f / %.2f" % (
+        len(np.unique(slot_id)), med(gap), gap.mean() / 1e3, med(akl), akl.mean() / 1e3, med(relaunch), relaunch.mean() / 1e3, med(pro), pro.mean() / 1e3))
+    print("slot time between waves: %.0f us = %.1f %% of the waves' own %.0f us" % (gap.sum() / 1e3, 100.0 * gap.sum() / dur.sum(), dur.sum() / 1e3))
     order = np.argsort(-dur)[:16]
     print("16 longest waves: (start, end, dur us, dispatch index)")
     idx = np.nonzero(ran)[0]
