@@ -404,6 +404,14 @@ def main():
             if not fs.collective:
                 kern.append(k0.elapsed_time(k1) / steps)
         launched = rta.capi.last_launch()               # what this thread's last (timed) render call launched
+        # The clock the card holds under this load: one more counting launch right behind the timed ones -- its longest
+        # wave's s_memtime (shader clock) over s_memrealtime (constant 100 MHz) span; counting launches are a diagnostic flavour, the
+        # timed kernels carry no stamp.
+        clk = None
+        if traversal == rta.RT_TRAVERSAL_SKIP:
+            st2 = fs.render_shard(want_stats=True)
+            if st2.get("longest_wave_ref100mhz"):
+                clk = {"mhz": 100.0 * st2["longest_wave_cycles"] / st2["longest_wave_ref100mhz"], "over_us": st2["longest_wave_ref100mhz"] / 100.0}
         crc, crc_ok = None, None
         if rank == 0:
             if mode == "frames" and fs.collective:
@@ -426,7 +434,7 @@ def main():
         srt = sorted(reps)
         return {"ms_reps": reps, "ms_per_step": srt[len(srt) // 2], "kern_ms": sorted(kern)[len(kern) // 2], "primary": primary, "shadow": shadow,
                 "my_tests": st["sphere_tests"] + st["bound_tests"], "my_stats": st, "crc": crc, "crc_ok": crc_ok, "launched": launched,
-                "timed_region_s": sum(r * steps for r in reps) / 1e3, "frames_per_step": world if (mode == "frames" and fs.collective) else 1}
+                "timed_region_s": sum(r * steps for r in reps) / 1e3, "frames_per_step": world if (mode == "frames" and fs.collective) else 1, "clock": clk}
 
     def measure_in_flight(wl, steps, n_streams=2):
         """N = 1 only, never `value`: the same `steps` launches dealt round-robin over n_streams HIP streams (each its own frame
@@ -539,6 +547,12 @@ def main():
                                "note": "16 B x tests / kernel time: a LOGICAL record rate -- the records come from the scalar cache / L2 / LDS, "
                                        "not from HBM, so it is not a fraction of the HBM peak (SURVEY.md H3)"},
                "note": note}
+        if m.get("clock"):
+            mhz = m["clock"]["mhz"]
+            out["clock_mhz_measured"] = round(mhz, 1)
+            out["frac_at_measured_clock"] = round(ach / (peak * mhz * 1e6 / CLOCK_HZ), 4)
+            out["clock_source"] = ("s_memtime / s_memrealtime x 100 MHz over the longest wave (%.0f us) of a counting launch issued right behind the timed "
+                                   "launches; `frac` stays priced at the nominal %.1f GHz" % (m["clock"]["over_us"], CLOCK_HZ / 1e9))
         pt = m["my_stats"].get("primary_tests")
         if pt is not None and kernel in ("k_render_skip", "k_render_skip2"):
             ops = 8 * pt + 16 * (m["my_tests"] - pt)
@@ -781,6 +795,13 @@ def main():
             try:
                 exp = json.load(open(os.path.join(ROOT, "profiles", "expected_shard_render.json")))
                 out["expected_shard_render_us"] = {"n_%d" % world: (exp.get("1080p") or {}).get(str(world)), "source": exp.get("source")}
+            except Exception:
+                pass
+            try:
+                # ... and what the builder's one-GPU measurements add up to for ONE frame at this N (shard render + one collective call + the
+                # root's blit) beside the N = 1 frame: written down before any curve exists
+                lat = json.load(open(os.path.join(ROOT, "profiles", "expected_frame_latency.json")))
+                out["expected_frame_latency_us"] = {"n_%d" % world: (lat.get("n") or {}).get(str(world)), "n_1": (lat.get("n") or {}).get("1"), "source": lat.get("source")}
             except Exception:
                 pass
         if seam is not None:

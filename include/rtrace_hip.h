@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RTRACE_HIP_ABI_VERSION 3
+#define RTRACE_HIP_ABI_VERSION 4
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -93,6 +93,9 @@ typedef struct rt_stats {
     double device_ms;       /* hipEvent time of all kernels of this call on its stream.  A call that asks for
                                stats runs the counting flavour of the kernels (same bytes, about 2.5x slower):
                                it is not the product's speed -- time calls without stats with your own events */
+    uint64_t longest_wave_cycles, longest_wave_ref100mhz;   /* (ABI 4; SKIP) the counting launch's longest wave on the shader clock (s_memtime) and on the
+                               constant 100 MHz reference (s_memrealtime): cycles / ref100mhz * 100 = the clock in MHz that launch ran at.
+                               Diagnostic -- what bench.py prices its roofline's peak at next to the nominal 2.4 GHz; 0 for FLAT */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;   /* opaque: device copies of a Scene (render.rs:138-142) */

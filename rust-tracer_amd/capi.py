@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("RTRACE_HIP_LIBRARY") or PRODUCT_LIB_PATH
 RT_OK, RT_ERR_INVALID_ARGUMENT, RT_ERR_INVALID_REGION, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_OUT_OF_MEMORY, RT_ERR_UNSUPPORTED = range(7)
 RT_F32, RT_F64 = 0, 1
 RT_TRAVERSAL_FLAT, RT_TRAVERSAL_SKIP = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/rtrace_hip.h declares
 SYMBOLS = ("rt_abi_version", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_scene_traits", "rt_render_tiles",
@@ -46,7 +46,7 @@ class Range(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("primary", C.c_uint64), ("hits", C.c_uint64), ("shadow", C.c_uint64), ("occluded", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("bound_tests", C.c_uint64), ("tests_executed", C.c_uint64),
-                ("primary_tests", C.c_uint64), ("device_ms", C.c_double)]
+                ("primary_tests", C.c_uint64), ("device_ms", C.c_double), ("longest_wave_cycles", C.c_uint64), ("longest_wave_ref100mhz", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -178,7 +178,7 @@ def selftest_rcp(device=0):
 (DEBUG_SKIP_VARIANT, DEBUG_BLOCK_ORDER, DEBUG_NARROW_MAX, DEBUG_PACKED_SAMPLES, DEBUG_PRINT_STEPS, DEBUG_PRINT_COSTS,
  DEBUG_HOST_COPY, DEBUG_COALESCE, DEBUG_LDS_BYTES, DEBUG_WG_POLICY, DEBUG_NARROW_L2, DEBUG_FLAT_KERNELS, DEBUG_SKIP_RAYS,
  DEBUG_FRAME_AHEAD, DEBUG_FILTER_RO_PERCENT, DEBUG_COOP, DEBUG_COOP_THR, DEBUG_COOP_MAX, DEBUG_COOP_LEVEL, DEBUG_COOP_REST, DEBUG_ASYNC_ORDERS,
- DEBUG_FAST_KERNEL) = range(22)
+ DEBUG_FAST_KERNEL, DEBUG_EXACT_COSTS) = range(23)
 if HAVE_TEST_HOOKS:
     lib.rt_debug_set.argtypes = [C.c_int, C.c_longlong]
     lib.rt_debug_wave_trace.argtypes = [C.c_char_p]

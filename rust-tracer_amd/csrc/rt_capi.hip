@@ -197,6 +197,7 @@ struct rt_scene {
     // Tests per primary ray (its shadow ray included) on a kCostRes x kCostRes grid over the camera's field of view,
     // rendered once per scene with the counting kernel.  It only ever decides the ORDER in which blocks are dispatched.
     std::once_flag cost_once;
+    std::mutex exact_mu;                   // exact_block_costs: the cost arena is also where a tile list's heaviest blocks are counted again
     hipStream_t cost_stream = nullptr;
     void *d_cost_arena = nullptr, *h_cost = nullptr;
     bool cost_started = false;
@@ -793,6 +794,10 @@ rt_status upload_tiles(Context *c, const std::vector<rt::TileDev> &tab, hipStrea
 }
 
 constexpr unsigned kCostRes = 256;
+// the cost arena's tile-table area: one tile for the map itself; up to kExactBlocks 16x16 blocks when a tile list's heaviest blocks are
+// counted again at the frame's own resolution (exact_block_costs)
+constexpr unsigned kExactBlocks = kCostRes * kCostRes / (rt::kBlockW * rt::kBlockH);       // what the arena's pixel areas hold: 256
+constexpr size_t kCostTileBytes = (kExactBlocks * sizeof(rt::TileDev) + 255) & ~(size_t)255;
 constexpr size_t kTableStageBytes = 256 * 1024;       // pinned staging for the tile tables of new lists (a 1080p list of 64x64 buckets: 10 KB)
 
 // The scene's cost map: one counting render of a kCostRes^2 image (same camera: x spans the same field of view at every
@@ -805,7 +810,7 @@ rt_status start_cost_map(rt_scene *s)
     constexpr unsigned R = kCostRes;
     const rt::TileDev tile{ 0, (uint16_t)R, (uint16_t)R, 0, 0u, 0u, R / rt::kBlockW };
     // ONE device allocation, kept until the scene goes (hipMalloc / hipFree wait for a busy device): tile | frame | costs | counters
-    constexpr size_t kTileBytes = 256, kPx = (size_t)R * R * 4, kCnt = sizeof(rt::Counters) * rt::kCounterStripes;
+    constexpr size_t kTileBytes = kCostTileBytes, kPx = (size_t)R * R * 4, kCnt = sizeof(rt::Counters) * rt::kCounterStripes;
     HIP_TRY(hipMalloc(&s->d_cost_arena, kTileBytes + 2 * kPx + kCnt));
     HIP_TRY(hipHostMalloc(&s->h_cost, kPx + kTileBytes + kTableStageBytes, hipHostMallocDefault));
     s->h_tab_stage = static_cast<char *>(s->h_cost) + kPx + kTileBytes;
@@ -839,6 +844,57 @@ const std::vector<uint32_t> *cost_map_of(rt_scene *s)
     return s->cost_map.empty() ? nullptr : &s->cost_map;
 }
 
+// Tests per pixel at the FRAME's resolution for a few blocks of a tile list (round 6).  The scene's cost map has one cell per 7.5 pixels of
+// a 1080p frame, and the rays that meet several hundred nodes follow silhouettes thinner than that: a threshold on the map picks some of a
+// heavy pixel's neighbours and misses the pixel, and the wave that keeps it is as long as ever (tools/wave_timeline.py, the cooperative walk
+// at 1080p: the quads walked in 14 us, the frame's longest wave still 41).  So the blocks the map ranks highest are counted again, exactly:
+// one counting launch over those blocks alone (<= 256 blocks = 65,536 pixels, ~30 us of device time, once per tile list, on the scene's own
+// stream), each lane storing the number of tests its pixel took.  px[i * 256 + (y - y0) * 16 + (x - x0)] for block i of `blocks`.
+struct ExactCosts { std::vector<uint32_t> block; std::vector<uint32_t> px; uint32_t top = 0; };      // block: raster index of the counted blocks
+template <typename T>
+rt_status exact_block_costs(rt_scene *s, const std::vector<rt::BlockDesc> &raster, const std::vector<uint32_t> &blocks, unsigned w, unsigned h, ExactCosts &out)
+{
+    out = ExactCosts{};
+    if (blocks.empty() || blocks.size() > kExactBlocks || !s->d_cost_arena || !s->h_cost) return RT_OK;
+    std::lock_guard<std::mutex> lk(s->exact_mu);                 // one counting launch at a time through the scene's arena
+    constexpr size_t kPx = (size_t)kCostRes * kCostRes * 4, kCnt = sizeof(rt::Counters) * rt::kCounterStripes;
+    char *base = static_cast<char *>(s->d_cost_arena);
+    rt::TileDev *d_tile = reinterpret_cast<rt::TileDev *>(base);
+    uint8_t *d_out = reinterpret_cast<uint8_t *>(base + kCostTileBytes);
+    uint32_t *d_cost = reinterpret_cast<uint32_t *>(base + kCostTileBytes + kPx);
+    rt::Counters *d_cnt = reinterpret_cast<rt::Counters *>(base + kCostTileBytes + 2 * kPx);
+    std::vector<rt::TileDev> tiles(blocks.size());
+    for (size_t i = 0; i < blocks.size(); ++i) {
+        const rt::BlockDesc &d = raster[blocks[i]];
+        // a 16 x 16 tile of its own, clipped like the block; 256 pixels of the tile-major output each
+        tiles[i] = rt::TileDev{ d.x0, (uint16_t)std::min<unsigned>(d.y0 + rt::kBlockH, d.t), (uint16_t)std::min<unsigned>(d.x0 + rt::kBlockW, d.r), d.y0,
+                                (uint32_t)(i * rt::kBlockW * rt::kBlockH), (uint32_t)i, 1u };
+    }
+    hipStream_t stream = s->cost_stream;
+    HIP_TRY(hipMemcpyAsync(d_tile, tiles.data(), tiles.size() * sizeof(rt::TileDev), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(d_cost, 0, kPx + kCnt, stream));
+    rt::SampleBuf<T> sb{ nullptr, nullptr, (unsigned)(blocks.size() * rt::kBlockW * rt::kBlockH) };
+    hipLaunchKernelGGL((rt::k_render_skip<T, true, 1, rt::kSkipLoop>), dim3((unsigned)blocks.size()), dim3(rt::kBlockThreads), 0, stream,
+                       skip_args<T>(s, nullptr, nullptr, w, h, 0u, d_out, d_tile, (unsigned)tiles.size(), 1u, d_cnt, d_cost, sb));
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> raw(blocks.size() * rt::kBlockW * rt::kBlockH);
+    HIP_TRY(hipMemcpyAsync(raw.data(), d_cost, raw.size() * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    // the kernel stores tile-major with the tile's own pitch (its clipped width): re-pitch to 16
+    out.block = blocks;
+    out.px.assign(raw.size(), 0u);
+    for (size_t i = 0; i < blocks.size(); ++i) {
+        const unsigned tw = (unsigned)tiles[i].r - tiles[i].l, th = (unsigned)tiles[i].t - tiles[i].b;
+        for (unsigned y = 0; y < th; ++y)
+            for (unsigned x = 0; x < tw; ++x) {
+                const uint32_t v = raw[i * 256 + (size_t)y * tw + x];
+                out.px[i * 256 + y * 16 + x] = v;
+                out.top = std::max(out.top, v);
+            }
+    }
+    return RT_OK;
+}
+
 // Dispatch order of a pass's 16x16 blocks: descending estimated cost (the largest cost-map value under the block),
 // ties in grid order.  The frame is as long as its last wave's chain of dependent node steps and the chains differ by
 // more than 10x across the image, so the long ones have to start first (measured at 1080p: 141 -> 115 us for the
@@ -863,7 +919,9 @@ constexpr size_t kResidentWorkgroups = 2048;
 // 2x2-pixel quads of that 16x16 block (bit (y >> 1) * 8 + (x >> 1)) which cooperative descriptors further down the list render instead.
 void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev> &tab, unsigned w, unsigned h, unsigned passes,
                  std::vector<rt::BlockDesc> &descs, std::vector<uint32_t> &wg_first, const rt::CoopView *coop = nullptr, std::vector<uint64_t> *holes = nullptr,
-                 int coop_percent = -1)            // 0: no cooperative quads; > 0: from that share of the pass's largest estimate; -1: as rt_debug.h says (default share)
+                 int coop_percent = -1,            // 0: no cooperative quads; > 0: from that share of the pass's largest estimate; -1: as rt_debug.h says (default share)
+                 const ExactCosts *exact = nullptr, uint32_t exact_thr = 0,      // cooperative quads by EXACT tests per pixel (exact_block_costs) from exact_thr on, instead
+                 std::vector<uint32_t> *heaviest = nullptr)                      // out: the raster indices of the heaviest blocks (what exact_block_costs is asked for); descs is not made
 {
     wg_first.clear();
     if (holes) holes->clear();
@@ -894,6 +952,11 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
     std::vector<uint32_t> order(cost.size());
     for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&cost](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    if (heaviest) {
+        heaviest->assign(order.begin(), order.begin() + std::min<size_t>(order.size(), kExactBlocks));
+        while (!heaviest->empty() && cost[heaviest->back()] == 0) heaviest->pop_back();        // (nothing to count where the map sees nothing)
+        return;
+    }
     // The most expensive blocks go out as four narrow workgroups each (rt_kernels.hpp, kBlockNarrow): those whose cost
     // estimate is at least kNarrowPercent of the pass's maximum, at most kNarrowMax and 1/128 of the pass (rt_debug.h can
     // override the cap for A/B runs -- the table is built once per tile list, when it is first seen).
@@ -925,14 +988,39 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
             while (n_coop < order.size() && n_coop < cap && cost[order[n_coop]] >= coop_thr) ++n_coop;
         }
     }
+    // ... or by EXACT tests per pixel (exact_block_costs: the counted blocks, this list's heaviest by the map): a 2x2-pixel quad is walked
+    // cooperatively when one of its pixels took exact_thr tests or more.  The blocks that hold such quads move to the front of the order
+    // (the holes of a pass are indexed by descriptor position); what is left of them goes out as 4x4-pixel quarters, like the narrow tier.
+    std::vector<uint64_t> exact_hole;                    // of order[0 .. n_coop)
+    const bool use_exact = exact && exact_thr > 0 && !exact->block.empty() && coop && holes && coop->fanout != 0u && passes == 1 && knob(RT_DEBUG_WG_POLICY) <= 0 &&
+                           coop_knob != 0 && !coop_all && !cost.empty();
+    const uint32_t top_estimate = cost.empty() ? 0u : cost[order[0]];
+    if (use_exact) {
+        std::vector<uint64_t> hole_of(cost.size(), 0ull);
+        for (size_t k = 0; k < exact->block.size(); ++k) {
+            const uint32_t *px = &exact->px[k * 256];
+            uint64_t hole = 0;
+            for (unsigned qy = 0; qy < 8; ++qy)
+                for (unsigned qx = 0; qx < 8; ++qx) {
+                    const uint32_t m = std::max(std::max(px[(2 * qy) * 16 + 2 * qx], px[(2 * qy) * 16 + 2 * qx + 1]), std::max(px[(2 * qy + 1) * 16 + 2 * qx], px[(2 * qy + 1) * 16 + 2 * qx + 1]));
+                    if (m >= exact_thr) hole |= 1ull << (qy * 8u + qx);
+                }
+            hole_of[exact->block[k]] = hole;
+        }
+        std::stable_partition(order.begin(), order.end(), [&hole_of](uint32_t b) { return hole_of[b] != 0ull; });
+        n_coop = 0;
+        while (n_coop < order.size() && hole_of[order[n_coop]] != 0ull) exact_hole.push_back(hole_of[order[n_coop++]]);
+        coop_thr = exact_thr;
+    }
     if (map && !cost.empty()) {
         const long long e = knob(RT_DEBUG_NARROW_MAX);
         // a pass of more blocks than kNarrowPassBlocks is throughput-bound: narrowing only adds work there (3840x2160 + 2 %)
         // (and only in single-pass launches: the packed sample-parallel mapping has its own, finer ray packets)
         // (behind a cooperative tier the next blocks are narrowed more generously: tools/coop_sweep.py, 800x600 28.4 -> 26.4 us)
-        const size_t cap = passes > 1 ? 0 : e >= 0 ? (size_t)e : order.size() > kNarrowPassBlocks ? 0 : std::min<size_t>(kNarrowMax, order.size() / (n_coop && !coop_all ? 32 : 128));
+        size_t cap = passes > 1 ? 0 : e >= 0 ? (size_t)e : order.size() > kNarrowPassBlocks ? 0 : std::min<size_t>(kNarrowMax, order.size() / (n_coop && !coop_all && !use_exact ? 32 : 128));
+        if (use_exact && e < 0) cap = cap > n_coop ? cap - n_coop : 0;        // (the blocks with exact holes are narrow already: the tier is as large as without them)
         // (with the heaviest blocks walked cooperatively, "expensive" is measured against the cooperative threshold)
-        const uint64_t top = n_coop && !coop_all ? coop_thr : cost[order[0]];
+        const uint64_t top = use_exact ? top_estimate : n_coop && !coop_all ? coop_thr : cost[order[0]];
         while (n_coop + n_narrow < order.size() && n_narrow < cap && cost[order[n_coop + n_narrow]] > 0 &&
                (uint64_t)cost[order[n_coop + n_narrow]] * 100 >= top * kNarrowPercent)
             ++n_narrow;
@@ -948,13 +1036,13 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
         const unsigned grain = std::max(2u, quad);           // a hole is decided for `grain` x `grain` pixels at once: whole cooperative quads
         // the chains follow silhouettes thinner than a map cell: where cells are small (a few pixels) their neighbours count too
         const int grow = (w + R - 1) / R <= 4 ? 1 : 0;
-        const unsigned rest_level = knob(RT_DEBUG_COOP_REST) >= 0 ? (unsigned)std::min(1ll, knob(RT_DEBUG_COOP_REST)) : kCoopRestLevel;
+        const unsigned rest_level = knob(RT_DEBUG_COOP_REST) >= 0 ? (unsigned)std::min(1ll, knob(RT_DEBUG_COOP_REST)) : use_exact ? 1u : kCoopRestLevel;
         std::vector<rt::BlockDesc> cdescs;
         std::vector<uint32_t> ccost;
         for (size_t i = 0; i < n_coop; ++i) {
             const rt::BlockDesc &d = raster[order[i]];
-            uint64_t hole = 0;
-            for (unsigned gy = 0; gy < 16u; gy += grain)
+            uint64_t hole = use_exact ? exact_hole[i] : 0ull;
+            for (unsigned gy = 0; !use_exact && gy < 16u; gy += grain)
                 for (unsigned gx = 0; gx < 16u; gx += grain) {
                     const unsigned px0 = d.x0 + gx, py0 = d.y0 + gy;
                     if (!(px0 < d.r && py0 < d.t)) continue;                    // outside a clipped edge tile
@@ -1128,7 +1216,7 @@ rt::BlockList pick_order(rt_scene::CachedTable &t, bool will_be_timed)      // w
 bool order_knobs_set()
 {
     for (int k : { RT_DEBUG_COOP, RT_DEBUG_COOP_THR, RT_DEBUG_COOP_MAX, RT_DEBUG_COOP_LEVEL, RT_DEBUG_COOP_REST, RT_DEBUG_NARROW_MAX, RT_DEBUG_NARROW_L2, RT_DEBUG_WG_POLICY,
-                   RT_DEBUG_PRINT_COSTS })
+                   RT_DEBUG_PRINT_COSTS, RT_DEBUG_EXACT_COSTS })
         if (knob(k) >= 0) return true;
     return knob(RT_DEBUG_ASYNC_ORDERS) == 0;
 }
@@ -1148,21 +1236,46 @@ rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std:
     const bool two_rays = rays < 0 ? skip2_by_default(total_px, 1, s->fused ? s->n_fnodes : s->n_nodes) : rays == 2;      // k_render_skip2 knows no cooperative quads
     // Candidate 0 is ALWAYS the plain order of a pass that could walk cooperatively (coop_percent 0: no holes, no cooperative descriptors):
     // pick_order and launch_skip_one hand it to every launch that cannot take holes (counters, f64, two rays per lane).
-    std::vector<int> percents;
-    if (coop_pass && map && !two_rays && total_blocks <= kCoopPassBlocks && knob(RT_DEBUG_COOP) < 0 && knob(RT_DEBUG_COOP_THR) < 0 && knob(RT_DEBUG_COOP_MAX) < 0)
-        percents = { 0, 28, 34, 40, 48, 58 };
-    else if (coop_pass && !two_rays && (knob(RT_DEBUG_COOP) > 0 || knob(RT_DEBUG_COOP_THR) >= 0 || knob(RT_DEBUG_COOP_MAX) >= 0)) percents = { 0, -1 };       // as asked, behind the plain one
-    else if (coop_pass) percents = { 0 };
-    else percents = { -1 };
+    // Candidates: the plain order first; then cooperative thresholds.  Where the scene's stream is there to count the list's heaviest blocks
+    // again at the frame's own resolution (exact_block_costs), the thresholds are shares of the largest EXACT count of tests per pixel and the
+    // quads are picked pixel by pixel -- any pass size; without it (or when a control of rt_debug.h asks for the old way) shares of the map's
+    // largest estimate, small passes only.
+    struct Want { int pc; uint32_t exact_thr; };
+    std::vector<Want> wants;
+    ExactCosts exact;
+    const bool knobs = knob(RT_DEBUG_COOP) >= 0 || knob(RT_DEBUG_COOP_THR) >= 0 || knob(RT_DEBUG_COOP_MAX) >= 0;
+    if (coop_pass && map && !two_rays && !knobs && knob(RT_DEBUG_EXACT_COSTS) != 0) {
+        std::vector<rt::BlockDesc> none; std::vector<uint32_t> none_wg, heaviest;
+        block_order(map, tab, w, h, passes, none, none_wg, nullptr, nullptr, 0, nullptr, 0, &heaviest);
+        std::vector<rt::BlockDesc> raster;
+        for (const rt::TileDev &t : tab) {          // (block_order's raster enumeration: the indices `heaviest` holds)
+            const unsigned bys = ((unsigned)(t.t - t.b) + rt::kBlockH - 1) / rt::kBlockH;
+            const uint32_t pitch = (uint32_t)t.r - t.l;
+            for (unsigned by = 0; by < bys; ++by)
+                for (unsigned bx = 0; bx < t.blks_x; ++bx)
+                    raster.push_back(rt::BlockDesc{ (uint16_t)(t.l + bx * rt::kBlockW), (uint16_t)(t.b + by * rt::kBlockH), t.r, t.t, pitch, 0u });
+        }
+        if (exact_block_costs<float>(s, raster, heaviest, w, h, exact) != RT_OK) { (void)hipGetLastError(); exact = ExactCosts{}; }
+    }
+    bool asked = false;
+    if (!exact.block.empty() && exact.top >= kCoopMinCost) {
+        wants.push_back({ 0, 0u });
+        for (unsigned pc : { 85u, 70u, 58u, 48u, 40u }) wants.push_back({ 0, std::max<uint32_t>((uint32_t)kCoopMinCost, exact.top * pc / 100u) });
+    } else if (coop_pass && map && !two_rays && total_blocks <= kCoopPassBlocks && !knobs)
+        wants = { { 0, 0u }, { 28, 0u }, { 34, 0u }, { 40, 0u }, { 48, 0u }, { 58, 0u } };
+    else if (coop_pass && !two_rays && knobs && (knob(RT_DEBUG_COOP) > 0 || knob(RT_DEBUG_COOP_THR) >= 0 || knob(RT_DEBUG_COOP_MAX) >= 0)) { wants = { { 0, 0u }, { -1, 0u } }; asked = true; }       // as asked, behind the plain one
+    else if (coop_pass) wants = { { 0, 0u } };
+    else wants = { { -1, 0u } };
     // every candidate on the host first, then ONE device allocation for all their arrays: hipMalloc / hipFree wait for a busy device,
     // and this may run in the background of a caller who keeps it busy
     struct Host { std::vector<rt::BlockDesc> order; std::vector<uint32_t> wg_first; std::vector<uint64_t> holes; bool any_hole = false; };
     std::vector<Host> cand;
-    for (int pc : percents) {
+    for (const Want &wt : wants) {
         Host c;
-        block_order(map, tab, w, h, passes, c.order, c.wg_first, coop_pass ? &s->coop : nullptr, &c.holes, pc);
+        block_order(map, tab, w, h, passes, c.order, c.wg_first, coop_pass ? &s->coop : nullptr, &c.holes, wt.pc, wt.exact_thr ? &exact : nullptr, wt.exact_thr);
         c.any_hole = std::any_of(c.holes.begin(), c.holes.end(), [](uint64_t v) { return v != 0; });
-        if (pc != percents[0] && !c.any_hole) continue;     // the same dispatch as the plain one
+        if (&wt != &wants[0] && !c.any_hole) continue;     // the same dispatch as the plain one
+        if (!cand.empty() && wt.exact_thr && cand.back().any_hole && cand.back().holes == c.holes && cand.back().order.size() == c.order.size()) continue;   // (two thresholds, the same quads)
         cand.push_back(std::move(c));
     }
     auto up = [](size_t n) { return (n + 255) & ~(size_t)255; };
@@ -1199,7 +1312,7 @@ rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std:
         return RT_ERR_INVALID_ARGUMENT;
     }
     chosen = 0;
-    if (orders.size() > 1 && percents.size() == 2) chosen = 1;      // asked for explicitly
+    if (orders.size() > 1 && asked) chosen = 1;      // asked for explicitly
     else if (orders.size() > 1) {
         chosen = -1;                                                // to be decided by measurement
         for (auto &od : orders)
@@ -1309,7 +1422,7 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
     // the cooperative walk's controls (rt_debug.h) are part of a dispatch table's identity: tests render one tile list with and without
     long long coop_key = 0;
     if (o && order_out)
-        for (int k : { RT_DEBUG_COOP, RT_DEBUG_COOP_THR, RT_DEBUG_COOP_MAX, RT_DEBUG_COOP_LEVEL, RT_DEBUG_COOP_REST, RT_DEBUG_NARROW_MAX, RT_DEBUG_NARROW_L2, RT_DEBUG_SKIP_RAYS })
+        for (int k : { RT_DEBUG_COOP, RT_DEBUG_COOP_THR, RT_DEBUG_COOP_MAX, RT_DEBUG_COOP_LEVEL, RT_DEBUG_COOP_REST, RT_DEBUG_NARROW_MAX, RT_DEBUG_NARROW_L2, RT_DEBUG_SKIP_RAYS, RT_DEBUG_EXACT_COSTS })
             coop_key = coop_key * 1000003ll + (knob(k) + 2);
     if (cacheable) {
         std::lock_guard<std::mutex> lk(s->mu);
@@ -1576,18 +1689,10 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
                 return RT_OK;
             }
         }
-        if constexpr (!COUNT && sizeof(T) == 4 && (VAR == 19 || VAR == 23 || VAR == 31)) {
-            if (spp == 1 && order.d && order.holes && !order.wg_first) {        // some quads of the pass are walked cooperatively (rt_coop.hpp)
-                count_event(RT_DEBUG_COUNT_COOP_LAUNCHES); g_launch_flags |= RT_LAUNCH_COOPERATIVE;
-                hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipOne, true>()), rgrid, b, lds, stream, 
-                                   skip_args<T>(s, order.d, order.wg_first, w, h, frame_w, d_out, d_tab, nt, spp, cnt, no_cost, sb, s->coop, order.holes, order.n_holes));
-                return RT_OK;
-            }
-        }
         // Steady-state frames -- f32, one sample per pixel, a dispatch list, the filtered assembly loops -- run the kernel that was written
-        // around a wave's fixed costs (rt_skip_fast.hpp); everything else the generic one.
+        // around a wave's fixed costs (rt_skip_fast.hpp), with or without cooperative quads; everything else the generic one.
         if constexpr (!COUNT && sizeof(T) == 4 && ((VAR & ~8) == 19 || (VAR & ~8) == 23)) {
-            if (spp == 1 && order.d && !order.wg_first && !order.holes && lds == 0 && knob(RT_DEBUG_FAST_KERNEL) != 0) {
+            if (spp == 1 && order.d && !order.wg_first && lds == 0 && knob(RT_DEBUG_FAST_KERNEL) != 0) {
                 rt::FastArgs fa{};
                 const rt::SkipView<float> sv = skip_view_of<float>(s);
                 constexpr bool kFused = (VAR & 4) != 0;
@@ -1599,7 +1704,19 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
                 memcpy(fa.fc, &s->fc, sizeof fa.fc);
                 fa.trace = no_cost;
                 g_launch_flags |= RT_LAUNCH_FAST_KERNEL;
-                hipLaunchKernelGGL((rt::k_render_skip_fast<(VAR & ~8), (VAR & 8) != 0>), rgrid, b, 0, stream, fa);
+                if (order.holes) {
+                    fa.holes = order.holes; fa.n_holes = order.n_holes; fa.cv = s->coop;
+                    count_event(RT_DEBUG_COUNT_COOP_LAUNCHES); g_launch_flags |= RT_LAUNCH_COOPERATIVE;
+                    hipLaunchKernelGGL((rt::k_render_skip_fast_coop<(VAR & ~8), (VAR & 8) != 0>), rgrid, b, 0, stream, fa);
+                } else hipLaunchKernelGGL((rt::k_render_skip_fast<(VAR & ~8), (VAR & 8) != 0>), rgrid, b, 0, stream, fa);
+                return RT_OK;
+            }
+        }
+        if constexpr (!COUNT && sizeof(T) == 4 && (VAR == 19 || VAR == 23 || VAR == 31)) {
+            if (spp == 1 && order.d && order.holes && !order.wg_first) {        // some quads of the pass are walked cooperatively (rt_coop.hpp)
+                count_event(RT_DEBUG_COUNT_COOP_LAUNCHES); g_launch_flags |= RT_LAUNCH_COOPERATIVE;
+                hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipOne, true>()), rgrid, b, lds, stream, 
+                                   skip_args<T>(s, order.d, order.wg_first, w, h, frame_w, d_out, d_tab, nt, spp, cnt, no_cost, sb, s->coop, order.holes, order.n_holes));
                 return RT_OK;
             }
         }
@@ -1845,6 +1962,7 @@ rt_status read_stats(rt_scene *s, Context *c, hipStream_t stream, rt_traversal t
                 h.wave_steps, h.wave_item_steps, h.max_wave_steps, h.max_wave_cycles, h.max_wave_ref100mhz / 100.0,
                 h.max_wave_ref100mhz ? 100.0 * h.max_wave_cycles / h.max_wave_ref100mhz : 0.0);
     st->device_ms = ms;
+    st->longest_wave_cycles = trav == RT_TRAVERSAL_FLAT ? 0 : h.max_wave_cycles; st->longest_wave_ref100mhz = trav == RT_TRAVERSAL_FLAT ? 0 : h.max_wave_ref100mhz;
     return RT_OK;
 }
 
@@ -3150,6 +3268,7 @@ static rt_status gang_render(rt_gang *g, const rt_options *o, rt_traversal trav,
                     total.sphere_tests += st.sphere_tests; total.bound_tests += st.bound_tests; total.tests_executed += st.tests_executed;
                     total.primary_tests += st.primary_tests;
                     total.device_ms = std::max(total.device_ms, st.device_ms);
+                    if (st.longest_wave_cycles > total.longest_wave_cycles) { total.longest_wave_cycles = st.longest_wave_cycles; total.longest_wave_ref100mhz = st.longest_wave_ref100mhz; }
                 }
             }
             if ((e = hipEventRecord(g->ev_rendered[p][d], g->streams[d])) != hipSuccess) return fail(hip_fail(e, "gang render", __LINE__));

@@ -56,7 +56,9 @@ typedef enum rt_debug_key {
                                     through the tile table */
     RT_DEBUG_FAST_KERNEL = 21,   /* 0: steady-state frames (f32, one sample per pixel, a dispatch list) run the generic k_render_skip_f32 instead of
                                     k_render_skip_fast (rt_skip_fast.hpp; A/B and parity: both must render the same bytes).  Default 1 */
-    RT_DEBUG_KEYS = 22
+    RT_DEBUG_EXACT_COSTS = 22,   /* 0: cooperative quads are picked by the scene's 256 x 256 cost map only (small passes), not by counting a tile list's heaviest
+                                    blocks again at the frame's own resolution (rt_capi.hip exact_block_costs).  Default 1 (read when a tile list is first seen) */
+    RT_DEBUG_KEYS = 23
 } rt_debug_key;
 
 /* value < 0 restores the default. */

@@ -19,6 +19,10 @@
 #pragma once
 #include "rt_skip.hpp"
 
+#ifndef RT_FAST_COOP_SGPRS
+#define RT_FAST_COOP_SGPRS 82
+#endif
+
 namespace rt {
 
 struct FastArgs {
@@ -38,23 +42,31 @@ struct FastArgs {
     float fc[16];                   // FilterConsts: m0, e1, e2, l, a0, k1, kc, ro2
     // (wave trace, hooks build)
     uint32_t *trace;
+    // the COOP flavour (some quads of the pass are walked lane-cooperatively, rt_coop.hpp): dwords [42, 46) ride with the entry batch
+    const uint64_t *holes;          // descriptors [0, n_holes): the 2x2-pixel quads of that block which cooperative descriptors render
+    unsigned n_holes, pad_;
+    CoopView cv;
 };
-static_assert(offsetof(FastArgs, items) == 64 && offsetof(FastArgs, fc) == 96 && offsetof(FastArgs, trace) == 160, "the batches of k_render_skip_fast");
+static_assert(offsetof(FastArgs, items) == 64 && offsetof(FastArgs, fc) == 96 && offsetof(FastArgs, trace) == 160 && offsetof(FastArgs, holes) == 168,
+              "the batches of k_render_skip_fast");
 static_assert(offsetof(FilterConsts, a0) == 48 && offsetof(FilterConsts, ro2) == 60, "fc[16] is the head of FilterConsts");
 
-// VAR: 19 (plain filtered streams) or 23 (fused); TRACE: the wave timeline's records (tools/wave_timeline.py; hooks build)
-template <int VAR, bool TRACE>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(82))) void k_render_skip_fast(FastArgs args)
+// VAR: 19 (plain filtered streams) or 23 (fused); TRACE: the wave timeline's records (tools/wave_timeline.py; hooks build); COOP: the list
+// carries cooperative descriptors and holes (rt_skip.hpp render_skip_body says how a pass is cut up for them)
+template <int VAR, bool TRACE, bool COOP>
+__device__ __forceinline__ void render_skip_fast_body(const FastArgs &args)
 {
     typedef float T;
     constexpr bool FUSED = (VAR & 4) != 0;
-    (void)args;         // (read through the kernel-argument segment pointer, in the batches below)
+    [[maybe_unused]] __shared__ CoopLds coop_lds[COOP ? kBlockThreads / 64 : 1];
     [[maybe_unused]] unsigned long long r_entry = 0, r_start = 0;
     if constexpr (TRACE) r_entry = __builtin_amdgcn_s_memrealtime();
     // ---- entry batch, then the descriptor ----
     const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
     rt_u32x16 q;
-    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q) : "s"(kp));
+    [[maybe_unused]] rt_u32x4 qc = { 0u, 0u, 0u, 0u };
+    if constexpr (COOP) asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0xa8\n\ts_waitcnt lgkmcnt(0)" : "=&s"(q), "=&s"(qc) : "s"(kp));
+    else asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q) : "s"(kp));
     typedef const rt_u32x4 __attribute__((address_space(4))) *desc_ptr;        // a BlockDesc as its four words
     const desc_ptr order = (desc_ptr)(((unsigned long long)q[1] << 32) | q[0]);
     const void *walk_prim = (const void *)(((unsigned long long)q[3] << 32) | q[2]);
@@ -73,7 +85,20 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(82)))
     const unsigned pw = 8u >> level, pbits = 3u - level;
     const unsigned x = bx0 + (wave & 1) * pw + (lane & (pw - 1));
     const unsigned y = by0 + (wave >> 1) * pw + ((lane >> pbits) & (pw - 1));
-    const bool inside = x < tile_r && y < tile_t && lane < pw * pw;
+    bool inside = x < tile_r && y < tile_t && lane < pw * pw;
+    [[maybe_unused]] bool coop_wave = false;
+    [[maybe_unused]] const unsigned coop_rays = pw * pw;
+    if constexpr (COOP) {
+        // a cooperative descriptor's other waves have nothing to do; an ordinary block leaves its holes to the cooperative descriptors
+        const unsigned coop_mask = (raw[2] >> kBlockCoopShift) & 15u;
+        coop_wave = __builtin_amdgcn_readfirstlane((int)((coop_mask >> wave) & 1u)) != 0;
+        if (coop_mask != 0u) inside = inside && coop_wave;
+        else if (blockIdx.x < qc[2]) {
+            typedef const unsigned long long __attribute__((address_space(4))) *hole_ptr;
+            const unsigned long long hole = ((hole_ptr)(((unsigned long long)qc[1] << 32) | qc[0]))[blockIdx.x];
+            inside = inside && ((hole >> (((y - by0) >> 1) * (8u >> level) + ((x - bx0) >> 1))) & 1ull) == 0ull;
+        }
+    }
     if (__ballot(inside) == 0) return;
     if constexpr (TRACE) r_start = __builtin_amdgcn_s_memrealtime();
     // where the pixel goes: known now, needed last -- as an address in two vector registers
@@ -91,14 +116,24 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(82)))
     const T half_w = fw / T(2.0), half_h = fh / T(2.0);
     V3<T> dir = { T(x) - half_w, (fh - T(y)) - half_h, fw };
     dir = normalized(dir);
-    const float fdx = inside ? dir.x : __builtin_nanf("");          // (a lane without a ray carries a direction no bound lets through)
 
     // ---- primary ray: s.group.intersect(&mut h, r)  render.rs:188-189 ----
     constexpr unsigned kStride = (unsigned)sizeof(Node<T>);
     T best = inf<T>();
     unsigned best_item = 0;
-    if constexpr (FUSED) skip_primary_rot_filt_fused(walk_prim, nb, fdx, dir.y, dir.z, inside ? 0u : nb, best, best_item);
-    else skip_primary_rot_filt(walk_prim, nb, fdx, dir.y, dir.z, inside ? 0u : nb, best, best_item);
+    // lanes whose ray the loops walk: all of them, or what the cooperative walk of this quad hands back
+    bool walk = inside;
+    [[maybe_unused]] T cbest = inf<T>();
+    [[maybe_unused]] unsigned citem = 0;
+    if constexpr (COOP) {
+        if (coop_wave) coop_primary(args.cv, coop_lds[wave], coop_rays, dir.x, dir.y, dir.z, inside, cbest, citem, walk);
+    }
+    const bool loops_run = !COOP || !coop_wave || __ballot(walk) != 0;
+    if (loops_run) {
+        const float fdx = walk ? dir.x : __builtin_nanf("");        // (a lane without a ray carries a direction no bound lets through)
+        if constexpr (FUSED) skip_primary_rot_filt_fused(walk_prim, nb, fdx, dir.y, dir.z, walk ? 0u : nb, best, best_item);
+        else skip_primary_rot_filt(walk_prim, nb, fdx, dir.y, dir.z, walk ? 0u : nb, best, best_item);
+    }
 
     // ---- late batch: requested here, where the wave is about to wait for the winner's centre anyway ----
     rt_u32x8 p;
@@ -115,6 +150,9 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(82)))
         if (best_item != 0u && !(best_item & kNodeItem)) best_item = own[best_item / kStride - 1u];
     }
     best_item &= kNodeIndexMask;
+    if constexpr (COOP) {
+        if (coop_wave && !walk) { best = cbest; best_item = citem; }
+    }
 
     // ---- shade  render.rs:190-199 ----
     const V3<T> OBJECT = { T(0xae) / T(255.0), T(0x31) / T(255.0), T(0x31) / T(255.0) };
@@ -143,7 +181,11 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(82)))
 
     // ---- shadow ray: any hit  render.rs:202-208 ----
     bool occluded = false;
-    if (__ballot(need_shadow) != 0) {
+    bool walk_s = need_shadow;
+    if constexpr (COOP) {
+        if (coop_wave && __ballot(need_shadow) != 0) coop_shadow(args.cv, coop_lds[wave], coop_rays, sp.x, sp.y, sp.z, sdir, need_shadow, occluded, walk_s);
+    }
+    if (__ballot(walk_s) != 0) {
         FilterConsts fc;
         fc.m0[0] = __uint_as_float(f[0]); fc.m0[1] = __uint_as_float(f[1]); fc.m0[2] = __uint_as_float(f[2]);
         fc.e1[0] = __uint_as_float(f[3]); fc.e1[1] = __uint_as_float(f[4]); fc.e1[2] = __uint_as_float(f[5]);
@@ -152,11 +194,11 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(82)))
         fc.a0 = __uint_as_float(f[12]); fc.k1 = __uint_as_float(f[13]); fc.kc = __uint_as_float(f[14]); fc.ro2 = __uint_as_float(f[15]);
         float q1, q2, fol;
         shadow_filter_origin(fc, sp.x, sp.y, sp.z, q1, q2, fol);
-        if (!need_shadow) q1 = inf<float>();            // no shadow ray: an in-plane origin at infinity is beyond every outer bound but END's
+        if (!walk_s) q1 = inf<float>();                 // no shadow ray: an in-plane origin at infinity is beyond every outer bound but END's
         // (the direction as scalars again: the loops take it as such)
         auto uniform = [](float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); };      // (the bits, not the value)
         const float slx = uniform(sdir.x), sly = uniform(sdir.y), slz = uniform(sdir.z);
-        unsigned resume = need_shadow ? 0u : nb;        // lanes without a shadow ray sleep until END
+        unsigned resume = walk_s ? 0u : nb;             // lanes without a shadow ray sleep until END
         unsigned i = 0;
         while (i < nb) {
             unsigned fin;
@@ -182,12 +224,25 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(82)))
             rec[0] = (uint32_t)r_start;
             rec[1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
             rec[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16);
-            rec[3] = blockIdx.x;
+            rec[3] = blockIdx.x | (coop_wave ? 0x80000000u : 0u);
             rec[4] = (uint32_t)r_entry;
             __builtin_amdgcn_s_waitcnt(0);
             rec[5] = (uint32_t)__builtin_amdgcn_s_memrealtime();
         }
     }
+}
+
+template <int VAR, bool TRACE>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(82))) void k_render_skip_fast(FastArgs args)
+{
+    render_skip_fast_body<VAR, TRACE, false>(args);
+}
+// ... with cooperative quads: the walk's state in LDS (16 KB per workgroup), more registers (what a CU admits is decided by the counts
+// tests/test_kernel_resources.py pins)
+template <int VAR, bool TRACE>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(RT_FAST_COOP_SGPRS))) void k_render_skip_fast_coop(FastArgs args)
+{
+    render_skip_fast_body<VAR, TRACE, true>(args);
 }
 
 }  // namespace rt

@@ -16,10 +16,10 @@ int main(void)
     printf("abi %d\n", rt_abi_version());
     printf("sizeof rt_options %zu rt_region %zu rt_range %zu rt_stats %zu\n", sizeof(rt_options), sizeof(rt_region),
            sizeof(rt_range), sizeof(rt_stats));
-    printf("offsets stats: primary %zu hits %zu shadow %zu occluded %zu sphere_tests %zu bound_tests %zu tests_executed %zu primary_tests %zu device_ms %zu\n",
+    printf("offsets stats: primary %zu hits %zu shadow %zu occluded %zu sphere_tests %zu bound_tests %zu tests_executed %zu primary_tests %zu device_ms %zu longest_wave_cycles %zu longest_wave_ref100mhz %zu\n",
            offsetof(rt_stats, primary), offsetof(rt_stats, hits), offsetof(rt_stats, shadow), offsetof(rt_stats, occluded),
            offsetof(rt_stats, sphere_tests), offsetof(rt_stats, bound_tests), offsetof(rt_stats, tests_executed),
-           offsetof(rt_stats, primary_tests), offsetof(rt_stats, device_ms));
+           offsetof(rt_stats, primary_tests), offsetof(rt_stats, device_ms), offsetof(rt_stats, longest_wave_cycles), offsetof(rt_stats, longest_wave_ref100mhz));
     printf("built with: %s; last launch flags %u\n", rt_build_info(), (unsigned)rt_last_launch_flags());
     printf("bytes %llu\n", (unsigned long long)rt_tiles_rgba_bytes(tiles, 2));
     printf("devices status %d n %d (%s)\n", (int)st, n, rt_strerror(st));

@@ -29,6 +29,7 @@ PINNED_INLINE_ASM_WARNINGS = {"product": 24, "test_hooks": 28}
 # (.sgpr_count, .vgpr_count) of the product's hot kernels, exactly
 PINNED_REGISTERS = {
     "rt::k_render_skip_fast<19, false>": (80, 34), "rt::k_render_skip_fast<23, false>": (80, 34),
+    "rt::k_render_skip_fast_coop<19, false>": (80, 40), "rt::k_render_skip_fast_coop<23, false>": (80, 40),
     "rt::k_render_skip_f32<false, 19, 0>": (80, 51), "rt::k_render_skip_f32<false, 19, 1>": (80, 43), "rt::k_render_skip_f32<false, 19, 2>": (80, 46),
     "rt::k_render_skip_f32<false, 19, 3>": (80, 45), "rt::k_render_skip_f32<false, 23, 0>": (80, 51), "rt::k_render_skip_f32<false, 23, 1>": (80, 43),
     "rt::k_render_skip_f32<false, 23, 2>": (80, 46), "rt::k_render_skip_f32<false, 23, 3>": (80, 45),
@@ -63,8 +64,8 @@ def _kernels(tmp_path, LIB=LIB):
 def test_the_hot_kernels_keep_the_registers_their_residency_needs(tmp_path):
     k = _kernels(tmp_path)
     eight = [n for n in k if re.match(r"rt::k_render_skip_f32<false, (19|23), \d>$", n) or re.match(r"rt::k_render_skip2<\d, true, (true|false)>$", n) or
-             re.match(r"rt::k_render_skip_fast<(19|23), false>$", n)]
-    assert len(eight) >= 10, sorted(k)[:20]
+             re.match(r"rt::k_render_skip_fast(_coop)?<(19|23), false>$", n)]
+    assert len(eight) >= 12, sorted(k)[:20]
     for n in eight:            # eight workgroups' worth of waves per SIMD: the one-ray f32 walk (every mode) and the filtered two-ray walk
         assert k[n]["sgpr"] <= 80 and k[n]["vgpr"] <= 64 and k[n]["scratch"] == 0, (n, k[n])
     for n in k:                # seven: the cooperative flavour (it would park 41 values at 80, and its passes do not fill the chip)
