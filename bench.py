@@ -244,8 +244,10 @@ def make_image_wall(cores):
                     parts = json.loads(line)
         res.update({"make_image_wall_ms": round(min(walls[1:]), 2), "wall_ms_each": [round(w, 2) for w in walls], "first_run_wall_ms": round(walls[0], 2),
                     "parts_ms": parts, "md5_ok": md5(out) == res["reference_md5"],
-                    "parts_note": "from main() of the last run: args; host_scene = Scene::default on the host; runtime_init = the first HIP call; device_scene = "
-                                  "rt_scene_create (uploads, code-object load, stream derivation); render_and_first_write = Renderer::render up to the Drop; "
+                    "parts_note": "from main() of the last run: args; host_scene = Scene::default on the host; runtime_init = the first HIP call; device_context = the first call "
+                                  "that needs the DEVICE (the runtime activates its context: address space, first queue -- the runtime's, whoever makes that call); "
+                                  "device_scene = rt_scene_create (its stream, the code object's load, uploads by kernel -- no copy engine --, stream derivation; the cost map "
+                                  "and the dispatch orders wait for a second frame); render_and_first_write = Renderer::render up to the Drop; "
                                   "drop_write = the writer's final write; wall - main_to_here = exec, dynamic linking, static initialisers, exit / runtime teardown"})
     except Exception as e:          # noqa: BLE001
         res["error"] = repr(e)

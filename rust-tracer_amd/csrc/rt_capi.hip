@@ -80,6 +80,18 @@ rt_status hip_fail(hipError_t e, const char *what, int line)
         if (e__ != hipSuccess) return hip_fail(e__, #expr, __LINE__);       \
     } while (0)
 
+// RT_DEBUG_PRINT_COSTS: where rt_scene_create and the first use of a tile list spend their host time
+struct StageClock {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (knob(RT_DEBUG_PRINT_COSTS) <= 0) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rtrace_hip] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(n - t).count());
+        t = n;
+    }
+};
+
 // Per-call working set: own stream, tile table, counters, staging output.  A scene keeps a pool of these so
 // concurrent callers (the reference's pool threads, render.rs:283) never share one.
 struct Context {
@@ -197,6 +209,8 @@ struct rt_scene {
     // Tests per primary ray (its shadow ray included) on a kCostRes x kCostRes grid over the camera's field of view,
     // rendered once per scene with the counting kernel.  It only ever decides the ORDER in which blocks are dispatched.
     std::once_flag cost_once;
+    // pinned staging of what rt_scene_create uploads (upload_words): bump-allocated, released when the scene's streams have been derived
+    char *h_up = nullptr; size_t up_cap = 0, up_used = 0;
     std::mutex exact_mu;                   // exact_block_costs: the cost arena is also where a tile list's heaviest blocks are counted again
     hipStream_t cost_stream = nullptr;
     void *d_cost_arena = nullptr, *h_cost = nullptr;
@@ -224,6 +238,31 @@ struct rt_scene {
 };
 
 namespace {
+
+// `bytes` (a multiple of 4) of host data into device memory on `stream`, through pinned staging and k_upload_words -- no copy engine
+// (rt_kernels.hpp says why).  The staging is the scene's arena while rt_scene_create runs (reserve_upload), else a buffer of the caller's.
+rt_status upload_words(void *d_dst, const void *h_pinned_src, size_t bytes, hipStream_t stream)
+{
+    void *alias = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&alias, const_cast<void *>(h_pinned_src), 0));
+    const size_t n = bytes / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(rt::k_upload_words, dim3(std::max(1u, blocks)), dim3(256), 0, stream, static_cast<const uint32_t *>(alias), static_cast<uint32_t *>(d_dst), n);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+rt_status scene_upload(rt_scene *s, void *d_dst, const void *src, size_t bytes)       // rt_scene_create's uploads, on the scene's stream
+{
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (s->h_up && s->up_used + need <= s->up_cap) {
+        char *h = s->h_up + s->up_used;
+        memcpy(h, src, bytes);
+        s->up_used += need;
+        return upload_words(d_dst, h, bytes, s->cost_stream);
+    }
+    HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, s->cost_stream));      // (no arena: the copy engine after all; `src` outlives the caller's synchronise)
+    return RT_OK;
+}
 
 // Contexts released by asynchronous callers and still in flight: enough to keep the device fed; each may hold per-sample
 // buffers (GBs at 4096^2 x 16).  Synchronous callers (one per host thread) each hold their own while they run.
@@ -579,7 +618,7 @@ rt_status derive_streams(const rt_scene *s, const std::vector<rt::RawNode<T>> &r
     const size_t n = raw.size(), total = n + rt::kNodePad;
     rt::RawNode<T> *d_raw = nullptr;
     HIP_TRY(hipMalloc(&d_raw, sizeof(rt::RawNode<T>) * n));
-    hipError_t e = hipMemcpyAsync(d_raw, raw.data(), sizeof(rt::RawNode<T>) * n, hipMemcpyHostToDevice, s->cost_stream);      // (`raw` outlives the synchronise below)
+    hipError_t e = scene_upload(const_cast<rt_scene *>(s), d_raw, raw.data(), sizeof(rt::RawNode<T>) * n) == RT_OK ? hipSuccess : hipErrorUnknown;      // (`raw` outlives the synchronise below)
     if (e == hipSuccess) e = hipMalloc(d_prim, sizeof(rt::Node<T>) * total);
     if (e == hipSuccess) e = hipMalloc(d_shad, sizeof(rt::Node<T>) * total);
     if (e == hipSuccess) {
@@ -616,7 +655,9 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
         if (raw[i].skip != 0u)
             fused = i + 1 < raw.size() && raw[i + 1].skip == 0u && memcmp(&raw[i].cx, &raw[i + 1].cx, 3 * sizeof(T)) == 0;
     s->fused = fused;
+    StageClock clk;
     if ((st = derive_streams<T>(s, raw, false, &s->d_prim, &s->d_shad)) != RT_OK) return st;
+    clk.lap("  streams: plain (first kernel)");
     if (fused) {
         // compacted streams: the ITEM behind every BOUND moves into the BOUND node (it is never a jump target: `skip` points
         // behind a whole subtree, and a subtree never starts with its group's own sphere)
@@ -641,12 +682,13 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
         }
         s->n_fnodes = (uint32_t)compact.size();
         if ((st = derive_streams<T>(s, compact, true, &s->d_cprim, &s->d_cshad)) != RT_OK) return st;
+        clk.lap("  streams: compacted");
     }
     if constexpr (sizeof(T) == 8) {
         // f64: FNode copies of the primary streams for the filtered primary walk (rt_skip.hpp k_build_fstream64)
         filter_constants<T>(s, raw, static_cast<const T *>(items));
         HIP_TRY(hipMalloc(&s->d_fc, sizeof(rt::FilterConsts)));
-        HIP_TRY(hipMemcpyAsync(s->d_fc, &s->fc, sizeof(rt::FilterConsts), hipMemcpyHostToDevice, s->cost_stream));
+        { rt_status ust = scene_upload(s, s->d_fc, &s->fc, sizeof(rt::FilterConsts)); if (ust != RT_OK) return ust; }
         auto derive64 = [&](const void *d_prim, const void *d_shad, size_t n_nodes, bool compacted, void **d_x, void **d_xs, void **d_own) -> rt_status {
             const size_t total = n_nodes + rt::kNodePad;
             HIP_TRY(hipMalloc(d_x, sizeof(rt::FNode) * total));
@@ -667,10 +709,13 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
     if constexpr (sizeof(T) == 4) {
         filter_constants<T>(s, raw, static_cast<const T *>(items));
         HIP_TRY(hipMalloc(&s->d_fc, sizeof(rt::FilterConsts)));
-        HIP_TRY(hipMemcpyAsync(s->d_fc, &s->fc, sizeof(rt::FilterConsts), hipMemcpyHostToDevice, s->cost_stream));
+        { rt_status ust = scene_upload(s, s->d_fc, &s->fc, sizeof(rt::FilterConsts)); if (ust != RT_OK) return ust; }
+        clk.lap("  streams: filter constants");
         if ((st = derive_fstreams(s, s->d_prim, s->d_shad, s->n_nodes, false, &s->d_xprim, &s->d_xshad, nullptr)) != RT_OK) return st;
         if (fused && (st = derive_fstreams(s, s->d_cprim, s->d_cshad, s->n_fnodes, true, &s->d_xcprim, &s->d_xcshad, &s->d_xown)) != RT_OK) return st;
+        clk.lap("  streams: filtered");
         if ((st = upload_coop(s, raw)) != RT_OK) return st;
+        clk.lap("  streams: cooperative copy");
     }
     return RT_OK;
 }
@@ -703,8 +748,8 @@ rt_status upload_coop(rt_scene *s, const std::vector<rt::RawNode<float>> &raw)
     uint32_t *d_perm = nullptr; uint2 *d_link = nullptr;
     hipError_t e = hipMalloc(&d_perm, sizeof(uint32_t) * n);
     if (e == hipSuccess) e = hipMalloc(&d_link, sizeof(uint2) * n);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_perm, perm.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s->cost_stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_link, link.data(), sizeof(uint2) * n, hipMemcpyHostToDevice, s->cost_stream);
+    if (e == hipSuccess && scene_upload(s, d_perm, perm.data(), sizeof(uint32_t) * n) != RT_OK) e = hipErrorUnknown;
+    if (e == hipSuccess && scene_upload(s, d_link, link.data(), sizeof(uint2) * n) != RT_OK) e = hipErrorUnknown;
     if (e == hipSuccess) e = hipMalloc(&s->d_coop_prim, sizeof(rt::CNode) * n);
     if (e == hipSuccess) e = hipMalloc(&s->d_coop_shad, sizeof(rt::CNode) * n);
     if (e == hipSuccess) {
@@ -802,32 +847,41 @@ constexpr size_t kTableStageBytes = 256 * 1024;       // pinned staging for the 
 
 // The scene's cost map: one counting render of a kCostRes^2 image (same camera: x spans the same field of view at every
 // width), each lane storing the number of tests its pixel took.
-// Enqueues the counting render of the cost map on the scene's own stream (rt_scene_create does this right away: by the time a tile list
-// wants the map it has usually been rendered); cost_map_of waits for it.
+// The pinned host side of the cost map: [map: kCostRes^2 words | tile-table area | staging for the tile tables of new lists].  Made by
+// rt_scene_create (0.15 ms); the device side and the counting render wait until a tile list wants dispatch orders (start_cost_map): a
+// process that renders ONE frame (`make image`) never pays for them.
+rt_status alloc_cost_host(rt_scene *s)
+{
+    constexpr size_t kPx = (size_t)kCostRes * kCostRes * 4;
+    HIP_TRY(hipHostMalloc(&s->h_cost, kPx + kCostTileBytes + kTableStageBytes, hipHostMallocDefault));
+    s->h_tab_stage = static_cast<char *>(s->h_cost) + kPx + kCostTileBytes;
+    return RT_OK;
+}
+
+// Enqueues the counting render of the cost map on the scene's own stream (by whoever first asks for the map: cost_map_of, normally the
+// scene's worker thread).  No copy engine: the one tile is read from pinned memory, the lanes store their counts into the pinned map.
 template <typename T>
 rt_status start_cost_map(rt_scene *s)
 {
     constexpr unsigned R = kCostRes;
     const rt::TileDev tile{ 0, (uint16_t)R, (uint16_t)R, 0, 0u, 0u, R / rt::kBlockW };
+    if (!s->h_cost) return RT_ERR_OUT_OF_MEMORY;
     // ONE device allocation, kept until the scene goes (hipMalloc / hipFree wait for a busy device): tile | frame | costs | counters
     constexpr size_t kTileBytes = kCostTileBytes, kPx = (size_t)R * R * 4, kCnt = sizeof(rt::Counters) * rt::kCounterStripes;
     HIP_TRY(hipMalloc(&s->d_cost_arena, kTileBytes + 2 * kPx + kCnt));
-    HIP_TRY(hipHostMalloc(&s->h_cost, kPx + kTileBytes + kTableStageBytes, hipHostMallocDefault));
-    s->h_tab_stage = static_cast<char *>(s->h_cost) + kPx + kTileBytes;
     hipStream_t stream = s->cost_stream;
     char *base = static_cast<char *>(s->d_cost_arena);
-    rt::TileDev *d_tile = reinterpret_cast<rt::TileDev *>(base);
     uint8_t *d_out = reinterpret_cast<uint8_t *>(base + kTileBytes);
-    uint32_t *d_cost = reinterpret_cast<uint32_t *>(base + kTileBytes + kPx);
     rt::Counters *d_cnt = reinterpret_cast<rt::Counters *>(base + kTileBytes + 2 * kPx);
-    memcpy(static_cast<char *>(s->h_cost) + kPx, &tile, sizeof tile);                 // (pinned: the copy below is truly asynchronous)
-    HIP_TRY(hipMemcpyAsync(d_tile, static_cast<char *>(s->h_cost) + kPx, sizeof tile, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemsetAsync(d_cost, 0, kPx + kCnt, stream));
+    memcpy(static_cast<char *>(s->h_cost) + kPx, &tile, sizeof tile);
+    void *h_alias = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&h_alias, s->h_cost, 0));
+    const rt::TileDev *tile_alias = reinterpret_cast<const rt::TileDev *>(static_cast<char *>(h_alias) + kPx);
+    hipLaunchKernelGGL(rt::k_zero_words, dim3(64), dim3(256), 0, stream, reinterpret_cast<uint32_t *>(d_cnt), kCnt / 4);
     rt::SampleBuf<T> sb{ nullptr, nullptr, R * R };
     hipLaunchKernelGGL((rt::k_render_skip<T, true, 1, rt::kSkipLoop>), dim3((R / rt::kBlockW) * (R / rt::kBlockH)), dim3(rt::kBlockThreads), 0, stream,
-                       skip_args<T>(s, nullptr, nullptr, R, R, 0u, d_out, d_tile, 1u, 1u, d_cnt, d_cost, sb));
+                       skip_args<T>(s, nullptr, nullptr, R, R, 0u, d_out, tile_alias, 1u, 1u, d_cnt, static_cast<uint32_t *>(h_alias), sb));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(s->h_cost, d_cost, kPx, hipMemcpyDeviceToHost, stream));
     s->cost_started = true;
     return RT_OK;
 }
@@ -836,7 +890,8 @@ rt_status start_cost_map(rt_scene *s)
 const std::vector<uint32_t> *cost_map_of(rt_scene *s)
 {
     std::call_once(s->cost_once, [s] {
-        if (s->n_nodes == 0 || !s->cost_started) return;
+        if (s->n_nodes == 0) return;
+        if ((s->precision == RT_F32 ? start_cost_map<float>(s) : start_cost_map<double>(s)) != RT_OK) { s->cost_started = false; (void)hipGetLastError(); return; }
         if (hipStreamSynchronize(s->cost_stream) != hipSuccess) { (void)hipGetLastError(); return; }
         const uint32_t *h = static_cast<const uint32_t *>(s->h_cost);
         s->cost_map.assign(h, h + (size_t)kCostRes * kCostRes);
@@ -859,10 +914,15 @@ rt_status exact_block_costs(rt_scene *s, const std::vector<rt::BlockDesc> &raste
     std::lock_guard<std::mutex> lk(s->exact_mu);                 // one counting launch at a time through the scene's arena
     constexpr size_t kPx = (size_t)kCostRes * kCostRes * 4, kCnt = sizeof(rt::Counters) * rt::kCounterStripes;
     char *base = static_cast<char *>(s->d_cost_arena);
-    rt::TileDev *d_tile = reinterpret_cast<rt::TileDev *>(base);
     uint8_t *d_out = reinterpret_cast<uint8_t *>(base + kCostTileBytes);
-    uint32_t *d_cost = reinterpret_cast<uint32_t *>(base + kCostTileBytes + kPx);
     rt::Counters *d_cnt = reinterpret_cast<rt::Counters *>(base + kCostTileBytes + 2 * kPx);
+    // (like the map itself: the tile table is read from the pinned arena, the counts are stored into it -- the map was copied out of it
+    // when it was collected)
+    void *h_alias = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&h_alias, s->h_cost, 0));
+    rt::TileDev *h_tiles = reinterpret_cast<rt::TileDev *>(static_cast<char *>(s->h_cost) + kPx);
+    const rt::TileDev *tile_alias = reinterpret_cast<const rt::TileDev *>(static_cast<char *>(h_alias) + kPx);
+    uint32_t *h_counts = static_cast<uint32_t *>(s->h_cost);
     std::vector<rt::TileDev> tiles(blocks.size());
     for (size_t i = 0; i < blocks.size(); ++i) {
         const rt::BlockDesc &d = raster[blocks[i]];
@@ -871,15 +931,15 @@ rt_status exact_block_costs(rt_scene *s, const std::vector<rt::BlockDesc> &raste
                                 (uint32_t)(i * rt::kBlockW * rt::kBlockH), (uint32_t)i, 1u };
     }
     hipStream_t stream = s->cost_stream;
-    HIP_TRY(hipMemcpyAsync(d_tile, tiles.data(), tiles.size() * sizeof(rt::TileDev), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemsetAsync(d_cost, 0, kPx + kCnt, stream));
+    memcpy(h_tiles, tiles.data(), tiles.size() * sizeof(rt::TileDev));
+    memset(h_counts, 0, blocks.size() * rt::kBlockW * rt::kBlockH * 4);           // (pixels outside a clipped block are not stored)
+    hipLaunchKernelGGL(rt::k_zero_words, dim3(64), dim3(256), 0, stream, reinterpret_cast<uint32_t *>(d_cnt), kCnt / 4);
     rt::SampleBuf<T> sb{ nullptr, nullptr, (unsigned)(blocks.size() * rt::kBlockW * rt::kBlockH) };
     hipLaunchKernelGGL((rt::k_render_skip<T, true, 1, rt::kSkipLoop>), dim3((unsigned)blocks.size()), dim3(rt::kBlockThreads), 0, stream,
-                       skip_args<T>(s, nullptr, nullptr, w, h, 0u, d_out, d_tile, (unsigned)tiles.size(), 1u, d_cnt, d_cost, sb));
+                       skip_args<T>(s, nullptr, nullptr, w, h, 0u, d_out, tile_alias, (unsigned)tiles.size(), 1u, d_cnt, static_cast<uint32_t *>(h_alias), sb));
     HIP_TRY(hipGetLastError());
-    std::vector<uint32_t> raw(blocks.size() * rt::kBlockW * rt::kBlockH);
-    HIP_TRY(hipMemcpyAsync(raw.data(), d_cost, raw.size() * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    const std::vector<uint32_t> raw(h_counts, h_counts + blocks.size() * rt::kBlockW * rt::kBlockH);
     // the kernel stores tile-major with the tile's own pitch (its clipped width): re-pitch to 16
     out.block = blocks;
     out.px.assign(raw.size(), 0u);
@@ -1138,17 +1198,6 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
 
 bool block_order_enabled() { return knob(RT_DEBUG_BLOCK_ORDER) != 0; }     // read per call: A/B timing interleaves both
 
-// RT_DEBUG_PRINT_COSTS: where the first use of a tile list spends its host time
-struct StageClock {
-    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    void lap(const char *what)
-    {
-        if (knob(RT_DEBUG_PRINT_COSTS) <= 0) return;
-        const auto n = std::chrono::steady_clock::now();
-        fprintf(stderr, "[rtrace_hip] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(n - t).count());
-        t = n;
-    }
-};
 
 void release_order(rt_scene::Order &od)           // (its arrays live in the table's arena)
 {
@@ -1459,7 +1508,7 @@ rt_status device_table(rt_scene *s, Context *c, const std::vector<rt::TileDev> &
                 hipEventCreateWithFlags(&t.landed, hipEventDisableTiming) == hipSuccess) {
                 char *h = s->h_tab_stage + s->tab_stage_used;
                 memcpy(h, tab.data(), bytes);
-                if (hipMemcpyAsync(t.dev, h, bytes, hipMemcpyHostToDevice, stream) == hipSuccess && hipEventRecord(t.landed, stream) == hipSuccess) {
+                if (upload_words(t.dev, h, bytes, stream) == RT_OK && hipEventRecord(t.landed, stream) == hipSuccess) {      // (a kernel, not the copy engine: rt_kernels.hpp k_upload_words)
                     s->tab_stage_used += staged;
                     t.landed_on = stream;
                     async_copy = true;
@@ -2133,7 +2182,9 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
         snprintf(g_err, sizeof g_err, "device %d out of range (%d visible)", device, ndev);
         return RT_ERR_NO_DEVICE;
     }
+    StageClock clk;
     HIP_TRY(hipSetDevice(device));
+    clk.lap("scene: hipSetDevice");
 
     std::unique_ptr<rt_scene> s(new (std::nothrow) rt_scene());
     if (!s) return RT_ERR_OUT_OF_MEMORY;
@@ -2165,20 +2216,32 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
     // ONE stream carries everything this call enqueues (uploads, the kernels that derive the streams, the cost map's counting render) and is
     // the first context's stream afterwards: the null stream is never touched
     if ((e = hipStreamCreateWithFlags(&s->cost_stream, hipStreamNonBlocking)) != hipSuccess) return fail(hip_fail(e, "hipStreamCreate(scene)", __LINE__));
+    clk.lap("scene: stream");
     if ((e = hipMalloc(&s->d_items, esz * 4 * n_items)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(items)", __LINE__));
-    if ((e = hipMemcpyAsync(s->d_items, s->h_items.data(), esz * 4 * n_items, hipMemcpyHostToDevice, s->cost_stream)) != hipSuccess)      // (the scene's own copy of the items)
-        return fail(hip_fail(e, "hipMemcpy(items)", __LINE__));
-    if ((e = hipStreamSynchronize(s->cost_stream)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy(items)", __LINE__));
+    {
+        // everything this call uploads goes through ONE pinned arena and k_upload_words: items, the raw streams (plain + compacted: a node per
+        // item and per bound, twice), the cooperative copy's tables, the filter's constants -- no hipMemcpy on the way to the first frame
+        const size_t nodes = (size_t)n_items + n_bounds;
+        const size_t raw_sz = f32 ? sizeof(rt::RawNode<float>) : sizeof(rt::RawNode<double>);
+        const size_t want = esz * 4 * n_items + 2 * nodes * raw_sz + nodes * (sizeof(uint32_t) + sizeof(uint2)) + 64 * 1024;
+        if (want <= ((size_t)1 << 30) && hipHostMalloc(reinterpret_cast<void **>(&s->h_up), want, hipHostMallocDefault) == hipSuccess) { s->up_cap = want; s->up_used = 0; }
+        else { (void)hipGetLastError(); s->h_up = nullptr; }
+    }
+    { rt_status ust = scene_upload(s.get(), s->d_items, s->h_items.data(), esz * 4 * n_items); if (ust != RT_OK) return fail(ust); }      // (the scene's own copy of the items)
+    if ((e = hipStreamSynchronize(s->cost_stream)) != hipSuccess) return fail(hip_fail(e, "upload(items)", __LINE__));
+    clk.lap("scene: items");
     if (n_bounds) {
         rt_status sst = f32 ? upload_streams<float>(s.get(), dfs_items, bounds, ranges) : upload_streams<double>(s.get(), dfs_items, bounds, ranges);
         if (sst != RT_OK) return fail(sst);
-        // the cost map the dispatch orders are made from: enqueued now, on a stream of its own, collected when a tile list first wants it
-        // (failing to start it only costs the ordering)
-        if ((f32 ? start_cost_map<float>(s.get()) : start_cost_map<double>(s.get())) != RT_OK) { s->cost_started = false; (void)hipGetLastError(); }
-        else {
-            try { s->worker = std::thread(worker_main, s.get()); note_builder(s.get()); } catch (...) {}      // (without it a new list starts a thread of its own)
-        }
+        clk.lap("scene: streams (total)");
+        // the cost map the dispatch orders are made from is rendered when a tile list first wants orders (cost_map_of, from the scene's worker
+        // thread); here only its pinned host side, which is also where new lists' tile tables are staged (failing only costs the ordering)
+        if (alloc_cost_host(s.get()) != RT_OK) { (void)hipGetLastError(); s->h_cost = nullptr; s->h_tab_stage = nullptr; }
+        try { s->worker = std::thread(worker_main, s.get()); note_builder(s.get()); } catch (...) {}      // (without it a new list starts a thread of its own)
+        clk.lap("scene: pinned cost arena + worker");
     }
+    // (every upload has been consumed: derive_streams and upload_coop synchronise the stream behind their kernels)
+    if (s->h_up) { (void)hipStreamSynchronize(s->cost_stream); (void)hipHostFree(s->h_up); s->h_up = nullptr; s->up_cap = s->up_used = 0; }
     *out = s.release();
     return RT_OK;
 }
@@ -2201,6 +2264,7 @@ rt_status rt_scene_destroy(rt_scene *s)
     for (void *p : { s->d_xprim, s->d_xshad, s->d_xcprim, s->d_xcshad, s->d_xown, s->d_fc, s->d_coop_prim, s->d_coop_shad, s->d_cost_arena }) if (p) (void)hipFree(p);
     if (s->cost_stream) { (void)hipStreamSynchronize(s->cost_stream); (void)hipStreamDestroy(s->cost_stream); }
     if (s->h_cost) (void)hipHostFree(s->h_cost);
+    if (s->h_up) (void)hipHostFree(s->h_up);
     if (s->ahead.ev) (void)hipEventDestroy(s->ahead.ev);
     if (s->ahead.h) (void)rt_host_free(s->ahead.h);
     if (s->ahead.h_next) (void)rt_host_free(s->ahead.h_next);

@@ -144,6 +144,19 @@ __global__ void k_selftest_rcp(unsigned first, unsigned long long count, unsigne
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// Host data into device memory WITHOUT a copy engine: `src` is the device alias of pinned host memory, read over PCIe by the lanes.  The
+// first hipMemcpy* of a process costs 7.5 ms (asynchronous: the copy queue's set-up) and its first blocking one as much again
+// (tools/_init_probe.hip, round 6); a kernel launch costs 0.4.  What `make image` waits for in rt_scene_create is a few MB, once.
+__global__ __launch_bounds__(256) void k_upload_words(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, size_t n_words)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void k_zero_words(uint32_t *__restrict__ dst, size_t n_words)        // (hipMemsetAsync loads the runtime's own kernels first)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) dst[i] = 0u;
+}
+
 // RGBABuffer::set_pixels_from_buffer (render.rs:112-126): tile-major tiles -> row-major frame, 4 B per lane.
 __global__ __launch_bounds__(kBlockThreads) void k_blit_tiles(unsigned width, const TileDev *__restrict__ tiles, unsigned n_tiles,
                                                              const unsigned *__restrict__ src, unsigned *__restrict__ frame)
