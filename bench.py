@@ -146,7 +146,7 @@ def cpu_baseline(width, height, spp, level, budget_s=12.0):
         import numpy as np
         from rust_tracer_amd.scene import build_hierarchy
         from tests.scenes import hundred_thousand_spheres
-        items, bounds, ranges, _ = build_hierarchy(hundred_thousand_spheres())
+        items, bounds, ranges, _ = build_hierarchy(hundred_thousand_spheres(), eye=(0.0, 0.0, -4.0))      # (as Scene.from_spheres_auto builds it)
         o = oracle.Scene.from_ranges(items.astype(np.float64), bounds.astype(np.float64), ranges)
     else:
         o = oracle.Scene.default(oracle.F32, level)
@@ -291,9 +291,9 @@ def main():
                          "'frames' = every GPU renders whole frames, N per step (weak scaling)")
     ap.add_argument("--frames-per-gather", type=int, default=4,
                     help="N > 1: frames (or, 'tiles' layout, shards) a rank renders per RCCL gather (fewer, larger collectives)")
-    ap.add_argument("--collective-backend", choices=("nccl", "gloo"), default="nccl",
-                    help="N > 1: nccl = RCCL over xGMI (the product path).  gloo = TEST INFRASTRUCTURE: the gather goes through pinned host memory "
-                         "and a CPU collective, so that several ranks can share ONE GPU (RCCL refuses that) and run the N > 1 code on real kernels")
+    ap.add_argument("--process-group-backend", choices=("nccl", "gloo"), default="nccl", help="N > 1: torch.distributed backend (nccl = RCCL over xGMI)")
+    ap.add_argument("--sharder", default="rust_tracer_amd.dist:FrameSharder",
+                    help="module:Class of the FrameSharder the ranks run (the product's; tests substitute one whose collective can share a GPU)")
     ap.add_argument("--no-make-image", action="store_true", help="N = 1: skip the `make image` process wall-time leg")
     ap.add_argument("--no-native-gang", action="store_true", help="N > 1: skip the single-process rt_gang side measurement (gang_bench child)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1080p",
@@ -325,7 +325,9 @@ def main():
     import numpy as np
     import torch
     import rust_tracer_amd as rta
-    from rust_tracer_amd.dist import FrameSharder
+    import importlib
+    _mod, _cls = args.sharder.split(":")
+    FrameSharder = getattr(importlib.import_module(_mod), _cls)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -335,12 +337,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        if args.collective_backend == "nccl":
+        if args.process_group_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    host_staged = dist is not None and args.collective_backend == "gloo"
-    comm_dev = "cpu" if host_staged else "cuda"          # where the few scalars the ranks exchange live
+    comm_dev = getattr(FrameSharder, "comm_device", "cuda") if dist is not None else "cuda"          # where the few scalars the ranks exchange live
+    real_rccl = dist is None or args.process_group_backend == "nccl"
 
     def barrier():
         if dist is not None:
@@ -364,7 +366,7 @@ def main():
         w, h, k, lv, gname = WORKLOADS[wl]
         opts = rta.RenderOptions(w, h, k)
         fs = FrameSharder(scene_of(lv), opts, rank, world, local, traversal, force_collective=args.force_collective, mode=mode,
-                          frames_per_gather=args.frames_per_gather, host_staged=host_staged)
+                          frames_per_gather=args.frames_per_gather)
         st = fs.render_shard(want_stats=True)          # counters of this rank's shard (equal the oracle's; tests)
         if traversal != rta.RT_TRAVERSAL_SKIP:
             st = dict(st, primary_tests=None)
@@ -652,7 +654,7 @@ def main():
         # ONE frame end to end, nothing batched, nothing pipelined: render -> gather -> blit, synchronised -- what a caller who wants
         # THIS frame waits for.  And the host cost of a collective call (what batching several frames per gather amortises).
         fs1 = FrameSharder(scene_of(8), rta.RenderOptions(1920, 1080, 1), rank, world, local, head_trav, force_collective=args.force_collective, mode="tiles",
-                           frames_per_gather=1, host_staged=host_staged)
+                           frames_per_gather=1)
         for _ in range(5):
             fs1.step()
         barrier()
@@ -821,7 +823,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        if world > 1 and not args.no_native_gang and not host_staged and args.workload == "1080p" and args.traversal == "skip":
+        if world > 1 and not args.no_native_gang and real_rccl and args.workload == "1080p" and args.traversal == "skip":
             # The other ranks are on their way out and their GPUs are free: ONE process over all N devices (rt_gang_*: ncclCommInitAll, one
             # ncclGather per frame, no torch.distributed call on the path).  A child process with a time limit: whatever happens to it, the
             # headline above stands.

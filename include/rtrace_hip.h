@@ -100,6 +100,17 @@ typedef struct rt_stats {
 
 typedef struct rt_scene rt_scene;   /* opaque: device copies of a Scene (render.rs:138-142) */
 
+/* (ABI 4; host-side, touches no device) The automatic bounding-sphere hierarchy for an ARBITRARY sphere list -- SURVEY.md 8f.4; the reference has
+ * no such builder (group.rs:28-65 builds its pyramid only), so this is an input generator, not reference arithmetic: median splits along the
+ * longest axis until at most leaf_size spheres remain, near-minimal enclosing spheres as bounds, the half nearer to `eye` first (eye = NULL:
+ * the split's own order).  The one implementation both hosts use (csrc/host/hierarchy.hpp).
+ *   spheres     double[4 * n]: cx, cy, cz, radius
+ *   items_out   REAL[4 * n]  in the tree's DFS order;  order_out uint64[n] (optional): items_out[k] = spheres[order_out[k]]
+ *   bounds_out  REAL[4 * 2n], ranges_out rt_range[2n]: room for the at most 2n - 1 groups; *n_groups_out of them are written (DFS pre-order)
+ * ready for rt_scene_create(dfs_items = items_out, bounds = bounds_out, ranges = ranges_out, n_bounds = *n_groups_out). */
+rt_status rt_build_hierarchy(const double *spheres, uint32_t n, uint32_t leaf_size, const double *eye, rt_precision precision,
+                             void *items_out, void *bounds_out, rt_range *ranges_out, uint64_t *order_out, uint32_t *n_groups_out);
+
 /* Number of usable devices (RT_ERR_NO_DEVICE and *n = 0 when there is none). */
 rt_status rt_device_count(int *n);
 

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "vec.hpp"
+#include "hierarchy.hpp"
 
 namespace rtrace {
 
@@ -65,17 +66,18 @@ struct SphericalGroup {                                           // TypedGroup<
     }
 
     // Bounding-sphere hierarchy for an ARBITRARY sphere list (not in the reference, whose only builder is `pyramid`):
-    // median splits along the longest axis of the centres until at most leaf_size spheres remain; a group's bound encloses its whole
-    // subtree (centre = box centre, radius = max(|c_i - centre| + r_i), inflated by 1e-4 so that it still encloses after rounding to
-    // RFloat).  The result is an ordinary TypedGroup tree.  Same arithmetic, in double, as scene.py's build_hierarchy: both hosts
-    // produce the same items, bounds and ranges bit for bit (tests/test_host_and_abi.py).
+    // csrc/host/hierarchy.hpp -- median splits along the longest axis of the centres until at most leaf_size spheres remain, near-minimal
+    // enclosing spheres as bounds, the half nearer to `eye` first.  The result is an ordinary TypedGroup tree.  The same code is what
+    // scene.py's build_hierarchy runs (the library exports it: rt_build_hierarchy), so both hosts produce the same items, bounds and
+    // ranges bit for bit (tests/test_host_and_abi.py).
     using Sphere4 = std::array<double, 4>;
-    static std::unique_ptr<SphericalGroup> from_spheres_auto(const std::vector<Sphere4> &sp, size_t leaf_size = 4)
+    static std::unique_ptr<SphericalGroup> from_spheres_auto(const std::vector<Sphere4> &sp, size_t leaf_size = 4, const Vector *eye = nullptr)
     {
         if (sp.empty()) throw std::invalid_argument("build_hierarchy needs at least one sphere");
-        std::vector<size_t> idx(sp.size());
-        std::iota(idx.begin(), idx.end(), (size_t)0);
-        return build_auto(sp, idx, std::max<size_t>(1, leaf_size));
+        const double e[3] = { eye ? (double)eye->x : 0.0, eye ? (double)eye->y : 0.0, eye ? (double)eye->z : 0.0 };
+        const rt_host::FlatHierarchy h = rt_host::build_hierarchy(&sp[0][0], sp.size(), leaf_size, eye ? e : nullptr);
+        size_t gi = 0;
+        return from_flat(h, gi);
     }
 
     // TypedGroup::count  group.rs:93-109 -> (num_groups, num_items)
@@ -88,43 +90,29 @@ struct SphericalGroup {                                           // TypedGroup<
     }
 
 private:
-    static std::unique_ptr<SphericalGroup> build_auto(const std::vector<Sphere4> &sp, std::vector<size_t> &idx, size_t leaf_size)
+    static std::unique_ptr<SphericalGroup> from_flat(const rt_host::FlatHierarchy &h, size_t &gi)
     {
         auto g = std::make_unique<SphericalGroup>();
-        double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 }, cmin[3] = { 1e300, 1e300, 1e300 }, cmax[3] = { -1e300, -1e300, -1e300 };
-        for (size_t i : idx)
-            for (int k = 0; k < 3; ++k) {
-                lo[k] = std::min(lo[k], sp[i][k] - sp[i][3]); hi[k] = std::max(hi[k], sp[i][k] + sp[i][3]);
-                cmin[k] = std::min(cmin[k], sp[i][k]); cmax[k] = std::max(cmax[k], sp[i][k]);
-            }
-        const double c[3] = { (lo[0] + hi[0]) * 0.5, (lo[1] + hi[1]) * 0.5, (lo[2] + hi[2]) * 0.5 };
-        double rad = 0.0;
-        for (size_t i : idx) {
-            const double dx = sp[i][0] - c[0], dy = sp[i][1] - c[1], dz = sp[i][2] - c[2];
-            rad = std::max(rad, std::sqrt(dx * dx + dy * dy + dz * dz) + sp[i][3]);
-        }
-        rad = rad * (1.0 + 1e-4) + 1e-30;
-        g->bound.center = Vector{ (RFloat)c[0], (RFloat)c[1], (RFloat)c[2] };
-        g->bound.radius = (RFloat)rad;
-        if (idx.size() <= leaf_size) {
-            for (size_t i : idx) {
-                Pair p;
-                p.item = Sphere{ Vector{ (RFloat)sp[i][0], (RFloat)sp[i][1], (RFloat)sp[i][2] }, (RFloat)sp[i][3] };
-                g->children.push_back(std::move(p));
-            }
-            return g;
-        }
-        int axis = 0;                                             // first axis of the largest extent (numpy argmax)
-        for (int k = 1; k < 3; ++k) if (cmax[k] - cmin[k] > cmax[axis] - cmin[axis]) axis = k;
-        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return sp[a][axis] < sp[b][axis]; });
-        const size_t half = idx.size() / 2;
-        std::vector<size_t> first(idx.begin(), idx.begin() + half), second(idx.begin() + half, idx.end());
-        for (std::vector<size_t> *part : { &first, &second }) {
+        const size_t me = gi++, n_groups = h.ranges.size() / 2;
+        g->bound.center = Vector{ (RFloat)h.bounds[4 * me], (RFloat)h.bounds[4 * me + 1], (RFloat)h.bounds[4 * me + 2] };
+        g->bound.radius = (RFloat)h.bounds[4 * me + 3];
+        const size_t first = (size_t)h.ranges[2 * me], end = first + (size_t)h.ranges[2 * me + 1];
+        auto item_child = [&](size_t k) {
+            Pair p;
+            p.item = Sphere{ Vector{ (RFloat)h.items[4 * k], (RFloat)h.items[4 * k + 1], (RFloat)h.items[4 * k + 2] }, (RFloat)h.items[4 * k + 3] };
+            g->children.push_back(std::move(p));
+        };
+        size_t item = first;
+        while (gi < n_groups && (size_t)h.ranges[2 * gi] < end) {            // pre-order: the next group is mine while it starts inside my range
+            for (; item < (size_t)h.ranges[2 * gi]; ++item) item_child(item);
+            const size_t child_end = (size_t)h.ranges[2 * gi] + (size_t)h.ranges[2 * gi + 1];
             Pair p;
             p.is_group = true;
-            p.group = build_auto(sp, *part, leaf_size);
+            p.group = from_flat(h, gi);
             g->children.push_back(std::move(p));
+            item = child_end;
         }
+        for (; item < end; ++item) item_child(item);
         return g;
     }
 };
@@ -195,7 +183,7 @@ struct Scene {                                                    // render.rs:1
         fclose(f);
         if (sp.empty()) throw std::runtime_error("scene file " + path + " holds no sphere");
         Scene s;
-        s.group = SphericalGroup::from_spheres_auto(sp, leaf_size);
+        s.group = SphericalGroup::from_spheres_auto(sp, leaf_size, &eye);
         s.directional_light = light.normalized();
         s.eye = eye;
         return s;

@@ -93,25 +93,6 @@ def run_pipeline(steps, ops):
     ops.op_drain()
 
 
-class _HostStagedWork:
-    """What FrameSharder.gather returns in host-staged mode: wait() has the semantics of a device collective's Work.wait() -- the
-    current stream is ordered behind the gathered data (rank 0: the gathered CPU rows are copied into the device buffer on it)."""
-
-    def __init__(self, sharder, work, slot, nbytes):
-        self.sharder, self.work, self.slot, self.nbytes = sharder, work, slot, nbytes
-
-    def wait(self):
-        fs = self.sharder
-        if self.work is not None:
-            self.work.wait()                                   # gloo: blocks the host until this rank's part of the gather is done
-        if fs.rank == 0:
-            for r in range(fs.world):                          # pinned -> device, on the current stream (the blit that follows is behind it)
-                fs.gathered[self.slot][r][:self.nbytes].copy_(fs.h_gathered[self.slot][r][:self.nbytes], non_blocking=True)
-            fs._h2d_done[self.slot] = fs.torch.cuda.Event()
-            fs._h2d_done[self.slot].record()
-        return True
-
-
 class FrameSharder:
     """One per process (= per GPU).  world == 1: a step renders the buckets straight into the row-major frame.
     world > 1: a step renders this rank's buckets tile-major, one RCCL gather brings the u8 shards to rank 0, and rank 0
@@ -119,7 +100,7 @@ class FrameSharder:
     the render of frame k+1, so a sequence of frames costs max(render, gather + blit) per frame instead of their sum."""
 
     def __init__(self, scene, options, rank=0, world=1, device=0, traversal=capi.RT_TRAVERSAL_SKIP, force_collective=False,
-                 mode="tiles", frames_per_gather=1, host_staged=False):
+                 mode="tiles", frames_per_gather=1):
         import torch
         self.torch = torch
         if mode not in ("tiles", "frames"):
@@ -133,11 +114,6 @@ class FrameSharder:
         # force_collective: take the shard -> gather -> blit path even for world == 1 (a one-rank RCCL gather); lets a
         # single-GPU test drive exactly the code the 8-GPU run executes
         self.collective = world > 1 or force_collective
-        # host_staged (TEST INFRASTRUCTURE: RCCL refuses two ranks on one device): the gather goes shard -> pinned host memory -> a CPU
-        # (gloo) gather -> rank 0's pinned rows -> the device buffer the blit reads.  Everything else -- sharding, the render / gather /
-        # blit ordering of run_pipeline on a sender and on the root, partial batches, buffer reuse -- is the code an RCCL job runs, so
-        # two ranks can execute it on ONE GPU (tests/test_gpu_dist.py)
-        self.host_staged = bool(host_staged) and self.collective
         self.options = RenderOptions(*options)
         self.rank, self.world, self.device = rank, world, device
         self.traversal = traversal
@@ -174,11 +150,6 @@ class FrameSharder:
                 # one buffer per in-flight frame for the blit; the gather lists are views of its rows
                 self.gathered_flat = [torch.zeros(world * self.batch * self.unit_bytes, dtype=torch.uint8, device=tdev) for _ in range(2)]
                 self.gathered = [list(g.view(world, self.batch * self.unit_bytes).unbind(0)) for g in self.gathered_flat]
-        if self.host_staged:
-            self.h_shards = [torch.zeros(self.batch * self.unit_bytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
-            self._h2d_done = [None, None]
-            if rank == 0:
-                self.h_gathered = [[torch.zeros(self.batch * self.unit_bytes, dtype=torch.uint8).pin_memory() for _ in range(world)] for _ in range(2)]
 
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
@@ -200,21 +171,11 @@ class FrameSharder:
                                             self.traversal, want_stats)
 
     def gather(self, slot=0, async_op=False, count=None):
-        """The one collective on the data path: equal-length u8 shards to rank 0 over RCCL (`count` frames of a batch)."""
+        """The one collective on the data path: equal-length u8 shards to rank 0 over RCCL (`count` frames of a batch).  (A subclass may
+        move the bytes another way -- tests/host_staged.py does, to run two ranks on one GPU --: what it returns for async_op must wait() like
+        a device collective's Work, the current stream ordered behind the gathered data.)"""
         import torch.distributed as dist
         count = self.batch if count is None else count
-        if self.host_staged:
-            nb = count * self.unit_bytes
-            if self.rank == 0 and self._h2d_done[slot] is not None:
-                self._h2d_done[slot].synchronize()              # the copy out of h_gathered[slot] of the slot's previous gather
-            self.h_shards[slot][:nb].copy_(self.shards[slot][:nb], non_blocking=True)
-            self.torch.cuda.current_stream(self.device).synchronize()      # the shard is rendered and in host memory
-            work = dist.gather(self.h_shards[slot][:nb], [g[:nb] for g in self.h_gathered[slot]] if self.rank == 0 else None, dst=0, async_op=async_op)
-            staged = _HostStagedWork(self, work if async_op else None, slot, nb)
-            if async_op:
-                return staged
-            staged.wait()
-            return None
         if count == self.batch:
             return dist.gather(self.shards[slot], self.gathered[slot] if self.rank == 0 else None, dst=0, async_op=async_op)
         nb = count * self.unit_bytes                              # the last, partial batch of a run

@@ -55,50 +55,96 @@ def normalized(v, precision=capi.RT_F32):
     return np.array([x * rc, y * rc, z * rc], dtype=R)
 
 
-def build_hierarchy(spheres, leaf_size=4, precision=capi.RT_F32):
+def build_hierarchy(spheres, leaf_size=4, precision=capi.RT_F32, eye=None):
     """Bounding-sphere hierarchy for an arbitrary sphere list (scenes other than the pyramid, e.g. BASELINE
     config 5 with exactly 100,000 spheres).  Not in the reference -- its only scene builder is `pyramid` -- but the result
     is an ordinary `TypedGroup` tree in the flat description the C ABI takes: median splits along the longest axis until
-    at most `leaf_size` spheres remain; every group's bound encloses its whole subtree (centre = box centre, radius =
-    max(|c_i - centre| + r_i), inflated by 1e-4 so that it also encloses after rounding to REAL).
+    at most `leaf_size` spheres remain; every group's bound is a near-minimal enclosing sphere of its whole subtree (inflated
+    by 1e-4 so that it also encloses after rounding to REAL); with `eye`, a group's nearer half comes first.
+
+    ONE implementation for both hosts: csrc/host/hierarchy.hpp, here through the library's rt_build_hierarchy (no device is
+    touched).  build_hierarchy_reference below restates the same arithmetic in numpy; the tests hold one against the other.
 
     Returns (items REAL[n,4] in the tree's DFS order, bounds REAL[g,4], ranges int32[g,2], order int64[n]) where
     items == spheres[order]."""
+    R = _real(precision)
+    sp = np.ascontiguousarray(np.asarray(spheres, dtype=np.float64).reshape(-1, 4))
+    n = sp.shape[0]
+    if n == 0:
+        raise ValueError("build_hierarchy needs at least one sphere")
+    items = np.zeros((n, 4), dtype=R)
+    bounds = np.zeros((2 * n, 4), dtype=R)
+    ranges = np.zeros((2 * n, 2), dtype=np.int32)
+    order = np.zeros(n, dtype=np.uint64)
+    ng = C.c_uint32(0)
+    e = None if eye is None else np.ascontiguousarray(np.asarray(eye, dtype=np.float64).reshape(3))
+    capi.check(capi.lib.rt_build_hierarchy(sp.ctypes.data, n, int(leaf_size), None if e is None else e.ctypes.data, precision, items.ctypes.data,
+                                           bounds.ctypes.data, ranges.ctypes.data, order.ctypes.data, C.byref(ng)), "rt_build_hierarchy")
+    g = int(ng.value)
+    return items, bounds[:g].copy(), ranges[:g].copy(), order.astype(np.int64)
+
+
+def build_hierarchy_reference(spheres, leaf_size=4, precision=capi.RT_F32, eye=None, steps=20):
+    """The arithmetic of csrc/host/hierarchy.hpp restated in numpy, operation for operation (test infrastructure: slow -- a few numpy calls
+    per group and per Badoiu-Clarkson step).  Same return value as build_hierarchy."""
     R = _real(precision)
     sp = np.asarray(spheres, dtype=np.float64).reshape(-1, 4)
     if sp.shape[0] == 0:
         raise ValueError("build_hierarchy needs at least one sphere")
     order, bounds, ranges = [], [], []
+    e = None if eye is None else np.asarray(eye, dtype=np.float64).reshape(3)
 
-    def bound_of(idx):
+    def reach(c, r, centre):
+        d = c - centre
+        return np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]) + r
+
+    def enclosing(idx):
         c, r = sp[idx, :3], sp[idx, 3]
         lo, hi = (c - r[:, None]).min(axis=0), (c + r[:, None]).max(axis=0)
         centre = (lo + hi) * 0.5
-        radius = float((np.linalg.norm(c - centre, axis=1) + r).max()) * (1.0 + 1e-4) + 1e-30
-        return (centre[0], centre[1], centre[2], radius)
+        for k in range(1, steps + 1):
+            if idx.size <= 1:
+                break
+            j = int(np.argmax(reach(c, r, centre)))            # the first of the farthest
+            v = c[j] - centre
+            nrm = np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])
+            if nrm == 0.0:
+                break
+            far = c[j] + (v / nrm) * r[j]
+            centre = centre + (far - centre) / float(k + 1)
+        radius = float(reach(c, r, centre).max()) * (1.0 + 1e-4) + 1e-30
+        return (float(centre[0]), float(centre[1]), float(centre[2]), radius)
 
-    # iterative pre-order build (no recursion limit for 100k+ spheres): "open" emits a group and schedules its halves,
-    # "close" fixes the group's item range once its subtree has been emitted
-    todo = [("open", np.arange(sp.shape[0]))]
-    while todo:
-        kind, idx = todo.pop()
-        if kind == "close":
-            gi, first = idx
-            ranges[gi] = (first, len(order) - first)
-            continue
+    def build(idx, bound):
         gi = len(bounds)
-        bounds.append(bound_of(idx))
+        bounds.append(bound)
         ranges.append(None)
-        todo.append(("close", (gi, len(order))))
+        first = len(order)
         if idx.size <= leaf_size:
             order.extend(int(i) for i in idx)
-            continue
-        c = sp[idx, :3]
-        axis = int(np.argmax(c.max(axis=0) - c.min(axis=0)))
-        srt = idx[np.argsort(c[:, axis], kind="stable")]
-        half = srt.size // 2
-        todo.append(("open", srt[half:]))      # popped second -> visited after the first half (pre-order)
-        todo.append(("open", srt[:half]))
+        else:
+            c = sp[idx, :3]
+            axis = int(np.argmax(c.max(axis=0) - c.min(axis=0)))
+            srt = idx[np.argsort(c[:, axis], kind="stable")]
+            half = srt.size // 2
+            parts = [srt[:half], srt[half:]]
+            b = [enclosing(parts[0]), enclosing(parts[1])]
+            nearer = 0
+            if e is not None:
+                key = []
+                for k in range(2):
+                    dx, dy, dz = b[k][0] - e[0], b[k][1] - e[1], b[k][2] - e[2]
+                    key.append((dx * dx + dy * dy) + dz * dz)
+                if key[1] < key[0]:
+                    nearer = 1
+            build(parts[nearer], b[nearer])
+            build(parts[1 - nearer], b[1 - nearer])
+        ranges[gi] = (first, len(order) - first)
+
+    import sys
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 10000))
+    all_idx = np.arange(sp.shape[0])
+    build(all_idx, enclosing(all_idx))
     order = np.asarray(order, dtype=np.int64)
     return (sp[order].astype(R), np.asarray(bounds, dtype=np.float64).astype(R),
             np.asarray(ranges, dtype=np.int32).reshape(-1, 2), order)
@@ -133,7 +179,7 @@ class Scene:
     @classmethod
     def from_spheres_auto(cls, spheres, light=(-1.0, -3.0, 2.0), eye=(0.0, 0.0, -4.0), leaf_size=4, precision=capi.RT_F32):
         """Arbitrary sphere list with an automatically built bounding-sphere hierarchy (build_hierarchy)."""
-        items, bounds, ranges, _ = build_hierarchy(spheres, leaf_size, precision)
+        items, bounds, ranges, _ = build_hierarchy(spheres, leaf_size, precision, eye=eye)
         return cls(items, normalized(light, precision), eye, bounds, ranges, precision)
 
     @classmethod

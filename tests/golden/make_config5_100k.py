@@ -21,7 +21,7 @@ from tests.golden.make_oracle_vectors import tile_crcs  # noqa: E402
 
 def main():
     w, h, spp = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (4096, 4096, 4)
-    items, bounds, ranges, _ = build_hierarchy(hundred_thousand_spheres())
+    items, bounds, ranges, _ = build_hierarchy(hundred_thousand_spheres(), eye=(0.0, 0.0, -4.0))      # (as Scene.from_spheres_auto builds it)
     o = oracle.Scene.from_ranges(items.astype(np.float64), bounds.astype(np.float64), ranges)
     t0 = time.time()
     frame, st, n = o.render(w, h, spp, nthreads=os.cpu_count() or 1, mode=oracle.MODE_HIERARCHY | oracle.MODE_ANYHIT_EXIT)

@@ -199,7 +199,7 @@ def test_bench_collective_path_checks_its_own_frame(multi):
 @pytest.mark.parametrize("multi,extra", [("tiles", []), ("frames", ["--no-extras"])])
 def test_two_real_bench_ranks_share_gpu_0(multi, extra):
     # First contact for the code the driver's scaling run executes: TWO bench.py processes (RANK 0 / 1, WORLD_SIZE 2), fresh children, both on
-    # GPU 0.  RCCL refuses two ranks on one device, so the collective is the test-only host-staged one (--collective-backend gloo: shard ->
+    # GPU 0.  RCCL refuses two ranks on one device, so the collective is the test-only host-staged one (tests/host_staged.py: shard ->
     # pinned host memory -> CPU gather -> rank 0's device buffer); everything else is what an RCCL job runs on real kernels: rank 1's
     # render / gather / buffer-reuse ordering (dist.py op_*), partial batches (7 steps in batches of 3 = 3 + 3 + 1), rank 0's blits of
     # two ranks' shards, the N > 1 keys of the JSON line (frame_latency_ms ...), weak_frames and config5_tiles riding along.  Rank 0's
@@ -216,7 +216,7 @@ def test_two_real_bench_ranks_share_gpu_0(multi, extra):
     procs = []
     for rank in (0, 1):
         env = util.product_env(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--collective-backend", "gloo", "--multi", multi,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--process-group-backend", "gloo", "--sharder", "tests.host_staged:HostStagedFrameSharder", "--multi", multi,
                                        "--frames-per-gather", "3", "--steps", "7", "--warmup", "3", "--repeats", "2", "--min-timed-region", "0",
                                        "--no-cpu-baseline"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     outs = []

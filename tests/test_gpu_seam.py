@@ -291,7 +291,7 @@ def test_rtrace_scene_file_with_an_automatically_built_hierarchy(tmp_path):
     r = subprocess.run([exe, "--width=400", "--height=300", "--samples-per-pixel=2", "--scene=" + str(path), out], capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()
     from rust_tracer_amd.scene import build_hierarchy
-    items, bounds, ranges, _ = build_hierarchy(sp)
+    items, bounds, ranges, _ = build_hierarchy(sp, eye=(0.1, -0.2, -4.5))
     o = oracle.Scene.from_ranges(items.astype(np.float64), bounds.astype(np.float64), ranges, (-1.0, -2.0, 1.5), (0.1, -0.2, -4.5))
     img, st, _ = o.render(400, 300, 2, nthreads=os.cpu_count() or 1)
     assert st["hits"] > 10000

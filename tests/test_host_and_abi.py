@@ -279,6 +279,26 @@ def test_native_gang_sharding_equals_the_python_shard_layout(size, world):
     assert [int(dev[i]) * padded + int(off[i]) for i in mine] == [int(v) for v in offsets]
 
 
+@pytest.mark.parametrize("precision", [rta.RT_F32, rta.RT_F64], ids=["f32", "f64"])
+@pytest.mark.parametrize("eye", [None, (0.3, -0.2, -4.0)], ids=["split-order", "nearer-first"])
+def test_the_hierarchy_builder_equals_its_numpy_restatement(precision, eye):
+    # csrc/host/hierarchy.hpp is the ONE builder both hosts run (the Python host through the library's rt_build_hierarchy); scene.py keeps a plain
+    # numpy restatement of its arithmetic -- near-minimal enclosing spheres by Badoiu-Clarkson steps, the nearer half first -- and the two
+    # must agree bit for bit: items, bounds, ranges, order
+    from rust_tracer_amd.scene import build_hierarchy, build_hierarchy_reference
+    rng = np.random.default_rng(91)
+    for n, leaf in ((1, 4), (5, 4), (777, 3), (3000, 4)):
+        sp = np.concatenate([rng.uniform([-3, -2, 0], [3, 2, 6], (n, 3)), rng.uniform(0.01, 0.2, (n, 1))], axis=1).astype(np.float32).astype(np.float64)
+        a = build_hierarchy(sp, leaf, precision, eye=eye)
+        b = build_hierarchy_reference(sp, leaf, precision, eye=eye)
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and np.array_equal(x, y), (n, leaf)
+    # tighter than the box-centre spheres of round 5 (steps = 0 is that builder)
+    tight = build_hierarchy_reference(sp, 4, precision, eye=eye)[1][:, 3].astype(np.float64)
+    loose = build_hierarchy_reference(sp, 4, precision, eye=eye, steps=0)[1][:, 3].astype(np.float64)
+    assert (tight ** 2).sum() < 0.95 * (loose ** 2).sum()            # (cross-sections: what a ray meets)
+
+
 def test_native_and_python_hierarchy_builders_agree_bit_for_bit(tmp_path):
     # SURVEY.md 8f.4 on both hosts: `rtrace --scene <file>` (csrc/host/scene.hpp, Scene::from_file) and scene.py's build_hierarchy
     # must produce the same items, bounds and ranges -- host_tests --hierarchy prints CRCs of the C++ side's flattened arrays
@@ -296,7 +316,7 @@ def test_native_and_python_hierarchy_builders_agree_bit_for_bit(tmp_path):
     out = subprocess.run([exe, "--hierarchy", str(path)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     from rust_tracer_amd.scene import build_hierarchy
-    items, bounds, ranges, _ = build_hierarchy(sp)
+    items, bounds, ranges, _ = build_hierarchy(sp, eye=(0.0, 0.0, -4.0))      # (Scene::from_file's default eye: the nearer half of a group first)
     want = "%d %d %d %d %d" % (items.shape[0], bounds.shape[0], zlib.crc32(items.tobytes()), zlib.crc32(bounds.tobytes()), zlib.crc32(ranges.tobytes()))
     assert out.stdout.strip() == want
     bad = tmp_path / "bad.txt"
