@@ -543,6 +543,7 @@ def main():
         logical = m["my_tests"] * BYTES_PER_TEST / t / 1e9
         out = {"bound": "valu_issue", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s (un-fused f32 lane ops)",
                "frac": round(ach / peak, 4), "traffic": None, "kernel": kernel, "kernel_ms": round(m["kern_ms"], 4),
+               "kernel_flavour": ("k_render_skip_fast" + ("_coop" if "cooperative" in m["launched"] else "") + " (rt_skip_fast.hpp)") if "fast_kernel" in m["launched"] else None,
                "tests_per_launch": m["my_tests"], "flops_per_test": flops_per_test,
                "peak_source": "MI355X_MICROARCH.md nominal: 1,024 SIMDs x 64 lanes x 2.4 GHz / 2 cycles per wave64 VALU op (un-fused: one lane-op per lane)",
                "peak_probe": round(peak_probe, 1) if peak_probe else None, "frac_probe": round(ach / peak_probe, 4) if peak_probe else None,

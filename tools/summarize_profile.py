@@ -20,7 +20,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import kernel_src_sha, git_head  # noqa: E402  (the stamp bench.py compares with the sources it runs on)
-SHORT = [("k_render_skip_f32<false", "k_render_skip"), ("k_render_skip_f32_coop<false", "k_render_skip"), ("k_render_skip<float, false", "k_render_skip"), ("k_flat_primary<float", "k_flat_primary"), ("k_flat_shadow<float", "k_flat_shadow"), ("k_flat_primary_sc", "k_flat_primary_sc"), ("k_flat_shadow_sc", "k_flat_shadow_sc"),
+SHORT = [("k_render_skip_fast", "k_render_skip"), ("k_render_skip_f32<false", "k_render_skip"), ("k_render_skip_f32_coop<false", "k_render_skip"), ("k_render_skip<float, false", "k_render_skip"), ("k_flat_primary<float", "k_flat_primary"), ("k_flat_shadow<float", "k_flat_shadow"), ("k_flat_primary_sc", "k_flat_primary_sc"), ("k_flat_shadow_sc", "k_flat_shadow_sc"),
          ("k_blit_tiles", "k_blit_tiles"), ("k_build_streams<float>", "k_build_streams"),
          ("k_resolve_samples<float>", "k_resolve_samples")]
 

@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import kernel_src_sha, git_head  # noqa: E402  (the stamp bench.py compares with the sources it runs on)
-KERNELS = [("k_render_skip_f32<false", "k_render_skip"), ("k_render_skip_f32_coop<false", "k_render_skip"), ("k_render_skip<float, false", "k_render_skip"), ("k_flat_primary<float", "k_flat_primary"), ("k_flat_shadow<float", "k_flat_shadow"), ("k_flat_primary_sc", "k_flat_primary_sc"), ("k_flat_shadow_sc", "k_flat_shadow_sc")]
+KERNELS = [("k_render_skip_fast", "k_render_skip"), ("k_render_skip_f32<false", "k_render_skip"), ("k_render_skip_f32_coop<false", "k_render_skip"), ("k_render_skip<float, false", "k_render_skip"), ("k_flat_primary<float", "k_flat_primary"), ("k_flat_shadow<float", "k_flat_shadow"), ("k_flat_primary_sc", "k_flat_primary_sc"), ("k_flat_shadow_sc", "k_flat_shadow_sc")]
 
 
 def main():
