@@ -74,7 +74,8 @@ rt_status upload_tiles(Context *c, const std::vector<rt::TileDev> &tab, hipStrea
 constexpr unsigned kCostRes = 256;
 // the cost arena's tile-table area: one tile for the map itself; up to kExactBlocks 16x16 blocks when a tile list's heaviest blocks are
 // counted again at the frame's own resolution (exact_block_costs)
-constexpr unsigned kExactBlocks = kCostRes * kCostRes / (rt::kBlockW * rt::kBlockH);       // what the arena's pixel areas hold: 256
+constexpr unsigned kExactBlocks = 1024;             // 262,144 pixels: an eighth of a 1080p frame, half of an 800x600 one
+constexpr size_t kCostArenaPx = (size_t)kExactBlocks * rt::kBlockW * rt::kBlockH > (size_t)kCostRes * kCostRes ? (size_t)kExactBlocks * rt::kBlockW * rt::kBlockH : (size_t)kCostRes * kCostRes;     // pixels each of the arena's areas holds
 constexpr size_t kCostTileBytes = (kExactBlocks * sizeof(rt::TileDev) + 255) & ~(size_t)255;
 constexpr size_t kTableStageBytes = 256 * 1024;       // pinned staging for the tile tables of new lists (a 1080p list of 64x64 buckets: 10 KB)
 
@@ -85,7 +86,7 @@ constexpr size_t kTableStageBytes = 256 * 1024;       // pinned staging for the 
 // process that renders ONE frame (`make image`) never pays for them.
 rt_status alloc_cost_host(rt_scene *s)
 {
-    constexpr size_t kPx = (size_t)kCostRes * kCostRes * 4;
+    constexpr size_t kPx = kCostArenaPx * 4;
     HIP_TRY(hipHostMalloc(&s->h_cost, kPx + kCostTileBytes + kTableStageBytes, hipHostMallocDefault));
     s->h_tab_stage = static_cast<char *>(s->h_cost) + kPx + kCostTileBytes;
     return RT_OK;
@@ -100,7 +101,7 @@ rt_status start_cost_map(rt_scene *s)
     const rt::TileDev tile{ 0, (uint16_t)R, (uint16_t)R, 0, 0u, 0u, R / rt::kBlockW };
     if (!s->h_cost) return RT_ERR_OUT_OF_MEMORY;
     // ONE device allocation, kept until the scene goes (hipMalloc / hipFree wait for a busy device): tile | frame | costs | counters
-    constexpr size_t kTileBytes = kCostTileBytes, kPx = (size_t)R * R * 4, kCnt = sizeof(rt::Counters) * rt::kCounterStripes;
+    constexpr size_t kTileBytes = kCostTileBytes, kPx = kCostArenaPx * 4, kCnt = sizeof(rt::Counters) * rt::kCounterStripes;
     HIP_TRY(hipMalloc(&s->d_cost_arena, kTileBytes + 2 * kPx + kCnt));
     hipStream_t stream = s->cost_stream;
     char *base = static_cast<char *>(s->d_cost_arena);
@@ -136,7 +137,7 @@ const std::vector<uint32_t> *cost_map_of(rt_scene *s)
 // a 1080p frame, and the rays that meet several hundred nodes follow silhouettes thinner than that: a threshold on the map picks some of a
 // heavy pixel's neighbours and misses the pixel, and the wave that keeps it is as long as ever (tools/wave_timeline.py, the cooperative walk
 // at 1080p: the quads walked in 14 us, the frame's longest wave still 41).  So the blocks the map ranks highest are counted again, exactly:
-// one counting launch over those blocks alone (<= 256 blocks = 65,536 pixels, ~30 us of device time, once per tile list, on the scene's own
+// one counting launch over those blocks alone (<= 1,024 blocks = 262,144 pixels, ~0.1 ms of device time, once per tile list, on the scene's own
 // stream), each lane storing the number of tests its pixel took.  px[i * 256 + (y - y0) * 16 + (x - x0)] for block i of `blocks`.
 struct ExactCosts { std::vector<uint32_t> block; std::vector<uint32_t> px; uint32_t top = 0; };      // block: raster index of the counted blocks
 template <typename T>
@@ -145,7 +146,7 @@ rt_status exact_block_costs(rt_scene *s, const std::vector<rt::BlockDesc> &raste
     out = ExactCosts{};
     if (blocks.empty() || blocks.size() > kExactBlocks || !s->d_cost_arena || !s->h_cost) return RT_OK;
     std::lock_guard<std::mutex> lk(s->exact_mu);                 // one counting launch at a time through the scene's arena
-    constexpr size_t kPx = (size_t)kCostRes * kCostRes * 4, kCnt = sizeof(rt::Counters) * rt::kCounterStripes;
+    constexpr size_t kPx = kCostArenaPx * 4, kCnt = sizeof(rt::Counters) * rt::kCounterStripes;
     char *base = static_cast<char *>(s->d_cost_arena);
     uint8_t *d_out = reinterpret_cast<uint8_t *>(base + kCostTileBytes);
     rt::Counters *d_cnt = reinterpret_cast<rt::Counters *>(base + kCostTileBytes + 2 * kPx);
@@ -311,9 +312,13 @@ void block_order(const std::vector<uint32_t> *map, const std::vector<rt::TileDev
         // (and only in single-pass launches: the packed sample-parallel mapping has its own, finer ray packets)
         // (behind a cooperative tier the next blocks are narrowed more generously: tools/coop_sweep.py, 800x600 28.4 -> 26.4 us)
         size_t cap = passes > 1 ? 0 : e >= 0 ? (size_t)e : order.size() > kNarrowPassBlocks ? 0 : std::min<size_t>(kNarrowMax, order.size() / (n_coop && !coop_all && !use_exact ? 32 : 128));
-        if (use_exact && e < 0) cap = cap > n_coop ? cap - n_coop : 0;        // (the blocks with exact holes are narrow already: the tier is as large as without them)
+        // (exact holes: those blocks are narrow already.  A pass that fills the chip keeps the tier as large as without them; a small one -- over
+        // when its first waves are -- narrows generously behind them: what it waits for next are 8x8 waves whose sixty-four moderate rays walk a
+        // long UNION of paths, 800x600: 24 us for pixels of fewer than 150 tests each)
+        const bool small_exact = use_exact && order.size() <= kCoopPassBlocks;
+        if (use_exact && e < 0) cap = small_exact ? std::min<size_t>(4 * kNarrowMax, order.size() / 8) : cap > n_coop ? cap - n_coop : 0;
         // (with the heaviest blocks walked cooperatively, "expensive" is measured against the cooperative threshold)
-        const uint64_t top = use_exact ? top_estimate : n_coop && !coop_all ? coop_thr : cost[order[0]];
+        const uint64_t top = use_exact && !small_exact ? top_estimate : n_coop && !coop_all ? coop_thr : cost[order[0]];
         while (n_coop + n_narrow < order.size() && n_narrow < cap && cost[order[n_coop + n_narrow]] > 0 &&
                (uint64_t)cost[order[n_coop + n_narrow]] * 100 >= top * kNarrowPercent)
             ++n_narrow;
@@ -542,7 +547,12 @@ rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std:
     bool asked = false;
     if (!exact.block.empty() && exact.top >= kCoopMinCost) {
         wants.push_back({ 0, 0u });
-        for (unsigned pc : { 85u, 70u, 58u, 48u, 40u }) wants.push_back({ 0, std::max<uint32_t>((uint32_t)kCoopMinCost, exact.top * pc / 100u) });
+        // (a pass that fills the chip several times over pays for every cooperative quad in throughput: high thresholds; one that is over when its
+        // first waves are -- 800x600: every wave dispatched by 10 us of 26 -- waits for chains only: the trial's times fell all the way to the
+        // lowest threshold there, so its candidates reach lower)
+        const bool small = total_blocks <= kCoopPassBlocks;
+        for (unsigned pc : { small ? 58u : 85u, small ? 48u : 70u, small ? 40u : 58u, small ? 33u : 48u, small ? 27u : 40u })
+            wants.push_back({ 0, std::max<uint32_t>((uint32_t)kCoopMinCost, exact.top * pc / 100u) });
     } else if (coop_pass && map && !two_rays && total_blocks <= kCoopPassBlocks && !knobs)
         wants = { { 0, 0u }, { 28, 0u }, { 34, 0u }, { 40, 0u }, { 48, 0u }, { 58, 0u } };
     else if (coop_pass && !two_rays && knobs && (knob(RT_DEBUG_COOP) > 0 || knob(RT_DEBUG_COOP_THR) >= 0 || knob(RT_DEBUG_COOP_MAX) >= 0)) { wants = { { 0, 0u }, { -1, 0u } }; asked = true; }       // as asked, behind the plain one
