@@ -191,7 +191,13 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
         // Steady-state frames -- f32, one sample per pixel, a dispatch list, the filtered assembly loops -- run the kernel that was written
         // around a wave's fixed costs (rt_skip_fast.hpp), with or without cooperative quads; everything else the generic one.
         if constexpr (!COUNT && sizeof(T) == 4 && ((VAR & ~8) == 19 || (VAR & ~8) == 23)) {
-            if (spp == 1 && order.d && !order.wg_first && lds == 0 && knob(RT_DEBUG_FAST_KERNEL) != 0) {
+            // (measured, one box, interleaved -- profiles/r06_ab_fast_vs_generic.log: WITHOUT cooperative quads the lean kernel is the generic one's
+            // equal, 1 - 2 % behind it at 1080p, 1 % ahead at 2560x1440 -- a wave's shorter start does not shorten a frame that is as long as its
+            // longest chain, and the late batch is a round trip the generic kernel's parked values do not make --; WITH them it is 39.8 against
+            // 43.5 us at 1080p and 38.4 against 40.5 at 1600x900: eight workgroups per CU where the generic cooperative flavour has seven.  So it runs
+            // where a list has holes; RT_DEBUG_FAST_KERNEL = 2 forces it for every ordered f32 spp-1 launch (tests, A/B))
+            const long long fk = knob(RT_DEBUG_FAST_KERNEL);
+            if (spp == 1 && order.d && !order.wg_first && lds == 0 && fk != 0 && (order.holes || fk == 2)) {
                 rt::FastArgs fa{};
                 const rt::SkipView<float> sv = skip_view_of<float>(s);
                 constexpr bool kFused = (VAR & 4) != 0;

@@ -54,8 +54,9 @@ typedef enum rt_debug_key {
     RT_DEBUG_ASYNC_ORDERS = 20,  /* 0: the dispatch orders of a tile list (and the scene's cost map) are made by the first call that uses the list, as they are
                                     whenever another dispatch control here is set; default: by a background thread, the first launches finding their blocks
                                     through the tile table */
-    RT_DEBUG_FAST_KERNEL = 21,   /* 0: steady-state frames (f32, one sample per pixel, a dispatch list) run the generic k_render_skip_f32 instead of
-                                    k_render_skip_fast (rt_skip_fast.hpp; A/B and parity: both must render the same bytes).  Default 1 */
+    RT_DEBUG_FAST_KERNEL = 21,   /* k_render_skip_fast (rt_skip_fast.hpp: f32, one sample per pixel, a dispatch list): 0 never -- the generic kernels, also for lists
+                                    with cooperative quads --, 2 for every such launch, with or without cooperative quads; default (1): where the list has
+                                    cooperative quads.  All three must render the same bytes */
     RT_DEBUG_EXACT_COSTS = 22,   /* 0: cooperative quads are picked by the scene's 256 x 256 cost map only (small passes), not by counting a tile list's heaviest
                                     blocks again at the frame's own resolution (rt_capi.hip exact_block_costs).  Default 1 (read when a tile list is first seen) */
     RT_DEBUG_KEYS = 23

@@ -105,10 +105,14 @@ def _check_both_launch_flavours(request, monkeypatch):
                 with rta.capi.debug(rta.capi.DEBUG_COOP, 2):
                     coop, _ = orig(self, options, regions, traversal, False)
                 assert np.array_equal(coop, data), "the lane-cooperative walk renders different bytes"
-                # ... and with the generic kernel where `plain` ran k_render_skip_fast (rt_skip_fast.hpp: f32, a dispatch list)
-                with rta.capi.debug(rta.capi.DEBUG_FAST_KERNEL, 0):
-                    generic, _ = orig(self, options, regions, traversal, False)
-                assert np.array_equal(generic, data), "k_render_skip_f32 and k_render_skip_fast render different bytes"
+                # ... and with the lean kernel (rt_skip_fast.hpp: f32, a dispatch list) where `plain` ran the generic one, and the other way round
+                for fast in (0, 2):
+                    with rta.capi.debug(rta.capi.DEBUG_FAST_KERNEL, fast):
+                        other, _ = orig(self, options, regions, traversal, False)
+                    assert np.array_equal(other, data), "k_render_skip_f32 and k_render_skip_fast render different bytes (%d)" % fast
+                with rta.capi.debug(rta.capi.DEBUG_COOP, 2), rta.capi.debug(rta.capi.DEBUG_FAST_KERNEL, 0):
+                    coop0, _ = orig(self, options, regions, traversal, False)
+                assert np.array_equal(coop0, data), "the lane-cooperative walk in the generic kernel renders different bytes"
         return data, st
 
     monkeypatch.setattr(rta.DeviceScene, "render_tiles", both)
