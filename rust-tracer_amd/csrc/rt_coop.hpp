@@ -134,6 +134,12 @@ __device__ __forceinline__ void coop_lds_sync()
 // The primary rays of a quad: lanes [0, n_rays) hold them (dir; `want`: the lane has a ray; n_rays = 16, 4 or 1).  Returns, in those lanes,
 // hit.distance / the DFS index of the nearest item, and `failed` = the ray has to be walked by the skip-pointer loops instead (its winner is
 // nearer than one of its ancestor bounds, or the wave's work list overflowed).  Wave-uniform control flow; `lds` is this wave's.
+// PIPE (round 6; k_render_skip_fast_coop, which has the registers for it): the records of the NEXT batch of pairs are requested before
+// the current batch is evaluated -- a round is one trip to L2 (~0.5 us in a busy frame) plus ~75 instructions, a heavy quad makes about
+// thirty of them, and whenever the list holds more than one batch the next one's pairs are known already.  The order in which pairs are
+// taken is free (a gather of the closure: minima by key), so the batch in flight simply counts as taken when the current one pushes.
+struct CoopBatchP { uint2 e; float4 g, h; unsigned n; bool have; };
+template <bool PIPE = false>
 __device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, unsigned n_rays, float dx, float dy, float dz, bool want, float &best_out,
                                              unsigned &item_out, bool &failed_out)
 {
@@ -151,24 +157,30 @@ __device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, u
     unsigned top = coop_uniform((unsigned)__popcll(wm));
     bool overflow = false;
     coop_lds_sync();                             // rays, minima and the first pairs are written: every lane may read them
-    // (Keeping a second round's records in flight -- fetched while the first is evaluated -- takes the kernel from 59 to 76 vector registers
-    // and every wave of the launch from 8 to 6 per SIMD: measured and dropped)
-    while (top > 0u) {
-        const unsigned n_e = min(sl.per, top);
-        const bool have = sl.e < n_e;
-        const uint2 e = lds.stack[have ? top - 1u - sl.e : 0u];
-        top -= n_e;
-        const unsigned cnt = (e.x >> 24) & 15u, ray = e.x >> 28;
-        const bool valid = have && sl.k < cnt;
-        const unsigned node = valid ? (e.x & 0xFFFFFFu) + sl.k : 0u;
+    // the pairs on top of the list, dealt to the lanes, and their records requested
+    auto fetch = [&]() {
+        CoopBatchP b;
+        b.n = min(sl.per, top);
+        b.have = sl.e < b.n;
+        b.e = lds.stack[b.have ? top - 1u - sl.e : 0u];
+        top -= b.n;
+        const unsigned cnt = (b.e.x >> 24) & 15u;
+        const bool valid = b.have && sl.k < cnt;
+        const unsigned node = valid ? (b.e.x & 0xFFFFFFu) + sl.k : 0u;
         const char *rec = reinterpret_cast<const char *>(cv.prim) + node * (unsigned)sizeof(CNode);        // (a 32-bit offset: fewer than 2^24 nodes)
-        const float4 g = *reinterpret_cast<const float4 *>(rec);
-        const float4 h = *reinterpret_cast<const float4 *>(rec + 16);                // {rr, first, count, -}
+        b.g = *reinterpret_cast<const float4 *>(rec);
+        b.h = *reinterpret_cast<const float4 *>(rec + 16);                // {rr, first, count, -}
+        return b;
+    };
+    // one round: the reference's test on every (ray, child) of the batch, minima, and the groups that go back on the list
+    auto eval = [&](const CoopBatchP &b) {
+        const unsigned cnt = (b.e.x >> 24) & 15u, ray = b.e.x >> 28;
+        const bool valid = b.have && sl.k < cnt;
         const float rx = lds.ray[ray][0], ry = lds.ray[ray][1], rz = lds.ray[ray][2];
-        const float d = coop_primary_distance(g, h.x, rx, ry, rz);
+        const float d = coop_primary_distance(b.g, b.h.x, rx, ry, rz);
         const bool finite = valid && d < inf<float>();
-        const unsigned link_first = __float_as_uint(h.y), link_count = __float_as_uint(h.z);
-        const float anc = __uint_as_float(e.y);
+        const unsigned link_first = __float_as_uint(b.h.y), link_count = __float_as_uint(b.h.z);
+        const float anc = __uint_as_float(b.e.y);
         // ITEM: keep the nearest by (distance, DFS index), and beside it the largest bound distance on its path
         const bool item_hit = finite && link_count == 0u;
         if (__ballot(item_hit) != 0ull) {
@@ -181,10 +193,26 @@ __device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, u
         const bool push = finite && link_count != 0u;
         const unsigned long long pm = __ballot(push);
         const unsigned n_push = (unsigned)__popcll(pm);
-        if (top + n_push > kCoopStack) { overflow = true; break; }
-        if (push) lds.stack[top + coop_lane_rank(pm)] = make_uint2(link_first | (link_count << 24) | (ray << 28), max(e.y, __float_as_uint(d)));      // (both >= +0: the bit patterns order like the values)
+        if (top + n_push > kCoopStack) { overflow = true; return; }
+        if (push) lds.stack[top + coop_lane_rank(pm)] = make_uint2(link_first | (link_count << 24) | (ray << 28), max(b.e.y, __float_as_uint(d)));      // (both >= +0: the bit patterns order like the values)
         top = coop_uniform(top + n_push);
         coop_lds_sync();                         // the pushed pairs are the next round's reads
+    };
+    if constexpr (!PIPE) {
+        while (top > 0u && !overflow) { const CoopBatchP b = fetch(); eval(b); }
+    } else {
+        // two batches in two sets of registers, by turns (a copy between rounds makes the compiler wait for the fetch it is meant to hide)
+        CoopBatchP a = fetch();
+        while (a.n != 0u) {
+            CoopBatchP b = fetch();              // (empty when the list holds no more than `a`: then it is fetched behind a's pushes)
+            eval(a);
+            if (overflow) break;
+            if (b.n == 0u) { b = fetch(); if (b.n == 0u) break; }
+            a = fetch();
+            eval(b);
+            if (overflow) break;
+            if (a.n == 0u) a = fetch();
+        }
     }
     coop_lds_sync();
     float best = inf<float>();
@@ -204,6 +232,8 @@ __device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, u
 
 // The shadow rays of a quad (any hit, render.rs:202-208): lanes [0, n_rays), origin (ox, oy, oz), `want`: the lane casts one.  Returns
 // `occluded` in those lanes and `failed` (work list overflow: the skip-pointer loops decide).
+struct CoopBatchS { uint2 e; float4 g; uint2 link; unsigned n; bool valid; };
+template <bool PIPE = false>
 __device__ __forceinline__ void coop_shadow(const CoopView &cv, CoopLds &lds, unsigned n_rays, float ox, float oy, float oz, V3<float> sdir, bool want,
                                             bool &occluded_out, bool &failed_out)
 {
@@ -217,31 +247,51 @@ __device__ __forceinline__ void coop_shadow(const CoopView &cv, CoopLds &lds, un
     unsigned top = coop_uniform((unsigned)__popcll(wm));
     bool overflow = false;
     coop_lds_sync();
-    while (top > 0u) {
-        const unsigned n_e = min(sl.per, top);
-        const bool have = sl.e < n_e;
-        const uint2 e = lds.stack[have ? top - 1u - sl.e : 0u];
+    auto fetch = [&]() {
+        CoopBatchS b;
+        b.n = min(sl.per, top);
+        const bool have = sl.e < b.n;
+        b.e = lds.stack[have ? top - 1u - sl.e : 0u];
         const unsigned occ = lds.occluded;
-        top -= n_e;
-        const unsigned cnt = (e.x >> 24) & 15u, ray = e.x >> 28;
-        const bool valid = have && sl.k < cnt && ((occ >> ray) & 1u) == 0u;       // a ray that is occluded wants nothing more
-        const unsigned node = valid ? (e.x & 0xFFFFFFu) + sl.k : 0u;
+        top -= b.n;
+        const unsigned cnt = (b.e.x >> 24) & 15u, ray = b.e.x >> 28;
+        b.valid = have && sl.k < cnt && ((occ >> ray) & 1u) == 0u;       // a ray that is occluded wants nothing more (PIPE: as of one round ago -- a test too many, never one too few)
+        const unsigned node = b.valid ? (b.e.x & 0xFFFFFFu) + sl.k : 0u;
         const char *rec = reinterpret_cast<const char *>(cv.shad) + node * (unsigned)sizeof(CNode);
-        const float4 g = *reinterpret_cast<const float4 *>(rec);
-        const uint2 link = *reinterpret_cast<const uint2 *>(rec + 20);
+        b.g = *reinterpret_cast<const float4 *>(rec);
+        b.link = *reinterpret_cast<const uint2 *>(rec + 20);
+        return b;
+    };
+    auto eval = [&](const CoopBatchS &b) {
+        const unsigned ray = b.e.x >> 28;
         const float rx = lds.ray[ray][0], ry = lds.ray[ray][1], rz = lds.ray[ray][2];
-        const bool hit = valid && coop_shadow_hit(g, rx, ry, rz, sdir);
-        const bool item_hit = hit && link.y == 0u;
+        const bool hit = b.valid && coop_shadow_hit(b.g, rx, ry, rz, sdir);
+        const bool item_hit = hit && b.link.y == 0u;
         if (__ballot(item_hit) != 0ull) {
             if (item_hit) atomicOr(&lds.occluded, 1u << ray);
         }
-        const bool push = hit && link.y != 0u;
+        const bool push = hit && b.link.y != 0u;
         const unsigned long long pm = __ballot(push);
         const unsigned n_push = (unsigned)__popcll(pm);
-        if (top + n_push > kCoopStack) { overflow = true; break; }
-        if (push) lds.stack[top + coop_lane_rank(pm)] = make_uint2(link.x | (link.y << 24) | (ray << 28), 0u);
+        if (top + n_push > kCoopStack) { overflow = true; return; }
+        if (push) lds.stack[top + coop_lane_rank(pm)] = make_uint2(b.link.x | (b.link.y << 24) | (ray << 28), 0u);
         top = coop_uniform(top + n_push);
         coop_lds_sync();                         // pushed pairs and occluded bits are the next round's reads
+    };
+    if constexpr (!PIPE) {
+        while (top > 0u && !overflow) { const CoopBatchS b = fetch(); eval(b); }
+    } else {
+        CoopBatchS a = fetch();
+        while (a.n != 0u) {
+            CoopBatchS b = fetch();
+            eval(a);
+            if (overflow) break;
+            if (b.n == 0u) { b = fetch(); if (b.n == 0u) break; }
+            a = fetch();
+            eval(b);
+            if (overflow) break;
+            if (a.n == 0u) a = fetch();
+        }
     }
     coop_lds_sync();
     const unsigned occ = lds.occluded;
