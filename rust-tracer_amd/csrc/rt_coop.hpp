@@ -134,10 +134,13 @@ __device__ __forceinline__ void coop_lds_sync()
 // The primary rays of a quad: lanes [0, n_rays) hold them (dir; `want`: the lane has a ray; n_rays = 16, 4 or 1).  Returns, in those lanes,
 // hit.distance / the DFS index of the nearest item, and `failed` = the ray has to be walked by the skip-pointer loops instead (its winner is
 // nearer than one of its ancestor bounds, or the wave's work list overflowed).  Wave-uniform control flow; `lds` is this wave's.
-// PIPE (round 6; k_render_skip_fast_coop, which has the registers for it): the records of the NEXT batch of pairs are requested before
-// the current batch is evaluated -- a round is one trip to L2 (~0.5 us in a busy frame) plus ~75 instructions, a heavy quad makes about
-// thirty of them, and whenever the list holds more than one batch the next one's pairs are known already.  The order in which pairs are
-// taken is free (a gather of the closure: minima by key), so the batch in flight simply counts as taken when the current one pushes.
+// PIPE (round 6, measured and NOT used): the records of the NEXT batch of pairs are requested before the current batch is evaluated -- a
+// round is one trip to L2 plus ~75 instructions, a heavy quad makes about thirty of them, and whenever the list holds more than one batch
+// the next one's pairs are known already; the order in which pairs are taken is free (a gather of the closure: minima by key), so the batch
+// in flight simply counts as taken when the current one pushes.  Round 4 had dropped this for its registers (76 in the generic cooperative
+// kernel); k_render_skip_fast_coop has them (40 -> 53 of 64), the waits land where they should (s_waitcnt vmcnt(2) at the head of a
+// round: the previous batch's two loads are back, this one's two are in flight), every parity test passes -- and a cooperative wave takes
+// 16.1 us instead of 13.7 (median, 800x600; the frame 25.2 against 25.4): the rounds are not waiting for their records.  Kept as an option.
 struct CoopBatchP { uint2 e; float4 g, h; unsigned n; bool have; };
 template <bool PIPE = false>
 __device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, unsigned n_rays, float dx, float dy, float dz, bool want, float &best_out,

@@ -126,7 +126,7 @@ __device__ __forceinline__ void render_skip_fast_body(const FastArgs &args)
     [[maybe_unused]] T cbest = inf<T>();
     [[maybe_unused]] unsigned citem = 0;
     if constexpr (COOP) {
-        if (coop_wave) coop_primary<true>(args.cv, coop_lds[wave], coop_rays, dir.x, dir.y, dir.z, inside, cbest, citem, walk);
+        if (coop_wave) coop_primary(args.cv, coop_lds[wave], coop_rays, dir.x, dir.y, dir.z, inside, cbest, citem, walk);
     }
     const bool loops_run = !COOP || !coop_wave || __ballot(walk) != 0;
     if (loops_run) {
@@ -183,7 +183,7 @@ __device__ __forceinline__ void render_skip_fast_body(const FastArgs &args)
     bool occluded = false;
     bool walk_s = need_shadow;
     if constexpr (COOP) {
-        if (coop_wave && __ballot(need_shadow) != 0) coop_shadow<true>(args.cv, coop_lds[wave], coop_rays, sp.x, sp.y, sp.z, sdir, need_shadow, occluded, walk_s);
+        if (coop_wave && __ballot(need_shadow) != 0) coop_shadow(args.cv, coop_lds[wave], coop_rays, sp.x, sp.y, sp.z, sdir, need_shadow, occluded, walk_s);
     }
     if (__ballot(walk_s) != 0) {
         FilterConsts fc;
