@@ -40,6 +40,7 @@ BANK = (SB, SB + 8, SB + 16)
 NX = "s%d" % (SB + 24)
 LIGHT = SB + 42                                                      # three registers: the shadow rays' direction (the fourth pads the pair)
 SGPR_LAST, VGPR_FIRST, VGPR_LAST = SB + 45, 32, 63
+RESERVED = (32, 72, 73)
 
 
 def sp(first):
@@ -835,6 +836,7 @@ __device__ __forceinline__ void %(name)s(const void *nodes, const float (&dx)[2]
     const float tiny = 0x1p-96f, kk = 0x1.00001p+0f;       // kk = 1 + 2^-20 (bound_shortcut)
     unsigned res0 = resume[0], res1 = resume[1];          // (the loop's RES pair; what it leaves there is of no interest)
     asm volatile(
+        "\\t; rt-loops two-ray: undeclared s32, s[72:73]\\n"
 %(body)s
         : [best0] "={v52}"(best_out[0]), [best1] "={v53}"(best_out[1]), [item0] "={v54}"(item_out[0]), [item1] "={v55}"(item_out[1]),
           [res0] "+{v38}"(res0), [res1] "+{v39}"(res1)
@@ -857,6 +859,7 @@ __device__ __forceinline__ unsigned skip2_shadow_rot_fused(const void *nodes, un
     unsigned stop;
     start = (unsigned)__builtin_amdgcn_readfirstlane((int)start);       // wave-uniform by construction; the operand must be an SGPR
     asm volatile(
+        "\\t; rt-loops two-ray: undeclared s32, s[72:73]\\n"
 %(body)s
         : [fin0] "=v"(fin[0]), [fin1] "=v"(fin[1]), [rout0] "=v"(resume[0]), [rout1] "=v"(resume[1]), [stop] "=&s"(stop)
         : [base] "s"(nodes), [n] "s"(n_bytes), [start] "s"(start), [ox0] "v"(ox[0]), [ox1] "v"(ox[1]), [oy0] "v"(oy[0]), [oy1] "v"(oy[1]),
@@ -880,6 +883,7 @@ __device__ __forceinline__ void %(name)s(const void *nodes, unsigned n_bytes, co
 {
     const float tiny = 0x1p-96f;
     asm volatile(
+        "\\t; rt-loops two-ray: undeclared s32, s[72:73]\\n"
 %(body)s
         : [res0] "+{v38}"(resume[0]), [res1] "+{v39}"(resume[1])
         : [base] "s"(nodes), [n] "s"(n_bytes), [ox0] "{v32}"(ox[0]), [ox1] "{v33}"(ox[1]), [oy0] "{v34}"(oy[0]), [oy1] "{v35}"(oy[1]),
@@ -896,7 +900,11 @@ SHADOW_BOUND = tuple(range(32, 40))                                # DX, DY, DZ 
 
 def clobbers(last=SGPR_LAST, bound=()):
     """bound: vector registers of the loops that ARE operands of the statement (the caller's values arrive in / leave from them directly)."""
-    regs = ['"s%d"' % r for r in range(SB, last + 1)] + ['"v%d"' % r for r in range(VGPR_FIRST, VGPR_LAST + 1) if r not in bound]
+    # Not named: what the compiler RESERVES in k_render_skip2 (s32, the stack pointer of a kernel that has no stack; s[72:73] under
+    # amdgpu_waves_per_eu(8)) -- it never allocates them, and naming them is what `-Winline-asm` objects to.  That the loops may use them
+    # rests on the kernel's .sgpr_count and on no compiler-generated instruction touching them: tests/test_kernel_resources.py checks both
+    # on the generated assembly (tools/check_reserved_registers.py).
+    regs = ['"s%d"' % r for r in range(SB, last + 1) if r not in RESERVED] + ['"v%d"' % r for r in range(VGPR_FIRST, VGPR_LAST + 1) if r not in bound]
     lines, cur = [], '"memory", "vcc", "scc"'
     for r in regs:
         if len(cur) + len(r) + 2 > 118:

@@ -476,6 +476,7 @@ class F64F(F64):
     NX = "s77"
     ACT, M54, M56, M58, TINY, EX = sp(78), sp(80), sp(82), sp(84), sp(86), sp(88)
     clobber_lo, clobber_hi = 36, 89
+    reserved = (88, 89)                              # k_render_skip_f64: amdgpu_num_sgpr(96) + amdgpu_waves_per_eu(7) leave the compiler s[0:87]
     load_op = "s_load_dwordx8"
 
     def fbank(self, b):
@@ -1108,7 +1109,11 @@ __device__ __forceinline__ unsigned %(name)s(const void *nodes, unsigned n_bytes
 
 
 def clobbers(P, vregs=()):
-    regs = ['"s%d"' % r for r in range(P.clobber_lo, P.clobber_hi + 1)] + list(vregs)
+    # Registers the compiler RESERVES in the one kernel a flavour's loops are built into are not named: it never allocates them, so there is
+    # nothing to tell it -- and naming them is what `-Winline-asm` ("clobber list contains reserved registers") objects to.  That the loops
+    # may use them rests on the kernel's .sgpr_count (the hardware's allocation covers them) and on no compiler-generated instruction
+    # touching them: tests/test_kernel_resources.py checks both on the generated assembly (tools/check_reserved_registers.py).
+    regs = ['"s%d"' % r for r in range(P.clobber_lo, P.clobber_hi + 1) if r not in getattr(P, "reserved", ())] + list(vregs)
     lines, cur = [], '"memory", "vcc", "scc"'
     for r in regs:
         if len(cur) + len(r) + 2 > 118:
@@ -1172,7 +1177,9 @@ def main():
                       "shadow_extra_in": P.shadow_extra_in, "shadow_extra_out": P.shadow_extra_out, "shadow_extra_decl": P.shadow_extra_decl,
                       "shadow_extra_args": ", float q1, float q2, float ol, float a0, float k1, float kc, const void *exact" if (P.filt and not P.primary_only) else "",
                       "primary_extra_args": P.primary_extra_args, "primary_extra_in": P.primary_extra_in}
-            text += PRIMARY_FN % dict(common, name="skip_primary_rot" + sfx, body=primary(P, fused), decl=P.primary_decl, out=P.primary_out)
+            # (what tools/check_reserved_registers.py finds a flavour's statements by in the compiler's assembly output)
+            mark = '        "\\t; rt-loops %s: undeclared s[%d:%d]\\n"\n' % (P.name, P.reserved[0], P.reserved[-1]) if getattr(P, "reserved", ()) else ""
+            text += PRIMARY_FN % dict(common, name="skip_primary_rot" + sfx, body=mark + primary(P, fused), decl=P.primary_decl, out=P.primary_out)
             if not P.primary_only:
                 text += SHADOW_FN % dict(common, name="skip_shadow_rot" + sfx, body=shadow(P, fused), decl=P.shadow_decl, out=P.shadow_out,
                                          clobbers=clobbers(P, P.shadow_vclobbers))
@@ -1180,7 +1187,7 @@ def main():
                 S = F64FS()
                 sc = dict(common, shadow_extra_in=S.shadow_extra_in, shadow_extra_out="", shadow_extra_decl="", clobbers=clobbers(S, S.shadow_vclobbers),
                           shadow_extra_args=", float q1, float q2, float ol, float a0, float k1, float kc, const void *exact")
-                text += SHADOW_FN % dict(sc, name="skip_shadow_rot" + sfx, body=shadow(S, fused), decl=S.shadow_decl, out=S.shadow_out)
+                text += SHADOW_FN % dict(sc, name="skip_shadow_rot" + sfx, body=mark + shadow(S, fused), decl=S.shadow_decl, out=S.shadow_out)
     text += "}  // namespace rt\n"
     with open(OUT, "w") as f:
         f.write(text)
