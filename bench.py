@@ -245,9 +245,11 @@ def make_image_wall(cores):
         res.update({"make_image_wall_ms": round(min(walls[1:]), 2), "wall_ms_each": [round(w, 2) for w in walls], "first_run_wall_ms": round(walls[0], 2),
                     "parts_ms": parts, "md5_ok": md5(out) == res["reference_md5"],
                     "parts_note": "from main() of the last run: args; host_scene = Scene::default on the host; runtime_init = the first HIP call; device_context = the first call "
-                                  "that needs the DEVICE (the runtime activates its context: address space, first queue -- the runtime's, whoever makes that call); "
-                                  "device_scene = rt_scene_create (its stream, the code object's load, uploads by kernel -- no copy engine --, stream derivation; the cost map "
-                                  "and the dispatch orders wait for a second frame); render_and_first_write = Renderer::render up to the Drop; "
+                                  "that needs the device (a pinned page); device_scene = rt_scene_create, of which first_queue = creating its stream -- in a process "
+                                  "without one that is where the RUNTIME makes its first hardware queue (~19 ms, whoever creates the first stream or launches the "
+                                  "first kernel: tools/init_probe.hip, profiles/r06_init_probe.log) -- and device_scene_own = the rest: the library's allocations, uploads "
+                                  "by kernel (no copy engine) and stream derivation, its code object loaded by a helper thread meanwhile; the cost map and the "
+                                  "dispatch orders wait for a second frame; render_and_first_write = Renderer::render up to the Drop; "
                                   "drop_write = the writer's final write; wall - main_to_here = exec, dynamic linking, static initialisers, exit / runtime teardown"})
     except Exception as e:          # noqa: BLE001
         res["error"] = repr(e)

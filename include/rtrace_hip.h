@@ -142,6 +142,12 @@ rt_status rt_scene_destroy(rt_scene *scene);
 enum { RT_SCENE_HAS_BOUNDS = 1u, RT_SCENE_CONCENTRIC = 2u };
 rt_status rt_scene_traits(const rt_scene *scene, uint32_t *traits);
 
+/* What rt_scene_create took on the host (diagnostic: a one-shot caller -- `make image` -- pays it once per process): total_ms for the whole
+ * call, stream_ms of it for creating the scene's stream.  In a process that has no stream yet that is where the RUNTIME makes its first
+ * hardware queue (~19 ms on MI355X / ROCm 7.2, whoever creates the first stream or launches the first kernel: tools/init_probe.hip); the
+ * library's own work -- allocations, uploads, deriving the streams; its code object is loaded meanwhile -- is the difference. */
+rt_status rt_scene_setup_cost(const rt_scene *scene, double *total_ms, double *stream_ms);
+
 /* rt_render_tiles with delivery in completion order (the reference's channel, render.rs:271,301-307): the buckets are rendered in
  * batches that are all enqueued at once, and `callback` is invoked -- on the calling thread -- for every bucket of a batch as soon
  * as that batch is complete, while later batches are still rendering.  tile_index: the bucket's position in `tiles`; rgba: its

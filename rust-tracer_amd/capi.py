@@ -21,7 +21,7 @@ RT_TRAVERSAL_FLAT, RT_TRAVERSAL_SKIP = 0, 1
 ABI_VERSION = 4
 
 # every symbol include/rtrace_hip.h declares
-SYMBOLS = ("rt_abi_version", "rt_build_hierarchy", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_scene_traits", "rt_render_tiles",
+SYMBOLS = ("rt_abi_version", "rt_build_hierarchy", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_scene_traits", "rt_scene_setup_cost", "rt_render_tiles",
            "rt_render_tiles_device", "rt_render_frame_device", "rt_render_region", "rt_blit_tiles_device", "rt_selftest_sqrt", "rt_selftest_rcp", "rt_tiles_rgba_bytes", "rt_strerror", "rt_last_error_message",
            "rt_host_alloc", "rt_host_free", "rt_host_register", "rt_host_unregister",
            "rt_gang_create", "rt_gang_destroy", "rt_gang_size", "rt_gang_render_frame", "rt_gang_render_frames", "rt_render_tiles_stream",
@@ -94,6 +94,7 @@ lib.rt_render_frame_stream.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int, 
 lib.rt_selftest_sqrt.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
 lib.rt_selftest_rcp.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
 lib.rt_scene_traits.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+lib.rt_scene_setup_cost.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
 RT_SCENE_HAS_BOUNDS, RT_SCENE_CONCENTRIC = 1, 2
 lib.rt_tiles_rgba_bytes.restype = C.c_uint64
 lib.rt_tiles_rgba_bytes.argtypes = [C.c_void_p, C.c_uint32]

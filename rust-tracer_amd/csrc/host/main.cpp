@@ -191,9 +191,10 @@ int main(int argc, char **argv)
             int n_visible = 0;
             (void)rt_device_count(&n_visible);
             t_runtime = ms_since(t0);
-            // ... and the first call that needs the DEVICE: the runtime activates its context then (~15 - 20 ms: address space, first queue).
-            // Without this bracket that time lands in whatever touches the device first -- rt_scene_create's stream -- and reads as the
-            // library's.  (A pinned allocation of one page: the writer makes its own with the same call a moment later.)
+            // ... and the first call that needs the DEVICE (a pinned allocation of one page: the writer makes its own with the same call a
+            // moment later).  What it does NOT bring about is the runtime's first hardware queue (~19 ms): that comes with the first stream
+            // or the first launch of the process -- rt_scene_create's stream -- and is reported apart below (first_queue_ms, from
+            // rt_scene_setup_cost; making and dropping a stream here instead would add 4 ms to the process).
             t0 = Clock::now();
             void *page = nullptr;
             if (rt_host_alloc(4096, &page) == RT_OK) (void)rt_host_free(page);
@@ -244,9 +245,13 @@ int main(int argc, char **argv)
         }                                                                                // Drop writes the final image
         const double t_drop_write = ms_since(t0);
         if (sink.is_file) { fclose(sink.f); sink.f = nullptr; } else fflush(stdout);
-        if (timings)
-            fprintf(stderr, "{\"args_ms\": %.3f, \"host_scene_ms\": %.3f, \"runtime_init_ms\": %.3f, \"device_context_ms\": %.3f, \"device_scene_ms\": %.3f, \"render_and_first_write_ms\": %.3f, "
-                            "\"drop_write_ms\": %.3f, \"main_to_here_ms\": %.3f}\n", t_args, t_host_scene, t_runtime, t_context, t_device_scene, t_render, t_drop_write, ms_since(t_main));
+        if (timings) {
+            double setup_ms = 0.0, queue_ms = 0.0;                // of the first device's rt_scene_create
+            if (!be.devices.empty()) (void)rt_scene_setup_cost(be.devices[0]->handle(), &setup_ms, &queue_ms);
+            fprintf(stderr, "{\"args_ms\": %.3f, \"host_scene_ms\": %.3f, \"runtime_init_ms\": %.3f, \"device_context_ms\": %.3f, \"device_scene_ms\": %.3f, \"first_queue_ms\": %.3f, "
+                            "\"device_scene_own_ms\": %.3f, \"render_and_first_write_ms\": %.3f, \"drop_write_ms\": %.3f, \"main_to_here_ms\": %.3f}\n",
+                    t_args, t_host_scene, t_runtime, t_context, t_device_scene, queue_ms, t_device_scene - queue_ms, t_render, t_drop_write, ms_since(t_main));
+        }
         if (stats)
             fprintf(stderr, "primary %llu hits %llu shadow %llu occluded %llu item_tests %llu bound_tests %llu device_ms %.3f\n",
                     (unsigned long long)st.primary, (unsigned long long)st.hits, (unsigned long long)st.shadow,

@@ -149,6 +149,7 @@ struct Context {
 
 struct rt_scene {
     int device = 0;
+    double setup_total_ms = 0.0, setup_first_stream_ms = 0.0;      // rt_scene_setup_cost
     rt_precision precision = RT_F32;
     uint32_t n_items = 0, n_bounds = 0;
     void *d_items = nullptr;       // Item<REAL>[n_items], DFS order

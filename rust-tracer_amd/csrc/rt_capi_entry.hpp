@@ -174,6 +174,8 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
         return RT_ERR_NO_DEVICE;
     }
     StageClock clk;
+    const auto t_setup = std::chrono::steady_clock::now();
+    auto ms_since_setup = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_setup).count(); };
     HIP_TRY(hipSetDevice(device));
     clk.lap("scene: hipSetDevice");
 
@@ -206,8 +208,21 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
     s->h_items.assign(static_cast<const unsigned char *>(dfs_items), static_cast<const unsigned char *>(dfs_items) + esz * 4 * n_items);
     // ONE stream carries everything this call enqueues (uploads, the kernels that derive the streams, the cost map's counting render) and is
     // the first context's stream afterwards: the null stream is never touched
-    if ((e = hipStreamCreateWithFlags(&s->cost_stream, hipStreamNonBlocking)) != hipSuccess) return fail(hip_fail(e, "hipStreamCreate(scene)", __LINE__));
+    // (the first stream of a process is ~19 ms -- the runtime makes its first hardware queue, tools/init_probe.hip --, and the library's code
+    // object another ~3.5 ms at its first launch: a helper asks for a kernel's attributes meanwhile, which is what loads the code object)
+    std::thread code_loader([device] {
+        if (hipSetDevice(device) != hipSuccess) return;
+        hipFuncAttributes fa;
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(rt::k_upload_words));
+        (void)hipGetLastError();
+    });
+    const double t_before_stream = ms_since_setup();
+    e = hipStreamCreateWithFlags(&s->cost_stream, hipStreamNonBlocking);
+    s->setup_first_stream_ms = ms_since_setup() - t_before_stream;
     clk.lap("scene: stream");
+    code_loader.join();
+    clk.lap("scene: code object (helper)");
+    if (e != hipSuccess) return fail(hip_fail(e, "hipStreamCreate(scene)", __LINE__));
     if ((e = hipMalloc(&s->d_items, esz * 4 * n_items)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(items)", __LINE__));
     {
         // everything this call uploads goes through ONE pinned arena and k_upload_words: items, the raw streams (plain + compacted: a node per
@@ -233,6 +248,7 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
     }
     // (every upload has been consumed: derive_streams and upload_coop synchronise the stream behind their kernels)
     if (s->h_up) { (void)hipStreamSynchronize(s->cost_stream); (void)hipHostFree(s->h_up); s->h_up = nullptr; s->up_cap = s->up_used = 0; }
+    s->setup_total_ms = ms_since_setup();
     *out = s.release();
     return RT_OK;
 }
@@ -788,6 +804,14 @@ rt_status rt_scene_traits(const rt_scene *s, uint32_t *traits)
 {
     if (!s || !traits) { snprintf(g_err, sizeof g_err, "NULL argument"); return RT_ERR_INVALID_ARGUMENT; }
     *traits = (s->n_nodes ? RT_SCENE_HAS_BOUNDS : 0u) | (s->fused ? RT_SCENE_CONCENTRIC : 0u);
+    return RT_OK;
+}
+
+rt_status rt_scene_setup_cost(const rt_scene *s, double *total_ms, double *stream_ms)
+{
+    if (!s || !total_ms || !stream_ms) { snprintf(g_err, sizeof g_err, "NULL argument"); return RT_ERR_INVALID_ARGUMENT; }
+    *total_ms = s->setup_total_ms;
+    *stream_ms = s->setup_first_stream_ms;
     return RT_OK;
 }
 

@@ -216,6 +216,12 @@ class DeviceScene:
         capi.check(capi.lib.rt_scene_traits(self._h, C.byref(t)), "rt_scene_traits")
         return t.value
 
+    def setup_cost(self):
+        """rt_scene_setup_cost -> (total_ms, stream_ms) of the rt_scene_create call that made this scene."""
+        total, stream = C.c_double(0), C.c_double(0)
+        capi.check(capi.lib.rt_scene_setup_cost(self._h, C.byref(total), C.byref(stream)), "rt_scene_setup_cost")
+        return total.value, stream.value
+
     def close(self):
         if getattr(self, "_h", None):
             capi.lib.rt_scene_destroy(self._h)
