@@ -161,7 +161,7 @@ struct rt_scene {
     void *d_fc = nullptr;          // device copy of fc
     uint32_t n_nodes = 0, n_fnodes = 0;
     bool fused = false;            // every BOUND is followed by an ITEM with the same centre (rt_skip.hpp, Node)
-    // f32: the hierarchy once more in sibling-contiguous order for the lane-cooperative walk (rt_coop.hpp); coop.fanout == 0: none
+    // the hierarchy once more in sibling-contiguous order for the lane-cooperative walk (rt_coop.hpp; f64: CNode64); coop.fanout == 0: none
     void *d_coop_prim = nullptr, *d_coop_shad = nullptr;
     rt::CoopView coop{};
     void *d_fprim = nullptr, *d_fprim_rr = nullptr, *d_fshad = nullptr;   // pre-formed per-item terms (RT_TRAVERSAL_FLAT)

@@ -513,14 +513,14 @@ bool order_knobs_set()
 rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std::vector<rt::TileDev> &tab, unsigned w, unsigned h, unsigned passes,
                        std::vector<rt_scene::Order> &orders, int &chosen, void **arena_out)
 {
-    const bool coop_pass = s->precision == RT_F32 && s->coop.fanout != 0u && passes == 1;
+    const bool coop_pass = s->coop.fanout != 0u && passes == 1;       // (f32; f64 scenes whose filtered streams exist)
     uint64_t total_px = 0, total_blocks = 0;
     for (const rt::TileDev &td : tab) {
         total_px += (uint64_t)(td.r - td.l) * (td.t - td.b);
         total_blocks += (uint64_t)td.blks_x * (((unsigned)(td.t - td.b) + rt::kBlockH - 1) / rt::kBlockH);
     }
     const long long rays = knob(RT_DEBUG_SKIP_RAYS);
-    const bool two_rays = rays < 0 ? skip2_by_default(total_px, 1, s->fused ? s->n_fnodes : s->n_nodes) : rays == 2;      // k_render_skip2 knows no cooperative quads
+    const bool two_rays = s->precision == RT_F32 && (rays < 0 ? skip2_by_default(total_px, 1, s->fused ? s->n_fnodes : s->n_nodes) : rays == 2);      // k_render_skip2 (f32) knows no cooperative quads
     // Candidate 0 is ALWAYS the plain order of a pass that could walk cooperatively (coop_percent 0: no holes, no cooperative descriptors):
     // pick_order and launch_skip_one hand it to every launch that cannot take holes (counters, f64, two rays per lane).
     // Candidates: the plain order first; then cooperative thresholds.  Where the scene's stream is there to count the list's heaviest blocks
@@ -542,7 +542,9 @@ rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std:
                 for (unsigned bx = 0; bx < t.blks_x; ++bx)
                     raster.push_back(rt::BlockDesc{ (uint16_t)(t.l + bx * rt::kBlockW), (uint16_t)(t.b + by * rt::kBlockH), t.r, t.t, pitch, 0u });
         }
-        if (exact_block_costs<float>(s, raster, heaviest, w, h, exact) != RT_OK) { (void)hipGetLastError(); exact = ExactCosts{}; }
+        if ((s->precision == RT_F32 ? exact_block_costs<float>(s, raster, heaviest, w, h, exact) : exact_block_costs<double>(s, raster, heaviest, w, h, exact)) != RT_OK) {
+            (void)hipGetLastError(); exact = ExactCosts{};
+        }
     }
     bool asked = false;
     if (!exact.block.empty() && exact.top >= kCoopMinCost) {

@@ -125,6 +125,7 @@ constexpr auto skip_kernel()
 {
     if constexpr (sizeof(T) == 4 && !COUNT && COOP) return &rt::k_render_skip_f32_coop<COUNT, VAR, MODE>;
     else if constexpr (sizeof(T) == 4 && !COUNT) return &rt::k_render_skip_f32<COUNT, VAR, MODE>;
+    else if constexpr (sizeof(T) == 8 && !COUNT && (VAR & 18) == 18 && COOP) return &rt::k_render_skip_f64_coop<VAR, MODE>;
     else if constexpr (sizeof(T) == 8 && !COUNT && (VAR & 18) == 18) return &rt::k_render_skip_f64<VAR, MODE>;
     else return &rt::k_render_skip<T, COUNT, VAR, MODE, COOP>;
 }
@@ -144,7 +145,7 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
         two_rays = two_rays && (spp == 1 || (use_split(spp) && packed_samples(spp)));
     }
     // an order with cooperative quads needs the COOP flavour of k_render_skip: everything else renders the plain order of the same list
-    constexpr bool kCoopFlavour = !COUNT && sizeof(T) == 4 && (VAR == 19 || VAR == 23 || VAR == 31);
+    constexpr bool kCoopFlavour = !COUNT && (VAR == 19 || VAR == 23 || VAR == 31);       // (f32, and since round 6 f64: the filtered assembly loops)
     if (order.holes && !(kCoopFlavour && spp == 1 && !two_rays && !order.wg_first)) {
         order.d = order.plain_d; order.n = order.plain_n; order.wg_first = order.plain_wg_first; order.n_wg = order.plain_n_wg;
         order.holes = nullptr; order.n_holes = 0;
@@ -217,7 +218,7 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
                 return RT_OK;
             }
         }
-        if constexpr (!COUNT && sizeof(T) == 4 && (VAR == 19 || VAR == 23 || VAR == 31)) {
+        if constexpr (!COUNT && (VAR == 19 || VAR == 23 || VAR == 31)) {
             if (spp == 1 && order.d && order.holes && !order.wg_first) {        // some quads of the pass are walked cooperatively (rt_coop.hpp)
                 count_event(RT_DEBUG_COUNT_COOP_LAUNCHES); g_launch_flags |= RT_LAUNCH_COOPERATIVE;
                 hipLaunchKernelGGL((skip_kernel<T, COUNT, VAR, rt::kSkipOne, true>()), rgrid, b, lds, stream, 

@@ -397,7 +397,7 @@ rt_status derive_streams(const rt_scene *s, const std::vector<rt::RawNode<T>> &r
     return RT_OK;
 }
 
-rt_status upload_coop(rt_scene *s, const std::vector<rt::RawNode<float>> &raw);
+template <typename T> rt_status upload_coop(rt_scene *s, const std::vector<rt::RawNode<T>> &raw);
 
 template <typename T>
 rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, const rt_range *ranges)
@@ -467,6 +467,7 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
         if ((uint64_t)(s->n_nodes + rt::kNodePad) * sizeof(rt::Node<T>) <= 0xFFFFFFFFull) {
             if ((st = derive64(s->d_prim, s->d_shad, s->n_nodes, false, &s->d_xprim, &s->d_xshad, nullptr)) != RT_OK) return st;
             if (fused && (st = derive64(s->d_cprim, s->d_cshad, s->n_fnodes, true, &s->d_xcprim, &s->d_xcshad, &s->d_xown)) != RT_OK) return st;
+            if ((st = upload_coop<T>(s, raw)) != RT_OK) return st;         // (with the filtered streams: the cooperative flavour is built for those loops)
         }
     }
     if constexpr (sizeof(T) == 4) {
@@ -477,7 +478,7 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
         if ((st = derive_fstreams(s, s->d_prim, s->d_shad, s->n_nodes, false, &s->d_xprim, &s->d_xshad, nullptr)) != RT_OK) return st;
         if (fused && (st = derive_fstreams(s, s->d_cprim, s->d_cshad, s->n_fnodes, true, &s->d_xcprim, &s->d_xcshad, &s->d_xown)) != RT_OK) return st;
         clk.lap("  streams: filtered");
-        if ((st = upload_coop(s, raw)) != RT_OK) return st;
+        if ((st = upload_coop<T>(s, raw)) != RT_OK) return st;
         clk.lap("  streams: cooperative copy");
     }
     return RT_OK;
@@ -486,8 +487,10 @@ rt_status upload_streams(rt_scene *s, const void *items, const void *bounds, con
 // The lane-cooperative walk's copy of the hierarchy (rt_coop.hpp): the nodes of the plain stream in breadth-first order, so that the
 // children of a group are consecutive records.  Scenes whose largest child count (or number of top-level nodes) exceeds what a
 // work-list word holds simply get none: the cooperative walk is an optimisation of the skip-pointer walk, never a requirement.
-rt_status upload_coop(rt_scene *s, const std::vector<rt::RawNode<float>> &raw)
+template <typename T>
+rt_status upload_coop(rt_scene *s, const std::vector<rt::RawNode<T>> &raw)
 {
+    typedef typename rt::CNodeOf<T>::type Rec;
     const uint32_t n = (uint32_t)raw.size();
     if (n == 0 || n >= rt::kCoopMaxNodes) return RT_OK;
     auto next_sibling = [&](uint32_t i) { return raw[i].skip ? raw[i].skip : i + 1u; };
@@ -513,19 +516,19 @@ rt_status upload_coop(rt_scene *s, const std::vector<rt::RawNode<float>> &raw)
     if (e == hipSuccess) e = hipMalloc(&d_link, sizeof(uint2) * n);
     if (e == hipSuccess && scene_upload(s, d_perm, perm.data(), sizeof(uint32_t) * n) != RT_OK) e = hipErrorUnknown;
     if (e == hipSuccess && scene_upload(s, d_link, link.data(), sizeof(uint2) * n) != RT_OK) e = hipErrorUnknown;
-    if (e == hipSuccess) e = hipMalloc(&s->d_coop_prim, sizeof(rt::CNode) * n);
-    if (e == hipSuccess) e = hipMalloc(&s->d_coop_shad, sizeof(rt::CNode) * n);
+    if (e == hipSuccess) e = hipMalloc(&s->d_coop_prim, sizeof(Rec) * n);
+    if (e == hipSuccess) e = hipMalloc(&s->d_coop_shad, sizeof(Rec) * n);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(rt::k_build_coop, dim3((n + 255) / 256), dim3(256), 0, s->cost_stream, s->d_prim, s->d_shad, (unsigned)sizeof(rt::Node<float>), d_perm, d_link, n,
-                           static_cast<rt::CNode *>(s->d_coop_prim), static_cast<rt::CNode *>(s->d_coop_shad));
+        hipLaunchKernelGGL(rt::k_build_coop<T>, dim3((n + 255) / 256), dim3(256), 0, s->cost_stream, s->d_prim, s->d_shad, (unsigned)sizeof(rt::Node<T>), d_perm, d_link, n,
+                           static_cast<Rec *>(s->d_coop_prim), static_cast<Rec *>(s->d_coop_shad));
         e = hipGetLastError();
     }
     { const hipError_t se = hipStreamSynchronize(s->cost_stream); if (e == hipSuccess) e = se; }
     if (d_perm) (void)hipFree(d_perm);
     if (d_link) (void)hipFree(d_link);
     if (e != hipSuccess) return hip_fail(e, "upload_coop", __LINE__);
-    s->coop.prim = static_cast<const rt::CNode *>(s->d_coop_prim);
-    s->coop.shad = static_cast<const rt::CNode *>(s->d_coop_shad);
+    s->coop.prim = s->d_coop_prim;
+    s->coop.shad = s->d_coop_shad;
     s->coop.n_roots = n_roots;
     s->coop.fanout = fanout;
     return RT_OK;

@@ -34,7 +34,7 @@
 namespace rt {
 
 // One node of the cooperative copy.  Primary array: a = {vx, vy, vz, vv}, a4 = rr (v = centre - eye: the same pre-formed terms as
-// Node<float>, rt_skip.hpp, copied from that stream bit for bit); shadow array: a = {cx, cy, cz, rr}, a4 unused.
+// Node<T>, rt_skip.hpp, copied from that stream bit for bit); shadow array: a = {cx, cy, cz, rr}, a4 unused.
 // count == 0: an ITEM, `first` is its DFS item index.  count > 0: a BOUND whose children are records [first, first + count).
 struct alignas(32) CNode {
     float a0, a1, a2, a3;
@@ -42,6 +42,16 @@ struct alignas(32) CNode {
     uint32_t first, count, pad;
 };
 static_assert(sizeof(CNode) == 32, "two 16-byte vector loads");
+// ... of an f64 scene (round 6): the same terms as Node<double> carries them; bytes [32, 48) = {a4, first, count} are one 16-byte load
+struct alignas(64) CNode64 {
+    double a0, a1, a2, a3;
+    double a4;
+    uint32_t first, count;
+    uint32_t pad[4];
+};
+static_assert(sizeof(CNode64) == 64, "three 16-byte vector loads of a 64-byte record");
+template <typename T> struct CNodeOf { typedef CNode type; };
+template <> struct CNodeOf<double> { typedef CNode64 type; };
 
 constexpr unsigned kCoopRays = 16;            // a wave's quad: at most 4x4 pixels (level-1 descriptors; level 2: 2x2, level 3: one)
 constexpr unsigned kCoopStack = 448;          // work-list capacity per wave (pairs)
@@ -49,7 +59,7 @@ constexpr unsigned kCoopMaxFanout = 15;       // `count` has four bits in a work
 constexpr uint32_t kCoopMaxNodes = 1u << 24;  // `first` has 24
 
 struct CoopView {
-    const CNode *prim = nullptr, *shad = nullptr;
+    const void *prim = nullptr, *shad = nullptr;      // CNodeOf<T>::type arrays of the scene's precision
     uint32_t n_roots = 0;       // the top-level nodes are records [0, n_roots)
     uint32_t fanout = 0;        // the largest child count of the scene (and n_roots): lanes are dealt to (pair, child) by it; 0: no cooperative copy
 };
@@ -63,6 +73,21 @@ struct CoopLds {
     uint2 stack[kCoopStack];
 };
 static_assert(sizeof(CoopLds) <= 4096, "four waves and eight workgroups per CU: 160 KB of LDS");
+// f64: a distance is 64 bits, so the minimum by (distance, DFS index) is kept in two words (coop_primary says how); `anc` travels as an f32
+// ROUNDED UP -- the check `anc <= F` may then fail for a ray it would have passed (that ray is walked by the loops: never wrong), never
+// pass one it should fail -- which keeps a work-list pair at eight bytes.
+struct CoopLds64 {
+    double ray[kCoopRays][4];
+    unsigned long long best[kCoopRays];         // distance bits, ~0 = no hit
+    uint32_t best_item[kCoopRays];              // the smallest DFS index among the items at that distance
+    float best_anc[kCoopRays];
+    uint32_t occluded;
+    uint32_t pad;
+    uint2 stack[kCoopStack];
+};
+static_assert(sizeof(CoopLds64) <= 4608, "four waves per workgroup: 18 KB");
+template <typename T> struct CoopLdsOf { typedef CoopLds type; };
+template <> struct CoopLdsOf<double> { typedef CoopLds64 type; };
 
 __device__ __forceinline__ unsigned coop_lane_rank(unsigned long long mask)      // set bits of mask below this lane
 {
@@ -80,32 +105,44 @@ __device__ __forceinline__ float coop_sqrt(float x)
     return __builtin_fmaf(r, h, g);
 }
 
+__device__ __forceinline__ double coop_sqrt(double x) { return __builtin_sqrt(x); }      // IEEE (rt_math.hpp: what the f64 loops use)
+
 // Sphere::distance_from_ray with the ray-independent terms pre-formed (primitive.rs:55-72), as the C++ loop of k_render_skip forms it.
-__device__ __forceinline__ float coop_primary_distance(const float4 g, float rr, float dx, float dy, float dz)
+template <typename T>
+__device__ __forceinline__ T coop_primary_distance(T vx, T vy, T vz, T vv, T rr, T dx, T dy, T dz)
 {
-    const float b = (g.x * dx + g.y * dy) + g.z * dz;
-    const float disc = (b * b - g.w) + rr;
-    float d = inf<float>();
-    if (!(disc < 0.0f)) {
-        const float s = coop_sqrt(disc);
-        const float t2 = b + s;
-        if (!(t2 < 0.0f)) {
-            const float t1 = b - s;
-            d = t1 > 0.0f ? t1 : t2;
+    const T b = (vx * dx + vy * dy) + vz * dz;
+    const T disc = (b * b - vv) + rr;
+    T d = inf<T>();
+    if (!(disc < T(0.0))) {
+        const T s = coop_sqrt(disc);
+        const T t2 = b + s;
+        if (!(t2 < T(0.0))) {
+            const T t1 = b - s;
+            d = t1 > T(0.0) ? t1 : t2;
         }
     }
     return d;
 }
 
 // ... for a ray with its own origin: does the shadow ray hit the sphere (finite distance)?  primitive.rs:55-68
-__device__ __forceinline__ bool coop_shadow_hit(const float4 g, float ox, float oy, float oz, V3<float> sdir)
+template <typename T>
+__device__ __forceinline__ bool coop_shadow_hit(T cx, T cy, T cz, T rr, T ox, T oy, T oz, V3<T> sdir)
 {
-    const V3<float> v = { g.x - ox, g.y - oy, g.z - oz };
-    const float b = dot(v, sdir);
-    const float disc = (b * b - dot(v, v)) + g.w;
+    const V3<T> v = { cx - ox, cy - oy, cz - oz };
+    const T b = dot(v, sdir);
+    const T disc = (b * b - dot(v, v)) + rr;
     bool hit = false;
-    if (!(disc < 0.0f)) hit = !((b + coop_sqrt(disc)) < 0.0f);
+    if (!(disc < T(0.0))) hit = !((b + coop_sqrt(disc)) < T(0.0));
     return hit;
+}
+
+// A bound distance (>= +0, finite) as the f32 the work list carries: the value itself in f32; in f64 the nearest f32 ABOVE it
+__device__ __forceinline__ uint32_t coop_anc_bits(float d) { return __float_as_uint(d); }
+__device__ __forceinline__ uint32_t coop_anc_bits(double d)
+{
+    const float f = (float)d;
+    return __float_as_uint(f) + ((double)f < d ? 1u : 0u);
 }
 
 // The pairs a round takes from the top of the work list, dealt to the lanes: lane (e, k) gets child k of the e-th pair from the top.
@@ -141,11 +178,14 @@ __device__ __forceinline__ void coop_lds_sync()
 // kernel); k_render_skip_fast_coop has them (40 -> 53 of 64), the waits land where they should (s_waitcnt vmcnt(2) at the head of a
 // round: the previous batch's two loads are back, this one's two are in flight), every parity test passes -- and a cooperative wave takes
 // 16.1 us instead of 13.7 (median, 800x600; the frame 25.2 against 25.4): the rounds are not waiting for their records.  Kept as an option.
-struct CoopBatchP { uint2 e; float4 g, h; unsigned n; bool have; };
-template <bool PIPE = false>
-__device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, unsigned n_rays, float dx, float dy, float dz, bool want, float &best_out,
+template <typename T> struct CoopBatchP { uint2 e; float4 g, h; unsigned n; bool have; };                      // g = {vx, vy, vz, vv}, h = {rr, first, count, -}
+template <> struct CoopBatchP<double> { uint2 e; double2 g01, g23; double a4; uint2 link; unsigned n; bool have; };
+template <bool PIPE = false, typename T = float>
+__device__ __forceinline__ void coop_primary(const CoopView &cv, typename CoopLdsOf<T>::type &lds, unsigned n_rays, T dx, T dy, T dz, bool want, T &best_out,
                                              unsigned &item_out, bool &failed_out)
 {
+    constexpr bool F64 = sizeof(T) == 8;
+    typedef typename CNodeOf<T>::type Rec;
     const unsigned lane = threadIdx.x & 63u;
     const CoopSlot sl = coop_slot(cv.fanout);
     const bool mine = want && lane < n_rays;
@@ -153,6 +193,7 @@ __device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, u
         lds.ray[lane][0] = dx; lds.ray[lane][1] = dy; lds.ray[lane][2] = dz;
         lds.best[lane] = ~0ull;
         lds.best_anc[lane] = 0.0f;
+        if constexpr (F64) lds.best_item[lane] = 0xFFFFFFFFu;
     }
     // one pair per ray: (ray, the top level)
     const unsigned long long wm = __ballot(mine);
@@ -162,7 +203,7 @@ __device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, u
     coop_lds_sync();                             // rays, minima and the first pairs are written: every lane may read them
     // the pairs on top of the list, dealt to the lanes, and their records requested
     auto fetch = [&]() {
-        CoopBatchP b;
+        CoopBatchP<T> b;
         b.n = min(sl.per, top);
         b.have = sl.e < b.n;
         b.e = lds.stack[b.have ? top - 1u - sl.e : 0u];
@@ -170,44 +211,75 @@ __device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, u
         const unsigned cnt = (b.e.x >> 24) & 15u;
         const bool valid = b.have && sl.k < cnt;
         const unsigned node = valid ? (b.e.x & 0xFFFFFFu) + sl.k : 0u;
-        const char *rec = reinterpret_cast<const char *>(cv.prim) + node * (unsigned)sizeof(CNode);        // (a 32-bit offset: fewer than 2^24 nodes)
-        b.g = *reinterpret_cast<const float4 *>(rec);
-        b.h = *reinterpret_cast<const float4 *>(rec + 16);                // {rr, first, count, -}
+        const char *rec = static_cast<const char *>(cv.prim) + node * (unsigned)sizeof(Rec);        // (a 32-bit offset: fewer than 2^24 nodes)
+        if constexpr (F64) {
+            b.g01 = *reinterpret_cast<const double2 *>(rec);
+            b.g23 = *reinterpret_cast<const double2 *>(rec + 16);
+            const uint4 t = *reinterpret_cast<const uint4 *>(rec + 32);       // {a4 (rr), first, count}
+            b.a4 = __hiloint2double((int)t.y, (int)t.x);
+            b.link = make_uint2(t.z, t.w);
+        } else {
+            b.g = *reinterpret_cast<const float4 *>(rec);
+            b.h = *reinterpret_cast<const float4 *>(rec + 16);            // {rr, first, count, -}
+        }
         return b;
     };
     // one round: the reference's test on every (ray, child) of the batch, minima, and the groups that go back on the list
-    auto eval = [&](const CoopBatchP &b) {
+    auto eval = [&](const CoopBatchP<T> &b) {
         const unsigned cnt = (b.e.x >> 24) & 15u, ray = b.e.x >> 28;
         const bool valid = b.have && sl.k < cnt;
-        const float rx = lds.ray[ray][0], ry = lds.ray[ray][1], rz = lds.ray[ray][2];
-        const float d = coop_primary_distance(b.g, b.h.x, rx, ry, rz);
-        const bool finite = valid && d < inf<float>();
-        const unsigned link_first = __float_as_uint(b.h.y), link_count = __float_as_uint(b.h.z);
+        const T rx = lds.ray[ray][0], ry = lds.ray[ray][1], rz = lds.ray[ray][2];
+        T d;
+        unsigned link_first, link_count;
+        if constexpr (F64) {
+            d = coop_primary_distance<double>(b.g01.x, b.g01.y, b.g23.x, b.g23.y, b.a4, rx, ry, rz);
+            link_first = b.link.x; link_count = b.link.y;
+        } else {
+            d = coop_primary_distance<float>(b.g.x, b.g.y, b.g.z, b.g.w, b.h.x, rx, ry, rz);
+            link_first = __float_as_uint(b.h.y); link_count = __float_as_uint(b.h.z);
+        }
+        const bool finite = valid && d < inf<T>();
         const float anc = __uint_as_float(b.e.y);
         // ITEM: keep the nearest by (distance, DFS index), and beside it the largest bound distance on its path
         const bool item_hit = finite && link_count == 0u;
         if (__ballot(item_hit) != 0ull) {
-            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | link_first;
-            if (item_hit) atomicMin(&lds.best[ray], key);
-            coop_lds_sync();                     // (every lane's minimum is in before any lane looks whether it holds it)
-            if (item_hit && lds.best[ray] == key) lds.best_anc[ray] = anc;
+            if constexpr (F64) {
+                // the distance's 64 bits are the key of the atomic minimum; the DFS index of the items AT the minimum is a second one.  A round
+                // that lowers the minimum throws the index of the old one away first.
+                const unsigned long long key = (unsigned long long)__double_as_longlong(d);
+                const unsigned long long before = lds.best[ray];
+                coop_lds_sync();                 // (every lane has read the minimum of the rounds before)
+                if (item_hit) atomicMin(&lds.best[ray], key);
+                coop_lds_sync();
+                const bool at_min = item_hit && lds.best[ray] == key;
+                if (at_min && key < before) lds.best_item[ray] = 0xFFFFFFFFu;
+                coop_lds_sync();
+                if (at_min) atomicMin(&lds.best_item[ray], link_first);
+                coop_lds_sync();
+                if (at_min && lds.best_item[ray] == link_first) lds.best_anc[ray] = anc;
+            } else {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | link_first;
+                if (item_hit) atomicMin(&lds.best[ray], key);
+                coop_lds_sync();                 // (every lane's minimum is in before any lane looks whether it holds it)
+                if (item_hit && lds.best[ray] == key) lds.best_anc[ray] = anc;
+            }
         }
         // BOUND with a finite distance: its children are wanted
         const bool push = finite && link_count != 0u;
         const unsigned long long pm = __ballot(push);
         const unsigned n_push = (unsigned)__popcll(pm);
         if (top + n_push > kCoopStack) { overflow = true; return; }
-        if (push) lds.stack[top + coop_lane_rank(pm)] = make_uint2(link_first | (link_count << 24) | (ray << 28), max(b.e.y, __float_as_uint(d)));      // (both >= +0: the bit patterns order like the values)
+        if (push) lds.stack[top + coop_lane_rank(pm)] = make_uint2(link_first | (link_count << 24) | (ray << 28), max(b.e.y, coop_anc_bits(d)));      // (both >= +0: the bit patterns order like the values)
         top = coop_uniform(top + n_push);
         coop_lds_sync();                         // the pushed pairs are the next round's reads
     };
     if constexpr (!PIPE) {
-        while (top > 0u && !overflow) { const CoopBatchP b = fetch(); eval(b); }
+        while (top > 0u && !overflow) { const CoopBatchP<T> b = fetch(); eval(b); }
     } else {
         // two batches in two sets of registers, by turns (a copy between rounds makes the compiler wait for the fetch it is meant to hide)
-        CoopBatchP a = fetch();
+        CoopBatchP<T> a = fetch();
         while (a.n != 0u) {
-            CoopBatchP b = fetch();              // (empty when the list holds no more than `a`: then it is fetched behind a's pushes)
+            CoopBatchP<T> b = fetch();           // (empty when the list holds no more than `a`: then it is fetched behind a's pushes)
             eval(a);
             if (overflow) break;
             if (b.n == 0u) { b = fetch(); if (b.n == 0u) break; }
@@ -218,15 +290,15 @@ __device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, u
         }
     }
     coop_lds_sync();
-    float best = inf<float>();
+    T best = inf<T>();
     unsigned item = 0u;
     bool failed = false;
     if (mine) {
         const unsigned long long k = lds.best[lane];
         if (k != ~0ull) {
-            best = __uint_as_float((unsigned)(k >> 32));
-            item = (unsigned)k;
-            failed = lds.best_anc[lane] > best;            // an ancestor bound is farther than the winner: the reference may have culled it
+            if constexpr (F64) { best = __longlong_as_double((long long)k); item = lds.best_item[lane]; }
+            else { best = __uint_as_float((unsigned)(k >> 32)); item = (unsigned)k; }
+            failed = (T)lds.best_anc[lane] > best;         // an ancestor bound is farther than the winner: the reference may have culled it
         }
         failed = failed || overflow;
     }
@@ -235,11 +307,14 @@ __device__ __forceinline__ void coop_primary(const CoopView &cv, CoopLds &lds, u
 
 // The shadow rays of a quad (any hit, render.rs:202-208): lanes [0, n_rays), origin (ox, oy, oz), `want`: the lane casts one.  Returns
 // `occluded` in those lanes and `failed` (work list overflow: the skip-pointer loops decide).
-struct CoopBatchS { uint2 e; float4 g; uint2 link; unsigned n; bool valid; };
-template <bool PIPE = false>
-__device__ __forceinline__ void coop_shadow(const CoopView &cv, CoopLds &lds, unsigned n_rays, float ox, float oy, float oz, V3<float> sdir, bool want,
+template <typename T> struct CoopBatchS { uint2 e; float4 g; uint2 link; unsigned n; bool valid; };
+template <> struct CoopBatchS<double> { uint2 e; double2 g01, g23; uint2 link; unsigned n; bool valid; };
+template <bool PIPE = false, typename T = float>
+__device__ __forceinline__ void coop_shadow(const CoopView &cv, typename CoopLdsOf<T>::type &lds, unsigned n_rays, T ox, T oy, T oz, V3<T> sdir, bool want,
                                             bool &occluded_out, bool &failed_out)
 {
+    constexpr bool F64 = sizeof(T) == 8;
+    typedef typename CNodeOf<T>::type Rec;
     const unsigned lane = threadIdx.x & 63u;
     const CoopSlot sl = coop_slot(cv.fanout);
     const bool mine = want && lane < n_rays;
@@ -251,7 +326,7 @@ __device__ __forceinline__ void coop_shadow(const CoopView &cv, CoopLds &lds, un
     bool overflow = false;
     coop_lds_sync();
     auto fetch = [&]() {
-        CoopBatchS b;
+        CoopBatchS<T> b;
         b.n = min(sl.per, top);
         const bool have = sl.e < b.n;
         b.e = lds.stack[have ? top - 1u - sl.e : 0u];
@@ -260,15 +335,23 @@ __device__ __forceinline__ void coop_shadow(const CoopView &cv, CoopLds &lds, un
         const unsigned cnt = (b.e.x >> 24) & 15u, ray = b.e.x >> 28;
         b.valid = have && sl.k < cnt && ((occ >> ray) & 1u) == 0u;       // a ray that is occluded wants nothing more (PIPE: as of one round ago -- a test too many, never one too few)
         const unsigned node = b.valid ? (b.e.x & 0xFFFFFFu) + sl.k : 0u;
-        const char *rec = reinterpret_cast<const char *>(cv.shad) + node * (unsigned)sizeof(CNode);
-        b.g = *reinterpret_cast<const float4 *>(rec);
-        b.link = *reinterpret_cast<const uint2 *>(rec + 20);
+        const char *rec = static_cast<const char *>(cv.shad) + node * (unsigned)sizeof(Rec);
+        if constexpr (F64) {
+            b.g01 = *reinterpret_cast<const double2 *>(rec);
+            b.g23 = *reinterpret_cast<const double2 *>(rec + 16);
+            b.link = *reinterpret_cast<const uint2 *>(rec + 40);
+        } else {
+            b.g = *reinterpret_cast<const float4 *>(rec);
+            b.link = *reinterpret_cast<const uint2 *>(rec + 20);
+        }
         return b;
     };
-    auto eval = [&](const CoopBatchS &b) {
+    auto eval = [&](const CoopBatchS<T> &b) {
         const unsigned ray = b.e.x >> 28;
-        const float rx = lds.ray[ray][0], ry = lds.ray[ray][1], rz = lds.ray[ray][2];
-        const bool hit = b.valid && coop_shadow_hit(b.g, rx, ry, rz, sdir);
+        const T rx = lds.ray[ray][0], ry = lds.ray[ray][1], rz = lds.ray[ray][2];
+        bool hit;
+        if constexpr (F64) hit = b.valid && coop_shadow_hit<double>(b.g01.x, b.g01.y, b.g23.x, b.g23.y, rx, ry, rz, sdir);
+        else hit = b.valid && coop_shadow_hit<float>(b.g.x, b.g.y, b.g.z, b.g.w, rx, ry, rz, sdir);
         const bool item_hit = hit && b.link.y == 0u;
         if (__ballot(item_hit) != 0ull) {
             if (item_hit) atomicOr(&lds.occluded, 1u << ray);
@@ -282,11 +365,11 @@ __device__ __forceinline__ void coop_shadow(const CoopView &cv, CoopLds &lds, un
         coop_lds_sync();                         // pushed pairs and occluded bits are the next round's reads
     };
     if constexpr (!PIPE) {
-        while (top > 0u && !overflow) { const CoopBatchS b = fetch(); eval(b); }
+        while (top > 0u && !overflow) { const CoopBatchS<T> b = fetch(); eval(b); }
     } else {
-        CoopBatchS a = fetch();
+        CoopBatchS<T> a = fetch();
         while (a.n != 0u) {
-            CoopBatchS b = fetch();
+            CoopBatchS<T> b = fetch();
             eval(a);
             if (overflow) break;
             if (b.n == 0u) { b = fetch(); if (b.n == 0u) break; }
@@ -305,17 +388,18 @@ __device__ __forceinline__ void coop_shadow(const CoopView &cv, CoopLds &lds, un
 
 // Device half of the cooperative copy: record j of the breadth-first arrays is node perm[j] of the (plain) skip streams, whose terms are
 // copied bit for bit; link[j] = {first, count}.
+template <typename T>
 __global__ void k_build_coop(const void *prim_stream, const void *shad_stream, unsigned node_stride, const uint32_t *__restrict__ perm,
-                             const uint2 *__restrict__ link, unsigned n, CNode *__restrict__ cprim, CNode *__restrict__ cshad)
+                             const uint2 *__restrict__ link, unsigned n, typename CNodeOf<T>::type *__restrict__ cprim, typename CNodeOf<T>::type *__restrict__ cshad)
 {
     const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const float *p = reinterpret_cast<const float *>(static_cast<const char *>(prim_stream) + (size_t)perm[j] * node_stride);
-    const float *s = reinterpret_cast<const float *>(static_cast<const char *>(shad_stream) + (size_t)perm[j] * node_stride);
-    CNode a, b;
+    const T *p = reinterpret_cast<const T *>(static_cast<const char *>(prim_stream) + (size_t)perm[j] * node_stride);
+    const T *s = reinterpret_cast<const T *>(static_cast<const char *>(shad_stream) + (size_t)perm[j] * node_stride);
+    typename CNodeOf<T>::type a = {}, b = {};
     a.a0 = p[0]; a.a1 = p[1]; a.a2 = p[2]; a.a3 = p[3]; a.a4 = p[4];
-    b.a0 = s[0]; b.a1 = s[1]; b.a2 = s[2]; b.a3 = s[3]; b.a4 = 0.0f;
-    a.first = b.first = link[j].x; a.count = b.count = link[j].y; a.pad = b.pad = 0u;
+    b.a0 = s[0]; b.a1 = s[1]; b.a2 = s[2]; b.a3 = s[3]; b.a4 = T(0.0);
+    a.first = b.first = link[j].x; a.count = b.count = link[j].y;
     cprim[j] = a;
     cshad[j] = b;
 }

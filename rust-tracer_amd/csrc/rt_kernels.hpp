@@ -146,7 +146,7 @@ __global__ void k_selftest_rcp(unsigned first, unsigned long long count, unsigne
 
 // Host data into device memory WITHOUT a copy engine: `src` is the device alias of pinned host memory, read over PCIe by the lanes.  The
 // first hipMemcpy* of a process costs 7.5 ms (asynchronous: the copy queue's set-up) and its first blocking one as much again
-// (tools/_init_probe.hip, round 6); a kernel launch costs 0.4.  What `make image` waits for in rt_scene_create is a few MB, once.
+// (tools/init_probe.hip, round 6); a kernel launch costs 0.4.  What `make image` waits for in rt_scene_create is a few MB, once.
 __global__ __launch_bounds__(256) void k_upload_words(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, size_t n_words)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];

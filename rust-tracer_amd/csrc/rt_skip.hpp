@@ -446,8 +446,8 @@ __device__ __forceinline__ void render_skip_body(const BlockDesc *__restrict__ o
                                                  [[maybe_unused]] unsigned long long r_entry)      // (wave trace: the wave's very first instruction)
 {
     constexpr bool PACKED = MODE == kSkipPacked, SPLIT = MODE == kSkipSplit || PACKED, ONE = MODE == kSkipOne;
-    static_assert(!COOP || (sizeof(T) == 4 && !COUNT && ONE && (VAR & 2) != 0), "the cooperative walk serves f32 spp-1 passes of the assembly loops");
-    [[maybe_unused]] __shared__ CoopLds coop_lds[COOP ? kBlockThreads / 64 : 1];
+    static_assert(!COOP || (!COUNT && ONE && (VAR & 2) != 0 && (sizeof(T) == 4 || (VAR & 16) != 0)), "the cooperative walk serves spp-1 passes of the assembly loops (f64: the filtered ones)");
+    [[maybe_unused]] __shared__ typename CoopLdsOf<T>::type coop_lds[COOP ? kBlockThreads / 64 : 1];
     const unsigned spp = ONE ? 1u : spp_arg;
     // `order` (optional): block descriptors in dispatch order, most expensive block first -- a pass is as long as its last
     // wave, so the long chains must not be the ones dispatched last (rt_capi.hip, block_order).  Without it the workgroup
@@ -938,6 +938,23 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(RT_F6
     if constexpr ((VAR & 8) != 0) r_entry = __builtin_amdgcn_s_memrealtime();
     const SkipArgs<double> &a = args;
     render_skip_body<double, false, VAR, MODE, false>(a.order, a.wg_first, a.width, a.height, a.frame_w, a.out, a.tiles, a.n_tiles, a.spp_arg, a.counters, a.lane_cost, a.holes,
+                     a.n_holes, a.sb, a.sc, a.cv, r_entry);
+}
+
+// ... with the lane-cooperative walk in f64 (round 6; rt_coop.hpp CNode64): the filtered loops need s[88:89] RESERVED as in k_render_skip_f64
+// (tools/check_reserved_registers.py) -- amdgpu_num_sgpr(96) does that by itself --; the walk's state takes the kernel beyond the 72 vector
+// registers of seven waves per SIMD, and the passes that take this flavour are the ones that wait for chains, not for slots.
+#ifndef RT_F64_COOP_WAVES
+#define RT_F64_COOP_WAVES 5
+#endif
+template <int VAR, int MODE>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(RT_F64_SGPRS), amdgpu_waves_per_eu(RT_F64_COOP_WAVES))) void k_render_skip_f64_coop(SkipArgs<double> args)
+{
+    static_assert((VAR & 16) != 0 && (VAR & 2) != 0 && MODE == kSkipOne, "the filtered assembly loops, one sample per pixel");
+    unsigned long long r_entry = 0;
+    if constexpr ((VAR & 8) != 0) r_entry = __builtin_amdgcn_s_memrealtime();
+    const SkipArgs<double> &a = args;
+    render_skip_body<double, false, VAR, MODE, true>(a.order, a.wg_first, a.width, a.height, a.frame_w, a.out, a.tiles, a.n_tiles, a.spp_arg, a.counters, a.lane_cost, a.holes,
                      a.n_holes, a.sb, a.sc, a.cv, r_entry);
 }
 

@@ -260,6 +260,96 @@ def test_work_list_overflow_goes_back_to_the_loops():
     np.testing.assert_array_equal(util.stitch((w, h), regs, data), ref)
 
 
+# ---- f64 (round 6): the same walk on CNode64 records -- the distance's 64 bits and the DFS index are two minima, `anc` travels as an f32
+# rounded up (rt_coop.hpp).  The oracle's f64 instantiation is the checker (parity unpinned: the reference holds no f64 vector).
+
+def render64(scene, w, h, regs, mode):
+    if not rta.capi.HAVE_TEST_HOOKS:
+        data, _ = scene.device().render_tiles((w, h, 1), regs, SKIP, want_stats=True)
+        return data, None
+    with rta.capi.debug(rta.capi.DEBUG_COOP, mode):
+        before = coop_launches()
+        data, _ = scene.device().render_tiles((w, h, 1), regs, SKIP, want_stats=False)
+        return data, coop_launches() - before
+
+
+def test_f64_baseline_frame_forced_by_default_and_never():
+    case = next(c for c in _vector_cases() if c["name"] == "config3_1920x1080_f64")
+    w, h = case["width"], case["height"]
+    regs = bucket_list(w, h)
+    for mode, expect_coop in ((2, True), (0, False)):
+        s = rta.Scene.default(8, rta.RT_F64)
+        data, n = render64(s, w, h, regs, mode)
+        assert n is None or (n > 0) == expect_coop, (mode, n)
+        assert tile_crcs(data, regs) == case["tile_crc32"], mode
+    # 800x600 in f64 (the frame that waits longest for one pixel's chain: 56 us before the walk existed in f64) against the oracle
+    s, o = util.scene_pair_default(rta.RT_F64)
+    w, h = 800, 600
+    regs = bucket_list(w, h)
+    ref, _, _ = o.render(w, h, 1, os.cpu_count() or 1, HIER_EXIT)
+    for mode in (2, -1):
+        data, n = render64(s, w, h, regs, mode)
+        assert n is None or mode != 2 or n > 0
+        np.testing.assert_array_equal(util.stitch((w, h), regs, data), ref)
+
+
+@pytest.mark.parametrize("seed", range(3100, 3120))
+def test_f64_random_nested_scenes(seed):
+    rng = np.random.default_rng(seed)
+    depth, fan, leaf = int(rng.integers(2, 6)), int(rng.integers(2, 5)), int(rng.integers(1, 4))
+    items, bounds, ranges = util.random_nested_scene(seed, depth=depth, fan=fan, leaf_items=leaf, concentric=seed % 3 == 1)
+    far = seed % 2 == 0
+    eye = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-9.0, -7.0) if far else rng.uniform(-4.5, -1.0)))
+    light = (float(rng.uniform(-2, 2)), float(rng.uniform(-3, -0.5)), float(rng.uniform(-2, 2)))
+    s, o = util.scene_pair_ranges(items, bounds, ranges, rta.RT_F64, light=light, eye=eye)
+    w, h = int(rng.integers(2, 7)) * 32 + int(rng.integers(0, 17)), int(rng.integers(2, 7)) * 24 + int(rng.integers(0, 13))
+    regs = bucket_list(w, h)
+    ref, _, _ = o.render(w, h, 1, os.cpu_count() or 1, HIER_EXIT)
+    data, n = render64(s, w, h, regs, 2)
+    assert n is None or n > 0
+    np.testing.assert_array_equal(util.stitch((w, h), regs, data), ref)
+
+
+def test_f64_inside_bound_quirk_tie_break_and_overflow():
+    regs = [(0, 64, 64, 0)]
+    s, o = util.scene_pair_ranges(util.INSIDE_ITEMS, util.INSIDE_BOUNDS, util.INSIDE_RANGES, rta.RT_F64)
+    ref, _ = o.render_region(64, 64, 1, 0, 64, 64, 0, HIER_EXIT)
+    flat, _ = o.render_region(64, 64, 1, 0, 64, 64, 0, oracle.MODE_FLAT)
+    assert not np.array_equal(ref, flat)
+    data, n = render64(s, 64, 64, regs, 2)
+    assert n is None or n > 0
+    np.testing.assert_array_equal(data.reshape(64, 64, 4), ref)
+    # two spheres at exactly the same f64 distance on the middle column: the first in DFS order keeps the hit -- both orders
+    for spheres in (util.TIE_SPHERES, util.TIE_SPHERES[::-1]):
+        s, o = util.scene_pair_spheres(spheres, util.TIE_BOUND, rta.RT_F64)
+        ref, _ = o.render_region(64, 64, 1, 0, 64, 64, 0, HIER_EXIT)
+        data, n = render64(s, 64, 64, regs, 2)
+        assert n is None or n > 0
+        np.testing.assert_array_equal(data.reshape(64, 64, 4), ref)
+    # the work list overflows (14 x 14 groups around the whole scene): the loops walk those rays
+    rng = np.random.default_rng(7)
+    items, bounds, ranges = [], [], []
+    bounds.append((0.0, 0.0, 0.0, 6.0)); ranges.append(None)
+    for _ in range(14):
+        bi = len(bounds)
+        bounds.append((0.0, 0.0, 0.0, 5.5)); ranges.append(None)
+        first = len(items)
+        for _ in range(14):
+            c = rng.uniform(-1.0, 1.0, 3)
+            bounds.append((0.0, 0.0, 0.0, 5.0)); ranges.append((len(items), 1))
+            items.append((c[0], c[1], c[2], float(rng.uniform(0.05, 0.2))))
+        ranges[bi] = (first, len(items) - first)
+    ranges[0] = (0, len(items))
+    s, o = util.scene_pair_ranges(np.asarray(items), np.asarray(bounds), np.asarray(ranges, dtype=np.int32), rta.RT_F64, eye=(0.0, 0.0, -9.0))
+    w, h = 96, 64
+    regs = bucket_list(w, h)
+    ref, rst, _ = o.render(w, h, 1, os.cpu_count() or 1, HIER_EXIT)
+    assert rst["hits"] > 100
+    data, n = render64(s, w, h, regs, 2)
+    assert n is None or n > 0
+    np.testing.assert_array_equal(util.stitch((w, h), regs, data), ref)
+
+
 def test_scenes_without_a_cooperative_copy_render_as_before():
     # a group with more children than a work-list word can count (15): no cooperative copy, the control changes nothing
     rng = np.random.default_rng(11)

@@ -3,6 +3,7 @@
 usage: f64_time.py [w h spp level]"""
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,9 +23,17 @@ def main():
             dev = rta.Scene.default(level, prec).device(0)
             regs_c = dev._regions([tuple(r) for r in rta.buckets(rta.RenderOptions(*opts))])
             n = 20 if tname == "skip" else 3
-            for _ in range(300 if tname == "skip" else 2):       # (a new list's dispatch orders arrive from the background and are tried: let both settle)
+            # (a new list's dispatch orders arrive from the background thread and are then tried against each other: wait for them, then
+            # let the trial settle -- 300 launches with a synchronisation each are over before the worker has made the orders)
+            t_end = time.time() + (3.0 if tname == "skip" else 0.0)
+            k = 0
+            while k < 2 or (time.time() < t_end and not (k > 600 and "ordered" in rta.capi.last_launch())):
                 dev.render_frame_device(opts, regs_c, out.data_ptr(), stream, trav)
-                torch.cuda.synchronize()
+                k += 1
+                if k % 50 == 0:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            flags = rta.capi.last_launch()
             ts = []
             for r in range(4):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -34,7 +43,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) / n * 1e3)
-            print("%dx%d spp %d L%d %s %s: %.1f us" % (w, h, spp, level, name, tname, min(ts[1:])))
+            print("%dx%d spp %d L%d %s %s: %.1f us   [%s]" % (w, h, spp, level, name, tname, min(ts[1:]), ",".join(sorted(flags))))
 
 
 if __name__ == "__main__":

@@ -74,8 +74,8 @@ while time.time() < t_end:
         rta.capi.debug_set(rta.capi.DEBUG_SKIP_VARIANT, v)
         got, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
         assert np.array_equal(got, ref), "seed %d: flavour %d differs" % (seed, v)
-    if prec == rta.RT_F32 and spp == 1:
-        # round 4: every quad through the lane-cooperative gather (rt_coop.hpp) -- rays whose winner is nearer than an ancestor bound go back to the loops
+    if spp == 1:
+        # round 4 (f64: round 6): every quad through the lane-cooperative gather (rt_coop.hpp) -- rays whose winner is nearer than an ancestor bound go back to the loops
         rta.capi.debug_set(rta.capi.DEBUG_SKIP_VARIANT, -1)
         with rta.capi.debug(rta.capi.DEBUG_COOP, 2):
             got, _ = dv.render_tiles((w, h, spp), regs, rta.RT_TRAVERSAL_SKIP, want_stats=False)
