@@ -553,7 +553,9 @@ rt_status build_orders(rt_scene *s, const std::vector<uint32_t> *map, const std:
         // first waves are -- 800x600: every wave dispatched by 10 us of 26 -- waits for chains only: the trial's times fell all the way to the
         // lowest threshold there, so its candidates reach lower)
         const bool small = total_blocks <= kCoopPassBlocks;
-        for (unsigned pc : { small ? 58u : 85u, small ? 48u : 70u, small ? 40u : 58u, small ? 33u : 48u, small ? 27u : 40u })
+        // (round 6, the trial's own times: the best candidate was the HIGHEST threshold of the five at 1024x768, 1280x720, 1080p and in f64
+        // everywhere -- profiles/r06_order_trials.log --, so the range now reaches further up, at both sizes)
+        for (unsigned pc : { small ? 85u : 95u, small ? 70u : 88u, small ? 58u : 80u, small ? 48u : 70u, small ? 40u : 58u, small ? 33u : 48u })
             wants.push_back({ 0, std::max<uint32_t>((uint32_t)kCoopMinCost, exact.top * pc / 100u) });
     } else if (coop_pass && map && !two_rays && total_blocks <= kCoopPassBlocks && !knobs)
         wants = { { 0, 0u }, { 28, 0u }, { 34, 0u }, { 40, 0u }, { 48, 0u }, { 58, 0u } };
