@@ -804,11 +804,18 @@ def main():
                 out["expected_shard_render_us"] = {"n_%d" % world: (exp.get("1080p") or {}).get(str(world)), "source": exp.get("source")}
             except Exception:
                 pass
+        if args.workload == "1080p" and args.traversal == "skip":
             try:
-                # ... and what the builder's one-GPU measurements add up to for ONE frame at this N (shard render + one collective call + the
-                # root's blit) beside the N = 1 frame: written down before any curve exists
+                # what the builder's one-GPU measurements add up to for ONE frame of BASELINE config 4 at N = 2 / 4 / 8 (rank 0's shard render + one
+                # collective call + the root's blit) beside the N = 1 frame: written down before any curve exists (tools/shard_expect.py)
                 lat = json.load(open(os.path.join(ROOT, "profiles", "expected_frame_latency.json")))
-                out["expected_frame_latency_us"] = {"n_%d" % world: (lat.get("n") or {}).get(str(world)), "n_1": (lat.get("n") or {}).get("1"), "source": lat.get("source")}
+                n = lat.get("n") or {}
+                out["expected_frame_latency_us"] = {"n_1": (n.get("1") or {}).get("frame_us"), "source": lat.get("source"), "kernel_src_sha": lat.get("kernel_src_sha"),
+                                                    "note": "ONE frame, nothing pipelined: at every N the gather + blit cost more than the shards save -- N GPUs buy throughput "
+                                                            "(ms_per_step at N > 1 pipelines frames) and larger frames, not the latency of a 1080p spp-1 frame"}
+                for k in ("2", "4", "8"):
+                    if k in n:
+                        out["expected_frame_latency_us"]["n_" + k] = n[k]
             except Exception:
                 pass
         if seam is not None:
