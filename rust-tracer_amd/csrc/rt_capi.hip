@@ -7,6 +7,7 @@
 #include "rt_kernels.hpp"
 #include "rt_skip.hpp"
 #include "rt_skip_fast.hpp"
+#include "rt_skip_fast64.hpp"
 #include "rt_skip2.hpp"
 #include "rt_flat.hpp"
 #include "rt_flat_wf.hpp"

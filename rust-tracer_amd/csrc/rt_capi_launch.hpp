@@ -218,6 +218,32 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
                 return RT_OK;
             }
         }
+        // ... and the f64 twin of the lean kernel (rt_skip_fast64.hpp): 57 vector registers and no scratch where k_render_skip_f64 has 72 and
+        // 12 - 36 bytes, and the cooperative walk at seven waves per SIMD where k_render_skip_f64_coop has five -- measured ahead of the generic
+        // kernels with AND without cooperative quads (profiles/r06_f64_lean_kernel.log: 2560x1440 91.6 -> 86.5 us without, 1280x720 42.0 -> 35.0
+        // with), so every ordered f64 spp-1 launch takes it (RT_DEBUG_FAST_KERNEL = 0: never)
+        if constexpr (!COUNT && sizeof(T) == 8 && ((VAR & ~8) == 19 || (VAR & ~8) == 23)) {
+            const long long fk = knob(RT_DEBUG_FAST_KERNEL);
+            if (spp == 1 && order.d && !order.wg_first && lds == 0 && fk != 0 && (!order.holes || s->coop.fanout != 0u)) {
+                rt::FastArgs64 fa{};
+                const rt::SkipView<double> sv = skip_view_of<double>(s);
+                constexpr bool kFused = (VAR & 4) != 0;
+                fa.order = order.d;
+                fa.walk_prim = kFused ? sv.xfprim : sv.xprim;
+                fa.exact_prim = kFused ? sv.fprim : sv.prim;
+                fa.width = w; fa.height = h; fa.nbf = (kFused ? sv.n_fnodes : sv.n_nodes) * (unsigned)sizeof(rt::FNode); fa.frame_w = frame_w; fa.out = d_out;
+                fa.items = sv.items; fa.own = sv.xown;
+                fa.eye[0] = sv.eye.x; fa.eye[1] = sv.eye.y; fa.eye[2] = sv.eye.z; fa.light[0] = sv.light.x; fa.light[1] = sv.light.y; fa.light[2] = sv.light.z;
+                fa.walk_shad = kFused ? sv.xfshad : sv.xshad; fa.exact_shad = kFused ? sv.fshad : sv.shad;
+                memcpy(fa.fc, &s->fc, sizeof fa.fc);
+                fa.trace = no_cost;
+                fa.holes = order.holes; fa.n_holes = order.holes ? order.n_holes : 0u; fa.cv = s->coop;
+                g_launch_flags |= RT_LAUNCH_FAST_KERNEL;
+                if (order.holes) { count_event(RT_DEBUG_COUNT_COOP_LAUNCHES); g_launch_flags |= RT_LAUNCH_COOPERATIVE; }
+                hipLaunchKernelGGL((rt::k_render_skip_fast64_coop<(VAR & ~8), (VAR & 8) != 0>), rgrid, b, 0, stream, fa);
+                return RT_OK;
+            }
+        }
         if constexpr (!COUNT && (VAR == 19 || VAR == 23 || VAR == 31)) {
             if (spp == 1 && order.d && order.holes && !order.wg_first) {        // some quads of the pass are walked cooperatively (rt_coop.hpp)
                 count_event(RT_DEBUG_COUNT_COOP_LAUNCHES); g_launch_flags |= RT_LAUNCH_COOPERATIVE;

@@ -6,7 +6,7 @@ tools/gen_skip2_asm.py (the two-ray loops: s32, s[72:73]) and tools/gen_skip_asm
 clobber lists the registers the compiler reserves in the one kernel they are built into -- it never allocates a reserved register, and
 naming one is what `-Winline-asm` ("clobber list contains reserved registers") objects to.  Every such statement starts with a comment
 `; rt-loops <flavour>: undeclared ...`, which survives into the .s.  For every function of the .s that holds such a statement:
-  * it is the kernel the flavour was written for (k_render_skip2 / k_render_skip_f64 and its cooperative flavour) -- in any other kernel those registers could hold
+  * it is the kernel the flavour was written for (k_render_skip2 / k_render_skip_f64, its cooperative flavour, k_render_skip_fast64_coop) -- in any other kernel those registers could hold
     the compiler's values;
   * no instruction OUTSIDE the inline-assembly blocks (;;#ASMSTART .. ;;#ASMEND) reads or writes one of those registers;
   * the wave's allocation covers them: 8 * (SGPRBlocks + 1) >= highest undeclared register + 1 + the six the hardware keeps at the end
@@ -19,7 +19,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEFAULT_S = os.path.join(ROOT, "rust-tracer_amd", "csrc", "rt_capi.gfx950.s")
-FLAVOURS = {"two-ray": ("void rt::k_render_skip2<", (32, 72, 73)), "f64": ("void rt::k_render_skip_f64", (88, 89))}
+FLAVOURS = {"two-ray": (("void rt::k_render_skip2<",), (32, 72, 73)),
+            "f64": (("void rt::k_render_skip_f64<", "void rt::k_render_skip_f64_coop<", "void rt::k_render_skip_fast64_coop<"), (88, 89))}
 
 
 def sgprs_of(text):
@@ -61,8 +62,8 @@ def check(path=DEFAULT_S):
                 blocks = int(m.group(1))
                 break
         for fl in sorted(flavours):
-            prefix, regs = FLAVOURS[fl]
-            if not name.startswith(prefix):
+            prefixes, regs = FLAVOURS[fl]
+            if not name.startswith(prefixes):
                 problems.append("%s holds %s loops, which leave %s undeclared" % (name, fl, regs))
             touched = [t for t in outside if sgprs_of(t) & set(regs)]
             if touched:
