@@ -210,17 +210,20 @@ rt_status rt_scene_create(int device, rt_precision precision, const void *dfs_it
     // the first context's stream afterwards: the null stream is never touched
     // (the first stream of a process is ~19 ms -- the runtime makes its first hardware queue, tools/init_probe.hip --, and the library's code
     // object another ~3.5 ms at its first launch: a helper asks for a kernel's attributes meanwhile, which is what loads the code object)
-    std::thread code_loader([device] {
-        if (hipSetDevice(device) != hipSuccess) return;
-        hipFuncAttributes fa;
-        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(rt::k_upload_words));
-        (void)hipGetLastError();
-    });
+    std::thread code_loader;
+    try {
+        code_loader = std::thread([device] {
+            if (hipSetDevice(device) != hipSuccess) return;
+            hipFuncAttributes fa;
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(rt::k_upload_words));
+            (void)hipGetLastError();
+        });
+    } catch (...) {}                              // (no thread to be had: the first launch loads the code object, as it always did)
     const double t_before_stream = ms_since_setup();
     e = hipStreamCreateWithFlags(&s->cost_stream, hipStreamNonBlocking);
     s->setup_first_stream_ms = ms_since_setup() - t_before_stream;
     clk.lap("scene: stream");
-    code_loader.join();
+    if (code_loader.joinable()) code_loader.join();
     clk.lap("scene: code object (helper)");
     if (e != hipSuccess) return fail(hip_fail(e, "hipStreamCreate(scene)", __LINE__));
     if ((e = hipMalloc(&s->d_items, esz * 4 * n_items)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(items)", __LINE__));
