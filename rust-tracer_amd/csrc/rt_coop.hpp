@@ -36,6 +36,7 @@ namespace rt {
 // One node of the cooperative copy.  Primary array: a = {vx, vy, vz, vv}, a4 = rr (v = centre - eye: the same pre-formed terms as
 // Node<T>, rt_skip.hpp, copied from that stream bit for bit); shadow array: a = {cx, cy, cz, rr}, a4 unused.
 // count == 0: an ITEM, `first` is its DFS item index.  count > 0: a BOUND whose children are records [first, first + count).
+typedef float rt_f32x3 __attribute__((ext_vector_type(3), aligned(4)));
 struct alignas(32) CNode {
     float a0, a1, a2, a3;
     float a4;
@@ -177,9 +178,11 @@ __device__ __forceinline__ void coop_lds_sync()
 // in flight simply counts as taken when the current one pushes.  Round 4 had dropped this for its registers (76 in the generic cooperative
 // kernel); k_render_skip_fast_coop has them (40 -> 53 of 64), the waits land where they should (s_waitcnt vmcnt(2) at the head of a
 // round: the previous batch's two loads are back, this one's two are in flight), every parity test passes -- and a cooperative wave takes
-// 16.1 us instead of 13.7 (median, 800x600; the frame 25.2 against 25.4): the rounds are not waiting for their records.  Kept as an option.
-template <typename T> struct CoopBatchP { uint2 e; float4 g, h; unsigned n; bool have; };                      // g = {vx, vy, vz, vv}, h = {rr, first, count, -}
-template <> struct CoopBatchP<double> { uint2 e; double2 g01, g23; double a4; uint2 link; unsigned n; bool have; };
+// 16.1 us instead of 13.7 (median, 800x600; the frame 25.2 against 25.4).  For the primary gather alone (an occluded shadow ray wants its
+// items soon, which the deeper order of one batch at a time finds sooner): 14.06 against 14.26 us per wave, the frame the same.  Kept as an option.
+// (the pair's ray travels with the batch: it is read from LDS while the records are on their way, not after they have arrived -- round 6)
+template <typename T> struct CoopBatchP { uint2 e; float4 g, h; float rx, ry, rz; unsigned n; bool have; };      // g = {vx, vy, vz, vv}, h = {rr, first, count, -}
+template <> struct CoopBatchP<double> { uint2 e; double2 g01, g23; double a4, rx, ry, rz; uint2 link; unsigned n; bool have; };
 template <bool PIPE = false, typename T = float>
 __device__ __forceinline__ void coop_primary(const CoopView &cv, typename CoopLdsOf<T>::type &lds, unsigned n_rays, T dx, T dy, T dz, bool want, T &best_out,
                                              unsigned &item_out, bool &failed_out)
@@ -220,15 +223,21 @@ __device__ __forceinline__ void coop_primary(const CoopView &cv, typename CoopLd
             b.link = make_uint2(t.z, t.w);
         } else {
             b.g = *reinterpret_cast<const float4 *>(rec);
-            b.h = *reinterpret_cast<const float4 *>(rec + 16);            // {rr, first, count, -}
+            // ({rr, first, count}: three words -- a fourth, dead one would be handed to the next instruction as a register, and that instruction
+            // would wait for the load)
+            const rt_f32x3 h3 = *reinterpret_cast<const rt_f32x3 *>(rec + 16);
+            b.h = make_float4(h3[0], h3[1], h3[2], 0.0f);
         }
+        const unsigned ray = b.e.x >> 28;
+        b.rx = lds.ray[ray][0]; b.ry = lds.ray[ray][1]; b.rz = lds.ray[ray][2];
+        __builtin_amdgcn_sched_barrier(0);       // (requests first, arithmetic behind them: the scheduler would sink the LDS reads below the wait for the records)
         return b;
     };
     // one round: the reference's test on every (ray, child) of the batch, minima, and the groups that go back on the list
     auto eval = [&](const CoopBatchP<T> &b) {
         const unsigned cnt = (b.e.x >> 24) & 15u, ray = b.e.x >> 28;
         const bool valid = b.have && sl.k < cnt;
-        const T rx = lds.ray[ray][0], ry = lds.ray[ray][1], rz = lds.ray[ray][2];
+        const T rx = b.rx, ry = b.ry, rz = b.rz;
         T d;
         unsigned link_first, link_count;
         if constexpr (F64) {
@@ -307,8 +316,8 @@ __device__ __forceinline__ void coop_primary(const CoopView &cv, typename CoopLd
 
 // The shadow rays of a quad (any hit, render.rs:202-208): lanes [0, n_rays), origin (ox, oy, oz), `want`: the lane casts one.  Returns
 // `occluded` in those lanes and `failed` (work list overflow: the skip-pointer loops decide).
-template <typename T> struct CoopBatchS { uint2 e; float4 g; uint2 link; unsigned n; bool valid; };
-template <> struct CoopBatchS<double> { uint2 e; double2 g01, g23; uint2 link; unsigned n; bool valid; };
+template <typename T> struct CoopBatchS { uint2 e; float4 g; float rx, ry, rz; uint2 link; unsigned n; bool valid; };
+template <> struct CoopBatchS<double> { uint2 e; double2 g01, g23; double rx, ry, rz; uint2 link; unsigned n; bool valid; };
 template <bool PIPE = false, typename T = float>
 __device__ __forceinline__ void coop_shadow(const CoopView &cv, typename CoopLdsOf<T>::type &lds, unsigned n_rays, T ox, T oy, T oz, V3<T> sdir, bool want,
                                             bool &occluded_out, bool &failed_out)
@@ -344,11 +353,13 @@ __device__ __forceinline__ void coop_shadow(const CoopView &cv, typename CoopLds
             b.g = *reinterpret_cast<const float4 *>(rec);
             b.link = *reinterpret_cast<const uint2 *>(rec + 20);
         }
+        b.rx = lds.ray[ray][0]; b.ry = lds.ray[ray][1]; b.rz = lds.ray[ray][2];
+        __builtin_amdgcn_sched_barrier(0);
         return b;
     };
     auto eval = [&](const CoopBatchS<T> &b) {
         const unsigned ray = b.e.x >> 28;
-        const T rx = lds.ray[ray][0], ry = lds.ray[ray][1], rz = lds.ray[ray][2];
+        const T rx = b.rx, ry = b.ry, rz = b.rz;
         bool hit;
         if constexpr (F64) hit = b.valid && coop_shadow_hit<double>(b.g01.x, b.g01.y, b.g23.x, b.g23.y, rx, ry, rz, sdir);
         else hit = b.valid && coop_shadow_hit<float>(b.g.x, b.g.y, b.g.z, b.g.w, rx, ry, rz, sdir);

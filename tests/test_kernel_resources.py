@@ -35,7 +35,7 @@ PINNED_REGISTERS = {
     "rt::k_render_skip_f32<false, 19, 0>": (80, 51), "rt::k_render_skip_f32<false, 19, 1>": (80, 43), "rt::k_render_skip_f32<false, 19, 2>": (80, 46),
     "rt::k_render_skip_f32<false, 19, 3>": (80, 45), "rt::k_render_skip_f32<false, 23, 0>": (80, 51), "rt::k_render_skip_f32<false, 23, 1>": (80, 43),
     "rt::k_render_skip_f32<false, 23, 2>": (80, 46), "rt::k_render_skip_f32<false, 23, 3>": (80, 45),
-    "rt::k_render_skip_f32_coop<false, 19, 2>": (92, 60), "rt::k_render_skip_f32_coop<false, 23, 2>": (92, 60),
+    "rt::k_render_skip_f32_coop<false, 19, 2>": (92, 61), "rt::k_render_skip_f32_coop<false, 23, 2>": (92, 61),
     "rt::k_render_skip2<2, true, false>": (78, 64), "rt::k_render_skip2<2, true, true>": (78, 64), "rt::k_render_skip2<3, true, false>": (78, 64),
     "rt::k_render_skip2<3, true, true>": (78, 64),
     "rt::k_render_skip_f64<19, 2>": (94, 72), "rt::k_render_skip_f64<23, 2>": (94, 72), "rt::k_render_skip_f64<23, 0>": (94, 72),
