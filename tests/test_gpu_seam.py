@@ -408,3 +408,11 @@ def test_device_encoded_frame_f64_and_a_large_scene():
         buf.array[:] = 0x11
         s.device().render_frame_stream((w, h, spp), regs, rta.capi.RT_FRAME_RGB, buf.array)
         np.testing.assert_array_equal(buf.array.reshape(h, w, 3), ref[..., :3])
+
+
+def test_scene_setup_cost_reports_the_create_call():
+    # rt_scene_setup_cost: what rt_scene_create took, and the stream's share of it (in a fresh process the runtime's first hardware queue)
+    d = rta.Scene.default().device()
+    total, stream = d.setup_cost()
+    assert 0.0 < stream <= total < 5000.0, (total, stream)
+    d.close()

@@ -337,3 +337,12 @@ def test_the_rccl_stand_in_exports_what_the_library_binds():
     with rta.capi.rccl_stand_in():
         pass
     assert rta.capi.lib.rt_debug_rccl_library(b"/nonexistent/librccl.so") == rta.capi.RT_ERR_INVALID_ARGUMENT
+
+
+def test_scene_setup_cost_rejects_null_arguments_without_a_device():
+    # rt_scene_setup_cost (ABI 4, diagnostic): like rt_scene_traits it reads the handle only -- NULL is an argument error, not a crash
+    import ctypes as C
+    from rust_tracer_amd import capi
+    total, stream = C.c_double(-1.0), C.c_double(-1.0)
+    assert capi.lib.rt_scene_setup_cost(None, C.byref(total), C.byref(stream)) == capi.RT_ERR_INVALID_ARGUMENT
+    assert b"NULL" in capi.lib.rt_last_error_message()
