@@ -65,8 +65,6 @@ __device__ __forceinline__ void render_skip_fast64_body(const FastArgs64 &args)
     const void *exact_prim = (const void *)(((unsigned long long)q[11] << 32) | q[10]);
     typedef const Item<T> __attribute__((address_space(1))) *item_ptr;
     typedef const uint32_t __attribute__((address_space(4))) *u32_ptr;
-    const unsigned long long items_bits = ((unsigned long long)q[13] << 32) | q[12];
-    const u32_ptr own = (u32_ptr)(((unsigned long long)q[15] << 32) | q[14]);
 
     const rt_u32x4 raw = order[blockIdx.x];
     const unsigned bx0 = raw[0] & 0xFFFFu, by0 = raw[0] >> 16, tile_r = raw[1] & 0xFFFFu, tile_t = raw[1] >> 16, pitch = raw[2] & 0xFFFFu, base = raw[3];
@@ -116,11 +114,29 @@ __device__ __forceinline__ void render_skip_fast64_body(const FastArgs64 &args)
         if (coop_wave) coop_primary<false, double>(args.cv, coop_lds[wave], coop_rays, dir.x, dir.y, dir.z, inside, cbest, citem, walk);
     }
     const bool loops_run = !COOP || !coop_wave || __ballot(walk) != 0;
+    // (the walk's three scalar operands as registers of their own: the entry batch is ONE sixteen-register tuple, which stays allocated -- parked
+    // in vector-register lanes across the loops, which leave the kernel s[0:19] -- as long as a single word of it is wanted)
+    unsigned long long wp_bits, ep_bits;
+    unsigned nbf_own;
+    asm volatile("s_mov_b64 %0, %3\n\ts_mov_b64 %1, %4\n\ts_mov_b32 %2, %5" : "=&s"(wp_bits), "=&s"(ep_bits), "=&s"(nbf_own)
+                 : "s"((unsigned long long)(uintptr_t)walk_prim), "s"((unsigned long long)(uintptr_t)exact_prim), "s"(nbf));
+    const void *walk_prim_own = (const void *)(uintptr_t)wp_bits, *exact_prim_own = (const void *)(uintptr_t)ep_bits;
     if (loops_run) {
         // (f64: the loops ask who is awake at the top of a step -- a lane without a ray sleeps until END; its filter sees a NaN as well)
         const float fdx = walk ? (float)dir.x : __builtin_nanf("");
-        if constexpr (FUSED) skip_primary_rot_filt_fused(walk_prim, nbf, dir.x, dir.y, dir.z, walk ? 0u : nbf, best, best_item, fdx, (float)dir.y, (float)dir.z, exact_prim);
-        else skip_primary_rot_filt(walk_prim, nbf, dir.x, dir.y, dir.z, walk ? 0u : nbf, best, best_item, fdx, (float)dir.y, (float)dir.z, exact_prim);
+        if constexpr (FUSED) skip_primary_rot_filt_lo_fused(walk_prim_own, nbf_own, dir.x, dir.y, dir.z, walk ? 0u : nbf_own, best, best_item, fdx, (float)dir.y, (float)dir.z, exact_prim_own);
+        else skip_primary_rot_filt_lo(walk_prim_own, nbf_own, dir.x, dir.y, dir.z, walk ? 0u : nbf_own, best, best_item, fdx, (float)dir.y, (float)dir.z, exact_prim_own);
+    }
+    // ---- late batch: eye, light, the shadow walk's pointers; the filter's constants (and what of the entry batch is wanted again) ----
+    // (in pieces: a register tuple stays allocated as long as ONE of its words is wanted, and the shadow loops leave the kernel s[0:19] --
+    // the two pointers they take are a tuple of their own, everything else is dead or in vector registers by then)
+    rt_u32x8 pe;
+    rt_u32x4 pl, pi;
+    asm volatile("s_load_dwordx8 %0, %3, 0x40\n\ts_load_dwordx4 %1, %3, 0x60\n\ts_load_dwordx4 %2, %3, 0x30\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(pe), "=&s"(pl), "=&s"(pi) : "s"(kp));
+    const unsigned long long items_bits = ((unsigned long long)pi[1] << 32) | pi[0];
+    const u32_ptr own = (u32_ptr)(((unsigned long long)pi[3] << 32) | pi[2]);
+    if (loops_run) {
         if constexpr (FUSED) {
             if (best_item != 0u && !(best_item & kNodeItem)) best_item = own[best_item / kFStride - 1u];
         }
@@ -129,20 +145,14 @@ __device__ __forceinline__ void render_skip_fast64_body(const FastArgs64 &args)
     if constexpr (COOP) {
         if (coop_wave && !walk) { best = cbest; best_item = citem; }
     }
-
-    // ---- late batch: eye, light, the shadow walk's pointers; the filter's constants ----
-    rt_u32x16 p, f;
-    asm volatile("s_load_dwordx16 %0, %2, 0x40\n\ts_load_dwordx16 %1, %2, 0x80\n\ts_waitcnt lgkmcnt(0)" : "=&s"(p), "=&s"(f) : "s"(kp));
-    auto dbl = [&p](int k) { return __hiloint2double((int)p[2 * k + 1], (int)p[2 * k]); };
-    const V3<T> eye = { dbl(0), dbl(1), dbl(2) }, light = { dbl(3), dbl(4), dbl(5) };
-    const void *walk_shad = (const void *)(((unsigned long long)p[13] << 32) | p[12]);
-    const void *exact_shad = (const void *)(((unsigned long long)p[15] << 32) | p[14]);
+    const V3<T> eye = { __hiloint2double((int)pe[1], (int)pe[0]), __hiloint2double((int)pe[3], (int)pe[2]), __hiloint2double((int)pe[5], (int)pe[4]) };
+    const V3<T> light = { __hiloint2double((int)pe[7], (int)pe[6]), __hiloint2double((int)pl[1], (int)pl[0]), __hiloint2double((int)pl[3], (int)pl[2]) };
 
     // ---- shade  render.rs:190-199 ----
     const V3<T> OBJECT = { T(0xae) / T(255.0), T(0x31) / T(255.0), T(0x31) / T(255.0) };
     const V3<T> BACKGROUND = { T(0x22) / T(255.0), T(0x0a) / T(255.0), T(0x0a) / T(255.0) };
     const V3<T> AMBIENT = { BACKGROUND.x * T(0.8), BACKGROUND.y * T(0.8), BACKGROUND.z * T(0.8) };
-    const V3<T> sdir = mulf(light, T(-1.0));                        // render.rs:206
+    V3<T> sdir = mulf(light, T(-1.0));                              // render.rs:206
     V3<T> g = { T(0.0), T(0.0), T(0.0) };
     T alpha = T(0.0);
     bool need_shadow = false;
@@ -171,6 +181,13 @@ __device__ __forceinline__ void render_skip_fast64_body(const FastArgs64 &args)
         if (coop_wave && __ballot(need_shadow) != 0) coop_shadow<false, double>(args.cv, coop_lds[wave], coop_rays, sp.x, sp.y, sp.z, sdir, need_shadow, occluded, walk_s);
     }
     if (__ballot(walk_s) != 0) {
+        // (the shadow walk's own arguments, where it starts: the filter's sixteen constants would otherwise wait in vector-register lanes)
+        rt_u32x4 ps;
+        rt_u32x16 f;
+        unsigned nbf2;
+        asm volatile("s_load_dwordx4 %0, %3, 0x70\n\ts_load_dwordx16 %1, %3, 0x80\n\ts_load_dword %2, %3, 0x18\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ps), "=&s"(f), "=&s"(nbf2) : "s"(kp));
+        const void *walk_shad = (const void *)(((unsigned long long)ps[1] << 32) | ps[0]);
+        const void *exact_shad = (const void *)(((unsigned long long)ps[3] << 32) | ps[2]);
         FilterConsts fc;
         fc.m0[0] = __uint_as_float(f[0]); fc.m0[1] = __uint_as_float(f[1]); fc.m0[2] = __uint_as_float(f[2]);
         fc.e1[0] = __uint_as_float(f[3]); fc.e1[1] = __uint_as_float(f[4]); fc.e1[2] = __uint_as_float(f[5]);
@@ -179,13 +196,19 @@ __device__ __forceinline__ void render_skip_fast64_body(const FastArgs64 &args)
         fc.a0 = __uint_as_float(f[12]); fc.k1 = __uint_as_float(f[13]); fc.kc = __uint_as_float(f[14]); fc.ro2 = __uint_as_float(f[15]);
         float fq1, fq2, fql;
         shadow_filter_origin64(fc, sp.x, sp.y, sp.z, fq1, fq2, fql);
+        // (the low-window loops take the direction and the constants from vector registers: copies made HERE, so that no word of the scalar
+        // tuples they came from is wanted inside the loop)
+        float fa0 = fc.a0, fk1 = fc.k1, fkc = fc.kc;
+        asm volatile("" : "+v"(fa0), "+v"(fk1), "+v"(fkc));
+        asm volatile("" : "+s"(sdir.x), "+s"(sdir.y), "+s"(sdir.z));
         constexpr unsigned kSStride = (unsigned)sizeof(FNodeS);
+        const unsigned nbf = nbf2;
         unsigned resume = walk_s ? 0u : nbf;            // lanes without a shadow ray sleep until END
         unsigned i = 0;
         while (i < nbf) {
             unsigned fin;
-            if constexpr (FUSED) i = skip_shadow_rot_filt_fused(walk_shad, nbf, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, fq1, fq2, fql, fc.a0, fc.k1, fc.kc, exact_shad);
-            else i = skip_shadow_rot_filt(walk_shad, nbf, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, fq1, fq2, fql, fc.a0, fc.k1, fc.kc, exact_shad);
+            if constexpr (FUSED) i = skip_shadow_rot_filt_lo_fused(walk_shad, nbf, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, fq1, fq2, fql, fa0, fk1, fkc, exact_shad);
+            else i = skip_shadow_rot_filt_lo(walk_shad, nbf, i, sp.x, sp.y, sp.z, sdir.x, sdir.y, sdir.z, resume, fin, fq1, fq2, fql, fa0, fk1, fkc, exact_shad);
             if (i >= nbf) break;
             if (fin) { occluded = true; resume = nbf; }
             i = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_min_u32(resume >= nbf ? nbf : (resume > i ? resume : i + kSStride)));
@@ -213,9 +236,10 @@ __device__ __forceinline__ void render_skip_fast64_body(const FastArgs64 &args)
     }
 }
 
-// (amdgpu_num_sgpr(96) + amdgpu_waves_per_eu: s[88:89] of the filtered f64 loops are reserved, as in k_render_skip_f64)
+// The loops' low-window copies (tools/gen_skip_asm.py F64F_LO: s[20:73]): .sgpr_count 80 -- EIGHT waves per SIMD, where the generic f64 kernels
+// (loops in s[36:89]) run seven.  Every register of the window is declared (nothing is reserved under amdgpu_num_sgpr(82)).
 template <int VAR, bool TRACE>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(RT_F64_SGPRS), amdgpu_waves_per_eu(RT_FAST64_WAVES))) void k_render_skip_fast64_coop(FastArgs64 args)
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(82))) void k_render_skip_fast64_coop(FastArgs64 args)
 {
     render_skip_fast64_body<VAR, TRACE, true>(args);
 }

@@ -40,7 +40,7 @@ PINNED_REGISTERS = {
     "rt::k_render_skip2<3, true, true>": (78, 64),
     "rt::k_render_skip_f64<19, 2>": (94, 72), "rt::k_render_skip_f64<23, 2>": (94, 72), "rt::k_render_skip_f64<23, 0>": (94, 72),
     "rt::k_render_skip_f64_coop<19, 2>": (94, 96), "rt::k_render_skip_f64_coop<23, 2>": (94, 96),
-    "rt::k_render_skip_fast64_coop<19, false>": (94, 57), "rt::k_render_skip_fast64_coop<23, false>": (94, 57),
+    "rt::k_render_skip_fast64_coop<19, false>": (80, 61), "rt::k_render_skip_fast64_coop<23, false>": (80, 61),
     "rt::k_render_skip<double, false, 7, 2, false>": (106, 65),
     "rt::k_flat_primary_sc": (94, 64), "rt::k_flat_shadow_sc": (94, 71),
 }
@@ -75,10 +75,9 @@ def test_the_hot_kernels_keep_the_registers_their_residency_needs(tmp_path):
     for n in k:                # seven: the cooperative flavour (it would park 41 values at 80, and its passes do not fill the chip)
         if re.match(r"rt::k_render_skip_f32_coop<false, (19|23), 2>$", n):
             assert k[n]["sgpr"] <= 96 and k[n]["vgpr"] <= 64 and k[n]["scratch"] == 0, (n, k[n])
-    for n in k:                # seven, without scratch: the lean f64 kernel (round 6; rt_skip_fast64.hpp) -- what every ordered f64 spp-1 launch runs
-        if re.match(r"rt::k_render_skip_fast64_coop<(19|23), false>$", n):
-            assert k[n]["sgpr"] <= 96 and k[n]["vgpr"] <= 72 and k[n]["scratch"] == 0, (n, k[n])
-            assert -(-k[n]["sgpr"] // 16) * 16 >= 89 + 1 + 6, (n, k[n])
+    for n in k:                # EIGHT, without scratch: the lean f64 kernel (round 6; rt_skip_fast64.hpp over the loops' low-window copies, s[20:73]) -- what every
+        if re.match(r"rt::k_render_skip_fast64_coop<(19|23), false>$", n):        # ordered f64 spp-1 launch runs
+            assert k[n]["sgpr"] <= 80 and k[n]["vgpr"] <= 64 and k[n]["scratch"] == 0, (n, k[n])
     for n in k:                # five: the cooperative flavour of the f64 walk in the generic body (the tests' twin of the lean kernel) (round 6; at six or seven it spills inside the rounds and every pass is slower)
         if re.match(r"rt::k_render_skip_f64_coop<(19|23), 2>$", n):
             assert k[n]["sgpr"] <= 96 and k[n]["vgpr"] <= 96 and k[n]["scratch"] == 0, (n, k[n])

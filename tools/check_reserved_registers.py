@@ -2,7 +2,7 @@
 """Checks, on the compiler's own assembly output (csrc/rt_capi.gfx950.s, `make -C rust-tracer_amd/csrc asm`), what the generated loops that use
 scalar registers WITHOUT declaring them rest on.
 
-tools/gen_skip2_asm.py (the two-ray loops: s32, s[72:73]) and tools/gen_skip_asm.py (the filtered f64 loops: s[88:89]) leave out of their
+tools/gen_skip2_asm.py (the two-ray loops: s32, s[72:73]) and tools/gen_skip_asm.py (the filtered f64 loops: s[88:89]; their low-window copies: s32) leave out of their
 clobber lists the registers the compiler reserves in the one kernel they are built into -- it never allocates a reserved register, and
 naming one is what `-Winline-asm` ("clobber list contains reserved registers") objects to.  Every such statement starts with a comment
 `; rt-loops <flavour>: undeclared ...`, which survives into the .s.  For every function of the .s that holds such a statement:
@@ -20,7 +20,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEFAULT_S = os.path.join(ROOT, "rust-tracer_amd", "csrc", "rt_capi.gfx950.s")
 FLAVOURS = {"two-ray": (("void rt::k_render_skip2<",), (32, 72, 73)),
-            "f64": (("void rt::k_render_skip_f64<", "void rt::k_render_skip_f64_coop<", "void rt::k_render_skip_fast64_coop<"), (88, 89))}
+            "f64": (("void rt::k_render_skip_f64<", "void rt::k_render_skip_f64_coop<"), (88, 89)),
+            "f64-lo": (("void rt::k_render_skip_fast64_coop<",), (32,))}
 
 
 def sgprs_of(text):

@@ -473,9 +473,11 @@ class F64F(F64):
     EXACT = 60
     # Round 5: s76 scratch, s77 NX, masks s[78:89] -- the filtered f64 loops end at s89 (96 scalar registers with the hardware's six: seven
     # waves per SIMD where the plain F64 loops' s[36:97] allow six; the f64 walk waits for its node records like the f32 one)
+    TMP = "s76"
     NX = "s77"
     ACT, M54, M56, M58, TINY, EX = sp(78), sp(80), sp(82), sp(84), sp(86), sp(88)
     clobber_lo, clobber_hi = 36, 89
+    fn_suffix = ""
     reserved = (88, 89)                              # k_render_skip_f64: amdgpu_num_sgpr(96) + amdgpu_waves_per_eu(7) leave the compiler s[0:87]
     load_op = "s_load_dwordx8"
 
@@ -507,7 +509,7 @@ class F64F(F64):
         a.op("v_cmp_le_f32_e32 vcc, %s, %%[tf1]" % self.thr(c))
 
     def fetch_exact(self, a):
-        tmp = "s76"                                  # (free: the filter banks end at s59, the exact record at s75, NX and the masks start at s77)
+        tmp = self.TMP                               # (free: the filter banks end at s59, the exact record at s75, NX and the masks start at s77)
         a.op("s_sub_u32 %s, %s, %d" % (tmp, self.NX, self.stride), "this node's offset in the filter stream ...")
         a.op("s_lshl_b32 %s, %s, 1" % (tmp, tmp), "... and in the Node<double> stream")
         a.op("s_load_dwordx16 %s, %%[base2], %s" % (sp(self.EXACT, 16), tmp), "its exact record")
@@ -621,7 +623,7 @@ class F64FS(F64F):
         a.op("v_cmp_ngt_f32_e64 vcc, %%[p2], |%s|" % self.s_r2o(c), "not beyond the outer bound (a NaN -- a ray the bounds do not cover -- passes)")
 
     def shadow_terms(self, a, c):
-        tmp = "s76"
+        tmp = self.TMP
         a.op("s_sub_u32 %s, %s, %d" % (tmp, self.NX, self.stride), "this node's offset in the filter stream ...")
         a.op("s_lshl_b32 %s, %s, 1" % (tmp, tmp), "... and in the Node<double> stream")
         a.op("s_load_dwordx16 %s, %%[base2], %s" % (sp(self.EXACT, 16), tmp), "its exact record")
@@ -635,6 +637,37 @@ class F64FS(F64F):
     shadow_subst = (("%[tf0]", "v%d" % TT[0]), ("%[inn]", "v%d" % TT[1]))
     shadow_extra_in = ', ' + QQ_IN + ', [ol] "v"(ol), [a0] "s"(a0), [k1] "s"(k1), [kc] "v"(kc), [base2] "s"(exact)'
     shadow_vclobbers = PACKED_CLOBBERS
+
+
+class F64F_LO(F64F):
+    """Round 6: the same loops in s[20:73] -- for k_render_skip_fast64_coop (rt_skip_fast64.hpp), which keeps so little across the loops that
+    s[0:19] are enough for it: .sgpr_count 80, EIGHT waves per SIMD where every other f64 kernel runs seven (MI355X_MICROARCH.md,
+    "Residency").  Nothing is reserved under amdgpu_num_sgpr(82): every register of the window is declared."""
+    fbank_first = (20, 28, 36)
+    EXACT = 44
+    TMP = "s60"
+    NX = "s61"
+    ACT, M54, M56, M58, TINY, EX = sp(62), sp(64), sp(66), sp(68), sp(70), sp(72)
+    clobber_lo, clobber_hi = 20, 73
+    fn_suffix = "_lo"
+    reserved = (32,)                                 # (the stack pointer of a kernel that has no stack: reserved in every kernel)
+    mark_name = "f64-lo"
+    lreg = "s"
+    # the kernel has s[0:19] for itself AND for the statements' scalar operands: the constants travel in vector registers here
+    extra_in = F64.extra_in.replace('[scalec] "s"(scalec)', '[scalec] "v"(scalec)')
+
+
+class F64FS_LO(F64FS):
+    fbank_first = F64F_LO.fbank_first
+    EXACT = F64F_LO.EXACT
+    TMP, NX = F64F_LO.TMP, F64F_LO.NX
+    ACT, M54, M56, M58, TINY, EX = F64F_LO.ACT, F64F_LO.M54, F64F_LO.M56, F64F_LO.M58, F64F_LO.TINY, F64F_LO.EX
+    clobber_lo, clobber_hi = F64F_LO.clobber_lo, F64F_LO.clobber_hi
+    fn_suffix = "_lo"
+    reserved = (32,)
+    mark_name = "f64-lo"
+    extra_in = F64F_LO.extra_in
+    shadow_extra_in = F64FS.shadow_extra_in.replace('[a0] "s"(a0)', '[a0] "v"(a0)').replace('[k1] "s"(k1)', '[k1] "v"(k1)')
 
 
 def top_of(name):
@@ -1097,8 +1130,8 @@ __device__ __forceinline__ unsigned %(name)s(const void *nodes, unsigned n_bytes
     asm volatile(
 %(body)s
         : [resume] "+v"(resume), [fin] "+v"(fin), [stop] "=&s"(stop), %(out)s%(shadow_extra_out)s
-        : [base] "s"(nodes), [n] "s"(n_bytes), [start] "s"(start), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [lx] "s"(lx), [ly] "s"(ly),
-          [lz] "s"(lz)%(extra_in)s%(shadow_extra_in)s
+        : [base] "s"(nodes), [n] "s"(n_bytes), [start] "s"(start), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [lx] "%(lreg)s"(lx), [ly] "%(lreg)s"(ly),
+          [lz] "%(lreg)s"(lz)%(extra_in)s%(shadow_extra_in)s
         : %(clobbers)s);
     resume_io = resume;
     fin_out = fin;
@@ -1170,21 +1203,21 @@ def shadow(P, fused):
 
 def main():
     text = HEADER
-    for P in (F32(), F64(), F32F(), F64F()):
+    for P in (F32(), F64(), F32F(), F64F(), F64F_LO()):
         for fused in (False, True):
-            sfx = ("_filt" if P.filt else "") + ("_fused" if fused else "")
-            common = {"ctype": P.ctype, "stride": P.stride, "inf": P.inf, "extra_in": P.extra_in, "clobbers": clobbers(P),
+            sfx = ("_filt" if P.filt else "") + getattr(P, "fn_suffix", "") + ("_fused" if fused else "")
+            common = {"ctype": P.ctype, "stride": P.stride, "inf": P.inf, "extra_in": P.extra_in, "clobbers": clobbers(P), "lreg": getattr(P, "lreg", "s"),
                       "shadow_extra_in": P.shadow_extra_in, "shadow_extra_out": P.shadow_extra_out, "shadow_extra_decl": P.shadow_extra_decl,
                       "shadow_extra_args": ", float q1, float q2, float ol, float a0, float k1, float kc, const void *exact" if (P.filt and not P.primary_only) else "",
                       "primary_extra_args": P.primary_extra_args, "primary_extra_in": P.primary_extra_in}
             # (what tools/check_reserved_registers.py finds a flavour's statements by in the compiler's assembly output)
-            mark = '        "\\t; rt-loops %s: undeclared s[%d:%d]\\n"\n' % (P.name, P.reserved[0], P.reserved[-1]) if getattr(P, "reserved", ()) else ""
+            mark = '        "\\t; rt-loops %s: undeclared s[%d:%d]\\n"\n' % (getattr(P, "mark_name", P.name), P.reserved[0], P.reserved[-1]) if getattr(P, "reserved", ()) else ""
             text += PRIMARY_FN % dict(common, name="skip_primary_rot" + sfx, body=mark + primary(P, fused), decl=P.primary_decl, out=P.primary_out)
             if not P.primary_only:
                 text += SHADOW_FN % dict(common, name="skip_shadow_rot" + sfx, body=shadow(P, fused), decl=P.shadow_decl, out=P.shadow_out,
                                          clobbers=clobbers(P, P.shadow_vclobbers))
             elif isinstance(P, F64F):
-                S = F64FS()
+                S = F64FS_LO() if isinstance(P, F64F_LO) else F64FS()
                 sc = dict(common, shadow_extra_in=S.shadow_extra_in, shadow_extra_out="", shadow_extra_decl="", clobbers=clobbers(S, S.shadow_vclobbers),
                           shadow_extra_args=", float q1, float q2, float ol, float a0, float k1, float kc, const void *exact")
                 text += SHADOW_FN % dict(sc, name="skip_shadow_rot" + sfx, body=mark + shadow(S, fused), decl=S.shadow_decl, out=S.shadow_out)
