@@ -8,6 +8,7 @@
 #include "rt_skip.hpp"
 #include "rt_skip_fast.hpp"
 #include "rt_skip_fast64.hpp"
+#include "rt_skip2_fast.hpp"
 #include "rt_skip2.hpp"
 #include "rt_flat.hpp"
 #include "rt_flat_wf.hpp"

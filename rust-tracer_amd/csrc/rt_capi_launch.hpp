@@ -130,6 +130,26 @@ constexpr auto skip_kernel()
     else return &rt::k_render_skip<T, COUNT, VAR, MODE, COOP>;
 }
 
+// The arguments of k_render_skip2_fast (rt_skip2_fast.hpp): the two-ray kernel's, in the order it reads them
+template <bool FUSED>
+rt::Fast2Args fast2_args(const rt_scene *s, const rt::BlockList &order, unsigned w, unsigned h, unsigned spp, unsigned frame_w, void *dst)
+{
+    const rt::SkipView<float> sv = skip_view_of<float>(s);
+    rt::Fast2Args a{};
+    a.order = order.d; a.wg_first = order.wg_first;
+    a.width = w; a.height = h; a.spp = spp;
+    a.nb = (FUSED ? sv.n_fnodes : sv.n_nodes) * (unsigned)sizeof(rt::Node<float>);
+    a.walk_prim = FUSED ? static_cast<const void *>(sv.xfprim) : static_cast<const void *>(sv.xprim);
+    a.frame_w = frame_w;
+    a.items = sv.items; a.own = sv.xown;
+    a.eye[0] = sv.eye.x; a.eye[1] = sv.eye.y; a.eye[2] = sv.eye.z; a.light[0] = sv.light.x; a.light[1] = sv.light.y; a.light[2] = sv.light.z;
+    a.walk_shad = FUSED ? static_cast<const void *>(sv.xfshad) : static_cast<const void *>(sv.xshad);
+    a.exact_shad = FUSED ? static_cast<const void *>(sv.fshad) : static_cast<const void *>(sv.shad);
+    a.fc = sv.fc;
+    a.dst = dst;
+    return a;
+}
+
 template <typename T, bool COUNT, int VAR>
 rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t stream, unsigned w, unsigned h, unsigned spp,
                           const rt::TileDev *d_tab, unsigned nt, uint64_t total_px, uint8_t *d_out, rt::Counters *cnt, unsigned frame_w,
@@ -184,6 +204,13 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
         if constexpr (kTwoRayFlavour) {
             if (two_rays) {
                 count_event(RT_DEBUG_COUNT_TWO_RAY_LAUNCHES); g_launch_flags |= RT_LAUNCH_TWO_RAYS;
+                if constexpr ((VAR & 16) != 0) {
+                    if (order.d && knob(RT_DEBUG_FAST_KERNEL) != 0) {      // the same kernel with its arguments fetched where they are needed (rt_skip2_fast.hpp; spp 1: lists are not dealt)
+                        g_launch_flags |= RT_LAUNCH_FAST_KERNEL;
+                        hipLaunchKernelGGL((rt::k_render_skip2_fast<rt::kSkipOne, (VAR & 4) != 0>), rgrid, b2, 0, stream, fast2_args<(VAR & 4) != 0>(s, order, w, h, spp, frame_w, d_out));
+                        return RT_OK;
+                    }
+                }
                 hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipOne, (VAR & 16) != 0, (VAR & 4) != 0>), rgrid, b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt, d_out, sb, frame_w,
                                    order.d, order.wg_first);
                 return RT_OK;
@@ -272,6 +299,20 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
     if constexpr (kTwoRayFlavour) {
         if (two_rays) {
             count_event(RT_DEBUG_COUNT_TWO_RAY_LAUNCHES); g_launch_flags |= RT_LAUNCH_TWO_RAYS;
+            bool lean2 = false;
+            if constexpr ((VAR & 16) != 0) {
+                // (measured, profiles/r06_two_ray_lean_kernel.log: ahead by 2 - 8 % on the pyramid scenes -- 3840x2160 127 -> 117 us, 1080p spp 4 473 -> 458,
+                // 4096^2 spp 4 L8 2.656 -> 2.608 ms; config 5 itself the same, 2.873 / 2.881 --, behind by 1.4 % on a plain-stream scene whose list is
+                // dealt to workgroups on the host, several descriptors each (100,000 arbitrary spheres, 15.87 / 16.09 ms: k_render_skip2 parks its
+                // arguments once per workgroup, this kernel fetches them once per descriptor): that case keeps k_render_skip2)
+                if (order.d && knob(RT_DEBUG_FAST_KERNEL) != 0 && ((VAR & 4) != 0 || !order.wg_first || knob(RT_DEBUG_FAST_KERNEL) == 2)) {
+                    g_launch_flags |= RT_LAUNCH_FAST_KERNEL;
+                    hipLaunchKernelGGL((rt::k_render_skip2_fast<rt::kSkipPacked, (VAR & 4) != 0>), dim3(rgrid.x, (unsigned)ns), b2, 0, stream,
+                                       fast2_args<(VAR & 4) != 0>(s, order, w, h, spp, frame_w, sb.gdot));
+                    lean2 = true;
+                }
+            }
+            if (!lean2)
             hipLaunchKernelGGL((rt::k_render_skip2<rt::kSkipPacked, (VAR & 16) != 0, (VAR & 4) != 0>), dim3(rgrid.x, (unsigned)ns), b2, 0, stream, skip_view_of<float>(s), w, h, spp, d_tab, nt,
                                d_out, sb, frame_w, order.d, order.wg_first);
             done2 = true;

@@ -54,9 +54,10 @@ typedef enum rt_debug_key {
     RT_DEBUG_ASYNC_ORDERS = 20,  /* 0: the dispatch orders of a tile list (and the scene's cost map) are made by the first call that uses the list, as they are
                                     whenever another dispatch control here is set; default: by a background thread, the first launches finding their blocks
                                     through the tile table */
-    RT_DEBUG_FAST_KERNEL = 21,   /* k_render_skip_fast (rt_skip_fast.hpp: f32, one sample per pixel, a dispatch list): 0 never -- the generic kernels, also for lists
-                                    with cooperative quads --, 2 for every such launch, with or without cooperative quads; default (1): where the list has
-                                    cooperative quads.  All three must render the same bytes */
+    RT_DEBUG_FAST_KERNEL = 21,   /* the lean kernels (rt_skip_fast.hpp f32, rt_skip_fast64.hpp f64, rt_skip2_fast.hpp two rays per lane: one mode each, arguments fetched
+                                    where they are needed): 0 never -- the generic kernels --, 2 wherever one exists; default: f32 where the list has cooperative
+                                    quads, f64 every ordered spp-1 launch, two rays per lane every launch with a dispatch list but a dealt list of a
+                                    plain-stream scene.  All must render the same bytes */
     RT_DEBUG_EXACT_COSTS = 22,   /* 0: cooperative quads are picked by the scene's 256 x 256 cost map only (small passes), not by counting a tile list's heaviest
                                     blocks again at the frame's own resolution (rt_capi.hip exact_block_costs).  Default 1 (read when a tile list is first seen) */
     RT_DEBUG_KEYS = 23

@@ -113,6 +113,13 @@ def _check_both_launch_flavours(request, monkeypatch):
                 with rta.capi.debug(rta.capi.DEBUG_COOP, 2), rta.capi.debug(rta.capi.DEBUG_FAST_KERNEL, 0):
                     coop0, _ = orig(self, options, regions, traversal, False)
                 assert np.array_equal(coop0, data), "the lane-cooperative walk in the generic kernel renders different bytes"
+            elif traversal in (None, rta.RT_TRAVERSAL_SKIP):
+                # several samples per pixel: where two rays per lane walk the pass (large passes; or asked for), k_render_skip2 and its lean twin
+                # (rt_skip2_fast.hpp) -- `plain` ran one of them, this is the other
+                for fast in (0, 2):
+                    with rta.capi.debug(rta.capi.DEBUG_FAST_KERNEL, fast):
+                        other, _ = orig(self, options, regions, traversal, False)
+                    assert np.array_equal(other, data), "the generic and the lean kernels render different bytes (%d)" % fast
         return data, st
 
     monkeypatch.setattr(rta.DeviceScene, "render_tiles", both)

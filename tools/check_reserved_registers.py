@@ -19,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEFAULT_S = os.path.join(ROOT, "rust-tracer_amd", "csrc", "rt_capi.gfx950.s")
-FLAVOURS = {"two-ray": (("void rt::k_render_skip2<",), (32, 72, 73)),
+FLAVOURS = {"two-ray": (("void rt::k_render_skip2<", "void rt::k_render_skip2_fast<"), (32, 72, 73)),
             "f64": (("void rt::k_render_skip_f64<", "void rt::k_render_skip_f64_coop<"), (88, 89)),
             "f64-lo": (("void rt::k_render_skip_fast64_coop<",), (32,))}
 
