@@ -245,10 +245,10 @@ rt_status launch_skip_one(const rt_scene *s, Context *c, dim3 grid, hipStream_t 
                 return RT_OK;
             }
         }
-        // ... and the f64 twin of the lean kernel (rt_skip_fast64.hpp): 57 vector registers and no scratch where k_render_skip_f64 has 72 and
-        // 12 - 36 bytes, and the cooperative walk at seven waves per SIMD where k_render_skip_f64_coop has five -- measured ahead of the generic
-        // kernels with AND without cooperative quads (profiles/r06_f64_lean_kernel.log: 2560x1440 91.6 -> 86.5 us without, 1280x720 42.0 -> 35.0
-        // with), so every ordered f64 spp-1 launch takes it (RT_DEBUG_FAST_KERNEL = 0: never)
+        // ... and the f64 twin of the lean kernel (rt_skip_fast64.hpp): 80 scalar / 61 vector registers and no scratch -- EIGHT waves per SIMD -- where
+        // k_render_skip_f64 has 96 / 72 and 12 - 36 bytes (seven) and k_render_skip_f64_coop 96 vector registers (five): measured ahead of the generic
+        // kernels with AND without cooperative quads (profiles/r06_f64_lean_kernel.log: 2560x1440 91.6 -> 82 us without, 1280x720 42.0 -> 34.5 with,
+        // 1080p 55.2 -> 50.2), so every ordered f64 spp-1 launch takes it (RT_DEBUG_FAST_KERNEL = 0: never)
         if constexpr (!COUNT && sizeof(T) == 8 && ((VAR & ~8) == 19 || (VAR & ~8) == 23)) {
             const long long fk = knob(RT_DEBUG_FAST_KERNEL);
             if (spp == 1 && order.d && !order.wg_first && lds == 0 && fk != 0 && (!order.holes || s->coop.fanout != 0u)) {

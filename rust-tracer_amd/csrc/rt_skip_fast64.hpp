@@ -1,19 +1,18 @@
-// rt_skip_fast64.hpp -- k_render_skip_fast64: rt_skip_fast.hpp's lean kernel for f64 scenes (round 6): the filtered f64 hierarchy walk of a
-// single-pass, ordered launch (spp 1, a dispatch list, no counters) WITH cooperative quads, at the registers of seven waves per SIMD.
+// rt_skip_fast64.hpp -- k_render_skip_fast64_coop: rt_skip_fast.hpp's lean kernel for f64 scenes (round 6): the filtered f64 hierarchy walk of a
+// single-pass, ordered launch (spp 1, a dispatch list, no counters), with or without cooperative quads, at EIGHT waves per SIMD.
 //
 // Why it exists.  The lane-cooperative walk (rt_coop.hpp, CNode64) took the small f64 frames from 57 - 63 us to 31, but inside the generic body
 // (k_render_skip_f64_coop) it needs 96 vector registers -- five waves per SIMD where the plain f64 kernel runs seven --, so the library's trial
 // left every pass that is bound by throughput (1280x720 and up; BASELINE config 3) on the plain kernel.  The generic body keeps the values of
-// every mode alive across the loops; this one serves ONE mode with its arguments laid out by when they are needed (entry batch: one
-// s_load_dwordx16; eye, light, the shadow walk's pointers and the filter's constants after the primary walk, where the wave waits for the
-// winner's centre anyway), exactly as the f32 lean kernel does.  Same inline functions, same generated loops (the filtered f64 ones, whose
-// s[88:89] the kernel must reserve: tools/check_reserved_registers.py), same bytes.
+// every mode alive across the loops; this one serves ONE mode with its arguments fetched where they are needed, as the f32 lean kernel does.
+// It keeps so little across its loops that s[0:19] are enough for it, so the loops are the LOW-WINDOW copies of the filtered f64 loops
+// (tools/gen_skip_asm.py F64F_LO: s[20:73] instead of s[36:89], constants in vector registers): .sgpr_count 80, 61 vector registers, no scratch.
+// What made the eighth wave pay was keeping register TUPLES short: LLVM keeps a tuple whole, so a sixteen-word batch of which one word is an
+// operand of a loop is parked -- all of it -- in vector-register lanes across that loop.  Hence: the walk's operands are copied into registers
+// of their own, `items` / `own` are loaded again behind the primary walk, the shadow walk's arguments where it starts.  Same inline functions,
+// same arithmetic, same bytes (the tests hold every f64 spp-1 frame of this kernel and of the generic ones against each other).
 #pragma once
 #include "rt_skip_fast.hpp"
-
-#ifndef RT_FAST64_WAVES
-#define RT_FAST64_WAVES 7
-#endif
 
 namespace rt {
 
