@@ -1,4 +1,4 @@
-// rt_coop.hpp -- the lane-cooperative walk of k_render_skip's heaviest pixels (f32).
+// rt_coop.hpp -- the lane-cooperative walk of the heaviest pixels of a pass (f32; f64 since round 6: CNode64).
 //
 // The skip-pointer walk (rt_skip.hpp) gives every lane a ray and moves the whole wave through the node stream one node at a time:
 // a pixel whose ray meets 400-500 nodes is a chain of that many DEPENDENT scalar loads, each an L2 round trip (a node is touched once

@@ -432,7 +432,7 @@ typedef unsigned rt_u32x16 __attribute__((ext_vector_type(16)));
 //   of their walk than 64 rays spread over 64 pixels (`make image`: 0.39 -> see DESIGN.md); samples are stored
 //   [pixel][sample], so a wave's stores are one contiguous run.
 enum { kSkipLoop = 0, kSkipSplit = 1, kSkipOne = 2, kSkipPacked = 3 };
-// COOP (f32, spp 1, the assembly loops): some quads of the pass are traced by the lane-cooperative walk (rt_coop.hpp):
+// COOP (spp 1, the assembly loops; f64: the filtered ones): some quads of the pass are traced by the lane-cooperative walk (rt_coop.hpp):
 //   a narrow descriptor (level 1: 8x8 pixels, a 4x4 quad per wave; level 2: 4x4, 2x2 per wave; level 3: 2x2, one pixel per wave) with a
 //   4-bit mask in pitch bits 20..23 is cooperative -- wave w of the workgroup traces its quad cooperatively when bit w is set and leaves
 //   otherwise; the rays the cooperative walk hands back (rt_coop.hpp: `failed`) are walked by the loops.  The 16x16 block those quads

@@ -1,5 +1,6 @@
-// rt_skip_fast.hpp -- k_render_skip_fast: the f32 hierarchy walk of a single-pass, ordered launch (spp 1, a dispatch list, no counters, no
-// cooperative quads -- every steady-state frame of a scheduler: BASELINE configs 2 - 4) with a wave's FIXED costs cut down (round 6).
+// rt_skip_fast.hpp -- k_render_skip_fast / k_render_skip_fast_coop: the f32 hierarchy walk of a single-pass, ordered launch (spp 1, a dispatch list,
+// no counters -- every steady-state frame of a scheduler: BASELINE configs 2 - 4) with a wave's FIXED costs cut down (round 6); the _coop flavour
+// also walks the list's cooperative quads (rt_coop.hpp) and is what such lists run (rt_capi_launch.hpp).
 //
 // What tools/wave_timeline.py showed on the generic kernel (k_render_skip_f32, rt_skip.hpp): between two waves a wave slot stands 2.3 us --
 // 0.16 store acknowledgement, 0.7 - 1.2 the hardware's relaunch, 1.4 the new wave's prologue -- and a wave that walks almost nothing still
@@ -14,7 +15,7 @@
 //     walk's pointers and the filter's constants BY VALUE (no dependent fetch through a pointer);
 //   * nothing parked: what shading needs of the entry batch (eye, light) waits in six vector registers, the pixel's address in two; the
 //     late batch is requested where it is used;
-//   * no raster search, no dealt loop, no sample loop, no holes.
+//   * no raster search, no dealt loop, no sample loop (holes and cooperative descriptors: the _coop flavour, four words more in the entry batch).
 // Launches that are not of this kind run the generic kernels (rt_capi.hip launch_skip_one).
 #pragma once
 #include "rt_skip.hpp"
